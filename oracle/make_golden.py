@@ -1,0 +1,189 @@
+"""TEST INFRASTRUCTURE (container-only): generate tests/golden/*.npz by RUNNING THE REFERENCE.
+
+    python oracle/make_golden.py            # needs /root/reference (read-only mount)
+
+The reference modules are imported through oracle/ref_import.py; inputs come from the
+deterministic generators in oracle/painn_ref.py (numpy PCG64) and from the reference's own
+test database tests/data/raw/test_database.db (geometry blobs only).  Outputs written:
+
+  painn_full_real4.npz   config/model/painn-oc.yaml (F=128, L=6, R=100, rc=5, K=100) on the first
+                         4 conformers of the reference test DB; energy, forces, loss, graph,
+                         edge geometry, per-layer node-state checksums, parameter gradients
+                         (full for tensors <= 8192 elements, 4096 seeded samples + norm otherwise)
+  painn_small_ragged.npz F=64, L=2, R=20, rc=3.0, K=6 (K binds) on ragged synthetic molecules
+                         including a 1-atom molecule; everything stored in full
+  graph_cases.npz        radius-graph/symmetrisation only: ragged clouds, K in {2, 5, 100},
+                         empty-neighbour molecules
+  real_conformers.npz    numbers/positions of the first 16 conformers of the test DB (data file
+                         held by the reference's tests) for real-geometry runs on the GPU box
+"""
+import os
+import sqlite3
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import painn_ref as R  # noqa: E402
+from oracle.ref_import import Data, load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+DB = "/root/reference/tests/data/raw/test_database.db"
+
+
+def read_conformers(n):
+    con = sqlite3.connect(DB)
+    rows = con.execute("select numbers, positions from systems order by id limit ?", (n,)).fetchall()
+    pos, z, batch = [], [], []
+    for m, (nb, pb) in enumerate(rows):
+        zz = np.frombuffer(nb, dtype=np.int32).astype(np.int64)
+        pp = np.frombuffer(pb, dtype=np.float64).reshape(-1, 3)
+        pos.append(pp), z.append(zz), batch.append(np.full(len(zz), m))
+    return (np.concatenate(pos).astype(np.float32), np.concatenate(z), np.concatenate(batch).astype(np.int64))
+
+
+def build_reference_model(ref, cfg, params):
+    m = ref["painn"].PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors,
+                           {"name": "gaussian"}, {"name": "polynomial", "exponent": cfg.envelope_exponent},
+                           True, False, False, True, cfg.num_elements)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected, (missing, unexpected)
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in R.param_shapes(cfg)]
+    return m
+
+
+def run_reference(ref, cfg, params, pos, z, batch, y, ft):
+    """One reference training step (PaiNNLightning.step semantics, painn.py:642-653)."""
+    model = build_reference_model(ref, cfg, params)
+    model.train()
+    trace = {}
+    hooks = []
+    for l in range(cfg.num_layers):
+        hooks.append(model.message_layers[l].register_forward_hook(
+            lambda mod, inp, out, l=l: trace.__setitem__(f"msg{l}", (inp[0] + out[0], inp[1] + out[1]))))
+        hooks.append(model.update_layers[l].register_forward_hook(
+            lambda mod, inp, out, l=l: trace.__setitem__(f"upd{l}", (inp[0] + out[0], inp[1] + out[1]))))
+    data = Data(torch.tensor(pos), torch.tensor(z), torch.tensor(batch))
+    g = model.generate_graph_values(data)
+    edge_index, neighbors, edge_dist, edge_vector, id_swap = g
+    edge_rbf = model.radial_basis(edge_dist)
+    energy, forces = model(data)
+    l1 = torch.nn.L1Loss()
+    l2 = ref["loss"].L2Loss()
+    loss = 1.0 * l1(energy, torch.tensor(y)) + 1.0 * l2(forces, torch.tensor(ft))
+    model.zero_grad()
+    loss.backward()
+    out = {
+        "edge_index": edge_index.numpy(), "neighbors": neighbors.numpy(), "id_swap": id_swap.numpy(),
+        "edge_dist": edge_dist.detach().numpy(), "edge_vector": edge_vector.detach().numpy(),
+        "edge_rbf_sum": edge_rbf.detach().sum(0).numpy(),
+        "energy": energy.detach().numpy(), "forces": forces.detach().numpy(), "loss": loss.detach().numpy(),
+    }
+    for k, (x, v) in trace.items():
+        out[f"x_{k}"] = x.detach().numpy()
+        out[f"vec_{k}"] = v.detach().numpy()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for k, p in model.named_parameters()}
+    # eval-mode forward (create_graph=False) must give the same energy/forces
+    model.eval()
+    e2, f2 = model(Data(torch.tensor(pos), torch.tensor(z), torch.tensor(batch)))
+    assert torch.allclose(e2.detach(), energy.detach(), rtol=1e-6, atol=1e-5) and torch.allclose(f2, forces.detach(), atol=1e-4, rtol=1e-5)
+    for h in hooks:
+        h.remove()
+    return out, grads
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---- data file held by the reference tests ------------------------------------------------
+    pos16, z16, b16 = read_conformers(16)
+    np.savez_compressed(os.path.join(OUT, "real_conformers.npz"), pos=pos16, z=z16, batch=b16)
+
+    # ---- full config on 4 real conformers -------------------------------------------------------
+    cfg = R.PaiNNConfig()
+    params = R.make_params(cfg, seed=23)
+    sel = b16 < 4
+    pos, z, batch = pos16[sel], z16[sel], b16[sel]
+    rng = np.random.Generator(np.random.PCG64(7))
+    y = rng.normal(0, 1, size=4).astype(np.float32)
+    ft = rng.normal(0, 0.05, size=pos.shape).astype(np.float32)
+    out, grads = run_reference(ref, cfg, params, pos, z, batch, y, ft)
+    fx = dict(cfg=np.array([cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.max_neighbors,
+                            cfg.envelope_exponent, cfg.num_elements]), cutoff=np.float64(cfg.cutoff),
+              param_seed=np.int64(23), pos=pos, z=z, batch=batch, y=y, f_target=ft)
+    for k, v in out.items():
+        if k.startswith("x_") or k.startswith("vec_"):
+            # per-layer node state: keep the last layer in full, checksums for the others
+            if k.endswith(f"upd{cfg.num_layers - 1}") or k.endswith("msg0"):
+                fx[k] = v
+            fx[k + "_abs_sum"] = np.float64(np.abs(v.astype(np.float64)).sum())
+        else:
+            fx[k] = v
+    srng = np.random.Generator(np.random.PCG64(99))
+    for k, gnp in grads.items():
+        flat = gnp.reshape(-1)
+        fx["gnorm:" + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        if flat.size <= 8192:
+            fx["grad:" + k] = gnp
+        else:
+            idx = srng.choice(flat.size, size=4096, replace=False)
+            fx["gidx:" + k] = idx.astype(np.int64)
+            fx["gval:" + k] = flat[idx]
+    np.savez_compressed(os.path.join(OUT, "painn_full_real4.npz"), **fx)
+    print("full_real4: E", out["energy"], "loss", out["loss"], "edges", out["edge_index"].shape)
+
+    # ---- small ragged config, K binds, 1-atom molecule -------------------------------------------
+    cfg = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=20, cutoff=3.0, max_neighbors=6,
+                        envelope_exponent=5, num_elements=100)
+    params = R.make_params(cfg, seed=5)
+    sizes = [1, 7, 23, 2, 40, 3]
+    pp, zz, bb = [], [], []
+    for m, n in enumerate(sizes):
+        p, zc, _, _, _ = R.gen_conformers(100 + m, 1, size=n)
+        pp.append(p.numpy()), zz.append(zc.numpy()), bb.append(np.full(n, m, dtype=np.int64))
+    pos, z, batch = np.concatenate(pp), np.concatenate(zz), np.concatenate(bb)
+    y = rng.normal(0, 1, size=len(sizes)).astype(np.float32)
+    ft = rng.normal(0, 0.05, size=pos.shape).astype(np.float32)
+    out, grads = run_reference(ref, cfg, params, pos, z, batch, y, ft)
+    fx = dict(cfg=np.array([cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.max_neighbors,
+                            cfg.envelope_exponent, cfg.num_elements]), cutoff=np.float64(cfg.cutoff),
+              param_seed=np.int64(5), pos=pos, z=z, batch=batch, y=y, f_target=ft)
+    fx.update(out)
+    for k, gnp in grads.items():
+        fx["grad:" + k] = gnp
+    np.savez_compressed(os.path.join(OUT, "painn_small_ragged.npz"), **fx)
+    print("small_ragged: E", out["energy"], "loss", out["loss"], "edges", out["edge_index"].shape,
+          "neighbors", out["neighbors"])
+
+    # ---- graph-only cases ----------------------------------------------------------------------------
+    model = build_reference_model(ref, R.PaiNNConfig(), R.make_params(R.PaiNNConfig(), seed=1))
+    gx = {}
+    case = 0
+    for seed, sizes, cutoff, K in [(1, [6], 2.2, 100), (2, [5, 1, 9, 30, 2], 2.0, 2), (3, [64, 65, 3], 4.0, 5),
+                                   (4, [90, 10, 41], 5.0, 100), (5, [1, 1, 2], 3.4, 100), (6, [130], 6.0, 100)]:
+        rg = np.random.Generator(np.random.PCG64(seed))
+        pp, bb = [], []
+        for m, n in enumerate(sizes):
+            pp.append(rg.uniform(0, max(2.0, n ** (1 / 3) * 1.6), size=(n, 3)).astype(np.float32))
+            bb.append(np.full(n, m, dtype=np.int64))
+        pos, batch = np.concatenate(pp), np.concatenate(bb)
+        model.cutoff, model.max_neighbors = cutoff, K
+        ei, nb, ed, ev, sw = model.generate_graph_values(Data(torch.tensor(pos), torch.ones(len(pos), dtype=torch.long),
+                                                               torch.tensor(batch)))
+        pre = f"c{case}_"
+        gx.update({pre + "pos": pos, pre + "batch": batch, pre + "cutoff": np.float64(cutoff), pre + "K": np.int64(K),
+                   pre + "edge_index": ei.numpy(), pre + "neighbors": nb.numpy(), pre + "id_swap": sw.numpy(),
+                   pre + "edge_dist": ed.numpy(), pre + "edge_vector": ev.numpy()})
+        print("graph case", case, sizes, "E =", ei.shape[1], "neighbors", nb.tolist())
+        case += 1
+    gx["n_cases"] = np.int64(case)
+    np.savez_compressed(os.path.join(OUT, "graph_cases.npz"), **gx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,278 @@
+"""TEST INFRASTRUCTURE -- CPU restatement (oracle) of the reference PaiNN hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file; the product (``nabladft_amd``) never does.
+
+Pure torch (fp32 or fp64, CPU), written from the reference's algorithm, each function
+citing the reference lines it restates (paths relative to /root/reference/):
+
+* graph:       nablaDFT/painn_pyg/painn.py:351-432 (_generate_graph, non-PBC branch),
+               :306-349 (generate_graph_values), :168-304 (symmetrize_edges, live branch
+               :233-282), painn_pyg/utils.py:469-481 (compute_neighbors)
+* radial:      painn_pyg/layers.py:14-33 (PolynomialEnvelope), :129-185 (RadialBasis),
+               PyG GaussianSmearing(0, 1, R)
+* model:       painn.py:89-148 (PaiNN.forward), :449-512 (PaiNNMessage), :515-548 (PaiNNUpdate),
+               layers.py:198-222 (AtomEmbedding)
+* loss:        painn.py:741-745 (_calculate_loss) with torch.nn.L1Loss + gemnet_oc/loss.py:5-22
+               (L2Loss), config/model/painn-oc.yaml:36-43
+
+Pinned by ``tests/golden/*.npz`` (produced by ``oracle/make_golden.py`` from the imported
+reference in the build container) -- see tests/test_oracle_golden.py.
+The third-party pieces (torch_cluster.radius_graph, torch_scatter.scatter) have no
+reference-side numeric test: their semantics are the documented ones.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+
+@dataclass
+class PaiNNConfig:
+    hidden_channels: int = 128
+    num_layers: int = 6
+    num_rbf: int = 100
+    cutoff: float = 5.0
+    max_neighbors: int = 100
+    envelope_exponent: int = 5
+    num_elements: int = 100
+
+
+# ----------------------------------------------------------------------------------------
+# deterministic inputs (numpy PCG64: stream is stable across numpy versions)
+# ----------------------------------------------------------------------------------------
+def param_shapes(cfg: PaiNNConfig):
+    """state_dict layout of the reference PaiNN (painn.py:63-87)."""
+    F, R = cfg.hidden_channels, cfg.num_rbf
+    shapes = [("atom_emb.embeddings.weight", (cfg.num_elements, F))]
+    for i in range(cfg.num_layers):
+        p = f"message_layers.{i}."
+        shapes += [(p + "x_proj.0.weight", (F, F)), (p + "x_proj.0.bias", (F,)),
+                   (p + "x_proj.2.weight", (3 * F, F)), (p + "x_proj.2.bias", (3 * F,)),
+                   (p + "rbf_proj.weight", (3 * F, R)), (p + "rbf_proj.bias", (3 * F,))]
+    for i in range(cfg.num_layers):
+        p = f"update_layers.{i}."
+        shapes += [(p + "vec_proj.weight", (2 * F, F)),
+                   (p + "xvec_proj.0.weight", (F, 2 * F)), (p + "xvec_proj.0.bias", (F,)),
+                   (p + "xvec_proj.2.weight", (3 * F, F)), (p + "xvec_proj.2.bias", (3 * F,))]
+    shapes += [("out_energy.0.weight", (F // 2, F)), ("out_energy.0.bias", (F // 2,)),
+               ("out_energy.2.weight", (1, F // 2)), ("out_energy.2.bias", (1,))]
+    return shapes
+
+
+def make_params(cfg: PaiNNConfig, seed: int, dtype=torch.float32):
+    """Seeded weights: xavier-uniform ranges for matrices (reference initialiser family,
+    painn.py:150-154,467-473,528-533), U(-sqrt3, sqrt3) embedding (layers.py:213), and small
+    non-zero biases (std 0.02: keeps the 6-layer net O(1)) so that every bias path is exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for name, shape in param_shapes(cfg):
+        if name.endswith("embeddings.weight"):
+            a = rng.uniform(-np.sqrt(3.0), np.sqrt(3.0), size=shape)
+        elif name.endswith("weight"):
+            bound = np.sqrt(6.0 / (shape[0] + shape[1]))
+            a = rng.uniform(-bound, bound, size=shape)
+        else:
+            a = rng.normal(0.0, 0.02, size=shape)
+        out[name] = torch.tensor(a.astype(np.float32)).to(dtype)
+    return out
+
+
+_ELEMENTS = np.array([1, 6, 7, 8, 16, 9, 17])
+_EL_P = np.array([0.470, 0.384, 0.068, 0.059, 0.009, 0.007, 0.003])
+
+
+def gen_conformers(seed: int, n_mol: int, size="drug", dtype=torch.float32):
+    """Synthetic drug-like conformers: self-avoiding random tree of heavy atoms
+    at ~1.5 A, hydrogens at 1.09 A. size: 'drug' -> n~clip(N(42,5),29,54); (lo,hi) -> U{lo..hi};
+    int -> fixed."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pos_all, z_all, batch_all = [], [], []
+    for m in range(n_mol):
+        if size == "drug":
+            n = int(np.clip(np.rint(rng.normal(42, 5)), 29, 54))
+        elif isinstance(size, tuple):
+            n = int(rng.integers(size[0], size[1] + 1))
+        else:
+            n = int(size)
+        n_heavy = max(1, int(round(n * 0.53)))
+        zs = rng.choice(_ELEMENTS[1:], size=n_heavy, p=_EL_P[1:] / _EL_P[1:].sum())
+        pts = [np.zeros(3)]
+        while len(pts) < n_heavy:
+            base = pts[rng.integers(len(pts))]
+            v = rng.normal(size=3)
+            cand = base + v / np.linalg.norm(v) * rng.normal(1.50, 0.05)
+            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= 1.20:
+                pts.append(cand)
+        heavy = len(pts)
+        tries = 0
+        while len(pts) < n:
+            base = pts[rng.integers(heavy)]
+            v = rng.normal(size=3)
+            cand = base + v / np.linalg.norm(v) * 1.09
+            tries += 1
+            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= 0.95 or tries > 2000:
+                pts.append(cand)
+        z = np.concatenate([zs, np.ones(n - heavy, dtype=zs.dtype)])
+        perm = rng.permutation(n)
+        pos_all.append(np.array(pts)[perm])
+        z_all.append(z[perm])
+        batch_all.append(np.full(n, m))
+    pos = torch.tensor(np.concatenate(pos_all).astype(np.float32)).to(dtype)
+    z = torch.tensor(np.concatenate(z_all).astype(np.int64))
+    batch = torch.tensor(np.concatenate(batch_all).astype(np.int64))
+    y = torch.tensor(rng.normal(0, 1, size=n_mol).astype(np.float32)).to(dtype)
+    f = torch.tensor(rng.normal(0, 0.05, size=(pos.shape[0], 3)).astype(np.float32)).to(dtype)
+    return pos, z, batch, y, f
+
+
+# ----------------------------------------------------------------------------------------
+# graph (integer work: bit-exact contract)
+# ----------------------------------------------------------------------------------------
+def build_graph(pos, batch, cutoff, max_neighbors):
+    """radius_graph (torch_cluster semantics: strict d^2 < r^2, no self loops, first K
+    neighbours per centre in ascending index) followed by the reference's symmetrisation:
+    keep j<i, then per graph [kept edges (i asc, j asc)] ++ [their flips] (painn.py:233-282).
+    Returns edge_index int64 [2,E] (row0=source j, row1=target i), neighbors int64 [B],
+    id_swap int64 [E] (painn.py:290-295)."""
+    pos = pos.detach()
+    B = int(batch.max()) + 1 if batch.numel() else 0
+    counts = torch.bincount(batch, minlength=B)
+    ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+    src, dst, nbrs, swap = [], [], [], []
+    off = 0
+    r2 = torch.tensor(cutoff * cutoff, dtype=pos.dtype)
+    for g in range(B):
+        a, b = int(ptr[g]), int(ptr[g + 1])
+        p = pos[a:b]
+        n = b - a
+        d2 = (p[:, None, :] - p[None, :, :]).pow(2).sum(-1)
+        adj = (d2 < r2) & ~torch.eye(n, dtype=torch.bool)
+        rank = torch.cumsum(adj.long(), dim=1) - 1
+        adj &= rank < max_neighbors
+        lower = torch.tril(adj, diagonal=-1)  # [centre i, neighbour j<i]
+        i_loc, j_loc = lower.nonzero(as_tuple=True)
+        k = i_loc.numel()
+        src += [j_loc + a, i_loc + a]
+        dst += [i_loc + a, j_loc + a]
+        nbrs.append(2 * k)
+        swap += [torch.arange(k) + off + k, torch.arange(k) + off]
+        off += 2 * k
+    if not src:
+        z = torch.zeros(0, dtype=torch.long)
+        return torch.stack([z, z]), torch.zeros(B, dtype=torch.long), z
+    edge_index = torch.stack([torch.cat(src), torch.cat(dst)])
+    return edge_index, torch.tensor(nbrs, dtype=torch.long), torch.cat(swap)
+
+
+def edge_geometry(pos, edge_index):
+    """painn.py:418-420 + :319-321."""
+    j, i = edge_index
+    distance_vec = pos[j] - pos[i]
+    edge_dist = (pos[i] - pos[j]).pow(2).sum(dim=-1).sqrt()
+    mask_zero = torch.isclose(edge_dist, torch.zeros((), dtype=pos.dtype), atol=1e-6).to(pos.dtype) * 1e-6
+    edge_vector = distance_vec / (edge_dist + mask_zero)[:, None]
+    return edge_dist, edge_vector
+
+
+def radial_basis(cfg: PaiNNConfig, d):
+    """layers.py:181-185 with PolynomialEnvelope (:23-33) and GaussianSmearing(0,1,R)."""
+    p = float(cfg.envelope_exponent)
+    a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+    ds = d * (1 / cfg.cutoff)
+    env = 1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)
+    env = torch.where(ds < 1, env, torch.zeros_like(ds))
+    offset = torch.linspace(0.0, 1.0, cfg.num_rbf).to(d.dtype)
+    coeff = -0.5 / (torch.linspace(0.0, 1.0, cfg.num_rbf)[1] - 0.0).item() ** 2
+    g = torch.exp(coeff * (ds.view(-1, 1) - offset.view(1, -1)).pow(2))
+    return env[:, None] * g
+
+
+# ----------------------------------------------------------------------------------------
+# model
+# ----------------------------------------------------------------------------------------
+def _scatter_sum(src, index, n):
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+def message_layer(P, pre, F, x, vec, edge_index, edge_rbf, edge_vector):
+    """painn.py:475-509."""
+    xh = Fn.linear(Fn.silu(Fn.linear(x, P[pre + "x_proj.0.weight"], P[pre + "x_proj.0.bias"])),
+                   P[pre + "x_proj.2.weight"], P[pre + "x_proj.2.bias"])
+    rbfh = Fn.linear(edge_rbf, P[pre + "rbf_proj.weight"], P[pre + "rbf_proj.bias"])
+    j, i = edge_index
+    m = xh[j] * rbfh
+    xa, xh2, xh3 = torch.split(m, F, dim=-1)
+    mvec = vec[j] * xh2.unsqueeze(1) + xh3.unsqueeze(1) * edge_vector.unsqueeze(2)
+    return _scatter_sum(xa, i, x.shape[0]), _scatter_sum(mvec, i, x.shape[0])
+
+
+def update_layer(P, pre, F, x, vec):
+    """painn.py:535-548."""
+    vec1, vec2 = torch.split(Fn.linear(vec, P[pre + "vec_proj.weight"]), F, dim=-1)
+    vec_dot = (vec1 * vec2).sum(dim=1)
+    cat = torch.cat([x, torch.sqrt(torch.sum(vec2**2, dim=-2) + 1e-8)], dim=-1)
+    h = Fn.linear(Fn.silu(Fn.linear(cat, P[pre + "xvec_proj.0.weight"], P[pre + "xvec_proj.0.bias"])),
+                  P[pre + "xvec_proj.2.weight"], P[pre + "xvec_proj.2.bias"])
+    xvec1, xvec2, xvec3 = torch.split(h, F, dim=-1)
+    return xvec1 + xvec2 * vec_dot, xvec3.unsqueeze(1) * vec1
+
+
+def painn_energy(P, cfg: PaiNNConfig, pos, z, batch, edge_index, trace=None):
+    """painn.py:89-128 (energy only; forces are taken by autograd in energy_forces)."""
+    F = cfg.hidden_channels
+    B = int(batch.max()) + 1
+    edge_dist, edge_vector = edge_geometry(pos, edge_index)
+    edge_rbf = radial_basis(cfg, edge_dist)
+    x = P["atom_emb.embeddings.weight"][z - 1]
+    vec = torch.zeros(x.size(0), 3, F, dtype=x.dtype)
+    for l in range(cfg.num_layers):
+        dx, dvec = message_layer(P, f"message_layers.{l}.", F, x, vec, edge_index, edge_rbf, edge_vector)
+        x, vec = x + dx, vec + dvec
+        if trace is not None:
+            trace[f"x_msg{l}"], trace[f"vec_msg{l}"] = x.detach(), vec.detach()
+        dx, dvec = update_layer(P, f"update_layers.{l}.", F, x, vec)
+        x, vec = x + dx, vec + dvec
+        if trace is not None:
+            trace[f"x_upd{l}"], trace[f"vec_upd{l}"] = x.detach(), vec.detach()
+    h = Fn.silu(Fn.linear(x, P["out_energy.0.weight"], P["out_energy.0.bias"]))
+    per_atom = Fn.linear(h, P["out_energy.2.weight"], P["out_energy.2.bias"]).squeeze(1)
+    if trace is not None:
+        trace["edge_dist"], trace["edge_vector"] = edge_dist.detach(), edge_vector.detach()
+        trace["edge_rbf"] = edge_rbf.detach()
+    return _scatter_sum(per_atom, batch, B)
+
+
+def energy_forces(P, cfg, pos, z, batch, edge_index=None, create_graph=False, trace=None):
+    """painn.py:130-146: forces = -dE/dpos with grad_outputs=ones."""
+    pos = pos.detach().clone().requires_grad_(True)
+    if edge_index is None:
+        edge_index, _, _ = build_graph(pos, batch, cfg.cutoff, cfg.max_neighbors)
+    with torch.enable_grad():
+        energy = painn_energy(P, cfg, pos, z, batch, edge_index, trace)
+        forces = -torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy),
+                                      create_graph=create_graph)[0]
+    if not create_graph:
+        energy, forces = energy.detach(), forces.detach()
+    return energy, forces
+
+
+def loss_fn(energy, forces, y, f_target, coef_e=1.0, coef_f=1.0):
+    """painn.py:741-745 with L1Loss (energy) + L2Loss (forces)."""
+    le = (energy - y).abs().mean()
+    lf = torch.linalg.vector_norm(forces - f_target, dim=-1).mean()
+    return coef_e * le + coef_f * lf
+
+
+def train_step(P, cfg, pos, z, batch, y, f_target, edge_index=None):
+    """One reference training step without the optimizer: forward, autograd forces with
+    create_graph=True, loss, backward to parameter gradients (painn.py:642-668)."""
+    names = list(P.keys())
+    Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    energy, forces = energy_forces(Pg, cfg, pos, z, batch, edge_index, create_graph=True)
+    loss = loss_fn(energy, forces, y, f_target)
+    grads = torch.autograd.grad(loss, [Pg[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(Pg[k])) for k, g in zip(names, grads)}
+    return energy.detach(), forces.detach(), loss.detach(), grads
