@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- conformer-steps/s of one PaiNN (PaiNN-OC config) training step on MI355X.
+
+A step = neighbour list + forward energies + forces (adjoint sweep) + L1/L2 loss + backward to the
+parameter gradients (tangent + dual-reverse sweeps) + gradient all-reduce (RCCL, N>1) + clip + AdamW,
+on a batch of synthetic drug-like conformers already resident in HBM.  fp32 throughout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F, L, R, CUTOFF, KNBR = 128, 6, 100, 5.0, 100
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
+
+
+def make_batches(seed, n_batches, B, device):
+    """n_batches distinct batches of B conformers: 64 generated molecules per batch seed, replicated with
+    independent random rotations and 0.02 A jitter (keeps the generator's statistics, costs O(64) python)."""
+    import nabladft_amd as nq
+    from nabladft_amd.synth import gen_conformers
+    out = []
+    for k in range(n_batches):
+        base = min(B, 64)
+        pos, z, batch, _, _ = gen_conformers(seed * 1000 + k, base)
+        rng = np.random.Generator(np.random.PCG64(seed * 7919 + k))
+        counts = torch.bincount(batch)
+        reps = (B + base - 1) // base
+        P, Z, Bt = [], [], []
+        for r in range(reps):
+            for m in range(base):
+                if r * base + m >= B:
+                    break
+                sel = batch == m
+                q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+                p = pos[sel].numpy() @ q.T.astype(np.float32) + rng.normal(0, 0.02, size=(int(counts[m]), 3)).astype(np.float32)
+                P.append(torch.tensor(p.astype(np.float32)))
+                Z.append(z[sel])
+                Bt.append(torch.full((int(counts[m]),), r * base + m, dtype=torch.long))
+        pos_b, z_b, b_b = torch.cat(P), torch.cat(Z), torch.cat(Bt)
+        y = torch.tensor(rng.normal(0, 1, size=B).astype(np.float32))
+        f = torch.tensor(rng.normal(0, 0.05, size=(pos_b.shape[0], 3)).astype(np.float32))
+        out.append(nq.Batch(pos_b, z_b, b_b, y, f).to(device))
+    return out
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
+    timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
+    from oracle import painn_ref as Rf
+    cfg = Rf.PaiNNConfig()
+    params = Rf.make_params(cfg, seed=23)
+    pos, z, batch, y, ft = Rf.gen_conformers(12345, 32)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ei, _, _ = Rf.build_graph(pos, batch, cfg.cutoff, cfg.max_neighbors)
+    t0 = time.perf_counter()
+    Rf.train_step(params, cfg, pos, z, batch, y, ft)          # warm-up (includes graph build inside)
+    warm = time.perf_counter() - t0
+    times = []
+    while sum(times) + warm < seconds_budget and len(times) < 5:
+        t0 = time.perf_counter()
+        Rf.train_step(params, cfg, pos, z, batch, y, ft)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times)) if times else warm
+    return {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "kind": "port",
+            "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms, {ei.shape[1]} edges), PaiNN-OC config, "
+                      f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 without optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="conformers per GPU per step (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import nabladft_amd as nq
+    from nabladft_amd import _lib, dist as nqdist
+    rank, world, local = nqdist.init_from_env()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
+    model = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
+    step = nq.FusedTrainStep(model, lr=5e-4, weight_decay=0.0, max_grad_norm=5.0)   # painn-oc.yaml optimizer + clip
+    batches = make_batches(1 + rank, 4, args.batch, dev)
+    n_atoms = sum(b.num_nodes for b in batches) / len(batches)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % len(batches)])
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    total_conf = args.batch * world * args.steps
+    value = total_conf / dt
+    n_edges = model._last_nl.E
+
+    roofline, kernels = None, None
+    if rank == 0 and not args.no_roofline:
+        # second, instrumented pass over the same steps: HIP events around every launch, on the launch stream
+        _lib.profile_enable(True)
+        for i in range(args.steps):
+            step(batches[i % len(batches)])
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        tot = sum(v[0] for v in prof.values())
+        kernels = sorted(((k, v[0] / args.steps, v[1] // args.steps) for k, v in prof.items()), key=lambda x: -x[1])
+        dom, dom_ms_step, dom_launches = kernels[0]
+        avg_ms = dom_ms_step / max(dom_launches, 1)
+        E = n_edges
+        if dom.startswith("gemm_nt") and dom.endswith(f"x{3 * F}x{R}"):
+            # filter-generating GEMM rho[E,R] x Wr^T[R,3F]: MFMA-bound, 2*E*R*3F flop per launch
+            flops = 2.0 * E * R * 3 * F
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": f"k_gemm<NT> {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
+        elif dom.startswith("gemm"):
+            dims = [int(x) for x in dom.split("_")[2].split("x")]
+            flops = 2.0 * dims[0] * dims[1] * dims[2]
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": f"k_gemm {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
+        else:
+            # message kernels: algorithmic bytes per launch: node state read+write 8*N*F*4 B + edge stream 24 B/edge
+            nbytes = 8.0 * n_atoms * F * 4 + 24.0 * E
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
+        roofline["device_ms_per_step_all_kernels"] = tot / args.steps
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "conformer-steps/sec (fwd+bwd)", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces "
+                                   f"train step incl. neighbour list, L1+L2 loss, grad all-reduce, clip 5.0, AdamW; synthetic ~42-atom "
+                                   f"drug-like conformers, {args.batch} conformers/GPU/step",
+                       "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
+                       "parallelism": f"dp{world}"},
+            "final_loss": float(loss),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
+            "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
+            "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:12]},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* nablaq.h -- C ABI of libnablaq.so, the MI355X (gfx950) engine for the nablaDFT PaiNN hot path.
+ *
+ * Drop-in boundary.  The reference is pure Python; its "FFI" for this path is the set
+ * of third-party native ops it calls from nablaDFT/painn_pyg (paths relative to /root/reference/):
+ *
+ *   nq_graph_count / nq_graph_fill   replace torch_cluster.radius_graph (painn.py:411-416), the edge
+ *                                    geometry (painn.py:418-423, :319-321), compute_neighbors
+ *                                    (utils.py:469-481) and symmetrize_edges (painn.py:168-304)
+ *   nq_painn_forward                 replaces PaiNN.forward (painn.py:89-148): RadialBasis
+ *                                    (layers.py:181-185), AtomEmbedding (layers.py:215-222), 6x
+ *                                    PaiNNMessage (painn.py:475-509; PyG propagate + torch_scatter.scatter)
+ *                                    and PaiNNUpdate (painn.py:535-548), out_energy + scatter
+ *                                    (painn.py:127-128) and forces = -autograd.grad (painn.py:135-146)
+ *   nq_painn_backward                replaces loss.backward() through the create_graph=True force graph
+ *                                    (painn.py:142; Lightning backward after painn.py:655-668)
+ *   nq_loss_l1_l2                    replaces _calculate_loss (painn.py:741-745) with L1Loss + L2Loss
+ *                                    (gemnet_oc/loss.py:5-22; config/model/painn-oc.yaml:36-43)
+ *   nq_adamw_step                    replaces clip_grad_norm (config/painn-oc.yaml:18-19) + torch.optim.AdamW
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (torch tensors) unless it is
+ * named *_host; all arrays are contiguous row-major fp32 / int32 / int64 as stated; `stream` is a
+ * hipStream_t passed as void*; functions are re-entrant (no global mutable state except the
+ * thread-local error string); return value 0 = NQ_OK, otherwise an NQ_ERR_* code and
+ * nq_last_error() describes it.  Nothing here allocates device memory.
+ */
+#ifndef NABLAQ_H
+#define NABLAQ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NQ_OK 0
+#define NQ_ERR_HIP 1
+#define NQ_ERR_ARG 2
+#define NQ_ERR_MOL_TOO_LARGE 3
+#define NQ_ERR_WORKSPACE 4
+#define NQ_ERR_NO_EDGES 5
+
+#define NQ_ABI_VERSION 1
+
+/* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
+typedef struct nq_painn_cfg {
+  int32_t hidden_channels;   /* F, multiple of 64, <= 1024 */
+  int32_t num_layers;        /* L */
+  int32_t num_rbf;           /* R */
+  int32_t num_elements;      /* rows of atom_emb.embeddings.weight */
+  int32_t max_neighbors;     /* K of radius_graph */
+  int32_t envelope_exponent; /* PolynomialEnvelope(exponent) */
+  double cutoff;             /* Angstrom */
+  float rbf_coeff;           /* GaussianSmearing.coeff = -0.5/(offset[1]-offset[0])^2 */
+  int32_t reserved;
+} nq_painn_cfg;
+
+/* Neighbour list in engine layout (CSR by target atom, sources ascending; symmetric). */
+typedef struct nq_graph {
+  int32_t N, B, E, reserved;
+  const int32_t* mol_ptr;   /* [B+1] first atom of each molecule */
+  const int32_t* row_ptr;   /* [N+1] */
+  const int32_t* col;       /* [E] source atom of the in-edge at this slot */
+  const int32_t* dst;       /* [E] target atom of the slot (row index) */
+  const int32_t* rev;       /* [E] slot of the reverse edge */
+  const float* geom;        /* [E][4] {rx, ry, rz, d}, r = (pos[col]-pos[dst])/d */
+  const int32_t* z;         /* [N] atomic numbers */
+  const int32_t* atom_mol;  /* [N] molecule of each atom */
+} nq_graph;
+
+int nq_abi_version(void);
+const char* nq_last_error(void);
+
+/* ---- neighbour list ------------------------------------------------------------------------ */
+/* Pass 1: degrees and prefix sums; returns the number of directed edges E in *E_host (synchronises
+ * `stream`).  deg/lowdeg: int32[N] scratch; row_ptr/lowptr: int32[N+1] outputs. */
+int nq_graph_count(const float* pos, const int32_t* mol_ptr, int32_t N, int32_t B, int32_t max_mol_atoms, double cutoff,
+                   int32_t max_neighbors, int32_t* deg, int32_t* lowdeg, int32_t* row_ptr, int32_t* lowptr, int32_t* E_host,
+                   void* stream);
+/* Pass 2: fills the CSR arrays (col, dst, rev, geom[E][4], slot2canon, atom_mol[N]) and, if edge_index != NULL,
+ * the reference's canonical outputs: edge_index int64[2][E] (row0 = source j, row1 = target i),
+ * edge_dist f32[E], edge_vector f32[E][3], id_swap int64[E], neighbors int64[B]. */
+int nq_graph_fill(const float* pos, const int32_t* mol_ptr, int32_t N, int32_t B, int32_t E, int32_t max_mol_atoms, double cutoff,
+                  int32_t max_neighbors, const int32_t* row_ptr, const int32_t* lowptr, int32_t* col, int32_t* dst, int32_t* rev,
+                  float* geom, int32_t* slot2canon, int32_t* atom_mol, int64_t* edge_index, float* edge_dist, float* edge_vector,
+                  int64_t* id_swap, int64_t* neighbors, void* stream);
+
+/* ---- model --------------------------------------------------------------------------------- */
+/* Flat parameter buffer: tensors concatenated in state_dict order of the reference PaiNN
+ * (atom_emb.embeddings.weight, message_layers.{l}.{x_proj.0,x_proj.2,rbf_proj}.{weight,bias} for all l,
+ * update_layers.{l}.{vec_proj.weight, xvec_proj.0.{weight,bias}, xvec_proj.2.{weight,bias}} for all l,
+ * out_energy.{0,2}.{weight,bias}). */
+size_t nq_painn_num_params(const nq_painn_cfg* cfg);
+size_t nq_painn_workspace_bytes(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B);
+
+/* energy[B] and (if forces != NULL) forces[N][3] = -dE_tot/dpos.  Keeps every activation in `workspace`
+ * for nq_painn_backward.  rbf_offsets: f32[R] = buffer radial_basis.rbf.offset. */
+int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                     size_t workspace_bytes, float* energy, float* forces, void* stream);
+/* Given dL/dE[B] and dL/dF[N][3] (either may be NULL = zeros) writes dL/dparams[num_params] (overwrites).
+ * Must follow nq_painn_forward (with forces) on the same workspace and graph. */
+int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_graph* graph, void* workspace, size_t workspace_bytes,
+                      const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
+/* Test/inspection hook: offset (in floats) and element count of a named workspace buffer, e.g.
+ * ("x_msg", 2, tangent=0).  Returns NQ_ERR_ARG for unknown names. */
+int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t layer, int32_t tangent,
+                       size_t* offset_floats, size_t* count);
+
+/* ---- loss / optimizer ------------------------------------------------------------------------ */
+/* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
+int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
+                  float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream);
+/* clip_grad_norm_(max_norm) (skipped if max_norm <= 0) + AdamW step over the flat buffers; step >= 1;
+ * scratch: f32[512]. */
+int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t count, float max_norm, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int32_t step, float* scratch, void* stream);
+
+/* ---- measurement hook ------------------------------------------------------------------------- */
+/* Opt-in per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * Process-global and not thread-safe: enable it only around a single-threaded measurement.
+ * nq_profile_read synchronises the device, writes up to `cap` rows {name (name_stride bytes, NUL
+ * terminated), total milliseconds, launch count}, clears the records and returns the number of names. */
+void nq_profile_enable(int32_t on);
+int nq_profile_read(char* names_host, int32_t name_stride, double* total_ms_host, int64_t* counts_host, int32_t cap);
+
+/* ---- building blocks exported for unit tests ----------------------------------------------- */
+/* C[M,N] = A[M,K] W[N,K]^T (+bias[N]); if C_silu != NULL also writes silu(C). */
+int nq_linear_forward(const float* A, const float* W, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K,
+                      void* stream);
+/* C[M,K] (+)= G[M,N] W[N,K] */
+int nq_linear_input_grad(const float* G, const float* W, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* gW[N,K] = G[rows,N]^T X[rows,K]; scratch: f32[nq_weight_grad_scratch_floats(rows,N,K)] */
+size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
+int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

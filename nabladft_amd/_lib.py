@@ -1,0 +1,104 @@
+"""ctypes binding of libnablaq.so (C ABI: include/nablaq.h).  No fallback: if the library or a
+symbol is missing this module raises, it never routes around the HIP engine."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnablaq.so")
+ABI_VERSION = 1
+
+NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
+
+
+class NablaqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libnablaq error {code}: {msg}")
+        self.code = code
+
+
+class PainnCfg(C.Structure):
+    _fields_ = [("hidden_channels", C.c_int32), ("num_layers", C.c_int32), ("num_rbf", C.c_int32),
+                ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
+                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("reserved", C.c_int32)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("N", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("reserved", C.c_int32),
+                ("mol_ptr", C.c_void_p), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("dst", C.c_void_p),
+                ("rev", C.c_void_p), ("geom", C.c_void_p), ("z", C.c_void_p), ("atom_mol", C.c_void_p)]
+
+
+_P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/nablaq.h declares
+SYMBOLS = {
+    "nq_abi_version": (C.c_int, []),
+    "nq_last_error": (C.c_char_p, []),
+    "nq_graph_count": (C.c_int, [_P, _P, _I32, _I32, _I32, _D, _I32, _P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    "nq_graph_fill": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _D, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nq_painn_num_params": (_SZ, [C.POINTER(PainnCfg)]),
+    "nq_painn_workspace_bytes": (_SZ, [C.POINTER(PainnCfg), _I32, _I32, _I32]),
+    "nq_painn_forward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
+    "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
+    "nq_painn_ws_lookup": (C.c_int, [C.POINTER(PainnCfg), _I32, _I32, _I32, C.c_char_p, _I32, _I32, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
+    "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),
+    "nq_profile_enable": (None, [_I32]),
+    "nq_profile_read": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "nq_linear_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "nq_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32]),
+    "nq_linear_weight_grad": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and binds every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found -- build it with `python -m nabladft_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.nq_abi_version() != ABI_VERSION:
+        raise ImportError(f"libnablaq ABI {lib.nq_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != NQ_OK:
+        raise NablaqError(rc, load().nq_last_error().decode(errors="replace"))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, None -> NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_enable(on: bool):
+    load().nq_profile_enable(1 if on else 0)
+
+
+def profile_read(cap=256, stride=64):
+    """-> {name: (total_ms, launches)} of everything recorded since the last read."""
+    names = C.create_string_buffer(cap * stride)
+    tot = (C.c_double * cap)()
+    cnt = (C.c_int64 * cap)()
+    n = load().nq_profile_read(names, stride, tot, cnt, cap)
+    out = {}
+    for i in range(min(n, cap)):
+        nm = names.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode()
+        out[nm] = (tot[i], cnt[i])
+    return out

@@ -1,0 +1,176 @@
+// nablaq -- MI355X (gfx950 / CDNA4) engine for the nablaDFT PaiNN hot path.
+// Shared device helpers and host-side launch/error plumbing.  gfx950 only: wavefront = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define NQ_WAVE 64
+
+// ---- status codes (mirrored in include/nablaq.h) -------------------------------------------
+#define NQ_OK 0
+#define NQ_ERR_HIP 1          // a HIP call failed; see nq_last_error()
+#define NQ_ERR_ARG 2          // bad argument (shape / alignment / unsupported size)
+#define NQ_ERR_MOL_TOO_LARGE 3
+#define NQ_ERR_WORKSPACE 4    // caller-provided workspace too small
+#define NQ_ERR_NO_EDGES 5
+
+extern thread_local char nq_err_buf[512];
+int nq_fail(int code, const char* fmt, ...);
+
+#define NQ_HIP(call)                                                                            \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess)                                                                      \
+      return nq_fail(NQ_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+  } while (0)
+
+#define NQ_LAUNCH_CHECK() NQ_HIP(hipGetLastError())
+
+#define NQ_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != NQ_OK) return rc__; \
+  } while (0)
+
+static inline int nq_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-kernel timing (HIP events on the launch stream; used by bench.py for the roofline) ----
+// Off by default (one branch per launch).  nq_profile_enable(1) makes every launcher record a
+// start/stop event pair around its kernel(s); nq_profile_read() synchronises and sums by name.
+struct NqProfScope {
+  hipStream_t st; int slot;
+  NqProfScope(hipStream_t s, const char* name);
+  ~NqProfScope();
+};
+extern int nq_profile_on;
+#define NQ_PROF(st, name) NqProfScope nq_prof_scope__((st), (name))
+
+// ---- device math ---------------------------------------------------------------------------
+__device__ __forceinline__ float nq_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+// SiLU and its first two derivatives (oracle/painn_sweeps.py: silu, dsilu, d2silu)
+__device__ __forceinline__ float nq_silu(float z) { return z * nq_sigmoid(z); }
+__device__ __forceinline__ float nq_dsilu(float z) {
+  float s = nq_sigmoid(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ float nq_d2silu(float z) {
+  float s = nq_sigmoid(z);
+  float ds = s * (1.0f - s);
+  return ds * (2.0f + z * (1.0f - 2.0f * s));
+}
+
+__device__ __forceinline__ float nq_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// kernels (implemented in the .hip files, launched by engine.hip) ------------------------------
+struct NqGraphView {
+  int N, B, E;
+  const int* mol_ptr;   // [B+1]
+  const int* row_ptr;   // [N+1]  CSR by target atom
+  const int* col;       // [E]    source atom of the in-edge stored at this slot
+  const int* rev;       // [E]    slot of the reverse edge
+  const float4* geom;   // [E]    {rx, ry, rz, d}: r = (pos[col]-pos[row])/d
+  const int* z;         // [N]    atomic numbers
+  const int* atom_mol;  // [N]
+};
+
+// ---- kernel argument blocks (shared between the kernel files and engine.hip) ---------------------
+struct GraphFillArgs {
+  const float* pos; const int* mol_ptr; const int* row_ptr; const int* lowptr;
+  float r2; int K;
+  int* col; int* dst; int* rev; float4* geom; int* slot2canon;  // CSR outputs
+  long long* c_src; long long* c_dst; float* c_dist; float* c_vec; long long* id_swap; long long* neighbors;  // canonical (nullable)
+  int* atom_mol;
+};
+
+struct MsgArgs {
+  NqGraphView g; int F;
+  // primal
+  const float* X; const float* V; const float* XH; const float* PHI; const float* PSI;
+  float* XM; float* VM;
+  // tangent
+  const float* TX; const float* TV; const float* TXH; const float* TD; const float* TR;  // TD[E], TR[E][3]
+  float* TXM; float* TVM;
+};
+
+struct MsgRevArgs {
+  NqGraphView g; int F;
+  const float* V; const float* XH; const float* PHI; const float* PSI;      // primal, layer input side
+  const float* TV; const float* TXH; const float* TD; const float* TR;      // tangents (dual only)
+  const float* GX; const float* GV;                                          // adjoints of x_msg / vec_msg   [N][F], [N][3F]
+  const float* GTX; const float* GTV;                                        // adjoints of their tangents (dual)
+  float* GXH; float* GTXH;                                                   // out: adjoint of xh (and t_xh)  [N][3F]
+  float* GV_out; float* GTV_out;                                             // out: gvec_msg + scatter part   [N][3F]
+  float* GPHI; float* GPSI;                                                  // dual out: [E][3F] each
+  float4* GEDGE;                                                             // force mode: [nwaves][E] {gd, grx, gry, grz} (+=)
+};
+
+struct UpdArgs {
+  int N, F;
+  const float* XM; const float* VM; const float* U; const float* Y;        // [N][F], [N][3][F], [N][3][2F], [N][3F]
+  float* S; float* CAT; float* X1; float* V1;                              // [N][F], [N][2F], outputs [N][F], [N][3][F]
+  const float* TXM; const float* TVM; const float* TU; const float* TY;
+  float* TS; float* TCAT; float* TX1; float* TV1;
+};
+
+struct UpdRevArgs {
+  int N, F;
+  const float* U; const float* Y; const float* S; const float* CAT;          // primal
+  const float* TU; const float* TY; const float* TS; const float* TCAT;      // tangent (dual)
+  float* GX; float* GV; float* GTX; float* GTV;                              // adjoints of x_upd/vec_upd (GX,GTX updated in rev2)
+  float* GY; float* GTY;                                                     // [N][3F] out of rev1
+  const float* GCAT; const float* GTCAT;                                     // [N][2F] in to rev2
+  float* GU; float* GTU;                                                     // [N][3][2F] out of rev2
+};
+
+struct ReadoutArgs {
+  int N, H;
+  const float* ZO; const float* TZO; const float* w2; float o2_dummy; const float* o2;
+  float* e_atom; float* te_atom;
+  const float* ge; const float* gte;           // per-atom seeds
+  float* GZO; float* GTZO;                     // [N][H]
+  float* TMPW;                                 // dual: [N][H] per-atom contribution to grad of w2
+};
+
+// ---- launchers ----------------------------------------------------------------------------------
+int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int max_mol_atoms, float cutoff2, int K, int* deg, int* lowdeg,
+                        int* row_ptr, int* lowptr, int* E_host, hipStream_t st);
+int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st);
+
+int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K, int lda,
+               int ldw, int ldc);
+int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc, int accumulate);
+size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
+int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch);
+size_t nq_colsum_scratch_floats(long rows, int cols);
+int nq_colsum(hipStream_t, const float* A, long rows, int cols, int lda, float* out, float* scratch);
+int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, long count, float* out);
+
+int nq_rbf(hipStream_t, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets, float* rho,
+           float* drho);
+int nq_msg_fwd(hipStream_t, const MsgArgs&, bool tangent);
+int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);
+int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* pos_dot, float* TD, float* TR);
+int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);
+
+int nq_upd_a(hipStream_t, const UpdArgs&, bool tan);
+int nq_upd_b(hipStream_t, const UpdArgs&, bool tan);
+int nq_silu_tan(hipStream_t, const float* Z, const float* TZ, float* TH, long count);
+int nq_silu_rev(hipStream_t, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual);
+int nq_upd_rev(hipStream_t, const UpdRevArgs&, int stage, bool dual);
+int nq_embed(hipStream_t, const int* z, const float* emb, int N, int F, float* X0);
+size_t nq_embed_grad_scratch_floats(int N, int F, int T);
+int nq_embed_grad(hipStream_t, const int* z, const float* GX, int N, int F, int T, float* out, float* scratch);
+int nq_readout(hipStream_t, const ReadoutArgs&, int mode);
+int nq_readout_rev(hipStream_t, const ReadoutArgs&, bool dual);
+int nq_mol_sum(hipStream_t, const float* e_atom, const int* mol_ptr, int B, float* out);
+int nq_atom_seeds(hipStream_t, const float* gE, const int* atom_mol, int N, float* ge, float* gte);
+int nq_negate(hipStream_t, const float* in, float* out, long count);
+int nq_loss_impl(hipStream_t, const float* E, const float* y, int B, const float* Fc, const float* Ft, int N, float ce, float cf, float* loss,
+                 float* gE, float* gF);
+int nq_adamw_impl(hipStream_t, float* p, const float* g, float* m, float* v, long count, float max_norm, float lr, float beta1, float beta2,
+                  float eps, float wd, int step, float* scratch);

@@ -1,0 +1,274 @@
+// Edge-level kernels of the PaiNN interaction block (reference: painn.py:475-509 PaiNNMessage,
+// layers.py:14-33,129-185 RadialBasis; math restated in oracle/painn_sweeps.py).
+//
+// All message kernels are node-centric over the symmetric CSR built by graph.hip: one workgroup
+// per atom, one thread per feature channel (blockDim.x == F), looping over the atom's CSR row in
+// ascending neighbour order.  The segment reduction therefore needs no atomics and its summation
+// order equals the reference's sequential scatter_add order.  In the reverse sweeps the same row
+// is read as the atom's OUT-edges (n -> k): phi/psi/d are symmetric, r and t_r change sign.
+#include "common.h"
+
+struct RbfArgs {
+  const float4* geom; int E; int R; float inv_cutoff; float p, a, b, c; float coeff; const float* mu;
+  float* rho; float* drho;
+};
+
+// rho[e,k] = env(d/rc) * exp(coeff (d/rc - mu_k)^2) and d rho/d d  (oracle: rbf_and_derivative)
+__global__ void k_rbf(RbfArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.E * q.R) return;
+  const int e = (int)(idx / q.R), k = (int)(idx % q.R);
+  const float d = q.geom[e].w;
+  const float ds = d * q.inv_cutoff;
+  float env = 0.f, denv = 0.f;
+  if (ds < 1.0f) {
+    const float pm1 = powf(ds, q.p - 1.0f);
+    const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
+    env = 1.0f + q.a * p0 + q.b * p1 + q.c * p2;
+    denv = q.a * q.p * pm1 + q.b * (q.p + 1.0f) * p0 + q.c * (q.p + 2.0f) * p1;
+  }
+  // same rounding order as GaussianSmearing: exp(coeff * (ds - mu_k)^2), mu = the module's fp32 offset buffer
+  const float diff = ds - q.mu[k];
+  const float g = expf(q.coeff * (diff * diff));
+  q.rho[idx] = env * g;
+  q.drho[idx] = q.inv_cutoff * g * (denv + env * (2.0f * q.coeff) * diff);
+}
+
+// ---------------------------------------------------------------------------------------------
+
+// x_msg = x + sum_j xh_a[j] phi_a ;  vec_msg[c] = vec[c] + sum_j vec[j][c] (xh_b[j] phi_b) + (xh_c[j] phi_c) r[c]
+__global__ void k_msg_fwd(MsgArgs q) {
+  const int n = blockIdx.x, f = threadIdx.x, F = q.F, F3 = 3 * q.F;
+  const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+  float dx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  for (int sp = beg; sp < end; ++sp) {
+    const int k = q.g.col[sp];
+    const float4 gm = q.g.geom[sp];
+    const float* ph = q.PHI + (long)sp * F3;
+    const float* xh = q.XH + (long)k * F3;
+    const float* vk = q.V + (long)k * F3;
+    const float ma = xh[f] * ph[f], mb = xh[F + f] * ph[F + f], mc = xh[2 * F + f] * ph[2 * F + f];
+    dx += ma;
+    d0 += vk[f] * mb + mc * gm.x;
+    d1 += vk[F + f] * mb + mc * gm.y;
+    d2 += vk[2 * F + f] * mb + mc * gm.z;
+  }
+  const long o = (long)n * F, o3 = (long)n * F3;
+  q.XM[o + f] = q.X[o + f] + dx;
+  q.VM[o3 + f] = q.V[o3 + f] + d0;
+  q.VM[o3 + F + f] = q.V[o3 + F + f] + d1;
+  q.VM[o3 + 2 * F + f] = q.V[o3 + 2 * F + f] + d2;
+}
+
+// JVP of k_msg_fwd along (TXH, TV, TD, TR); phi_dot = psi * t_d
+__global__ void k_msg_tan(MsgArgs q) {
+  const int n = blockIdx.x, f = threadIdx.x, F = q.F, F3 = 3 * q.F;
+  const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+  float dx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  for (int sp = beg; sp < end; ++sp) {
+    const int k = q.g.col[sp];
+    const float4 gm = q.g.geom[sp];
+    const float td = q.TD[sp];
+    const float tr0 = q.TR[3 * (long)sp], tr1 = q.TR[3 * (long)sp + 1], tr2 = q.TR[3 * (long)sp + 2];
+    const float* ph = q.PHI + (long)sp * F3;
+    const float* ps = q.PSI + (long)sp * F3;
+    const float* xh = q.XH + (long)k * F3;
+    const float* txh = q.TXH + (long)k * F3;
+    const float* vk = q.V + (long)k * F3;
+    const float* tvk = q.TV + (long)k * F3;
+    const float xa = xh[f], xb = xh[F + f], xc = xh[2 * F + f];
+    const float pa = ph[f], pb = ph[F + f], pc = ph[2 * F + f];
+    const float mb = xb * pb, mc = xc * pc;
+    const float tma = txh[f] * pa + xa * (ps[f] * td);
+    const float tmb = txh[F + f] * pb + xb * (ps[F + f] * td);
+    const float tmc = txh[2 * F + f] * pc + xc * (ps[2 * F + f] * td);
+    dx += tma;
+    d0 += tvk[f] * mb + vk[f] * tmb + tmc * gm.x + mc * tr0;
+    d1 += tvk[F + f] * mb + vk[F + f] * tmb + tmc * gm.y + mc * tr1;
+    d2 += tvk[2 * F + f] * mb + vk[2 * F + f] * tmb + tmc * gm.z + mc * tr2;
+  }
+  const long o = (long)n * F, o3 = (long)n * F3;
+  q.TXM[o + f] = q.TX[o + f] + dx;
+  q.TVM[o3 + f] = q.TV[o3 + f] + d0;
+  q.TVM[o3 + F + f] = q.TV[o3 + F + f] + d1;
+  q.TVM[o3 + 2 * F + f] = q.TV[o3 + 2 * F + f] + d2;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+// Reverse of the message block at node n in its SOURCE role: loops over out-edges (n -> k).
+//   DUAL=false  force adjoint: accumulates d(E)/d(d_e), d(E)/d(r_e) per out-edge into GEDGE
+//   DUAL=true   second-order sweep: also adjoints of the tangents, and gphi/gpsi for the rbf_proj gradient
+template <bool DUAL>
+__global__ void k_msg_rev(MsgRevArgs q) {
+  const int n = blockIdx.x, f = threadIdx.x, F = q.F, F3 = 3 * q.F;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+  const long o3 = (long)n * F3;
+  const float xa = q.XH[o3 + f], xb = q.XH[o3 + F + f], xc = q.XH[o3 + 2 * F + f];
+  const float v0 = q.V[o3 + f], v1 = q.V[o3 + F + f], v2 = q.V[o3 + 2 * F + f];
+  float txa = 0.f, txb = 0.f, txc = 0.f, tv0 = 0.f, tv1 = 0.f, tv2 = 0.f;
+  if (DUAL) {
+    txa = q.TXH[o3 + f]; txb = q.TXH[o3 + F + f]; txc = q.TXH[o3 + 2 * F + f];
+    tv0 = q.TV[o3 + f]; tv1 = q.TV[o3 + F + f]; tv2 = q.TV[o3 + 2 * F + f];
+  }
+  float gxa = 0.f, gxb = 0.f, gxc = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;        // adjoints of xh[n], vec[n]
+  float gtxa = 0.f, gtxb = 0.f, gtxc = 0.f, gtv0 = 0.f, gtv1 = 0.f, gtv2 = 0.f;  // adjoints of t_xh[n], t_vec[n]
+  for (int sp = beg; sp < end; ++sp) {
+    const int k = q.g.col[sp];                       // target of the out-edge (n -> k)
+    const float4 gm = q.g.geom[sp];
+    const float r0 = -gm.x, r1 = -gm.y, r2 = -gm.z;  // unit vector of (n -> k)
+    const float* ph = q.PHI + (long)sp * F3;
+    const float pa = ph[f], pb = ph[F + f], pc = ph[2 * F + f];
+    const float* A = q.GV + (long)k * F3;
+    const float A0 = A[f], A1 = A[F + f], A2 = A[2 * F + f];
+    const float gma = q.GX[(long)k * F + f];
+    const float mb = xb * pb, mc = xc * pc;
+    float gmb = A0 * v0 + A1 * v1 + A2 * v2;
+    float gmc = A0 * r0 + A1 * r1 + A2 * r2;
+    gv0 += A0 * mb; gv1 += A1 * mb; gv2 += A2 * mb;
+    if (DUAL) {
+      const float td = q.TD[sp];
+      const float tr0 = -q.TR[3 * (long)sp], tr1 = -q.TR[3 * (long)sp + 1], tr2 = -q.TR[3 * (long)sp + 2];
+      const float* ps = q.PSI + (long)sp * F3;
+      const float tpa = ps[f] * td, tpb = ps[F + f] * td, tpc = ps[2 * F + f] * td;  // phi_dot
+      const float* T = q.GTV + (long)k * F3;
+      const float T0 = T[f], T1 = T[F + f], T2 = T[2 * F + f];
+      const float gtma = q.GTX[(long)k * F + f];
+      const float tmb = txb * pb + xb * tpb;
+      gmb += T0 * tv0 + T1 * tv1 + T2 * tv2;
+      const float gtmb = T0 * v0 + T1 * v1 + T2 * v2;
+      gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
+      const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
+      gv0 += T0 * tmb; gv1 += T1 * tmb; gv2 += T2 * tmb;
+      gtv0 += T0 * mb; gtv1 += T1 * mb; gtv2 += T2 * mb;
+      gxa += gma * pa + gtma * tpa; gxb += gmb * pb + gtmb * tpb; gxc += gmc * pc + gtmc * tpc;
+      gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
+      float* gp = q.GPHI + (long)sp * F3;
+      float* gs = q.GPSI + (long)sp * F3;
+      gp[f] = gma * xa + gtma * txa; gp[F + f] = gmb * xb + gtmb * txb; gp[2 * F + f] = gmc * xc + gtmc * txc;
+      gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
+    } else {
+      gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
+      const float* ps = q.PSI + (long)sp * F3;
+      // per-edge scalars reduced over the channels of this wavefront
+      float gd = gma * xa * ps[f] + gmb * xb * ps[F + f] + gmc * xc * ps[2 * F + f];
+      float e0 = A0 * mc, e1 = A1 * mc, e2 = A2 * mc;
+      gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
+      if (lane == 0) {
+        float4* dstp = q.GEDGE + (long)wave * q.g.E + sp;
+        float4 acc = *dstp;
+        acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
+        *dstp = acc;
+      }
+    }
+  }
+  q.GXH[o3 + f] = gxa; q.GXH[o3 + F + f] = gxb; q.GXH[o3 + 2 * F + f] = gxc;
+  q.GV_out[o3 + f] = q.GV[o3 + f] + gv0;
+  q.GV_out[o3 + F + f] = q.GV[o3 + F + f] + gv1;
+  q.GV_out[o3 + 2 * F + f] = q.GV[o3 + 2 * F + f] + gv2;
+  if (DUAL) {
+    q.GTXH[o3 + f] = gtxa; q.GTXH[o3 + F + f] = gtxb; q.GTXH[o3 + 2 * F + f] = gtxc;
+    q.GTV_out[o3 + f] = q.GTV[o3 + f] + gtv0;
+    q.GTV_out[o3 + F + f] = q.GTV[o3 + F + f] + gtv1;
+    q.GTV_out[o3 + 2 * F + f] = q.GTV[o3 + 2 * F + f] + gtv2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry tangent: t_d = r . (pd[src] - pd[dst]);  t_r = ((pd[src]-pd[dst]) - r t_d) / d      (per CSR slot)
+__global__ void k_geom_tan(NqGraphView g, const int* __restrict__ dst, const float* __restrict__ pd, float* __restrict__ TD,
+                           float* __restrict__ TR) {
+  const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sp >= g.E) return;
+  const int k = g.col[sp], n = dst[sp];
+  const float4 gm = g.geom[sp];
+  const float wx = pd[3 * (long)k] - pd[3 * (long)n], wy = pd[3 * (long)k + 1] - pd[3 * (long)n + 1],
+              wz = pd[3 * (long)k + 2] - pd[3 * (long)n + 2];
+  const float td = gm.x * wx + gm.y * wy + gm.z * wz;
+  const float inv = 1.0f / gm.w;
+  TD[sp] = td;
+  TR[3 * (long)sp] = (wx - gm.x * td) * inv;
+  TR[3 * (long)sp + 1] = (wy - gm.y * td) * inv;
+  TR[3 * (long)sp + 2] = (wz - gm.z * td) * inv;
+}
+
+// geometry reverse: per out-edge (n->k) stored at slot sp of row n: r_out = -geom.xyz,
+//   gw(sp) = gd r_out + (gr - (gr.r_out) r_out)/d ;  dE/dpos[n] = sum_sp gw(sp) - gw(rev[sp]) ;  F = -dE/dpos
+__device__ __forceinline__ void edge_gw(const NqGraphView& g, const float4* __restrict__ GEDGE, int nwaves, int sp, float& x, float& y, float& z) {
+  float4 a = GEDGE[sp];
+  for (int w = 1; w < nwaves; ++w) {
+    const float4 b = GEDGE[(long)w * g.E + sp];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  const float4 gm = g.geom[sp];
+  const float r0 = -gm.x, r1 = -gm.y, r2 = -gm.z;
+  const float dot = a.y * r0 + a.z * r1 + a.w * r2;
+  const float inv = 1.0f / gm.w;
+  x = a.x * r0 + (a.y - dot * r0) * inv;
+  y = a.x * r1 + (a.z - dot * r1) * inv;
+  z = a.x * r2 + (a.w - dot * r2) * inv;
+}
+
+__global__ void k_geom_rev(NqGraphView g, const float4* __restrict__ GEDGE, int nwaves, float* __restrict__ forces) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= g.N) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int sp = g.row_ptr[n]; sp < g.row_ptr[n + 1]; ++sp) {
+    float ax, ay, az, bx, by, bz;
+    edge_gw(g, GEDGE, nwaves, sp, ax, ay, az);
+    edge_gw(g, GEDGE, nwaves, g.rev[sp], bx, by, bz);
+    fx += ax - bx; fy += ay - by; fz += az - bz;
+  }
+  forces[3 * (long)n] = -fx; forces[3 * (long)n + 1] = -fy; forces[3 * (long)n + 2] = -fz;
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+int nq_rbf(hipStream_t st, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets,
+           float* rho, float* drho) {
+  NQ_PROF(st, "rbf");
+  if (E <= 0) return NQ_OK;
+  RbfArgs q;
+  q.geom = geom; q.E = E; q.R = R; q.inv_cutoff = (float)(1.0 / cutoff);
+  const double p = env_p;
+  q.p = (float)p; q.a = (float)(-(p + 1) * (p + 2) / 2); q.b = (float)(p * (p + 2)); q.c = (float)(-p * (p + 1) / 2);
+  q.mu = offsets;   // GaussianSmearing(0, 1, R).offset (state_dict buffer radial_basis.rbf.offset)
+  q.coeff = coeff;  // -0.5 / (offset[1]-offset[0])^2, computed by the host exactly as PyG does
+  q.rho = rho; q.drho = drho;
+  hipLaunchKernelGGL(k_rbf, dim3(nq_cdiv((long)E * R, 256)), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_msg_fwd(hipStream_t st, const MsgArgs& q, bool tangent) {
+  NQ_PROF(st, "msg_fwd");
+  if (q.g.N <= 0) return NQ_OK;
+  if (tangent) hipLaunchKernelGGL(k_msg_tan, dim3(q.g.N), dim3(q.F), 0, st, q);
+  else hipLaunchKernelGGL(k_msg_fwd, dim3(q.g.N), dim3(q.F), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_msg_rev(hipStream_t st, const MsgRevArgs& q, bool dual) {
+  NQ_PROF(st, "msg_rev");
+  if (q.g.N <= 0) return NQ_OK;
+  if (dual) hipLaunchKernelGGL((k_msg_rev<true>), dim3(q.g.N), dim3(q.F), 0, st, q);
+  else hipLaunchKernelGGL((k_msg_rev<false>), dim3(q.g.N), dim3(q.F), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_geom_tan(hipStream_t st, const NqGraphView& g, const int* dst, const float* pos_dot, float* TD, float* TR) {
+  NQ_PROF(st, "geom_tan");
+  if (g.E <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_geom_tan, dim3(nq_cdiv(g.E, 256)), dim3(256), 0, st, g, dst, pos_dot, TD, TR);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_geom_rev(hipStream_t st, const NqGraphView& g, const float4* GEDGE, int nwaves, float* forces) {
+  NQ_PROF(st, "geom_rev");
+  hipLaunchKernelGGL(k_geom_rev, dim3(nq_cdiv(g.N, 128)), dim3(128), 0, st, g, GEDGE, nwaves, forces);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}

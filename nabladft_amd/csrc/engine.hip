@@ -1,0 +1,459 @@
+// Host orchestration + C ABI (include/nablaq.h).  A PaiNN step is four sweeps over a caller-owned
+// workspace (see oracle/painn_sweeps.py for the math and buffer names):
+//   forward, force adjoint                 -> nq_painn_forward
+//   tangent forward, dual reverse          -> nq_painn_backward
+// Every dual-capable buffer is stored stacked [2][rows][width] (primal, tangent) so that the second-
+// order sweep runs each GEMM once over 2x the rows and each weight gradient as ONE contraction.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/nablaq.h"
+#include "common.h"
+
+thread_local char nq_err_buf[512] = "";
+int nq_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(nq_err_buf, sizeof(nq_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- profiler ---------------------------------------------------------------------------------------
+#include <map>
+#include <string>
+#include <vector>
+int nq_profile_on = 0;
+struct ProfRec { hipEvent_t a, b; int name_id; };
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<std::string> g_prof_names;
+static std::map<std::string, int> g_prof_ids;
+NqProfScope::NqProfScope(hipStream_t s, const char* name) : st(s), slot(-1) {
+  if (!nq_profile_on) return;
+  auto it = g_prof_ids.find(name);
+  int id;
+  if (it == g_prof_ids.end()) { id = (int)g_prof_names.size(); g_prof_names.push_back(name); g_prof_ids[name] = id; }
+  else id = it->second;
+  ProfRec r; r.name_id = id;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  hipEventRecord(r.a, st);
+  slot = (int)g_prof_recs.size();
+  g_prof_recs.push_back(r);
+}
+NqProfScope::~NqProfScope() {
+  if (slot >= 0) hipEventRecord(g_prof_recs[slot].b, st);
+}
+
+// ---- parameter layout --------------------------------------------------------------------------
+struct MsgP { size_t W1, b1, W2, b2, Wr, br; };
+struct UpdP { size_t U, V1, c1, V2, c2; };
+struct ParamLayout {
+  size_t emb, O1, o1, w2, o2, total;
+  MsgP msg[64];
+  UpdP upd[64];
+};
+static int make_param_layout(const nq_painn_cfg* c, ParamLayout* P) {
+  const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, T = c->num_elements;
+  if (c->num_layers < 1 || c->num_layers > 64) return nq_fail(NQ_ERR_ARG, "num_layers=%d out of range [1,64]", c->num_layers);
+  if (F % 64 != 0 || F < 64 || F > 1024) return nq_fail(NQ_ERR_ARG, "hidden_channels=%zu must be a multiple of 64 in [64,1024]", F);
+  if (R < 1 || T < 1) return nq_fail(NQ_ERR_ARG, "num_rbf / num_elements must be positive");
+  size_t o = 0;
+  P->emb = o; o += T * F;
+  for (int l = 0; l < c->num_layers; ++l) {
+    MsgP& m = P->msg[l];
+    m.W1 = o; o += F * F; m.b1 = o; o += F; m.W2 = o; o += 3 * F * F; m.b2 = o; o += 3 * F; m.Wr = o; o += 3 * F * R; m.br = o; o += 3 * F;
+  }
+  for (int l = 0; l < c->num_layers; ++l) {
+    UpdP& u = P->upd[l];
+    u.U = o; o += 2 * F * F; u.V1 = o; o += F * 2 * F; u.c1 = o; o += F; u.V2 = o; o += 3 * F * F; u.c2 = o; o += 3 * F;
+  }
+  P->O1 = o; o += H * F; P->o1 = o; o += H; P->w2 = o; o += H; P->o2 = o; o += 1;
+  P->total = o;
+  return NQ_OK;
+}
+
+// ---- workspace layout ------------------------------------------------------------------------
+struct WsLayer {
+  size_t Z1, Hh, XH, PHI, PSI, XM, VM, UU, S, CAT, ZQ, Q, Y;  // float offsets; dual buffers hold [2][rows][w]
+};
+struct WsLayout {
+  size_t X[65], V[65];
+  WsLayer lay[64];
+  size_t RHO2, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
+  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
+  size_t scratch_floats, total_floats;
+};
+static size_t a4(size_t x) { return (x + 3) & ~(size_t)3; }  // keep every buffer 16-byte aligned
+
+static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, WsLayout* W) {
+  const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, L = c->num_layers, T = c->num_elements;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += a4(n); return r; };
+  for (size_t l = 0; l <= L; ++l) { W->X[l] = take(2 * N * F); W->V[l] = take(2 * N * 3 * F); }
+  for (size_t l = 0; l < L; ++l) {
+    WsLayer& y = W->lay[l];
+    y.Z1 = take(2 * N * F); y.Hh = take(2 * N * F); y.XH = take(2 * N * 3 * F);
+    y.PHI = take(E * 3 * F); y.PSI = take(E * 3 * F);
+    y.XM = take(2 * N * F); y.VM = take(2 * N * 3 * F); y.UU = take(2 * N * 6 * F);
+    y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
+  }
+  W->RHO2 = take(2 * E * R);
+  W->ZO = take(2 * N * H); W->e_atom = take(N); W->te_atom = take(N);
+  W->TD = take(E); W->TR = take(3 * E); W->pos_dot = take(3 * N); W->ge = take(N); W->gte = take(N);
+  W->GX = take(2 * N * F); W->GVa = take(2 * N * 3 * F); W->GVb = take(2 * N * 3 * F);
+  W->GY = take(2 * N * 3 * F); W->GQ = take(2 * N * F); W->GCAT = take(2 * N * 2 * F); W->GU = take(2 * N * 6 * F);
+  W->GXH = take(2 * N * 3 * F); W->GH = take(2 * N * F);
+  W->GPHI2 = take(2 * E * 3 * F);
+  W->GEDGE = take((F / 64) * E * 4);
+  W->GZO = take(2 * N * H); W->TMPW = take(N * H);
+  // scratch for split-K partials / column sums / embedding partials: max over all uses
+  size_t s = 0;
+  auto mx = [&](size_t v) { if (v > s) s = v; };
+  mx(nq_gemm_tn_scratch_floats(2 * N, 3 * F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, F, 2 * F)); mx(nq_gemm_tn_scratch_floats(6 * N, 2 * F, F));
+  mx(nq_gemm_tn_scratch_floats(2 * E, 3 * F, R)); mx(nq_gemm_tn_scratch_floats(2 * N, F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, H, F));
+  mx(nq_colsum_scratch_floats(N > E ? N : E, 3 * F));
+  mx(nq_embed_grad_scratch_floats((int)N, (int)F, (int)T));
+  W->scratch_floats = s;
+  W->scratch = take(s);
+  W->total_floats = o;
+  (void)B;
+}
+
+static NqGraphView view_of(const nq_graph* g) {
+  NqGraphView v;
+  v.N = g->N; v.B = g->B; v.E = g->E;
+  v.mol_ptr = g->mol_ptr; v.row_ptr = g->row_ptr; v.col = g->col; v.rev = g->rev;
+  v.geom = reinterpret_cast<const float4*>(g->geom); v.z = g->z; v.atom_mol = g->atom_mol;
+  return v;
+}
+
+static int check_common(const nq_painn_cfg* cfg, const nq_graph* g, const void* ws, size_t ws_bytes, WsLayout* W, ParamLayout* P) {
+  if (!cfg || !g || !ws) return nq_fail(NQ_ERR_ARG, "null argument");
+  NQ_TRY(make_param_layout(cfg, P));
+  if (g->N <= 0 || g->B <= 0) return nq_fail(NQ_ERR_ARG, "empty batch");
+  if (g->E <= 0) return nq_fail(NQ_ERR_NO_EDGES, "batch has no edges within the cutoff");
+  if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return nq_fail(NQ_ERR_ARG, "workspace must be 16-byte aligned");
+  make_ws_layout(cfg, g->N, g->E, g->B, W);
+  if (ws_bytes < W->total_floats * sizeof(float))
+    return nq_fail(NQ_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, W->total_floats * sizeof(float));
+  return NQ_OK;
+}
+
+// ================================================================================================
+extern "C" {
+
+int nq_abi_version(void) { return NQ_ABI_VERSION; }
+
+void nq_profile_enable(int32_t on) { nq_profile_on = on; }
+// Synchronises the device, folds all recorded event pairs into per-name totals and clears them.
+// Fills up to `cap` entries; returns the number of distinct names.
+int nq_profile_read(char* names, int32_t name_stride, double* total_ms, int64_t* counts, int32_t cap) {
+  hipDeviceSynchronize();
+  std::vector<double> tot(g_prof_names.size(), 0.0);
+  std::vector<long long> cnt(g_prof_names.size(), 0);
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot[r.name_id] += ms; cnt[r.name_id] += 1; }
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+  }
+  g_prof_recs.clear();
+  int n = (int)g_prof_names.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    snprintf(names + (size_t)i * name_stride, name_stride, "%s", g_prof_names[i].c_str());
+    total_ms[i] = tot[i]; counts[i] = cnt[i];
+  }
+  return n;
+}
+const char* nq_last_error(void) { return nq_err_buf; }
+
+int nq_graph_count(const float* pos, const int32_t* mol_ptr, int32_t N, int32_t B, int32_t max_mol_atoms, double cutoff,
+                   int32_t max_neighbors, int32_t* deg, int32_t* lowdeg, int32_t* row_ptr, int32_t* lowptr, int32_t* E_host, void* stream) {
+  if (!pos || !mol_ptr || !deg || !lowdeg || !row_ptr || !lowptr || !E_host) return nq_fail(NQ_ERR_ARG, "null argument");
+  if (max_neighbors < 1) return nq_fail(NQ_ERR_ARG, "max_neighbors must be >= 1");
+  return nq_graph_count_impl(pos, mol_ptr, N, B, max_mol_atoms, (float)(cutoff * cutoff), max_neighbors, deg, lowdeg, row_ptr, lowptr,
+                             E_host, (hipStream_t)stream);
+}
+
+int nq_graph_fill(const float* pos, const int32_t* mol_ptr, int32_t N, int32_t B, int32_t E, int32_t max_mol_atoms, double cutoff,
+                  int32_t max_neighbors, const int32_t* row_ptr, const int32_t* lowptr, int32_t* col, int32_t* dst, int32_t* rev, float* geom,
+                  int32_t* slot2canon, int32_t* atom_mol, int64_t* edge_index, float* edge_dist, float* edge_vector, int64_t* id_swap,
+                  int64_t* neighbors, void* stream) {
+  if (!pos || !mol_ptr || !row_ptr || !lowptr || !col || !dst || !rev || !geom || !slot2canon || !atom_mol)
+    return nq_fail(NQ_ERR_ARG, "null argument");
+  if (edge_index && (!edge_dist || !edge_vector || !id_swap)) return nq_fail(NQ_ERR_ARG, "canonical outputs must be all set or all NULL");
+  if ((reinterpret_cast<uintptr_t>(geom) & 15) != 0) return nq_fail(NQ_ERR_ARG, "geom must be 16-byte aligned");
+  GraphFillArgs a;
+  a.pos = pos; a.mol_ptr = mol_ptr; a.row_ptr = row_ptr; a.lowptr = lowptr;
+  a.r2 = (float)(cutoff * cutoff); a.K = max_neighbors;
+  a.col = col; a.dst = dst; a.rev = rev; a.geom = reinterpret_cast<float4*>(geom); a.slot2canon = slot2canon;
+  a.c_src = (long long*)edge_index; a.c_dst = edge_index ? (long long*)edge_index + E : nullptr;
+  a.c_dist = edge_dist; a.c_vec = edge_vector; a.id_swap = (long long*)id_swap; a.neighbors = (long long*)neighbors;
+  a.atom_mol = atom_mol;
+  (void)N;
+  return nq_graph_fill_impl(a, B, max_mol_atoms, (hipStream_t)stream);
+}
+
+size_t nq_painn_num_params(const nq_painn_cfg* cfg) {
+  ParamLayout P;
+  if (!cfg || make_param_layout(cfg, &P) != NQ_OK) return 0;
+  return P.total;
+}
+
+size_t nq_painn_workspace_bytes(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B) {
+  ParamLayout P;
+  if (!cfg || make_param_layout(cfg, &P) != NQ_OK || N <= 0 || E < 0) return 0;
+  WsLayout W;
+  make_ws_layout(cfg, N, E, B, &W);
+  return W.total_floats * sizeof(float);
+}
+
+int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t l, int32_t tangent,
+                       size_t* off, size_t* count) {
+  ParamLayout P;
+  if (!cfg || !name || !off || !count) return nq_fail(NQ_ERR_ARG, "null argument");
+  NQ_TRY(make_param_layout(cfg, &P));
+  WsLayout W;
+  make_ws_layout(cfg, N, E, B, &W);
+  const size_t F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, n = N, e = E;
+  const int L = cfg->num_layers;
+  size_t base = 0, rows = 0, w = 0;
+  bool dual = true;
+#define LAYER_OK(maxl) if (l < 0 || l > (maxl)) return nq_fail(NQ_ERR_ARG, "layer %d out of range", l)
+  if (!strcmp(name, "x_in")) { LAYER_OK(L); base = W.X[l]; rows = n; w = F; }
+  else if (!strcmp(name, "vec_in")) { LAYER_OK(L); base = W.V[l]; rows = n; w = 3 * F; }
+  else if (!strcmp(name, "z1")) { LAYER_OK(L - 1); base = W.lay[l].Z1; rows = n; w = F; }
+  else if (!strcmp(name, "h")) { LAYER_OK(L - 1); base = W.lay[l].Hh; rows = n; w = F; }
+  else if (!strcmp(name, "xh")) { LAYER_OK(L - 1); base = W.lay[l].XH; rows = n; w = 3 * F; }
+  else if (!strcmp(name, "phi")) { LAYER_OK(L - 1); base = W.lay[l].PHI; rows = e; w = 3 * F; dual = false; }
+  else if (!strcmp(name, "psi")) { LAYER_OK(L - 1); base = W.lay[l].PSI; rows = e; w = 3 * F; dual = false; }
+  else if (!strcmp(name, "x_msg")) { LAYER_OK(L - 1); base = W.lay[l].XM; rows = n; w = F; }
+  else if (!strcmp(name, "vec_msg")) { LAYER_OK(L - 1); base = W.lay[l].VM; rows = n; w = 3 * F; }
+  else if (!strcmp(name, "u")) { LAYER_OK(L - 1); base = W.lay[l].UU; rows = n; w = 6 * F; }
+  else if (!strcmp(name, "s")) { LAYER_OK(L - 1); base = W.lay[l].S; rows = n; w = F; }
+  else if (!strcmp(name, "cat")) { LAYER_OK(L - 1); base = W.lay[l].CAT; rows = n; w = 2 * F; }
+  else if (!strcmp(name, "zq")) { LAYER_OK(L - 1); base = W.lay[l].ZQ; rows = n; w = F; }
+  else if (!strcmp(name, "q")) { LAYER_OK(L - 1); base = W.lay[l].Q; rows = n; w = F; }
+  else if (!strcmp(name, "y")) { LAYER_OK(L - 1); base = W.lay[l].Y; rows = n; w = 3 * F; }
+  else if (!strcmp(name, "rho")) { base = W.RHO2; rows = e; w = R; }          // tangent=1 -> drho
+  else if (!strcmp(name, "zo")) { base = W.ZO; rows = n; w = H; }
+  else if (!strcmp(name, "e_atom")) { base = tangent ? W.te_atom : W.e_atom; rows = n; w = 1; dual = false; tangent = 0; }
+  else if (!strcmp(name, "t_d")) { base = W.TD; rows = e; w = 1; dual = false; }
+  else if (!strcmp(name, "t_r")) { base = W.TR; rows = e; w = 3; dual = false; }
+  else if (!strcmp(name, "gedge")) { base = W.GEDGE; rows = (F / 64) * e; w = 4; dual = false; }
+  else return nq_fail(NQ_ERR_ARG, "unknown workspace buffer '%s'", name);
+#undef LAYER_OK
+  if (tangent && !dual) return nq_fail(NQ_ERR_ARG, "buffer '%s' has no tangent half", name);
+  *off = base + (tangent ? rows * w : 0);
+  *count = rows * w;
+  return NQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                     size_t workspace_bytes, float* energy, float* forces, void* stream) {
+  WsLayout W; ParamLayout P;
+  NQ_TRY(check_common(cfg, graph, workspace, workspace_bytes, &W, &P));
+  if (!params || !rbf_offsets || !energy) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const NqGraphView g = view_of(graph);
+  const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers;
+  const size_t NF = (size_t)N * F;
+
+  // embedding; zero vec_in0 and the tangent halves of layer-0 inputs (d x0 / d pos = 0)
+  NQ_TRY(nq_embed(st, g.z, params + P.emb, N, F, ws + W.X[0]));
+  NQ_HIP(hipMemsetAsync(ws + W.X[0] + NF, 0, NF * sizeof(float), st));
+  NQ_HIP(hipMemsetAsync(ws + W.V[0], 0, 6 * NF * sizeof(float), st));
+  float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
+  NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho));
+
+  for (int l = 0; l < L; ++l) {
+    const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.Hh, params + mp.W2, ws + y.XH, params + mp.b2, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F));
+    MsgArgs m{};
+    m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
+    m.XM = ws + y.XM; m.VM = ws + y.VM;
+    NQ_TRY(nq_msg_fwd(st, m, false));
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F));
+    UpdArgs u{};
+    u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
+    u.X1 = ws + W.X[l + 1]; u.V1 = ws + W.V[l + 1];
+    NQ_TRY(nq_upd_a(st, u, false));
+    NQ_TRY(nq_gemm_nt(st, ws + y.CAT, params + up.V1, ws + y.ZQ, params + up.c1, ws + y.Q, N, F, 2 * F, 2 * F, 2 * F, F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.Q, params + up.V2, ws + y.Y, params + up.c2, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_upd_b(st, u, false));
+  }
+  NQ_TRY(nq_gemm_nt(st, ws + W.X[L], params + P.O1, ws + W.ZO, params + P.o1, nullptr, N, H, F, F, F, H));
+  ReadoutArgs r{};
+  r.N = N; r.H = H; r.ZO = ws + W.ZO; r.w2 = params + P.w2; r.o2 = params + P.o2; r.e_atom = ws + W.e_atom;
+  NQ_TRY(nq_readout(st, r, 0));
+  NQ_TRY(nq_mol_sum(st, ws + W.e_atom, g.mol_ptr, g.B, energy));
+  if (!forces) return NQ_OK;
+
+  // ---- force adjoint sweep: seeds dE_tot/de_i = 1 --------------------------------------------
+  NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.ge, nullptr));
+  r.ge = ws + W.ge; r.GZO = ws + W.GZO;
+  NQ_TRY(nq_readout_rev(st, r, false));
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, N, H, F, H, F, F, 0));
+  float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
+  NQ_HIP(hipMemsetAsync(gv_cur, 0, 3 * NF * sizeof(float), st));
+  const int nwaves = F / 64;
+  NQ_HIP(hipMemsetAsync(ws + W.GEDGE, 0, (size_t)nwaves * E * 4 * sizeof(float), st));
+  for (int l = L - 1; l >= 0; --l) {
+    const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    UpdRevArgs u{};
+    u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
+    u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
+    NQ_TRY(nq_upd_rev(st, u, 1, false));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_silu_rev(st, ws + y.ZQ, nullptr, ws + W.GQ, nullptr, (long)NF, false));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0));
+    NQ_TRY(nq_upd_rev(st, u, 2, false));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1));
+    MsgRevArgs m{};
+    m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
+    m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
+    NQ_TRY(nq_msg_rev(st, m, false));
+    { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
+    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_silu_rev(st, ws + y.Z1, nullptr, ws + W.GH, nullptr, (long)NF, false));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1));
+  }
+  NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
+  return NQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_graph* graph, void* workspace, size_t workspace_bytes,
+                      const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
+  WsLayout W; ParamLayout P;
+  NQ_TRY(check_common(cfg, graph, workspace, workspace_bytes, &W, &P));
+  if (!params || !grad_params) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  float* gp = grad_params;
+  float* scr = ws + W.scratch;
+  const NqGraphView g = view_of(graph);
+  const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers, T = cfg->num_elements;
+  const size_t NF = (size_t)N * F;
+
+  // ---- tangent forward along pos_dot = -dL/dF --------------------------------------------------
+  if (grad_forces) NQ_TRY(nq_negate(st, grad_forces, ws + W.pos_dot, 3L * N));
+  else NQ_HIP(hipMemsetAsync(ws + W.pos_dot, 0, 3 * (size_t)N * sizeof(float), st));
+  NQ_TRY(nq_geom_tan(st, g, graph->dst, ws + W.pos_dot, ws + W.TD, ws + W.TR));
+  for (int l = 0; l < L; ++l) {
+    const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    float* TZ1 = ws + y.Z1 + NF; float* TH = ws + y.Hh + NF; float* TXH = ws + y.XH + 3 * NF;
+    NQ_TRY(nq_gemm_nt(st, ws + W.X[l] + NF, params + mp.W1, TZ1, nullptr, nullptr, N, F, F, F, F, F));
+    NQ_TRY(nq_silu_tan(st, ws + y.Z1, TZ1, TH, (long)NF));
+    NQ_TRY(nq_gemm_nt(st, TH, params + mp.W2, TXH, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F));
+    MsgArgs m{};
+    m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
+    m.TX = ws + W.X[l] + NF; m.TV = ws + W.V[l] + 3 * NF; m.TXH = TXH; m.TD = ws + W.TD; m.TR = ws + W.TR;
+    m.TXM = ws + y.XM + NF; m.TVM = ws + y.VM + 3 * NF;
+    NQ_TRY(nq_msg_fwd(st, m, true));
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F));
+    UpdArgs u{};
+    u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
+    u.TXM = ws + y.XM + NF; u.TVM = ws + y.VM + 3 * NF; u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF;
+    u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF; u.TX1 = ws + W.X[l + 1] + NF; u.TV1 = ws + W.V[l + 1] + 3 * NF;
+    NQ_TRY(nq_upd_a(st, u, true));
+    float* TZQ = ws + y.ZQ + NF; float* TQ = ws + y.Q + NF;
+    NQ_TRY(nq_gemm_nt(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, nullptr, nullptr, N, F, 2 * F, 2 * F, 2 * F, F));
+    NQ_TRY(nq_silu_tan(st, ws + y.ZQ, TZQ, TQ, (long)NF));
+    NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_upd_b(st, u, true));
+  }
+  const size_t NH = (size_t)N * H;
+  NQ_TRY(nq_gemm_nt(st, ws + W.X[L] + NF, params + P.O1, ws + W.ZO + NH, nullptr, nullptr, N, H, F, F, F, H));
+  ReadoutArgs r{};
+  r.N = N; r.H = H; r.ZO = ws + W.ZO; r.TZO = ws + W.ZO + NH; r.w2 = params + P.w2; r.o2 = params + P.o2;
+  r.e_atom = ws + W.e_atom; r.te_atom = ws + W.te_atom;
+  NQ_TRY(nq_readout(st, r, 1));
+
+  // ---- dual reverse: seeds (dL/dE_b, 1) on (E_b, Edot) -----------------------------------------
+  if (grad_energy) NQ_TRY(nq_atom_seeds(st, grad_energy, g.atom_mol, N, ws + W.ge, ws + W.gte));
+  else {
+    NQ_HIP(hipMemsetAsync(ws + W.ge, 0, (size_t)N * sizeof(float), st));
+    NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.gte, nullptr));  // gte = 1
+  }
+  r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
+  NQ_TRY(nq_readout_rev(st, r, true));
+  NQ_TRY(nq_colsum(st, ws + W.TMPW, N, H, H, gp + P.w2, scr));
+  NQ_TRY(nq_colsum(st, ws + W.ge, N, 1, 1, gp + P.o2, scr));
+  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr));
+  NQ_TRY(nq_colsum(st, ws + W.GZO, N, H, H, gp + P.o1, scr));
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0));
+  float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
+  NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
+  float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
+  for (int l = L - 1; l >= 0; --l) {
+    const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    UpdRevArgs u{};
+    u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
+    u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF; u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF;
+    u.GX = ws + W.GX; u.GTX = ws + W.GX + NF; u.GV = gv_cur; u.GTV = gv_cur + 3 * NF;
+    u.GY = ws + W.GY; u.GTY = ws + W.GY + 3 * NF; u.GCAT = ws + W.GCAT; u.GTCAT = ws + W.GCAT + 2 * NF;
+    u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
+    NQ_TRY(nq_upd_rev(st, u, 1, true));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr));
+    NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + up.c2, scr));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr));
+    NQ_TRY(nq_colsum(st, ws + W.GQ, N, F, F, gp + up.c1, scr));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0));
+    NQ_TRY(nq_upd_rev(st, u, 2, true));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1));
+    MsgRevArgs m{};
+    m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
+    m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
+    m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
+    m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
+    m.GPHI = gphi; m.GPSI = gpsi;
+    NQ_TRY(nq_msg_rev(st, m, true));
+    { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
+    NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr));
+    NQ_TRY(nq_colsum(st, gphi, E, 3 * F, 3 * F, gp + mp.br, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr));
+    NQ_TRY(nq_colsum(st, ws + W.GXH, N, 3 * F, 3 * F, gp + mp.b2, scr));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr));
+    NQ_TRY(nq_colsum(st, ws + W.GH, N, F, F, gp + mp.b1, scr));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1));
+  }
+  NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));
+  return NQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
+                  float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream) {
+  if (!energy || !y || !forces || !f_target || !loss || !grad_energy || !grad_forces) return nq_fail(NQ_ERR_ARG, "null argument");
+  return nq_loss_impl((hipStream_t)stream, energy, y, B, forces, f_target, N, coef_e, coef_f, loss, grad_energy, grad_forces);
+}
+
+int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t count, float max_norm, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, float* scratch, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || step < 1) return nq_fail(NQ_ERR_ARG, "bad argument");
+  return nq_adamw_impl((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)count, max_norm, lr, beta1, beta2, eps, weight_decay,
+                       step, scratch);
+}
+
+int nq_linear_forward(const float* A, const float* Wt, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K, void* stream) {
+  return nq_gemm_nt((hipStream_t)stream, A, Wt, C, bias, C_silu, M, N, K, K, K, N);
+}
+int nq_linear_input_grad(const float* G, const float* Wt, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
+  return nq_gemm_nn((hipStream_t)stream, G, Wt, C, M, N, K, N, K, K, accumulate);
+}
+size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K) { return nq_gemm_tn_scratch_floats(rows, N, K); }
+int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream) {
+  return nq_gemm_tn((hipStream_t)stream, G, X, gW, rows, N, K, N, K, scratch);
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// Dense fp32 GEMMs of the PaiNN path on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
+// bitwise an fmaf chain, 157 TFLOP/s chip peak).  These are the filter-generating / node MLP
+// contractions the reference runs through ATen mm (nn.Linear in painn.py:459-464,520-525,79-83)
+// and, in the backward sweeps, their input- and weight-gradient forms.
+//
+//   C[M,N] = sum_k A(m,k) * B(k,n)   (+ bias[n])  with three operand layouts
+//     NT  A[m*lda+k], B = W[n*ldb+k]   y = x W^T + b        (forward / tangent)
+//     NN  A[m*lda+k], B = W[k*ldb+n]   gx = gy W            (input gradient)
+//     TN  A[k*lda+m], B[k*ldb+n]       gW = gy^T x          (weight gradient; K = rows, split over
+//                                                            workgroups, partials reduced in a
+//                                                            fixed order -> run-to-run deterministic)
+// Tile: 128x128x32 per 256-thread workgroup; 4 wavefronts as 2x2, each owning a 64x64 sub-tile =
+// 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Both operands are staged in LDS k-major
+// ([BK][BM+pad]) so that the MFMA operand fetch (lane l: row l&31, k = l>>5) is a conflict-free
+// ds_read_b32 of 32 consecutive floats per half-wave.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define GEMM_THREADS 256
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3 };
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias; float* C2;
+  int M, N, K, lda, ldb, ldc;
+  int k_per_split;       // EPI_PARTIAL: K range per blockIdx.z
+  long part_stride;      // EPI_PARTIAL: floats between partial slabs
+};
+
+// K-contiguous source (element (r, k) at src[r*ld + k]) -> LDS tile[k][r], stride LDS_KC
+#define LDS_KC (BM + 1)
+// MN-contiguous source (element (k, r) at src[k*ld + r]) -> LDS tile[k][r], stride LDS_MC (16-B aligned rows)
+#define LDS_MC (BM + 4)
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(float* __restrict__ tile, const float* __restrict__ src, int ld, int r0, int R, int k0,
+                                          int Kend, bool vec_ok) {
+  const int t = threadIdx.x;
+  if (KC) {
+    // 128 rows x 32 k = 1024 float4, 4 per thread; consecutive lanes walk k (coalesced 128-B rows)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = t + GEMM_THREADS * it;
+      const int row = idx >> 3, kq = (idx & 7) * 4;
+      const int gr = r0 + row, gk = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < R) {
+        const float* ptr = src + (long)gr * ld + gk;
+        if (vec_ok && gk + 3 < Kend) {
+          v = *reinterpret_cast<const float4*>(ptr);
+        } else {
+          if (gk + 0 < Kend) v.x = ptr[0];
+          if (gk + 1 < Kend) v.y = ptr[1];
+          if (gk + 2 < Kend) v.z = ptr[2];
+          if (gk + 3 < Kend) v.w = ptr[3];
+        }
+      }
+      tile[(kq + 0) * LDS_KC + row] = v.x;
+      tile[(kq + 1) * LDS_KC + row] = v.y;
+      tile[(kq + 2) * LDS_KC + row] = v.z;
+      tile[(kq + 3) * LDS_KC + row] = v.w;
+    }
+  } else {
+    // 32 k x 128 cols = 1024 float4; consecutive lanes walk the contiguous dimension (512-B rows)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = t + GEMM_THREADS * it;
+      const int k = idx >> 5, rq = (idx & 31) * 4;
+      const int gk = k0 + k, gr = r0 + rq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < Kend) {
+        const float* ptr = src + (long)gk * ld + gr;
+        if (vec_ok && gr + 3 < R) {
+          v = *reinterpret_cast<const float4*>(ptr);
+        } else {
+          if (gr + 0 < R) v.x = ptr[0];
+          if (gr + 1 < R) v.y = ptr[1];
+          if (gr + 2 < R) v.z = ptr[2];
+          if (gr + 3 < R) v.w = ptr[3];
+        }
+      }
+      *reinterpret_cast<float4*>(tile + k * LDS_MC + rq) = v;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
+  constexpr int LDA_S = A_KC ? LDS_KC : LDS_MC;
+  constexpr int LDB_S = B_KC ? LDS_KC : LDS_MC;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int kbeg = 0, kend = p.K;
+  if (EPI == EPI_PARTIAL) {
+    kbeg = blockIdx.z * p.k_per_split;
+    kend = min(p.K, kbeg + p.k_per_split);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+  const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    load_tile<A_KC>(As, p.A, p.lda, m0, p.M, k0, kend, a_vec);
+    load_tile<B_KC>(Bs, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[(kk + lk) * LDA_S + wm * 64 + lr];
+      const float a1 = As[(kk + lk) * LDA_S + wm * 64 + 32 + lr];
+      const float b0 = Bs[(kk + lk) * LDB_S + wn * 64 + lr];
+      const float b1 = Bs[(kk + lk) * LDB_S + wn * 64 + 32 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* Cout = p.C;
+  if (EPI == EPI_PARTIAL) Cout += (long)blockIdx.z * p.part_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lr;
+      if (col >= p.N) continue;
+      const float bv = (EPI != EPI_PARTIAL && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= p.M) continue;
+        const long off = (long)row * p.ldc + col;
+        const float v = acc[i][j][r] + bv;
+        if (EPI == EPI_ACC) Cout[off] += v;
+        else Cout[off] = v;
+        if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
+      }
+    }
+}
+
+// out[i] = sum_s part[s*stride + i]  (fixed order -> deterministic)
+__global__ void k_reduce_partials(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += part[(long)k * stride + i];
+  out[i] = s;
+}
+
+// column sums of A[rows][cols] (bias gradients): partial per row-chunk, then k_reduce_partials
+__global__ void k_colsum_partial(const float* __restrict__ A, long rows, int cols, int lda, int rows_per_chunk, float* __restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += A[r * lda + c];
+  part[(long)blockIdx.y * cols + c] = s;
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K,
+               int lda, int ldw, int ldc) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt_%dx%dx%d", M, N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0};
+  dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
+  if (C2_silu) hipLaunchKernelGGL((k_gemm<true, true, EPI_SILU>), grid, dim3(GEMM_THREADS), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm<true, true, EPI_STORE>), grid, dim3(GEMM_THREADS), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// C[M, Kin] (+)= G[M, Nout] * W[Nout, Kin]
+int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc,
+               int accumulate) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn_%dx%dx%d", M, Kin, Nout); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0};
+  dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
+  if (accumulate) hipLaunchKernelGGL((k_gemm<true, false, EPI_ACC>), grid, dim3(GEMM_THREADS), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm<true, false, EPI_STORE>), grid, dim3(GEMM_THREADS), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// out[Mo, No] = sum_{r<rows} GY[r, Mo] * X[r, No];  scratch must hold nq_gemm_tn_scratch_floats()
+static int tn_splits(long rows) {
+  long s = (rows + 2047) / 2048;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows) * Mo * No; }
+
+int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_tn_%dx%dx%ld", Mo, No, rows); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (rows <= 0) {
+    NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Mo * No, st));
+    return NQ_OK;
+  }
+  if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
+  const int ns = tn_splits(rows);
+  int kper = (int)((rows + ns - 1) / ns);
+  kper = (kper + BK - 1) / BK * BK;
+  GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No};
+  dim3 grid(nq_cdiv(Mo, BM), nq_cdiv(No, BN), ns);
+  hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL>), grid, dim3(GEMM_THREADS), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  const long cnt = (long)Mo * No;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 256)), dim3(256), 0, st, scratch, ns, cnt, cnt, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+size_t nq_colsum_scratch_floats(long rows, int cols) { return (size_t)nq_cdiv(rows, 1024) * cols; }
+
+int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, float* out, float* scratch) {
+  NQ_PROF(st, "colsum");
+  if (rows <= 0) {
+    NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+    return NQ_OK;
+  }
+  const int chunks = nq_cdiv(rows, 1024);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(64), 0, st, A, rows, cols, lda, 1024, scratch);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cols, 256)), dim3(256), 0, st, scratch, chunks, (long)cols, (long)cols, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_reduce_partials(hipStream_t st, const float* part, int nsplit, long stride, long count, float* out) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(count, 256)), dim3(256), 0, st, part, nsplit, stride, count, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}

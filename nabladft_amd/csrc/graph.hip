@@ -1,0 +1,239 @@
+// Neighbour list for the PaiNN path, one workgroup per molecule.
+//
+// Replaces (reference, /root/reference/nablaDFT/painn_pyg/):
+//   painn.py:411-416   torch_cluster.radius_graph(pos, r, batch, max_num_neighbors)
+//   painn.py:418-423   distance_vec / edge_dist / compute_neighbors (utils.py:469-481)
+//   painn.py:319-321   unit vectors
+//   painn.py:233-295   symmetrize_edges (mask j<i, concat flips, per-graph reorder, id_swap)
+//
+// Output 1 (what the reference returns; bit-exact contract): canonical edge list, per graph
+//   [kept edges (src j < dst i), dst ascending then src ascending] ++ [their flips].
+// Output 2 (what the engine consumes): CSR by target atom with sources ascending, the slot of
+//   the reverse edge, and {unit vector, distance} per slot.  Because the canonical list is
+//   symmetric, the CSR row of atom n is both "in-edges of n" and "out-edges of n".
+//
+// Mapping to the hardware: positions of one molecule live in LDS; a wavefront owns one centre
+// atom, its 64 lanes test 64 candidate neighbours at once, __ballot gives the adjacency word
+// and popcount prefixes give compaction slots: no atomics, no sort, deterministic order.
+#include "common.h"
+
+#define NQ_MAX_MOL_ATOMS 512
+#define GRAPH_THREADS 256
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 bits_below(int b) {  // mask of bit positions < b (b may be <=0 or >=64)
+  if (b <= 0) return 0ull;
+  if (b >= 64) return ~0ull;
+  return (1ull << b) - 1ull;
+}
+
+// squared distance exactly as torch evaluates (x_i - x_j).pow(2).sum(-1): ((dx*dx + dy*dy) + dz*dz), no FMA
+__device__ __forceinline__ float dist2_nofma(const float* a, const float* b) {
+#pragma clang fp contract(off)
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  float s = xx + yy;
+  return s + zz;
+}
+
+// Build in LDS: LK[i][w] = kept lower neighbours (j < i, first K in ascending j) of atom i,
+//               S[i][w]  = symmetric adjacency = LK[i] | {j > i : i in LK[j]}.
+__device__ void build_adjacency(const float* sp, int n, int W, float r2, int K, u64* LK, u64* S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int i = wave; i < n; i += nwaves) {
+    int kept = 0;
+    for (int w = 0; w < W; ++w) {
+      u64 m = 0ull;
+      if (64 * w < i) {  // only candidates j < i matter (wave-uniform branch)
+        int j = 64 * w + lane;
+        bool pred = (j < i) && (dist2_nofma(sp + 3 * i, sp + 3 * j) < r2);
+        m = __ballot(pred);
+        int c = __popcll(m);
+        if (kept + c > K) {  // keep the first (K - kept) neighbours of this word
+          int allow = K - kept;
+          while (c > allow) {
+            m &= ~(1ull << (63 - __clzll((long long)m)));
+            --c;
+          }
+        }
+        kept += c;
+      }
+      if (lane == 0) LK[i * W + w] = m;
+    }
+  }
+  __syncthreads();
+  for (int i = wave; i < n; i += nwaves) {
+    const int wi = i >> 6, bi = i & 63;
+    for (int w = 0; w < W; ++w) {
+      int j = 64 * w + lane;
+      bool up = (j > i) && (j < n) && ((LK[j * W + wi] >> bi) & 1ull);
+      u64 m = __ballot(up) | LK[i * W + w];
+      if (lane == 0) S[i * W + w] = m;
+    }
+  }
+  __syncthreads();
+}
+
+// correctly rounded sqrt (the CPU reference uses IEEE sqrt): v_sqrt_f32 is 1 ulp, one FMA-residual
+// Newton step s + (x - s*s) * (0.5/s) rounds to the exact result.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (!(x > 0.0f)) return x == 0.0f ? 0.0f : sqrtf(x);
+  const float s = __builtin_sqrtf(x);
+  const float r = fmaf(-s, s, x);
+  return fmaf(r, 0.5f / s, s);
+}
+
+__device__ __forceinline__ int rank_in_row(const u64* row, int idx) {  // set bits of row at positions < idx
+  int r = 0;
+  const int wi = idx >> 6;
+  for (int w = 0; w < wi; ++w) r += __popcll(row[w]);
+  return r + __popcll(row[wi] & bits_below(idx & 63));
+}
+
+__global__ __launch_bounds__(GRAPH_THREADS) void k_graph_count(const float* __restrict__ pos, const int* __restrict__ mol_ptr,
+                                                               float r2, int K, int* __restrict__ deg, int* __restrict__ lowdeg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int a = mol_ptr[blockIdx.x], n = mol_ptr[blockIdx.x + 1] - a;
+  if (n <= 0) return;
+  const int W = (n + 63) >> 6;
+  u64* LK = (u64*)smem;
+  u64* S = LK + n * W;
+  float* sp = (float*)(S + n * W);
+  for (int t = threadIdx.x; t < 3 * n; t += blockDim.x) sp[t] = pos[3 * (long)a + t];
+  __syncthreads();
+  build_adjacency(sp, n, W, r2, K, LK, S);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int d = 0, l = 0;
+    for (int w = 0; w < W; ++w) {
+      d += __popcll(S[i * W + w]);
+      l += __popcll(LK[i * W + w]);
+    }
+    deg[a + i] = d;
+    lowdeg[a + i] = l;
+  }
+}
+
+// exclusive scan of two int arrays by ONE workgroup (N is at most a few 1e5 atoms; ~0.1 ms)
+__global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ in0, const int* __restrict__ in1, int n,
+                                                int* __restrict__ out0, int* __restrict__ out1) {
+  __shared__ int wsum0[16], wsum1[16];
+  __shared__ int carry0, carry1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry0 = carry1 = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + threadIdx.x;
+    int v0 = i < n ? in0[i] : 0, v1 = i < n ? in1[i] : 0;
+    int s0 = v0, s1 = v1;  // inclusive wave scan
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int t0 = __shfl_up(s0, off, 64), t1 = __shfl_up(s1, off, 64);
+      if (lane >= off) { s0 += t0; s1 += t1; }
+    }
+    if (lane == 63) { wsum0[wave] = s0; wsum1[wave] = s1; }
+    __syncthreads();
+    int p0 = carry0, p1 = carry1;
+    for (int w = 0; w < wave; ++w) { p0 += wsum0[w]; p1 += wsum1[w]; }
+    if (i < n) { out0[i] = p0 + s0 - v0; out1[i] = p1 + s1 - v1; }
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry0 = p0 + s0; carry1 = p1 + s1; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out0[n] = carry0; out1[n] = carry1; }
+}
+
+
+__global__ __launch_bounds__(GRAPH_THREADS) void k_graph_fill(GraphFillArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x;
+  const int a = p.mol_ptr[g], n = p.mol_ptr[g + 1] - a;
+  if (n <= 0) {
+    if (threadIdx.x == 0 && p.neighbors) p.neighbors[g] = 0;
+    return;
+  }
+  const int W = (n + 63) >> 6;
+  u64* LK = (u64*)smem;
+  u64* S = LK + n * W;
+  float* sp = (float*)(S + n * W);
+  for (int t = threadIdx.x; t < 3 * n; t += blockDim.x) sp[t] = p.pos[3 * (long)a + t];
+  for (int t = threadIdx.x; t < n; t += blockDim.x) p.atom_mol[a + t] = g;
+  __syncthreads();
+  build_adjacency(sp, n, W, p.r2, p.K, LK, S);
+  const int low_a = p.lowptr[a];
+  const int half = p.lowptr[a + n] - low_a;
+  const int gbase = 2 * low_a;
+  if (threadIdx.x == 0 && p.neighbors) p.neighbors[g] = 2 * (long long)half;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int i = wave; i < n; i += nwaves) {
+    int before = 0;
+    const int row_base = p.row_ptr[a + i];
+    for (int w = 0; w < W; ++w) {
+      const u64 s = S[i * W + w];
+      if ((s >> lane) & 1ull) {
+        const int j = 64 * w + lane;
+        const int slot = row_base + before + __popcll(s & bits_below(lane));
+        const int rslot = p.row_ptr[a + j] + rank_in_row(S + j * W, i);
+        int cid;
+        if (j < i) cid = gbase + (p.lowptr[a + i] - low_a) + rank_in_row(LK + i * W, j);
+        else       cid = gbase + half + (p.lowptr[a + j] - low_a) + rank_in_row(LK + j * W, i);
+        // geometry exactly as painn.py:418-420,319-321: vec = pos[src]-pos[dst], d = sqrt(sum((pos[dst]-pos[src])^2))
+        float d, rx, ry, rz;
+        {
+#pragma clang fp contract(off)
+          const float* pi = sp + 3 * i; const float* pj = sp + 3 * j;
+          float wx = pj[0] - pi[0], wy = pj[1] - pi[1], wz = pj[2] - pi[2];
+          d = sqrt_rn(dist2_nofma(pi, pj));
+          float c0 = (d <= 1e-6f) ? 1e-6f : 0.0f;
+          float den = d + c0;
+          rx = __fdiv_rn(wx, den); ry = __fdiv_rn(wy, den); rz = __fdiv_rn(wz, den);
+        }
+        p.col[slot] = a + j;
+        p.dst[slot] = a + i;
+        p.rev[slot] = rslot;
+        p.geom[slot] = make_float4(rx, ry, rz, d);
+        p.slot2canon[slot] = cid;
+        if (p.c_src) {
+          p.c_src[cid] = a + j;
+          p.c_dst[cid] = a + i;
+          p.c_dist[cid] = d;
+          p.c_vec[3 * (long)cid + 0] = rx; p.c_vec[3 * (long)cid + 1] = ry; p.c_vec[3 * (long)cid + 2] = rz;
+          p.id_swap[cid] = (j < i) ? cid + half : cid - half;
+        }
+      }
+      before += __popcll(s);
+    }
+  }
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+static size_t graph_lds_bytes(int max_mol_atoms) {
+  int W = (max_mol_atoms + 63) / 64;
+  return (size_t)max_mol_atoms * W * 8 * 2 + (size_t)max_mol_atoms * 3 * 4;
+}
+
+int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int max_mol_atoms, float cutoff2, int K,
+                        int* deg, int* lowdeg, int* row_ptr, int* lowptr, int* E_host, hipStream_t st) {
+  NQ_PROF(st, "graph_count");
+  if (max_mol_atoms > NQ_MAX_MOL_ATOMS)
+    return nq_fail(NQ_ERR_MOL_TOO_LARGE, "molecule with %d atoms exceeds NQ_MAX_MOL_ATOMS=%d", max_mol_atoms, NQ_MAX_MOL_ATOMS);
+  if (N <= 0 || B <= 0) return nq_fail(NQ_ERR_ARG, "empty batch (N=%d, B=%d)", N, B);
+  size_t lds = graph_lds_bytes(max_mol_atoms);
+  NQ_HIP(hipFuncSetAttribute((const void*)k_graph_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_graph_count, dim3(B), dim3(GRAPH_THREADS), lds, st, pos, mol_ptr, cutoff2, K, deg, lowdeg);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, st, deg, lowdeg, N, row_ptr, lowptr);
+  NQ_LAUNCH_CHECK();
+  NQ_HIP(hipMemcpyAsync(E_host, row_ptr + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  NQ_HIP(hipStreamSynchronize(st));
+  return NQ_OK;
+}
+
+int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st) {
+  NQ_PROF(st, "graph_fill");
+  size_t lds = graph_lds_bytes(max_mol_atoms);
+  NQ_HIP(hipFuncSetAttribute((const void*)k_graph_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_graph_fill, dim3(B), dim3(GRAPH_THREADS), lds, st, args);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}

@@ -1,0 +1,430 @@
+// Node-level (per atom x channel) kernels of the PaiNN path: update block (painn.py:535-548),
+// SiLU derivative steps, readout (painn.py:79-83,127-128), embedding (layers.py:215-222), loss
+// (painn.py:741-745 with L1Loss + gemnet_oc/loss.py:5-22), optimizer.  Math: oracle/painn_sweeps.py.
+// Thread mapping everywhere: channel index fastest -> fully coalesced rows of F floats.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+
+// s = sum_c v1 v2 ; n = sqrt(sum_c v2^2 + 1e-8) ; cat = [x_msg | n]
+template <bool TAN>
+__global__ void k_upd_a(UpdArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.N * q.F) return;
+  const int F = q.F;
+  const long n = idx / F; const int f = (int)(idx % F);
+  const float* u = q.U + n * 6 * F;
+  float a[3], b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { a[c] = u[c * 2 * F + f]; b[c] = u[c * 2 * F + F + f]; }
+  if (!TAN) {
+    const float s = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    const float nn = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + 1e-8f);
+    q.S[idx] = s;
+    q.CAT[n * 2 * F + f] = q.XM[idx];
+    q.CAT[n * 2 * F + F + f] = nn;
+  } else {
+    const float* tu = q.TU + n * 6 * F;
+    float ta[3], tb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ta[c] = tu[c * 2 * F + f]; tb[c] = tu[c * 2 * F + F + f]; }
+    const float nn = q.CAT[n * 2 * F + F + f];
+    const float ts = ta[0] * b[0] + a[0] * tb[0] + ta[1] * b[1] + a[1] * tb[1] + ta[2] * b[2] + a[2] * tb[2];
+    const float tn = (b[0] * tb[0] + b[1] * tb[1] + b[2] * tb[2]) / nn;
+    q.TS[idx] = ts;
+    q.TCAT[n * 2 * F + f] = q.TXM[idx];
+    q.TCAT[n * 2 * F + F + f] = tn;
+  }
+}
+
+// x_upd = x_msg + y_a + y_b s ; vec_upd[c] = vec_msg[c] + y_c v1[c]
+template <bool TAN>
+__global__ void k_upd_b(UpdArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.N * q.F) return;
+  const int F = q.F;
+  const long n = idx / F; const int f = (int)(idx % F);
+  const float* u = q.U + n * 6 * F;
+  const float* y = q.Y + n * 3 * F;
+  const float s = q.S[idx];
+  if (!TAN) {
+    q.X1[idx] = q.XM[idx] + y[f] + y[F + f] * s;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q.V1[n * 3 * F + c * F + f] = q.VM[n * 3 * F + c * F + f] + y[2 * F + f] * u[c * 2 * F + f];
+  } else {
+    const float* tu = q.TU + n * 6 * F;
+    const float* ty = q.TY + n * 3 * F;
+    q.TX1[idx] = q.TXM[idx] + ty[f] + ty[F + f] * s + y[F + f] * q.TS[idx];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      q.TV1[n * 3 * F + c * F + f] = q.TVM[n * 3 * F + c * F + f] + ty[2 * F + f] * u[c * 2 * F + f] + y[2 * F + f] * tu[c * 2 * F + f];
+  }
+}
+
+// tangent of SiLU: TH = dsilu(Z) * TZ
+__global__ void k_silu_tan(const float* __restrict__ Z, const float* __restrict__ TZ, float* __restrict__ TH, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) TH[i] = nq_dsilu(Z[i]) * TZ[i];
+}
+
+// reverse of SiLU, in place on the adjoint(s):  G <- G dsilu(Z) (+ GT d2silu(Z) TZ) ;  GT <- GT dsilu(Z)
+template <bool DUAL>
+__global__ void k_silu_rev(const float* __restrict__ Z, const float* __restrict__ TZ, float* __restrict__ G, float* __restrict__ GT, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float z = Z[i];
+  const float d1 = nq_dsilu(z);
+  float g = G[i] * d1;
+  if (DUAL) {
+    const float gt = GT[i];
+    g += gt * nq_d2silu(z) * TZ[i];
+    GT[i] = gt * d1;
+  }
+  G[i] = g;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+// rev1: adjoints of y = (ya, yb, yc) from x_upd = x_msg + ya + yb s, vec_upd = vec_msg + yc v1
+template <bool DUAL>
+__global__ void k_upd_rev1(UpdRevArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.N * q.F) return;
+  const int F = q.F;
+  const long n = idx / F; const int f = (int)(idx % F);
+  const float* u = q.U + n * 6 * F;
+  const float gx = q.GX[idx], s = q.S[idx];
+  const float* gv = q.GV + n * 3 * F;
+  float gyb = gx * s;
+  float gyc = gv[f] * u[f] + gv[F + f] * u[2 * F + f] + gv[2 * F + f] * u[4 * F + f];
+  if (DUAL) {
+    const float* tu = q.TU + n * 6 * F;
+    const float gtx = q.GTX[idx];
+    const float* gtv = q.GTV + n * 3 * F;
+    gyb += gtx * q.TS[idx];
+    gyc += gtv[f] * tu[f] + gtv[F + f] * tu[2 * F + f] + gtv[2 * F + f] * tu[4 * F + f];
+    float* gty = q.GTY + n * 3 * F;
+    gty[f] = gtx;
+    gty[F + f] = gtx * s;
+    gty[2 * F + f] = gtv[f] * u[f] + gtv[F + f] * u[2 * F + f] + gtv[2 * F + f] * u[4 * F + f];
+  }
+  float* gy = q.GY + n * 3 * F;
+  gy[f] = gx; gy[F + f] = gyb; gy[2 * F + f] = gyc;
+}
+
+// rev2: given gcat = adjoint of [x_msg | n]: adjoints of u = (v1, v2) and gx_msg = gx_upd + gcat[:F]
+template <bool DUAL>
+__global__ void k_upd_rev2(UpdRevArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.N * q.F) return;
+  const int F = q.F;
+  const long n = idx / F; const int f = (int)(idx % F);
+  const float* u = q.U + n * 6 * F;
+  const float* y = q.Y + n * 3 * F;
+  const float yb = y[F + f], yc = y[2 * F + f];
+  const float nn = q.CAT[n * 2 * F + F + f];
+  const float gx = q.GX[idx];
+  const float* gv = q.GV + n * 3 * F;
+  const float gn = q.GCAT[n * 2 * F + F + f];
+  float gs = gx * yb;
+  float gts = 0.f, gtn = 0.f, tn = 0.f, tyc = 0.f, gtx = 0.f;
+  const float* tu = nullptr; const float* gtv = nullptr;
+  if (DUAL) {
+    tu = q.TU + n * 6 * F;
+    gtv = q.GTV + n * 3 * F;
+    gtx = q.GTX[idx];
+    const float* ty = q.TY + n * 3 * F;
+    gs += gtx * ty[F + f];
+    gts = gtx * yb;
+    tyc = ty[2 * F + f];
+    gtn = q.GTCAT[n * 2 * F + F + f];
+    tn = q.TCAT[n * 2 * F + F + f];
+  }
+  const float gn_n = gn / nn, gtn_n = gtn / nn, tn_n = tn / nn;
+  float* gu = q.GU + n * 6 * F;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = u[c * 2 * F + f], b = u[c * 2 * F + F + f];
+    float g1 = gv[c * F + f] * yc + gs * b;
+    float g2 = gn_n * b + gs * a;
+    if (DUAL) {
+      const float ta = tu[c * 2 * F + f], tb = tu[c * 2 * F + F + f];
+      const float gtvc = gtv[c * F + f];
+      g1 += gtvc * tyc + gts * tb;
+      g2 += gtn_n * (tb - tn_n * b) + gts * ta;
+      float* gtu = q.GTU + n * 6 * F;
+      gtu[c * 2 * F + f] = gtvc * yc + gts * b;
+      gtu[c * 2 * F + F + f] = gtn_n * b + gts * a;
+    }
+    gu[c * 2 * F + f] = g1;
+    gu[c * 2 * F + F + f] = g2;
+  }
+  q.GX[idx] = gx + q.GCAT[n * 2 * F + f];
+  if (DUAL) q.GTX[idx] = gtx + q.GTCAT[n * 2 * F + f];
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather: X0[n][f] = Emb[z[n]-1][f]
+__global__ void k_embed(const int* __restrict__ z, const float* __restrict__ emb, int N, int F, float* __restrict__ X0) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * F) return;
+  const long n = idx / F; const int f = (int)(idx % F);
+  X0[idx] = emb[(long)(z[n] - 1) * F + f];
+}
+
+// embedding gradient, deterministic: one workgroup per chunk of atoms, thread f owns column f of an LDS
+// accumulator [T][F]; partial slabs are then reduced in fixed order by k_reduce_partials.
+__global__ void k_embed_grad_partial(const int* __restrict__ z, const float* __restrict__ GX, int N, int F, int T, int chunk,
+                                     float* __restrict__ part) {
+  extern __shared__ float acc[];
+  const int f = threadIdx.x;
+  for (int t = 0; t < T; ++t) acc[t * F + f] = 0.f;
+  const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
+  for (int n = n0; n < n1; ++n) acc[(z[n] - 1) * F + f] += GX[(long)n * F + f];
+  for (int t = 0; t < T; ++t) part[((long)blockIdx.x * T + t) * F + f] = acc[t * F + f];
+}
+
+// readout: e[n] = w2 . silu(zo[n]) + o2 (one wavefront per atom), tangent, and reverse
+
+template <int MODE>  // 0 fwd, 1 tangent
+__global__ void k_readout(ReadoutArgs q) {
+  const int lane = threadIdx.x & 63;
+  const long n = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= q.N) return;
+  float acc = 0.f;
+  for (int h = lane; h < q.H; h += 64) {
+    const float z = q.ZO[n * q.H + h];
+    acc += q.w2[h] * (MODE == 0 ? nq_silu(z) : nq_dsilu(z) * q.TZO[n * q.H + h]);
+  }
+  acc = nq_wave_sum(acc);
+  if (lane == 0) {
+    if (MODE == 0) q.e_atom[n] = acc + q.o2[0];
+    else q.te_atom[n] = acc;
+  }
+}
+
+template <bool DUAL>
+__global__ void k_readout_rev(ReadoutArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.N * q.H) return;
+  const long n = idx / q.H; const int h = (int)(idx % q.H);
+  const float z = q.ZO[idx], w = q.w2[h];
+  const float d1 = nq_dsilu(z);
+  const float ge = q.ge[n];
+  float g = ge * w * d1;
+  if (DUAL) {
+    const float gte = q.gte[n], tz = q.TZO[idx];
+    g += gte * w * nq_d2silu(z) * tz;
+    q.GTZO[idx] = gte * w * d1;
+    q.TMPW[idx] = ge * nq_silu(z) + gte * d1 * tz;
+  }
+  q.GZO[idx] = g;
+}
+
+// energy[b] = sum of e_atom over the molecule's atoms, sequential order (== index_add order)
+__global__ void k_mol_sum(const float* __restrict__ e_atom, const int* __restrict__ mol_ptr, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int n = mol_ptr[b]; n < mol_ptr[b + 1]; ++n) s += e_atom[n];
+  out[b] = s;
+}
+
+// per-atom seeds for the reverse sweeps: ge[n] = gE[mol(n)] (or 1), gte[n] = 1
+__global__ void k_atom_seeds(const float* __restrict__ gE, const int* __restrict__ atom_mol, int N, float* __restrict__ ge, float* __restrict__ gte) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  ge[n] = gE ? gE[atom_mol[n]] : 1.0f;
+  if (gte) gte[n] = 1.0f;
+}
+
+__global__ void k_scale_neg(const float* __restrict__ in, float* __restrict__ out, long count) {  // out = -in
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = -in[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss = ce * mean_b |E_b - y_b| + cf * mean_i ||F_i - Ft_i||_2 and its seeds dL/dE, dL/dF   (single workgroup)
+__global__ __launch_bounds__(1024) void k_loss(const float* __restrict__ E, const float* __restrict__ y, int B, const float* __restrict__ Fc,
+                                               const float* __restrict__ Ft, int N, float ce, float cf, float* __restrict__ loss,
+                                               float* __restrict__ gE, float* __restrict__ gF) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float d = E[b] - y[b];
+    acc += ce * fabsf(d) / (float)B;
+    gE[b] = ce * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (float)B;
+  }
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const float dx = Fc[3 * (long)n] - Ft[3 * (long)n], dy = Fc[3 * (long)n + 1] - Ft[3 * (long)n + 1], dz = Fc[3 * (long)n + 2] - Ft[3 * (long)n + 2];
+    const float nr = sqrtf(dx * dx + dy * dy + dz * dz);
+    acc += cf * nr / (float)N;
+    const float sc = nr > 0.f ? cf / (nr * (float)N) : 0.f;
+    gF[3 * (long)n] = dx * sc; gF[3 * (long)n + 1] = dy * sc; gF[3 * (long)n + 2] = dz * sc;
+  }
+  acc = nq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    loss[0] = s;
+  }
+}
+
+// ---- optimizer: squared grad norm (two stage), clip + AdamW in one pass ----------------------
+__global__ void k_sqnorm_partial(const float* __restrict__ g, long count, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) acc += g[i] * g[i];
+  acc = nq_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_sqnorm_final(const float* __restrict__ part, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    out[0] = s;
+  }
+}
+// torch.optim.AdamW semantics (decoupled weight decay) with clip_grad_norm_(max_norm) folded in:
+//   g <- g * min(1, max_norm / (||g|| + 1e-6))
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long count,
+                        const float* __restrict__ sqnorm, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                        float bc1, float bc2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float scale = 1.0f;
+  if (max_norm > 0.f) {
+    const float nrm = sqrtf(sqnorm[0]);
+    scale = fminf(1.0f, max_norm / (nrm + 1e-6f));
+  }
+  const float gi = g[i] * scale;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = pi - (lr / bc1) * mi / denom;
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+static inline dim3 grid1d(long count, int block) { return dim3(nq_cdiv(count, block)); }
+
+int nq_upd_a(hipStream_t st, const UpdArgs& q, bool tan) {
+  NQ_PROF(st, "upd_a");
+  if (q.N <= 0) return NQ_OK;
+  if (tan) hipLaunchKernelGGL((k_upd_a<true>), grid1d((long)q.N * q.F, 256), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((k_upd_a<false>), grid1d((long)q.N * q.F, 256), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_upd_b(hipStream_t st, const UpdArgs& q, bool tan) {
+  NQ_PROF(st, "upd_b");
+  if (q.N <= 0) return NQ_OK;
+  if (tan) hipLaunchKernelGGL((k_upd_b<true>), grid1d((long)q.N * q.F, 256), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((k_upd_b<false>), grid1d((long)q.N * q.F, 256), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_silu_tan(hipStream_t st, const float* Z, const float* TZ, float* TH, long count) {
+  NQ_PROF(st, "silu_tan");
+  if (count <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_silu_tan, grid1d(count, 256), dim3(256), 0, st, Z, TZ, TH, count);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_silu_rev(hipStream_t st, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual) {
+  NQ_PROF(st, "silu_rev");
+  if (count <= 0) return NQ_OK;
+  if (dual) hipLaunchKernelGGL((k_silu_rev<true>), grid1d(count, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
+  else hipLaunchKernelGGL((k_silu_rev<false>), grid1d(count, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_upd_rev(hipStream_t st, const UpdRevArgs& q, int stage, bool dual) {
+  NQ_PROF(st, "upd_rev");
+  if (q.N <= 0) return NQ_OK;
+  dim3 g = grid1d((long)q.N * q.F, 256), b(256);
+  if (stage == 1) {
+    if (dual) hipLaunchKernelGGL((k_upd_rev1<true>), g, b, 0, st, q);
+    else hipLaunchKernelGGL((k_upd_rev1<false>), g, b, 0, st, q);
+  } else {
+    if (dual) hipLaunchKernelGGL((k_upd_rev2<true>), g, b, 0, st, q);
+    else hipLaunchKernelGGL((k_upd_rev2<false>), g, b, 0, st, q);
+  }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_embed(hipStream_t st, const int* z, const float* emb, int N, int F, float* X0) {
+  NQ_PROF(st, "embed");
+  hipLaunchKernelGGL(k_embed, grid1d((long)N * F, 256), dim3(256), 0, st, z, emb, N, F, X0);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+#define EMB_CHUNK 512
+size_t nq_embed_grad_scratch_floats(int N, int F, int T) { return (size_t)nq_cdiv(N, EMB_CHUNK) * T * F; }
+int nq_embed_grad(hipStream_t st, const int* z, const float* GX, int N, int F, int T, float* out, float* scratch) {
+  NQ_PROF(st, "embed_grad");
+  const int chunks = nq_cdiv(N, EMB_CHUNK);
+  const size_t lds = (size_t)T * F * sizeof(float);
+  if (lds > 160 * 1024) return nq_fail(NQ_ERR_ARG, "embed_grad: num_elements*F too large for LDS (%zu B)", lds);
+  NQ_HIP(hipFuncSetAttribute((const void*)k_embed_grad_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_embed_grad_partial, dim3(chunks), dim3(F), lds, st, z, GX, N, F, T, EMB_CHUNK, scratch);
+  NQ_LAUNCH_CHECK();
+  return nq_reduce_partials(st, scratch, chunks, (long)T * F, (long)T * F, out);
+}
+int nq_readout(hipStream_t st, const ReadoutArgs& q, int mode) {
+  NQ_PROF(st, "readout");
+  if (q.N <= 0) return NQ_OK;
+  if (mode == 0) hipLaunchKernelGGL((k_readout<0>), dim3(nq_cdiv(q.N, 4)), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((k_readout<1>), dim3(nq_cdiv(q.N, 4)), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_readout_rev(hipStream_t st, const ReadoutArgs& q, bool dual) {
+  NQ_PROF(st, "readout_rev");
+  if (q.N <= 0) return NQ_OK;
+  if (dual) hipLaunchKernelGGL((k_readout_rev<true>), grid1d((long)q.N * q.H, 256), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((k_readout_rev<false>), grid1d((long)q.N * q.H, 256), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_mol_sum(hipStream_t st, const float* e_atom, const int* mol_ptr, int B, float* out) {
+  hipLaunchKernelGGL(k_mol_sum, grid1d(B, 128), dim3(128), 0, st, e_atom, mol_ptr, B, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_atom_seeds(hipStream_t st, const float* gE, const int* atom_mol, int N, float* ge, float* gte) {
+  hipLaunchKernelGGL(k_atom_seeds, grid1d(N, 256), dim3(256), 0, st, gE, atom_mol, N, ge, gte);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_negate(hipStream_t st, const float* in, float* out, long count) {
+  hipLaunchKernelGGL(k_scale_neg, grid1d(count, 256), dim3(256), 0, st, in, out, count);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_loss_impl(hipStream_t st, const float* E, const float* y, int B, const float* Fc, const float* Ft, int N, float ce, float cf,
+                 float* loss, float* gE, float* gF) {
+  NQ_PROF(st, "loss");
+  hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, st, E, y, B, Fc, Ft, N, ce, cf, loss, gE, gF);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+#define SQN_BLOCKS 256
+int nq_adamw_impl(hipStream_t st, float* p, const float* g, float* m, float* v, long count, float max_norm, float lr, float beta1,
+                  float beta2, float eps, float wd, int step, float* scratch /* >= SQN_BLOCKS+1 floats */) {
+  NQ_PROF(st, "adamw");
+  hipLaunchKernelGGL(k_sqnorm_partial, dim3(SQN_BLOCKS), dim3(256), 0, st, g, count, scratch);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(64), 0, st, scratch, SQN_BLOCKS, scratch + SQN_BLOCKS);
+  NQ_LAUNCH_CHECK();
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(k_adamw, grid1d(count, 256), dim3(256), 0, st, p, g, m, v, count, scratch + SQN_BLOCKS, max_norm, lr, beta1,
+                     beta2, eps, wd, bc1, bc2);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}

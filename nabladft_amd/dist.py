@@ -1,0 +1,56 @@
+"""Data-parallel plumbing: one process per GPU, gradient all-reduce over RCCL (backend "nccl" on ROCm)
+or gloo (CPU tests).  Conformers are independent graphs, so the flat parameter-gradient buffer is the
+only thing ever exchanged (reference: Lightning DDPStrategy, nablaDFT/utils/pipelines.py:65-68)."""
+import os
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if a launcher set them. Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over ranks of ONE contiguous buffer (a single collective per step; PaiNN: 5.4 MB)."""
+    w = world_size(group)
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / w)
+    return flat
+
+
+def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def shard_by_cost(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Greedy longest-processing-time partition of conformers over ranks by edge-count proxy n^2
+    (keeps the 10-90 atom mix balanced; each rank's list is returned in ascending conformer order)."""
+    order = sorted(range(len(sizes)), key=lambda i: -sizes[i])
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += sizes[i] * sizes[i]
+    return [sorted(o) for o in out]

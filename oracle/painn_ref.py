@@ -79,52 +79,7 @@ def make_params(cfg: PaiNNConfig, seed: int, dtype=torch.float32):
     return out
 
 
-_ELEMENTS = np.array([1, 6, 7, 8, 16, 9, 17])
-_EL_P = np.array([0.470, 0.384, 0.068, 0.059, 0.009, 0.007, 0.003])
-
-
-def gen_conformers(seed: int, n_mol: int, size="drug", dtype=torch.float32):
-    """Synthetic drug-like conformers: self-avoiding random tree of heavy atoms
-    at ~1.5 A, hydrogens at 1.09 A. size: 'drug' -> n~clip(N(42,5),29,54); (lo,hi) -> U{lo..hi};
-    int -> fixed."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    pos_all, z_all, batch_all = [], [], []
-    for m in range(n_mol):
-        if size == "drug":
-            n = int(np.clip(np.rint(rng.normal(42, 5)), 29, 54))
-        elif isinstance(size, tuple):
-            n = int(rng.integers(size[0], size[1] + 1))
-        else:
-            n = int(size)
-        n_heavy = max(1, int(round(n * 0.53)))
-        zs = rng.choice(_ELEMENTS[1:], size=n_heavy, p=_EL_P[1:] / _EL_P[1:].sum())
-        pts = [np.zeros(3)]
-        while len(pts) < n_heavy:
-            base = pts[rng.integers(len(pts))]
-            v = rng.normal(size=3)
-            cand = base + v / np.linalg.norm(v) * rng.normal(1.50, 0.05)
-            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= 1.20:
-                pts.append(cand)
-        heavy = len(pts)
-        tries = 0
-        while len(pts) < n:
-            base = pts[rng.integers(heavy)]
-            v = rng.normal(size=3)
-            cand = base + v / np.linalg.norm(v) * 1.09
-            tries += 1
-            if np.min(np.linalg.norm(np.array(pts) - cand, axis=1)) >= 0.95 or tries > 2000:
-                pts.append(cand)
-        z = np.concatenate([zs, np.ones(n - heavy, dtype=zs.dtype)])
-        perm = rng.permutation(n)
-        pos_all.append(np.array(pts)[perm])
-        z_all.append(z[perm])
-        batch_all.append(np.full(n, m))
-    pos = torch.tensor(np.concatenate(pos_all).astype(np.float32)).to(dtype)
-    z = torch.tensor(np.concatenate(z_all).astype(np.int64))
-    batch = torch.tensor(np.concatenate(batch_all).astype(np.int64))
-    y = torch.tensor(rng.normal(0, 1, size=n_mol).astype(np.float32)).to(dtype)
-    f = torch.tensor(rng.normal(0, 0.05, size=(pos.shape[0], 3)).astype(np.float32)).to(dtype)
-    return pos, z, batch, y, f
+from nabladft_amd.synth import gen_conformers  # noqa: E402,F401  (data generator shared with bench.py)
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,332 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI, against
+  * the golden vectors produced by the real reference (tests/golden/*.npz), and
+  * the CPU oracle (oracle/painn_ref.py, oracle/painn_sweeps.py) on the same seeded inputs,
+plus size-independent properties at larger batch sizes.
+Tolerances (fp32): energies/forces 1e-5 relative (north-star), gradients 5e-5 relative to the
+tensor's max, integer outputs and edge geometry bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import painn_ref as R
+from oracle.painn_sweeps import Sweeps, loss_and_seeds
+from tests.helpers import GOLDEN, check_grads, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(cfg, params, dev):
+    import nabladft_amd as nq
+    m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": "gaussian"},
+                 {"name": "polynomial", "exponent": cfg.envelope_exponent}, True, False, False, True, cfg.num_elements)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected
+    return m.to(dev)
+
+
+def _batch(fx, dev):
+    from nabladft_amd import Batch
+    return Batch(torch.tensor(fx["pos"]), torch.tensor(fx["z"]), torch.tensor(fx["batch"]), torch.tensor(fx["y"]),
+                 torch.tensor(fx["f_target"])).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_is_loaded_native():
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    assert lib.nq_abi_version() == _lib.ABI_VERSION
+    with open("/proc/self/maps") as f:
+        assert "libnablaq.so" in f.read()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 100), (1000, 128, 128), (257, 64, 128), (129, 384, 20), (4096, 256, 128), (77, 128, 256)])
+def test_gemm_forward_and_grads(M, N, K):
+    from nabladft_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    G = torch.randn(M, N, generator=g)
+    Ad, Wd, bd, Gd = A.to(dev), W.to(dev), b.to(dev), G.to(dev)
+    Cd, Sd = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(lib.nq_linear_forward(_lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(Cd), _lib.ptr(Sd), M, N, K, st))
+    ref = (A.double() @ W.double().T + b.double())
+    assert rel_err(Cd.cpu().numpy(), ref.numpy()) < 2e-6
+    assert rel_err(Sd.cpu().numpy(), torch.nn.functional.silu(ref).numpy()) < 2e-6
+    # transpose-detecting: asymmetric operands above; no-bias / no-silu variant
+    _lib.check(lib.nq_linear_forward(_lib.ptr(Ad), _lib.ptr(Wd), None, _lib.ptr(Cd), None, M, N, K, st))
+    assert rel_err(Cd.cpu().numpy(), (A.double() @ W.double().T).numpy()) < 2e-6
+    # input gradient, with and without accumulation
+    Xd = torch.full((M, K), 0.5, device=dev)
+    _lib.check(lib.nq_linear_input_grad(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(Xd), M, N, K, 1, st))
+    refx = G.double() @ W.double() + 0.5
+    assert rel_err(Xd.cpu().numpy(), refx.numpy()) < 2e-6
+    _lib.check(lib.nq_linear_input_grad(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(Xd), M, N, K, 0, st))
+    assert rel_err(Xd.cpu().numpy(), (G.double() @ W.double()).numpy()) < 2e-6
+    # weight gradient (split-K over rows)
+    scr = torch.empty(lib.nq_weight_grad_scratch_floats(M, N, K), device=dev)
+    gW = torch.empty(N, K, device=dev)
+    _lib.check(lib.nq_linear_weight_grad(_lib.ptr(Gd), _lib.ptr(Ad), _lib.ptr(gW), M, N, K, _lib.ptr(scr), st))
+    assert rel_err(gW.cpu().numpy(), (G.double().T @ A.double()).numpy()) < 3e-6
+
+
+def test_weight_grad_many_rows_deterministic():
+    from nabladft_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    rows, N, K = 70001, 384, 100
+    g = torch.Generator().manual_seed(1)
+    G, X = torch.randn(rows, N, generator=g).to(dev), torch.randn(rows, K, generator=g).to(dev)
+    scr = torch.empty(lib.nq_weight_grad_scratch_floats(rows, N, K), device=dev)
+    o1, o2 = torch.empty(N, K, device=dev), torch.empty(N, K, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(lib.nq_linear_weight_grad(_lib.ptr(G), _lib.ptr(X), _lib.ptr(o1), rows, N, K, _lib.ptr(scr), st))
+    _lib.check(lib.nq_linear_weight_grad(_lib.ptr(G), _lib.ptr(X), _lib.ptr(o2), rows, N, K, _lib.ptr(scr), st))
+    assert torch.equal(o1, o2)
+    ref = (G.double().T @ X.double()).cpu()
+    assert rel_err(o1.cpu().numpy(), ref.numpy()) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def test_graph_cases_bit_exact():
+    import nabladft_amd as nq
+    dev = _dev()
+    gx = np.load(GOLDEN + "/graph_cases.npz")
+    for c in range(int(gx["n_cases"])):
+        pre = f"c{c}_"
+        pos, batch = torch.tensor(gx[pre + "pos"]).to(dev), torch.tensor(gx[pre + "batch"]).to(dev)
+        nl = nq.build_neighbor_list(pos, batch, None, float(gx[pre + "cutoff"]), int(gx[pre + "K"]), canonical=True)
+        assert np.array_equal(nl.edge_index.cpu().numpy(), gx[pre + "edge_index"]), f"case {c} edge_index"
+        assert np.array_equal(nl.neighbors.cpu().numpy(), gx[pre + "neighbors"]), f"case {c} neighbors"
+        assert np.array_equal(nl.id_swap.cpu().numpy(), gx[pre + "id_swap"]), f"case {c} id_swap"
+        assert np.array_equal(nl.edge_dist.cpu().numpy(), gx[pre + "edge_dist"]), f"case {c} edge_dist"
+        assert np.array_equal(nl.edge_vector.cpu().numpy(), gx[pre + "edge_vector"]), f"case {c} edge_vector"
+        # CSR invariants: sorted sources per row, rev is an involution that flips (col, dst)
+        col, dst, rev, rp = (nl.t[k].cpu().long() for k in ("col", "dst", "rev", "row_ptr"))
+        assert torch.equal(rev[rev], torch.arange(nl.E))
+        assert torch.equal(col[rev], dst) and torch.equal(dst[rev], col)
+        assert torch.equal(torch.repeat_interleave(torch.arange(nl.N), rp[1:] - rp[:-1]), dst)
+        same_row = dst[1:] == dst[:-1]
+        assert bool((col[1:][same_row] > col[:-1][same_row]).all())
+        s2c = nl.t["slot2canon"].cpu().long()
+        assert torch.equal(torch.tensor(gx[pre + "edge_index"])[0][s2c], col)
+        assert torch.equal(torch.tensor(gx[pre + "edge_index"])[1][s2c], dst)
+
+
+def test_graph_errors():
+    import nabladft_amd as nq
+    from nabladft_amd._lib import NablaqError
+    dev = _dev()
+    pos = torch.rand(600, 3, device=dev) * 30
+    with pytest.raises(NablaqError):  # molecule larger than NQ_MAX_MOL_ATOMS
+        nq.build_neighbor_list(pos, torch.zeros(600, dtype=torch.long, device=dev), None, 5.0, 100)
+    m = nq.PaiNN(64, 1, 8, 0.5, 10, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 10).to(dev)
+    far = nq.Batch(torch.tensor([[0.0, 0, 0], [9.0, 0, 0]], device=dev), torch.tensor([1, 1], device=dev), torch.tensor([0, 0], device=dev))
+    with pytest.raises(IndexError):  # the reference raises IndexError in repeat_blocks when no edge exists
+        m(far)
+
+
+# ------------------------------------------------------------------------------------------------
+def _trace_report(name, model, sw, s2c, tag, lines):
+    """Compares every named engine buffer with the CPU sweeps; returns worst relative error."""
+    L, worst = model.num_layers, 0.0
+    node_bufs = ["x_in", "vec_in", "z1", "h", "xh", "x_msg", "vec_msg", "u", "s", "cat", "zq", "q", "y"]
+    for tangent in ([False, True] if tag == "bwd" else [False]):
+        pre = "t_" if tangent else ""
+        for l in range(L):
+            for b in node_bufs:
+                key = f"{pre}{b}{l}" if b in ("x_in", "vec_in", "x_msg", "vec_msg") else f"{pre}{b}_{l}"
+                if key not in sw.ws:
+                    continue
+                ref = sw.ws[key].reshape(-1).numpy()
+                got = model.workspace_view(b, l, tangent).cpu().numpy()
+                e = rel_err(got, ref)
+                worst = max(worst, e)
+                lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+            if not tangent:
+                for b in ("phi", "psi"):
+                    ref = sw.ws[f"{b}_{l}"][s2c].reshape(-1).numpy()
+                    got = model.workspace_view(b, l).cpu().numpy()
+                    e = rel_err(got, ref)
+                    worst = max(worst, e)
+                    lines.append(f"{name} {tag} {b}_{l:<10d} rel_err {e:.3e}")
+    for b, key in (("rho", "rho"), ("rho", "drho")):
+        ref = sw.ws[key][s2c].reshape(-1).numpy()
+        got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
+        e = rel_err(got, ref)
+        worst = max(worst, e)
+        lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    if tag == "bwd":
+        for b in ("t_d", "t_r"):
+            ref = sw.ws[b][s2c].reshape(-1).numpy()
+            got = model.workspace_view(b).cpu().numpy()
+            e = rel_err(got, ref)
+            worst = max(worst, e)
+            lines.append(f"{name} {tag} {b:14s} rel_err {e:.3e}")
+    return worst
+
+
+@pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz"])
+def test_engine_matches_reference_golden(name):
+    dev = _dev()
+    fx, cfg, params = load_case(name)
+    model = _model(cfg, params, dev)
+    batch = _batch(fx, dev)
+    lines = []
+    # graph: bit-exact against the reference
+    ei, nb, ed, ev, sw_ = model.generate_graph_values(batch)
+    assert np.array_equal(ei.cpu().numpy(), fx["edge_index"])
+    assert np.array_equal(nb.cpu().numpy(), fx["neighbors"])
+    assert np.array_equal(sw_.cpu().numpy(), fx["id_swap"])
+    assert np.array_equal(ed.cpu().numpy(), fx["edge_dist"])
+    assert np.array_equal(ev.cpu().numpy(), fx["edge_vector"])
+    # forward + forces through the autograd boundary
+    model.train()
+    energy, forces = model(batch)
+    s2c = model._last_nl.t["slot2canon"].cpu().long()
+    # CPU sweeps on the same inputs (buffer-by-buffer localisation)
+    sw = Sweeps(params, cfg, torch.tensor(fx["pos"]), torch.tensor(fx["z"]), torch.tensor(fx["batch"]), torch.tensor(fx["edge_index"]))
+    e_cpu, f_cpu = sw.energy_forces()
+    worst_f = _trace_report(name, model, sw, s2c, "fwd", lines)
+    e_err, f_err = rel_err(energy.detach().cpu().numpy(), fx["energy"]), rel_err(forces.detach().cpu().numpy(), fx["forces"])
+    lines.append(f"{name} energy rel_err {e_err:.3e}  forces rel_err {f_err:.3e}  worst fwd buffer {worst_f:.3e}")
+    # loss + backward exactly as PaiNNLightning.step / Lightning do it
+    from nabladft_amd import L2Loss
+    loss = torch.nn.L1Loss()(energy, batch.y) + L2Loss()(forces, batch.forces)
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    loss_cpu, gE, gF = loss_and_seeds(e_cpu, f_cpu, torch.tensor(fx["y"]), torch.tensor(fx["f_target"]))
+    G = sw.backward(gE, gF)
+    worst_b = _trace_report(name, model, sw, s2c, "bwd", lines)
+    g_worst = max(rel_err(grads[k], G[k].numpy()) for k in G)
+    lines.append(f"{name} loss {float(loss):.7f} (golden {float(fx['loss']):.7f})  worst bwd buffer {worst_b:.3e}  worst grad vs sweeps {g_worst:.3e}")
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"trace_{name}.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    assert e_err < 1e-5 and f_err < 1e-5, lines[-2]
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    assert rel_err(model.workspace_view("x_msg", 0).cpu().numpy(), fx["x_msg0"].reshape(-1)) < 1e-5
+    Lm = cfg.num_layers
+    assert rel_err(model.workspace_view("x_in", Lm).cpu().numpy(), fx[f"x_upd{Lm - 1}"].reshape(-1)) < 1e-5
+    assert rel_err(model.workspace_view("vec_in", Lm).cpu().numpy(), fx[f"vec_upd{Lm - 1}"].reshape(-1)) < 1e-5
+    worst = check_grads(fx, grads, 5e-5, name)
+    with open(os.path.join(OUT, f"trace_{name}.txt"), "a") as f:
+        f.write(f"worst grad vs golden: {worst}\n")
+
+
+def test_fused_step_matches_golden_and_is_deterministic():
+    """C-ABI-only path (HIP loss kernel, no autograd): same gradients, bitwise reproducible."""
+    import nabladft_amd as nq
+    dev = _dev()
+    fx, cfg, params = load_case("painn_full_real4.npz")
+    model = _model(cfg, params, dev)
+    batch = _batch(fx, dev)
+    step = nq.FusedTrainStep(model, max_grad_norm=0.0)
+    l1 = float(step(batch, update=False))
+    g1, e1, f1 = step.grad.clone(), step.energy.clone(), step.forces.clone()
+    l2 = float(step(batch, update=False))
+    assert l1 == l2 and torch.equal(g1, step.grad) and torch.equal(e1, step.energy) and torch.equal(f1, step.forces)
+    assert abs(l1 - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    grads = {k: g1[o:o + n].view(s).cpu().numpy() for (k, _), (o, n, s) in zip(model.named_parameters(), model._param_slices)}
+    check_grads(fx, grads, 5e-5, "fused")
+
+
+def test_loss_kernel_and_adamw_match_torch():
+    from nabladft_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    g = torch.Generator().manual_seed(3)
+    B, N = 37, 1500
+    E, y = torch.randn(B, generator=g), torch.randn(B, generator=g)
+    F_, Ft = torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+    loss_ref, gE_ref, gF_ref = loss_and_seeds(E, F_, y, Ft, 0.7, 1.3)
+    out, gE, gF = torch.zeros(1, device=dev), torch.empty(B, device=dev), torch.empty(N, 3, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(lib.nq_loss_l1_l2(_lib.ptr(E.to(dev)), _lib.ptr(y.to(dev)), B, _lib.ptr(F_.to(dev)), _lib.ptr(Ft.to(dev)), N, 0.7, 1.3,
+                                 _lib.ptr(out), _lib.ptr(gE), _lib.ptr(gF), st))
+    assert abs(float(out) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    assert rel_err(gE.cpu().numpy(), gE_ref.numpy()) < 1e-6 and rel_err(gF.cpu().numpy(), gF_ref.numpy()) < 1e-5
+    # clip + AdamW, three steps, against torch
+    P = 100003
+    p0, grads = torch.randn(P, generator=g), [torch.randn(P, generator=g) * 0.05 for _ in range(3)]
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=5e-4, weight_decay=0.01)
+    pd, m, v = p0.clone().to(dev), torch.zeros(P, device=dev), torch.zeros(P, device=dev)
+    scr = torch.empty(512, device=dev)
+    for t, gr in enumerate(grads, 1):
+        pt.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 5.0)
+        opt.step()
+        _lib.check(lib.nq_adamw_step(_lib.ptr(pd), _lib.ptr(gr.to(dev)), _lib.ptr(m), _lib.ptr(v), P, 5.0, 5e-4, 0.9, 0.999, 1e-8, 0.01, t,
+                                     _lib.ptr(scr), st))
+    assert rel_err(pd.cpu().numpy(), pt.detach().numpy()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def _rand_rotation(seed):
+    q, _ = np.linalg.qr(np.random.Generator(np.random.PCG64(seed)).normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return torch.tensor(q.astype(np.float32))
+
+
+def test_properties_full_size_batch():
+    """Size-independent properties at a BASELINE-sized batch (64 drug-like conformers, full config):
+    batching invariance, E(3) invariance/equivariance, zero net force, determinism, oracle agreement."""
+    import nabladft_amd as nq
+    dev = _dev()
+    cfg = R.PaiNNConfig()
+    params = R.make_params(cfg, seed=23)
+    model = _model(cfg, params, dev).eval()
+    pos, z, batch, y, ft = R.gen_conformers(1, 64)
+    full = nq.Batch(pos, z, batch, y, ft).to(dev)
+    with torch.no_grad():
+        e, f = model(full)
+        e2, f2 = model(full)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    # oracle on a slice (first 6 molecules) at full config
+    sel = batch < 6
+    e_ref, f_ref = R.energy_forces(params, cfg, pos[sel], z[sel], batch[sel])
+    assert rel_err(e[:6].cpu().numpy(), e_ref.numpy()) < 1e-5
+    assert rel_err(f[sel.to(dev)].cpu().numpy(), f_ref.numpy()) < 1e-5
+    # batching invariance: every molecule evaluated alone gives the same energy/forces
+    for mol in (0, 17, 63):
+        s = batch == mol
+        one = nq.Batch(pos[s], z[s], torch.zeros(int(s.sum()), dtype=torch.long)).to(dev)
+        with torch.no_grad():
+            e1, f1 = model(one)
+        assert rel_err(e1.cpu().numpy(), e[mol:mol + 1].cpu().numpy()) < 2e-6
+        assert rel_err(f1.cpu().numpy(), f[s.to(dev)].cpu().numpy()) < 1e-5
+    # net force per molecule vanishes (translation invariance)
+    net = torch.zeros(64, 3, device=dev).index_add_(0, full.batch, f)
+    assert float(net.abs().max()) < 2e-4 * float(f.abs().max())
+    # rotation + translation: E invariant, F rotates
+    Rm = _rand_rotation(5)
+    rot = nq.Batch(pos @ Rm.T + torch.tensor([1.5, -2.0, 0.7]), z, batch).to(dev)
+    with torch.no_grad():
+        er, fr = model(rot)
+    assert rel_err(er.cpu().numpy(), e.cpu().numpy()) < 2e-5
+    assert rel_err(fr.cpu().numpy(), (f.cpu() @ Rm.T).numpy()) < 5e-5
+
+
+def test_training_reduces_loss():
+    """A few fused steps on a fixed batch must lower the loss (end-to-end sanity of grads + optimizer)."""
+    import nabladft_amd as nq
+    dev = _dev()
+    cfg = R.PaiNNConfig(hidden_channels=64, num_layers=3, num_rbf=20)
+    model = _model(cfg, R.make_params(cfg, seed=2), dev)
+    pos, z, batch, y, ft = R.gen_conformers(4, 8)
+    b = nq.Batch(pos, z, batch, y, ft).to(dev)
+    step = nq.FusedTrainStep(model, lr=2e-3)
+    losses = [float(step(b)) for _ in range(30)]
+    assert losses[-1] < 0.7 * losses[0], losses
