@@ -58,6 +58,23 @@ def make_batches(seed, n_batches, B, device):
     return out
 
 
+def gemm_flops(name, N, E, launches):
+    """Average flop per launch of a role-tagged GEMM class, e.g. 'gemm_tn:Wr[384x100]' or 'gemm_nt:W2[n=384,k=128]'."""
+    kind, rest = name.split(":", 1)
+    tag = rest.split("[")[0]
+    dims = [int(x) for x in rest.split("[")[1].rstrip("]").replace("n=", "").replace("k=", "").replace("x", ",").split(",")]
+    rows_single = {"Wr": E, "U": 3 * N}.get(tag, N)
+    if kind == "gemm_tn":          # weight gradients: always over the stacked (primal+tangent) rows
+        return 2.0 * (2 * rows_single) * dims[0] * dims[1]
+    # nt / nn: 1x rows in forward / force adjoint / tangent, 2x rows in the dual reverse -> average over the step's launches
+    per_layer = launches / float(L) if tag not in ("O1",) else launches
+    if kind == "gemm_nt":
+        mult = 1.0                                      # forward and tangent passes: single rows each
+    else:
+        mult = 1.5                                      # nn: force adjoint (1x) + dual reverse (2x)
+    return 2.0 * rows_single * mult * dims[0] * dims[1]
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
     timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
@@ -138,18 +155,19 @@ def main():
         _lib.profile_enable(False)
         tot = sum(v[0] for v in prof.values())
         kernels = sorted(((k, v[0] / args.steps, v[1] // args.steps) for k, v in prof.items()), key=lambda x: -x[1])
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "kernel_events.txt"), "w") as fh:
+            fh.write(f"# HIP-event timing per launcher class, batch={args.batch}, steps={args.steps}: name ms/step launches/step\n")
+            for k, ms, n in kernels:
+                fh.write(f"{k:40s} {ms:10.4f} {n:5d}\n")
+            fh.write(f"{'TOTAL':40s} {tot / args.steps:10.4f}\n")
         dom, dom_ms_step, dom_launches = kernels[0]
         avg_ms = dom_ms_step / max(dom_launches, 1)
         E = n_edges
-        if dom.startswith("gemm_nt") and dom.endswith(f"x{3 * F}x{R}"):
-            # filter-generating GEMM rho[E,R] x Wr^T[R,3F]: MFMA-bound, 2*E*R*3F flop per launch
-            flops = 2.0 * E * R * 3 * F
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            roofline = {"kernel": f"k_gemm<NT> {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
-        elif dom.startswith("gemm"):
-            dims = [int(x) for x in dom.split("_")[2].split("x")]
-            flops = 2.0 * dims[0] * dims[1] * dims[2]
+        if dom.startswith("gemm"):
+            # dense contraction on the fp32 matrix cores: flop per launch from the role tag (rows: E for rbf_proj, N/3N for node MLPs;
+            # x2 rows in the dual sweep are averaged in through launches_per_step)
+            flops = gemm_flops(dom, n_atoms, E, prof[dom][1] // args.steps)
             ach = flops / (avg_ms * 1e-3) / 1e12
             roofline = {"kernel": f"k_gemm {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
@@ -180,7 +198,7 @@ def main():
             "cpu_baseline": cpu,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
-            "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:12]},
+            "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},
         }
         print(json.dumps(out))
     if world > 1:

@@ -142,10 +142,12 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
 int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st);
 
 int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K, int lda,
-               int ldw, int ldc);
-int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc, int accumulate);
+               int ldw, int ldc, const char* tag = nullptr);
+int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc, int accumulate,
+               const char* tag = nullptr);
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
-int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch);
+int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
+               const char* tag = nullptr);
 size_t nq_colsum_scratch_floats(long rows, int cols);
 int nq_colsum(hipStream_t, const float* A, long rows, int cols, int lda, float* out, float* scratch);
 int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, long count, float* out);

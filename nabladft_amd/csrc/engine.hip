@@ -269,24 +269,24 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
-    NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F));
-    NQ_TRY(nq_gemm_nt(st, ws + y.Hh, params + mp.W2, ws + y.XH, params + mp.b2, nullptr, N, 3 * F, F, F, F, 3 * F));
-    NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F));
-    NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F, "W1"));
+    NQ_TRY(nq_gemm_nt(st, ws + y.Hh, params + mp.W2, ws + y.XH, params + mp.b2, nullptr, N, 3 * F, F, F, F, 3 * F, "W2"));
+    NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
+    NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
     MsgArgs m{};
     m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.XM = ws + y.XM; m.VM = ws + y.VM;
     NQ_TRY(nq_msg_fwd(st, m, false));
-    NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.X1 = ws + W.X[l + 1]; u.V1 = ws + W.V[l + 1];
     NQ_TRY(nq_upd_a(st, u, false));
-    NQ_TRY(nq_gemm_nt(st, ws + y.CAT, params + up.V1, ws + y.ZQ, params + up.c1, ws + y.Q, N, F, 2 * F, 2 * F, 2 * F, F));
-    NQ_TRY(nq_gemm_nt(st, ws + y.Q, params + up.V2, ws + y.Y, params + up.c2, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.CAT, params + up.V1, ws + y.ZQ, params + up.c1, ws + y.Q, N, F, 2 * F, 2 * F, 2 * F, F, "V1"));
+    NQ_TRY(nq_gemm_nt(st, ws + y.Q, params + up.V2, ws + y.Y, params + up.c2, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
     NQ_TRY(nq_upd_b(st, u, false));
   }
-  NQ_TRY(nq_gemm_nt(st, ws + W.X[L], params + P.O1, ws + W.ZO, params + P.o1, nullptr, N, H, F, F, F, H));
+  NQ_TRY(nq_gemm_nt(st, ws + W.X[L], params + P.O1, ws + W.ZO, params + P.o1, nullptr, N, H, F, F, F, H, "O1"));
   ReadoutArgs r{};
   r.N = N; r.H = H; r.ZO = ws + W.ZO; r.w2 = params + P.w2; r.o2 = params + P.o2; r.e_atom = ws + W.e_atom;
   NQ_TRY(nq_readout(st, r, 0));
@@ -297,7 +297,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.ge, nullptr));
   r.ge = ws + W.ge; r.GZO = ws + W.GZO;
   NQ_TRY(nq_readout_rev(st, r, false));
-  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, N, H, F, H, F, F, 0));
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 3 * NF * sizeof(float), st));
   const int nwaves = F / 64;
@@ -308,19 +308,19 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
     NQ_TRY(nq_upd_rev(st, u, 1, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, 3 * F, F, F, 0, "V2"));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, nullptr, ws + W.GQ, nullptr, (long)NF, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
     NQ_TRY(nq_msg_rev(st, m, false));
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, nullptr, ws + W.GH, nullptr, (long)NF, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1, "W1"));
   }
   NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
   return NQ_OK;
@@ -347,28 +347,28 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     float* TZ1 = ws + y.Z1 + NF; float* TH = ws + y.Hh + NF; float* TXH = ws + y.XH + 3 * NF;
-    NQ_TRY(nq_gemm_nt(st, ws + W.X[l] + NF, params + mp.W1, TZ1, nullptr, nullptr, N, F, F, F, F, F));
+    NQ_TRY(nq_gemm_nt(st, ws + W.X[l] + NF, params + mp.W1, TZ1, nullptr, nullptr, N, F, F, F, F, F, "W1"));
     NQ_TRY(nq_silu_tan(st, ws + y.Z1, TZ1, TH, (long)NF));
-    NQ_TRY(nq_gemm_nt(st, TH, params + mp.W2, TXH, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, TH, params + mp.W2, TXH, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "W2"));
     MsgArgs m{};
     m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TX = ws + W.X[l] + NF; m.TV = ws + W.V[l] + 3 * NF; m.TXH = TXH; m.TD = ws + W.TD; m.TR = ws + W.TR;
     m.TXM = ws + y.XM + NF; m.TVM = ws + y.VM + 3 * NF;
     NQ_TRY(nq_msg_fwd(st, m, true));
-    NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.TXM = ws + y.XM + NF; u.TVM = ws + y.VM + 3 * NF; u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF;
     u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF; u.TX1 = ws + W.X[l + 1] + NF; u.TV1 = ws + W.V[l + 1] + 3 * NF;
     NQ_TRY(nq_upd_a(st, u, true));
     float* TZQ = ws + y.ZQ + NF; float* TQ = ws + y.Q + NF;
-    NQ_TRY(nq_gemm_nt(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, nullptr, nullptr, N, F, 2 * F, 2 * F, 2 * F, F));
+    NQ_TRY(nq_gemm_nt(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, nullptr, nullptr, N, F, 2 * F, 2 * F, 2 * F, F, "V1"));
     NQ_TRY(nq_silu_tan(st, ws + y.ZQ, TZQ, TQ, (long)NF));
-    NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F));
+    NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
     NQ_TRY(nq_upd_b(st, u, true));
   }
   const size_t NH = (size_t)N * H;
-  NQ_TRY(nq_gemm_nt(st, ws + W.X[L] + NF, params + P.O1, ws + W.ZO + NH, nullptr, nullptr, N, H, F, F, F, H));
+  NQ_TRY(nq_gemm_nt(st, ws + W.X[L] + NF, params + P.O1, ws + W.ZO + NH, nullptr, nullptr, N, H, F, F, F, H, "O1"));
   ReadoutArgs r{};
   r.N = N; r.H = H; r.ZO = ws + W.ZO; r.TZO = ws + W.ZO + NH; r.w2 = params + P.w2; r.o2 = params + P.o2;
   r.e_atom = ws + W.e_atom; r.te_atom = ws + W.te_atom;
@@ -384,9 +384,9 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
   NQ_TRY(nq_readout_rev(st, r, true));
   NQ_TRY(nq_colsum(st, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(st, ws + W.ge, N, 1, 1, gp + P.o2, scr));
-  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr));
+  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1"));
   NQ_TRY(nq_colsum(st, ws + W.GZO, N, H, H, gp + P.o1, scr));
-  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0));
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
   float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
@@ -399,16 +399,16 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
     u.GY = ws + W.GY; u.GTY = ws + W.GY + 3 * NF; u.GCAT = ws + W.GCAT; u.GTCAT = ws + W.GCAT + 2 * NF;
     u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
     NQ_TRY(nq_upd_rev(st, u, 1, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2"));
     NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + up.c2, scr));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2"));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1"));
     NQ_TRY(nq_colsum(st, ws + W.GQ, N, F, F, gp + up.c1, scr));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     NQ_TRY(nq_upd_rev(st, u, 2, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
@@ -417,15 +417,15 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
     m.GPHI = gphi; m.GPSI = gpsi;
     NQ_TRY(nq_msg_rev(st, m, true));
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr));
+    NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     NQ_TRY(nq_colsum(st, gphi, E, 3 * F, 3 * F, gp + mp.br, scr));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2"));
     NQ_TRY(nq_colsum(st, ws + W.GXH, N, 3 * F, 3 * F, gp + mp.b2, scr));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1"));
     NQ_TRY(nq_colsum(st, ws + W.GH, N, F, F, gp + mp.b1, scr));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
   }
   NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));
   return NQ_OK;

@@ -166,20 +166,32 @@ __global__ void k_reduce_partials(const float* __restrict__ part, int nsplit, lo
   out[i] = s;
 }
 
-// column sums of A[rows][cols] (bias gradients): partial per row-chunk, then k_reduce_partials
-__global__ void k_colsum_partial(const float* __restrict__ A, long rows, int cols, int lda, int rows_per_chunk, float* __restrict__ part) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += A[r * lda + c];
-  part[(long)blockIdx.y * cols + c] = s;
+// column sums of A[rows][cols] (bias gradients): 256 threads = 64 columns x 4 row lanes, one 2048-row chunk per
+// workgroup (coalesced 256-B row segments, 4 independent accumulators per thread), lanes combined through LDS;
+// the per-chunk partials are then summed in fixed order by k_reduce_partials -> deterministic.
+#define CS_ROWS 2048
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ A, long rows, int cols, int lda, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    long r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      s0 += A[r * lda + c]; s1 += A[(r + 4) * lda + c]; s2 += A[(r + 8) * lda + c]; s3 += A[(r + 12) * lda + c];
+    }
+    for (; r < r1; r += 4) s0 += A[r * lda + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // ---- host launchers ------------------------------------------------------------------------
 int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K,
-               int lda, int ldw, int ldc) {
-  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt_%dx%dx%d", M, N, K); else nm__[0] = 0;
+               int lda, int ldw, int ldc, const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0};
@@ -192,8 +204,8 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
 
 // C[M, Kin] (+)= G[M, Nout] * W[Nout, Kin]
 int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc,
-               int accumulate) {
-  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn_%dx%dx%d", M, Kin, Nout); else nm__[0] = 0;
+               int accumulate, const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0};
@@ -213,8 +225,9 @@ static int tn_splits(long rows) {
 }
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows) * Mo * No; }
 
-int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch) {
-  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_tn_%dx%dx%ld", Mo, No, rows); else nm__[0] = 0;
+int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
+               const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_tn:%s[%dx%d]", tag ? tag : "", Mo, No); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (rows <= 0) {
     NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Mo * No, st));
@@ -234,7 +247,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   return NQ_OK;
 }
 
-size_t nq_colsum_scratch_floats(long rows, int cols) { return (size_t)nq_cdiv(rows, 1024) * cols; }
+size_t nq_colsum_scratch_floats(long rows, int cols) { return (size_t)nq_cdiv(rows, CS_ROWS) * cols; }
 
 int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, float* out, float* scratch) {
   NQ_PROF(st, "colsum");
@@ -242,8 +255,8 @@ int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, floa
     NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
     return NQ_OK;
   }
-  const int chunks = nq_cdiv(rows, 1024);
-  hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(64), 0, st, A, rows, cols, lda, 1024, scratch);
+  const int chunks = nq_cdiv(rows, CS_ROWS);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(256), 0, st, A, rows, cols, lda, scratch);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cols, 256)), dim3(256), 0, st, scratch, chunks, (long)cols, (long)cols, out);
   NQ_LAUNCH_CHECK();

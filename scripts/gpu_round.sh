@@ -16,10 +16,11 @@ echo "== bench"
 timeout 900 python bench.py --steps 5 --warmup 2 --batch $BATCH 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
 echo "== rocprof"
 rm -rf gpurun_out/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o painn -- python bench.py --steps 3 --warmup 1 --batch $BATCH --no-cpu-baseline --no-roofline > gpurun_out/rocprof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o painn -- python bench.py --steps 3 --warmup 1 --batch $BATCH --no-cpu-baseline --no-roofline > gpurun_out/rocprof_$TAG.log 2>&1
 find gpurun_out/prof_$TAG -name "*kernel_stats*" | head -3
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats*.csv" | head -1)
 [ -n "$f" ] && head -25 "$f"
 # keep only the small summaries
 find gpurun_out/prof_$TAG -type f ! -name "*stats*" -size +2M -delete
+echo "== kernel events"; cat gpurun_out/kernel_events.txt 2>/dev/null | head -50
 echo "== trace reports"; tail -n 8 gpurun_out/trace_*.txt 2>/dev/null
