@@ -107,6 +107,7 @@ struct MsgRevArgs {
   float* GV_out; float* GTV_out;                                             // out: gvec_msg + scatter part   [N][3F]
   float* GPHI; float* GPSI;                                                  // dual out: [E][3F] each
   float4* GEDGE;                                                             // force mode: [nwaves][E] {gd, grx, gry, grz} (+=)
+  float* GBR;                                                                // dual out: [N][3F] per-atom sums of gphi (bias gradient partials)
 };
 
 struct UpdArgs {

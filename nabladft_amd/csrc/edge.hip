@@ -114,6 +114,7 @@ __global__ void k_msg_rev(MsgRevArgs q) {
   }
   float gxa = 0.f, gxb = 0.f, gxc = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;        // adjoints of xh[n], vec[n]
   float gtxa = 0.f, gtxb = 0.f, gtxc = 0.f, gtv0 = 0.f, gtv1 = 0.f, gtv2 = 0.f;  // adjoints of t_xh[n], t_vec[n]
+  float sba = 0.f, sbb = 0.f, sbc = 0.f;                                            // sum over this atom's edges of gphi
   for (int sp = beg; sp < end; ++sp) {
     const int k = q.g.col[sp];                       // target of the out-edge (n -> k)
     const float4 gm = q.g.geom[sp];
@@ -146,7 +147,9 @@ __global__ void k_msg_rev(MsgRevArgs q) {
       gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
       float* gp = q.GPHI + (long)sp * F3;
       float* gs = q.GPSI + (long)sp * F3;
-      gp[f] = gma * xa + gtma * txa; gp[F + f] = gmb * xb + gtmb * txb; gp[2 * F + f] = gmc * xc + gtmc * txc;
+      const float ga = gma * xa + gtma * txa, gb = gmb * xb + gtmb * txb, gc = gmc * xc + gtmc * txc;
+      gp[f] = ga; gp[F + f] = gb; gp[2 * F + f] = gc;
+      sba += ga; sbb += gb; sbc += gc;
       gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
     } else {
       gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
@@ -169,6 +172,7 @@ __global__ void k_msg_rev(MsgRevArgs q) {
   q.GV_out[o3 + 2 * F + f] = q.GV[o3 + 2 * F + f] + gv2;
   if (DUAL) {
     q.GTXH[o3 + f] = gtxa; q.GTXH[o3 + F + f] = gtxb; q.GTXH[o3 + 2 * F + f] = gtxc;
+    q.GBR[o3 + f] = sba; q.GBR[o3 + F + f] = sbb; q.GBR[o3 + 2 * F + f] = sbc;
     q.GTV_out[o3 + f] = q.GTV[o3 + f] + gtv0;
     q.GTV_out[o3 + F + f] = q.GTV[o3 + F + f] + gtv1;
     q.GTV_out[o3 + 2 * F + f] = q.GTV[o3 + 2 * F + f] + gtv2;

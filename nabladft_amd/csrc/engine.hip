@@ -414,11 +414,11 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
     m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
-    m.GPHI = gphi; m.GPSI = gpsi;
+    m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
     NQ_TRY(nq_msg_rev(st, m, true));
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
     NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
-    NQ_TRY(nq_colsum(st, gphi, E, 3 * F, 3 * F, gp + mp.br, scr));
+    NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
     NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2"));
     NQ_TRY(nq_colsum(st, ws + W.GXH, N, 3 * F, 3 * F, gp + mp.b2, scr));
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));

@@ -161,9 +161,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
 __global__ void k_reduce_partials(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += part[(long)k * stride + i];
-  out[i] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nsplit; k += 4) {  // 4 independent loads in flight; the combination order is fixed
+    s0 += part[(long)k * stride + i]; s1 += part[(long)(k + 1) * stride + i];
+    s2 += part[(long)(k + 2) * stride + i]; s3 += part[(long)(k + 3) * stride + i];
+  }
+  for (; k < nsplit; ++k) s0 += part[(long)k * stride + i];
+  out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // column sums of A[rows][cols] (bias gradients): 256 threads = 64 columns x 4 row lanes, one 2048-row chunk per
@@ -217,13 +222,18 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 }
 
 // out[Mo, No] = sum_{r<rows} GY[r, Mo] * X[r, No];  scratch must hold nq_gemm_tn_scratch_floats()
-static int tn_splits(long rows) {
-  long s = (rows + 2047) / 2048;
+// Split count for the weight-gradient contraction: enough workgroups to fill 256 CUs (~768) given the number
+// of 128x128 output tiles, but at least 512 rows per split so the 64-KB partial slab stays amortised.
+static int tn_splits(long rows, int Mo, int No) {
+  const long tiles = (long)nq_cdiv(Mo, BM) * nq_cdiv(No, BN);
+  long s = (768 + tiles - 1) / tiles;
+  const long by_rows = (rows + 511) / 512;
+  if (s > by_rows) s = by_rows;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
   return (int)s;
 }
-size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows) * Mo * No; }
+size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No) * Mo * No; }
 
 int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
                const char* tag) {
@@ -234,7 +244,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
     return NQ_OK;
   }
   if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
-  const int ns = tn_splits(rows);
+  const int ns = tn_splits(rows, Mo, No);
   int kper = (int)((rows + ns - 1) / ns);
   kper = (kper + BK - 1) / BK * BK;
   GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No};
@@ -242,7 +252,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL>), grid, dim3(GEMM_THREADS), 0, st, p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 256)), dim3(256), 0, st, scratch, ns, cnt, cnt, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -98,7 +98,7 @@ class _EnergyForces(torch.autograd.Function):
         flat = model._flat
         dev = flat.device
         ws_bytes = lib.nq_painn_workspace_bytes(C.byref(model._cfg), nl.N, nl.E, nl.B)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        ws = model._take_workspace(ws_bytes, dev)
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32) if want_forces else None
         _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c),
@@ -120,6 +120,7 @@ class _EnergyForces(torch.autograd.Function):
         _lib.check(lib.nq_painn_backward(C.byref(model._cfg), _lib.ptr(flat), C.byref(nl.c), _lib.ptr(ctx.ws), ctx.ws_bytes,
                                          _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_flat), _lib.stream_ptr()))
         model._last_grad_flat = grad_flat
+        model._release_workspace(ctx.ws)
         grads = tuple(grad_flat[o:o + n].view(s) for (o, n, s) in model._param_slices)
         return (None, None, None) + grads
 
@@ -229,6 +230,7 @@ class PaiNN(nn.Module):
         self._flat = None
         self._param_slices = None
         self._last_ws = self._last_nl = self._last_grad_flat = None
+        self._ws_cache, self._ws_busy = None, False
         cfg = _lib.PainnCfg()
         cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = hidden_channels, num_layers, num_rbf, num_elements
         cfg.max_neighbors, cfg.envelope_exponent = max_neighbors, self.radial_basis.exponent
@@ -243,8 +245,9 @@ class PaiNN(nn.Module):
     def __getstate__(self):
         # transient engine handles (device pointers) are rebuilt lazily; keep copies/pickles clean
         state = self.__dict__.copy()
-        for k in ("_flat", "_param_slices", "_last_ws", "_last_nl", "_last_grad_flat"):
+        for k in ("_flat", "_param_slices", "_last_ws", "_last_nl", "_last_grad_flat", "_ws_cache"):
             state[k] = None
+        state["_ws_busy"] = False
         return state
 
     # ---- flat parameter buffer (state_dict order) the C ABI consumes -------------------------------
@@ -271,6 +274,23 @@ class PaiNN(nn.Module):
                 raise RuntimeError(f"parameter count {o} != engine layout {expect}")
             self._flat, self._param_slices = flat, slices
         return self._flat
+
+    # ---- workspace cache: one grow-only buffer, handed out again once the backward that owns it has run ----
+    def _take_workspace(self, nbytes, dev):
+        ws = self._ws_cache
+        if ws is not None and not self._ws_busy and ws.device == dev and ws.numel() >= nbytes:
+            self._ws_busy = torch.is_grad_enabled()
+            return ws
+        if not self._ws_busy:
+            self._ws_cache = None                                      # drop the old buffer before growing
+            self._ws_cache = torch.empty(int(nbytes * 1.08) + 4096, device=dev, dtype=torch.uint8)
+            self._ws_busy = torch.is_grad_enabled()
+            return self._ws_cache
+        return torch.empty(nbytes, device=dev, dtype=torch.uint8)     # a second forward before the pending backward
+
+    def _release_workspace(self, ws):
+        if ws is self._ws_cache:
+            self._ws_busy = False
 
     # ---- reference API -----------------------------------------------------------------------------------
     def generate_graph_values(self, data):

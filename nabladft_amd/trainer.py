@@ -41,6 +41,7 @@ class FusedTrainStep:
         self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.t = 0
         self.energy = self.forces = None
+        self._ws = None   # persistent, grow-only workspace (forward+backward finish inside one call, so reuse is safe)
 
     def __call__(self, batch, update=True):
         lib = _lib.load()
@@ -53,7 +54,10 @@ class FusedTrainStep:
             raise IndexError("batch has no edges within the cutoff")
         dev = flat.device
         ws_bytes = lib.nq_painn_workspace_bytes(cfg, nl.N, nl.E, nl.B)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        if self._ws is None or self._ws.numel() < ws_bytes:
+            self._ws = None                                            # release before growing (27 GB at B=1024)
+            self._ws = torch.empty(int(ws_bytes * 1.08) + 4096, device=dev, dtype=torch.uint8)
+        ws = self._ws
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32)
         gE, gF = torch.empty_like(energy), torch.empty_like(forces)

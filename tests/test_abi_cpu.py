@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nablaq.h declares; host-side logic
+(parameter layout, config struct, workspace sizing, state_dict surface, error paths) without any compute."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import painn_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nabladft_amd.build import build
+    build(verbose=False)
+    from nabladft_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from nabladft_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nablaq.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nq_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/nablaq.h but not exported by libnablaq.so"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert lib.nq_abi_version() == 1
+
+
+def test_param_layout_matches_reference_state_dict(lib):
+    import nabladft_amd as nq
+    cfg = R.PaiNNConfig()
+    m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": "gaussian"},
+                 {"name": "polynomial", "exponent": 5}, True, False, False, True, cfg.num_elements)
+    names = [(k, tuple(p.shape)) for k, p in m.named_parameters()]
+    assert names == R.param_shapes(cfg)                       # == reference named_parameters (asserted in make_golden.py)
+    assert m.num_params == 1341313 == lib.nq_painn_num_params(C.byref(m._cfg))
+    sd = m.state_dict()
+    assert len(sd) == 72 and "radial_basis.rbf.offset" in sd
+    assert torch.equal(sd["radial_basis.rbf.offset"], torch.linspace(0, 1, 100))
+    # flat buffer: parameters become views in state_dict order, load_state_dict writes through
+    flat = m.flat_parameters()
+    assert flat.numel() == 1341313
+    params = R.make_params(cfg, seed=23)
+    m.load_state_dict(params, strict=False)
+    assert m.flat_parameters().data_ptr() == flat.data_ptr()
+    assert torch.equal(flat, torch.cat([params[k].reshape(-1) for k, _ in names]))
+
+
+def test_workspace_and_lookup(lib):
+    import nabladft_amd as nq
+    m = nq.PaiNN(64, 2, 20, 3.0, 6, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100)
+    cfg = C.byref(m._cfg)
+    total = lib.nq_painn_workspace_bytes(cfg, 100, 900, 4)
+    assert total > 0 and total % 16 == 0
+    off, cnt = C.c_size_t(), C.c_size_t()
+    seen = []
+    for name, lay, tan in [("x_in", 0, 0), ("x_in", 2, 1), ("vec_msg", 1, 0), ("phi", 0, 0), ("rho", 0, 1), ("zo", 0, 0), ("gedge", 0, 0)]:
+        assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, name.encode(), lay, tan, C.byref(off), C.byref(cnt)) == 0
+        assert (off.value + cnt.value) * 4 <= total and off.value % 4 == 0
+        seen.append((off.value, cnt.value))
+    assert len(set(seen)) == len(seen)
+    assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"nonsense", 0, 0, C.byref(off), C.byref(cnt)) != 0
+    assert b"unknown workspace buffer" in lib.nq_last_error()
+    assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 1, C.byref(off), C.byref(cnt)) != 0   # no tangent half
+
+
+def test_unsupported_configs_fail_loudly():
+    import nabladft_amd as nq
+    kw = dict(rbf={"name": "gaussian"}, envelope={"name": "polynomial", "exponent": 5}, regress_forces=True, direct_forces=False,
+              use_pbc=False, otf_graph=True, num_elements=100)
+    with pytest.raises(ValueError):
+        nq.PaiNN(100, 6, 100, 5.0, 100, **kw)                # hidden_channels not a multiple of 64
+    with pytest.raises(NotImplementedError):
+        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "rbf": {"name": "spherical_bessel"}})
+    with pytest.raises(NotImplementedError):
+        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "use_pbc": True})
+    with pytest.raises(NotImplementedError):
+        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "direct_forces": True})
+    m = nq.PaiNN(128, 1, 100, 5.0, 100, **kw)
+    pos, z, batch, _, _ = R.gen_conformers(0, 1, size=5)
+    with pytest.raises(RuntimeError, match="MI355X only"):      # no CPU fallback
+        m(nq.Batch(pos, z, batch))
+
+
+def test_bad_cfg_rejected_by_abi(lib):
+    from nabladft_amd import _lib
+    cfg = _lib.PainnCfg()
+    cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = 96, 6, 100, 100
+    assert lib.nq_painn_num_params(C.byref(cfg)) == 0
+    assert lib.nq_painn_workspace_bytes(C.byref(cfg), 10, 10, 1) == 0

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the N>1 path (flat-gradient mean all-reduce, parameter broadcast, conformer
+sharding).  Each rank computes the ORACLE's gradient on its shard; the all-reduced mean must equal the mean of the
+two single-process results -- the data-parallel semantics of the reference (Lightning DDP, utils/pipelines.py:65-68)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nabladft_amd import dist as nqdist
+from oracle import painn_ref as R
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _shard_grad(cfg, params, shard_ids, pos, z, batch, y, ft):
+    sel = torch.isin(batch, torch.tensor(shard_ids))
+    remap = {m: i for i, m in enumerate(shard_ids)}
+    b = torch.tensor([remap[int(m)] for m in batch[sel]])
+    _, _, loss, g = R.train_step(params, cfg, pos[sel], z[sel], b, y[shard_ids], ft[sel])
+    return loss, torch.cat([g[k].reshape(-1) for k, _ in R.param_shapes(cfg)])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    r, w, _ = nqdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=12, cutoff=4.0)
+    pos, z, batch, y, ft = R.gen_conformers(5, 6, size=(6, 16))
+    sizes = torch.bincount(batch).tolist()
+    shards = nqdist.shard_by_cost(sizes, world)
+    # rank 0's parameters win (broadcast), like DDP at wrap time
+    params = R.make_params(cfg, seed=100 + rank)
+    flat = torch.cat([params[k].reshape(-1) for k, _ in R.param_shapes(cfg)])
+    nqdist.broadcast_(flat, 0)
+    o = 0
+    for k, shp in R.param_shapes(cfg):
+        n = int(np.prod(shp))
+        params[k] = flat[o:o + n].view(shp).clone()
+        o += n
+    _, g = _shard_grad(cfg, params, shards[rank], pos, z, batch, y, ft)
+    nqdist.allreduce_mean_(g)
+    torch.save({"g": g, "flat": flat, "shards": shards}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_mean_matches_single_process(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["flat"], r1["flat"])
+    cfg = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=12, cutoff=4.0)
+    params = R.make_params(cfg, seed=100)
+    assert torch.equal(r0["flat"], torch.cat([params[k].reshape(-1) for k, _ in R.param_shapes(cfg)]))
+    pos, z, batch, y, ft = R.gen_conformers(5, 6, size=(6, 16))
+    gs = [_shard_grad(cfg, params, s, pos, z, batch, y, ft)[1] for s in r0["shards"]]
+    expect = (gs[0] + gs[1]) / 2
+    assert float((r0["g"] - expect).abs().max()) <= 1e-6 * float(expect.abs().max())
+
+
+def test_shard_by_cost_balanced_and_complete():
+    rng = np.random.Generator(np.random.PCG64(0))
+    sizes = rng.integers(10, 91, size=257).tolist()
+    for world in (1, 2, 4, 8):
+        shards = nqdist.shard_by_cost(sizes, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(sizes)))
+        load = [sum(sizes[i] ** 2 for i in s) for s in shards]
+        assert max(load) <= 1.05 * (sum(load) / world) + 90 * 90
+        assert all(s == sorted(s) for s in shards)
