@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 1
+#define NQ_ABI_VERSION 2
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -98,8 +98,8 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
                      size_t workspace_bytes, float* energy, float* forces, void* stream);
 /* Given dL/dE[B] and dL/dF[N][3] (either may be NULL = zeros) writes dL/dparams[num_params] (overwrites).
  * Must follow nq_painn_forward (with forces) on the same workspace and graph. */
-int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_graph* graph, void* workspace, size_t workspace_bytes,
-                      const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
+int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                      size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
 /* Test/inspection hook: offset (in floats) and element count of a named workspace buffer, e.g.
  * ("x_msg", 2, tangent=0).  Returns NQ_ERR_ARG for unknown names. */
 int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t layer, int32_t tangent,

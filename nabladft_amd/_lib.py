@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnablaq.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -39,7 +39,7 @@ SYMBOLS = {
     "nq_painn_num_params": (_SZ, [C.POINTER(PainnCfg)]),
     "nq_painn_workspace_bytes": (_SZ, [C.POINTER(PainnCfg), _I32, _I32, _I32]),
     "nq_painn_forward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
-    "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
+    "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
     "nq_painn_ws_lookup": (C.c_int, [C.POINTER(PainnCfg), _I32, _I32, _I32, C.c_char_p, _I32, _I32, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

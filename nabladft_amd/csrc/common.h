@@ -97,6 +97,15 @@ struct MsgArgs {
   float* TXM; float* TVM;
 };
 
+// in-kernel radial filter: phi = br + Wr rho(d), psi = Wr drho(d) evaluated from an LDS-resident transposed Wr
+struct FilterArgs {
+  const float* WRT;   // [R][3F] = rbf_proj.weight^T (written once per forward by k_transpose)
+  const float* br;    // [3F]
+  const float* mu;    // [R] GaussianSmearing offsets
+  int R;
+  float inv_cutoff, p, a, b, c, coeff;
+};
+
 struct MsgRevArgs {
   NqGraphView g; int F;
   const float* V; const float* XH; const float* PHI; const float* PSI;      // primal, layer input side
@@ -156,6 +165,11 @@ int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, 
 int nq_rbf(hipStream_t, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets, float* rho,
            float* drho);
 int nq_msg_fwd(hipStream_t, const MsgArgs&, bool tangent);
+bool nq_filter_fits_lds(int F, int R);
+void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, int R, double cutoff, int env_p, float coeff);
+int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
+int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
+int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual);
 int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);
 int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* pos_dot, float* TD, float* TR);
 int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);

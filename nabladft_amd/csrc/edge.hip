@@ -179,6 +179,224 @@ __global__ void k_msg_rev(MsgRevArgs q) {
   }
 }
 
+
+// =============================================================================================
+// Fused message kernels: the radial filter is evaluated inside the kernel.
+//
+// GaussianSmearing(0,1,R) has sigma = Delta = 1/(R-1): a basis function k contributes
+// exp(-0.5 ((d/rc - mu_k)/Delta)^2) < 7e-10 once it is more than 6.5 Delta away, i.e. below fp32
+// resolution of the sum.  So per edge only the WIN = 13 Gaussians around the nearest centre are
+// evaluated: phi_e[f] = br[f] + sum_{t<13} WrT[k0+t][f] rho_{k0+t}(d_e)  (13 FMAs per output instead of a
+// K=100 GEMM, 7.7x fewer flops) and phi/psi never touch HBM.
+//
+// Mapping: one persistent 1024-thread workgroup per CU keeps WrT (R x 3F fp32 = 153.6 kB at F=128,R=100)
+// resident in the 160-kB LDS; the workgroup's 1024/F node slots (2 wavefronts each at F=128) walk CSR
+// rows.  Per edge, lane t < 13 of every wavefront evaluates rho/drho for basis k0+t (one expf per wave
+// and edge), v_readlane broadcasts them as scalars, and each thread reads its WrT column entries with
+// conflict-free ds_read_b32 (consecutive channels -> consecutive banks).
+// =============================================================================================
+#define FWIN 13
+#define FUSED_THREADS 1024
+#define FUSED_THREADS_DUAL 768   // the dual reverse needs ~150 VGPRs: 12 waves per CU instead of 16, no spills
+
+__device__ __forceinline__ float bcast_lane(float v, int t) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
+}
+
+// window start and this lane's basis values (lane t <-> basis k0 + t)
+__device__ __forceinline__ void rbf_window(const FilterArgs& fa, float d, int lane, int& k0, int& nwin, float& rl, float& drl) {
+  const float ds = d * fa.inv_cutoff;
+  const int R = fa.R;
+  nwin = R < FWIN ? R : FWIN;
+  int kc = (int)rintf(ds * (float)(R - 1));
+  kc = min(max(kc, 0), R - 1);
+  k0 = min(max(kc - FWIN / 2, 0), R - nwin);
+  rl = 0.f; drl = 0.f;
+  if (lane < nwin) {
+    float env = 0.f, denv = 0.f;
+    if (ds < 1.0f) {
+      const float pm1 = powf(ds, fa.p - 1.0f);
+      const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
+      env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
+      denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
+    }
+    const float diff = ds - fa.mu[k0 + lane];
+    const float g = expf(fa.coeff * (diff * diff));
+    rl = env * g;
+    drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
+  }
+}
+
+#define FILTER_EVAL(WITH_PSI)                                                                  \
+  float pa = bra, pb = brb, pc = brc, qa = 0.f, qb = 0.f, qc = 0.f;                            \
+  {                                                                                            \
+    int k0, nwin; float rl, drl;                                                               \
+    rbf_window(fa, gm.w, lane, k0, nwin, rl, drl);                                             \
+    const float* wk = wrt + (long)k0 * F3 + f;                                                 \
+    _Pragma("unroll") for (int t = 0; t < FWIN; ++t) {                                         \
+      if (t < nwin) {                                                                          \
+        const float r = bcast_lane(rl, t);                                                     \
+        const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];             \
+        pa = fmaf(wa, r, pa); pb = fmaf(wb, r, pb); pc = fmaf(wc, r, pc);                      \
+        if (WITH_PSI) {                                                                        \
+          const float dr = bcast_lane(drl, t);                                                 \
+          qa = fmaf(wa, dr, qa); qb = fmaf(wb, dr, qb); qc = fmaf(wc, dr, qc);                 \
+        }                                                                                      \
+      }                                                                                        \
+    }                                                                                          \
+  }
+
+#define FUSED_PROLOGUE                                                                          \
+  extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
+  const int F = q.F, F3 = 3 * q.F;                                                             \
+  {                                                                                            \
+    const int total4 = (fa.R * F3) >> 2;                                                       \
+    const float4* src = reinterpret_cast<const float4*>(fa.WRT);                               \
+    float4* dst4 = reinterpret_cast<float4*>(wrt);                                             \
+    for (int i = threadIdx.x; i < total4; i += blockDim.x) dst4[i] = src[i];                   \
+  }                                                                                            \
+  __syncthreads();                                                                             \
+  const int nslots = blockDim.x / F, slot = threadIdx.x / F, f = threadIdx.x % F;              \
+  const int lane = threadIdx.x & 63;                                                           \
+  const float bra = fa.br[f], brb = fa.br[F + f], brc = fa.br[2 * F + f];
+
+template <bool TAN>
+__global__ __launch_bounds__(FUSED_THREADS) void k_msgf_fwd(MsgArgs q, FilterArgs fa) {
+  FUSED_PROLOGUE
+  for (int n = blockIdx.x * nslots + slot; n < q.g.N; n += gridDim.x * nslots) {
+    const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+    float dx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int sp = beg; sp < end; ++sp) {
+      const int k = q.g.col[sp];
+      const float4 gm = q.g.geom[sp];
+      FILTER_EVAL(TAN)
+      const float* xh = q.XH + (long)k * F3;
+      const float* vk = q.V + (long)k * F3;
+      const float xa = xh[f], xb = xh[F + f], xc = xh[2 * F + f];
+      const float mb = xb * pb, mc = xc * pc;
+      if (!TAN) {
+        dx += xa * pa;
+        d0 += vk[f] * mb + mc * gm.x;
+        d1 += vk[F + f] * mb + mc * gm.y;
+        d2 += vk[2 * F + f] * mb + mc * gm.z;
+      } else {
+        const float td = q.TD[sp];
+        const float tr0 = q.TR[3 * (long)sp], tr1 = q.TR[3 * (long)sp + 1], tr2 = q.TR[3 * (long)sp + 2];
+        const float* txh = q.TXH + (long)k * F3;
+        const float* tvk = q.TV + (long)k * F3;
+        const float tma = txh[f] * pa + xa * (qa * td);
+        const float tmb = txh[F + f] * pb + xb * (qb * td);
+        const float tmc = txh[2 * F + f] * pc + xc * (qc * td);
+        dx += tma;
+        d0 += tvk[f] * mb + vk[f] * tmb + tmc * gm.x + mc * tr0;
+        d1 += tvk[F + f] * mb + vk[F + f] * tmb + tmc * gm.y + mc * tr1;
+        d2 += tvk[2 * F + f] * mb + vk[2 * F + f] * tmb + tmc * gm.z + mc * tr2;
+      }
+    }
+    const long o = (long)n * F, o3 = (long)n * F3;
+    if (!TAN) {
+      q.XM[o + f] = q.X[o + f] + dx;
+      q.VM[o3 + f] = q.V[o3 + f] + d0; q.VM[o3 + F + f] = q.V[o3 + F + f] + d1; q.VM[o3 + 2 * F + f] = q.V[o3 + 2 * F + f] + d2;
+    } else {
+      q.TXM[o + f] = q.TX[o + f] + dx;
+      q.TVM[o3 + f] = q.TV[o3 + f] + d0; q.TVM[o3 + F + f] = q.TV[o3 + F + f] + d1; q.TVM[o3 + 2 * F + f] = q.TV[o3 + 2 * F + f] + d2;
+    }
+  }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_msgf_rev(MsgRevArgs q, FilterArgs fa) {
+  FUSED_PROLOGUE
+  const int wave_in_slot = (threadIdx.x % F) >> 6;
+  for (int n = blockIdx.x * nslots + slot; n < q.g.N; n += gridDim.x * nslots) {
+    const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+    const long o3 = (long)n * F3;
+    const float xa = q.XH[o3 + f], xb = q.XH[o3 + F + f], xc = q.XH[o3 + 2 * F + f];
+    const float v0 = q.V[o3 + f], v1 = q.V[o3 + F + f], v2 = q.V[o3 + 2 * F + f];
+    float txa = 0.f, txb = 0.f, txc = 0.f, tv0 = 0.f, tv1 = 0.f, tv2 = 0.f;
+    if (DUAL) {
+      txa = q.TXH[o3 + f]; txb = q.TXH[o3 + F + f]; txc = q.TXH[o3 + 2 * F + f];
+      tv0 = q.TV[o3 + f]; tv1 = q.TV[o3 + F + f]; tv2 = q.TV[o3 + 2 * F + f];
+    }
+    float gxa = 0.f, gxb = 0.f, gxc = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
+    float gtxa = 0.f, gtxb = 0.f, gtxc = 0.f, gtv0 = 0.f, gtv1 = 0.f, gtv2 = 0.f;
+    float sba = 0.f, sbb = 0.f, sbc = 0.f;
+    for (int sp = beg; sp < end; ++sp) {
+      const int k = q.g.col[sp];
+      const float4 gm = q.g.geom[sp];
+      const float r0 = -gm.x, r1 = -gm.y, r2 = -gm.z;
+      FILTER_EVAL(true)
+      const float* A = q.GV + (long)k * F3;
+      const float A0 = A[f], A1 = A[F + f], A2 = A[2 * F + f];
+      const float gma = q.GX[(long)k * F + f];
+      const float mb = xb * pb, mc = xc * pc;
+      float gmb = A0 * v0 + A1 * v1 + A2 * v2;
+      float gmc = A0 * r0 + A1 * r1 + A2 * r2;
+      gv0 += A0 * mb; gv1 += A1 * mb; gv2 += A2 * mb;
+      if (DUAL) {
+        const float td = q.TD[sp];
+        const float tr0 = -q.TR[3 * (long)sp], tr1 = -q.TR[3 * (long)sp + 1], tr2 = -q.TR[3 * (long)sp + 2];
+        const float tpa = qa * td, tpb = qb * td, tpc = qc * td;
+        const float* T = q.GTV + (long)k * F3;
+        const float T0 = T[f], T1 = T[F + f], T2 = T[2 * F + f];
+        const float gtma = q.GTX[(long)k * F + f];
+        const float tmb = txb * pb + xb * tpb;
+        gmb += T0 * tv0 + T1 * tv1 + T2 * tv2;
+        const float gtmb = T0 * v0 + T1 * v1 + T2 * v2;
+        gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
+        const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
+        gv0 += T0 * tmb; gv1 += T1 * tmb; gv2 += T2 * tmb;
+        gtv0 += T0 * mb; gtv1 += T1 * mb; gtv2 += T2 * mb;
+        gxa += gma * pa + gtma * tpa; gxb += gmb * pb + gtmb * tpb; gxc += gmc * pc + gtmc * tpc;
+        gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
+        float* gp = q.GPHI + (long)sp * F3;
+        float* gs = q.GPSI + (long)sp * F3;
+        const float ga = gma * xa + gtma * txa, gb = gmb * xb + gtmb * txb, gc = gmc * xc + gtmc * txc;
+        gp[f] = ga; gp[F + f] = gb; gp[2 * F + f] = gc;
+        sba += ga; sbb += gb; sbc += gc;
+        gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
+      } else {
+        gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
+        float gd = gma * xa * qa + gmb * xb * qb + gmc * xc * qc;
+        float e0 = A0 * mc, e1 = A1 * mc, e2 = A2 * mc;
+        gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
+        if (lane == 0) {
+          float4* dstp = q.GEDGE + (long)wave_in_slot * q.g.E + sp;
+          float4 acc = *dstp;
+          acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
+          *dstp = acc;
+        }
+      }
+    }
+    q.GXH[o3 + f] = gxa; q.GXH[o3 + F + f] = gxb; q.GXH[o3 + 2 * F + f] = gxc;
+    q.GV_out[o3 + f] = q.GV[o3 + f] + gv0;
+    q.GV_out[o3 + F + f] = q.GV[o3 + F + f] + gv1;
+    q.GV_out[o3 + 2 * F + f] = q.GV[o3 + 2 * F + f] + gv2;
+    if (DUAL) {
+      q.GTXH[o3 + f] = gtxa; q.GTXH[o3 + F + f] = gtxb; q.GTXH[o3 + 2 * F + f] = gtxc;
+      q.GBR[o3 + f] = sba; q.GBR[o3 + F + f] = sbb; q.GBR[o3 + 2 * F + f] = sbc;
+      q.GTV_out[o3 + f] = q.GTV[o3 + f] + gtv0;
+      q.GTV_out[o3 + F + f] = q.GTV[o3 + F + f] + gtv1;
+      q.GTV_out[o3 + 2 * F + f] = q.GTV[o3 + 2 * F + f] + gtv2;
+    }
+  }
+}
+
+// out[c][r] = in[r][c]  (rbf_proj.weight [3F][R] -> WrT [R][3F]); 32x32 LDS tile, coalesced both ways
+__global__ void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) out[(long)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // geometry tangent: t_d = r . (pd[src] - pd[dst]);  t_r = ((pd[src]-pd[dst]) - r t_d) / d      (per CSR slot)
 __global__ void k_geom_tan(NqGraphView g, const int* __restrict__ dst, const float* __restrict__ pd, float* __restrict__ TD,
@@ -273,6 +491,63 @@ int nq_geom_tan(hipStream_t st, const NqGraphView& g, const int* dst, const floa
 int nq_geom_rev(hipStream_t st, const NqGraphView& g, const float4* GEDGE, int nwaves, float* forces) {
   NQ_PROF(st, "geom_rev");
   hipLaunchKernelGGL(k_geom_rev, dim3(nq_cdiv(g.N, 128)), dim3(128), 0, st, g, GEDGE, nwaves, forces);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// ---- fused-filter launchers ------------------------------------------------------------------
+bool nq_filter_fits_lds(int F, int R) { return (size_t)R * 3 * F * sizeof(float) <= 156 * 1024 && FUSED_THREADS_DUAL / F >= 1; }
+
+void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, int R, double cutoff, int env_p, float coeff) {
+  const double p = env_p;
+  fa->WRT = WRT; fa->br = br; fa->mu = mu; fa->R = R; fa->inv_cutoff = (float)(1.0 / cutoff);
+  fa->p = (float)p; fa->a = (float)(-(p + 1) * (p + 2) / 2); fa->b = (float)(p * (p + 2)); fa->c = (float)(-p * (p + 1) / 2);
+  fa->coeff = coeff;
+}
+
+int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out) {
+  NQ_PROF(st, "transpose");
+  hipLaunchKernelGGL(k_transpose, dim3(nq_cdiv(cols, 32), nq_cdiv(rows, 32)), dim3(32, 8), 0, st, in, rows, cols, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
+  const int nslots = max_threads / F;
+  *threads = nslots * F;
+  *lds = (size_t)R * 3 * F * sizeof(float);
+  int blocks = nq_cdiv(N, nslots);
+  return blocks < 256 ? blocks : 256;   // one persistent workgroup per CU (LDS-limited to 1 per CU anyway)
+}
+
+int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tangent) {
+  NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
+  if (q.g.N <= 0) return NQ_OK;
+  int threads; size_t lds;
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R);
+  if (tangent) {
+    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_msgf_fwd<true>), dim3(grid), dim3(threads), lds, st, q, fa);
+  } else {
+    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_msgf_fwd<false>), dim3(grid), dim3(threads), lds, st, q, fa);
+  }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool dual) {
+  NQ_PROF(st, dual ? "msgf_rev_dual" : "msgf_rev_force");
+  if (q.g.N <= 0) return NQ_OK;
+  int threads; size_t lds;
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, dual ? FUSED_THREADS_DUAL : FUSED_THREADS);
+  if (dual) {
+    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_msgf_rev<true>), dim3(grid), dim3(threads), lds, st, q, fa);
+  } else {
+    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_msgf_rev<false>), dim3(grid), dim3(threads), lds, st, q, fa);
+  }
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

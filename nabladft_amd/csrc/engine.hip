@@ -5,6 +5,7 @@
 // Every dual-capable buffer is stored stacked [2][rows][width] (primal, tangent) so that the second-
 // order sweep runs each GEMM once over 2x the rows and each weight gradient as ONE contraction.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/nablaq.h"
@@ -75,6 +76,7 @@ static int make_param_layout(const nq_painn_cfg* c, ParamLayout* P) {
 // ---- workspace layout ------------------------------------------------------------------------
 struct WsLayer {
   size_t Z1, Hh, XH, PHI, PSI, XM, VM, UU, S, CAT, ZQ, Q, Y;  // float offsets; dual buffers hold [2][rows][w]
+  size_t WRT;                                                  // [R][3F] transposed rbf_proj.weight
 };
 struct WsLayout {
   size_t X[65], V[65];
@@ -82,18 +84,26 @@ struct WsLayout {
   size_t RHO2, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
   size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
   size_t scratch_floats, total_floats;
+  bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
 };
 static size_t a4(size_t x) { return (x + 3) & ~(size_t)3; }  // keep every buffer 16-byte aligned
 
+static bool use_fused_filter(const nq_painn_cfg* c) {
+  const char* off = getenv("NQ_NO_FUSED_FILTER");
+  return nq_filter_fits_lds(c->hidden_channels, c->num_rbf) && !(off && off[0] == '1');
+}
+
 static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, WsLayout* W) {
   const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, L = c->num_layers, T = c->num_elements;
+  W->fused = use_fused_filter(c);
+  const size_t EP = W->fused ? 0 : E;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += a4(n); return r; };
   for (size_t l = 0; l <= L; ++l) { W->X[l] = take(2 * N * F); W->V[l] = take(2 * N * 3 * F); }
   for (size_t l = 0; l < L; ++l) {
     WsLayer& y = W->lay[l];
     y.Z1 = take(2 * N * F); y.Hh = take(2 * N * F); y.XH = take(2 * N * 3 * F);
-    y.PHI = take(E * 3 * F); y.PSI = take(E * 3 * F);
+    y.PHI = take(EP * 3 * F); y.PSI = take(EP * 3 * F); y.WRT = take(R * 3 * F);
     y.XM = take(2 * N * F); y.VM = take(2 * N * 3 * F); y.UU = take(2 * N * 6 * F);
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
   }
@@ -224,8 +234,11 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
   else if (!strcmp(name, "z1")) { LAYER_OK(L - 1); base = W.lay[l].Z1; rows = n; w = F; }
   else if (!strcmp(name, "h")) { LAYER_OK(L - 1); base = W.lay[l].Hh; rows = n; w = F; }
   else if (!strcmp(name, "xh")) { LAYER_OK(L - 1); base = W.lay[l].XH; rows = n; w = 3 * F; }
-  else if (!strcmp(name, "phi")) { LAYER_OK(L - 1); base = W.lay[l].PHI; rows = e; w = 3 * F; dual = false; }
-  else if (!strcmp(name, "psi")) { LAYER_OK(L - 1); base = W.lay[l].PSI; rows = e; w = 3 * F; dual = false; }
+  else if (!strcmp(name, "phi") || !strcmp(name, "psi")) {
+    LAYER_OK(L - 1);
+    if (W.fused) return nq_fail(NQ_ERR_ARG, "buffer '%s' is not materialised (filter is fused into the message kernels)", name);
+    base = name[1] == 'h' ? W.lay[l].PHI : W.lay[l].PSI; rows = e; w = 3 * F; dual = false;
+  }
   else if (!strcmp(name, "x_msg")) { LAYER_OK(L - 1); base = W.lay[l].XM; rows = n; w = F; }
   else if (!strcmp(name, "vec_msg")) { LAYER_OK(L - 1); base = W.lay[l].VM; rows = n; w = 3 * F; }
   else if (!strcmp(name, "u")) { LAYER_OK(L - 1); base = W.lay[l].UU; rows = n; w = 6 * F; }
@@ -271,12 +284,19 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F, "W1"));
     NQ_TRY(nq_gemm_nt(st, ws + y.Hh, params + mp.W2, ws + y.XH, params + mp.b2, nullptr, N, 3 * F, F, F, F, 3 * F, "W2"));
-    NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
-    NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
     MsgArgs m{};
     m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.XM = ws + y.XM; m.VM = ws + y.VM;
-    NQ_TRY(nq_msg_fwd(st, m, false));
+    if (W.fused) {
+      FilterArgs fa;
+      NQ_TRY(nq_transpose(st, params + mp.Wr, 3 * F, R, ws + y.WRT));
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      NQ_TRY(nq_msgf_fwd(st, m, fa, false));
+    } else {
+      NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
+      NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
+      NQ_TRY(nq_msg_fwd(st, m, false));
+    }
     NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
@@ -316,7 +336,13 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
-    NQ_TRY(nq_msg_rev(st, m, false));
+    if (W.fused) {
+      FilterArgs fa;
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      NQ_TRY(nq_msgf_rev(st, m, fa, false));
+    } else {
+      NQ_TRY(nq_msg_rev(st, m, false));
+    }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, nullptr, ws + W.GH, nullptr, (long)NF, false));
@@ -327,11 +353,11 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_graph* graph, void* workspace, size_t workspace_bytes,
-                      const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
+int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                      size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
   WsLayout W; ParamLayout P;
   NQ_TRY(check_common(cfg, graph, workspace, workspace_bytes, &W, &P));
-  if (!params || !grad_params) return nq_fail(NQ_ERR_ARG, "null argument");
+  if (!params || !grad_params || !rbf_offsets) return nq_fail(NQ_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   float* gp = grad_params;
@@ -354,7 +380,13 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
     m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TX = ws + W.X[l] + NF; m.TV = ws + W.V[l] + 3 * NF; m.TXH = TXH; m.TD = ws + W.TD; m.TR = ws + W.TR;
     m.TXM = ws + y.XM + NF; m.TVM = ws + y.VM + 3 * NF;
-    NQ_TRY(nq_msg_fwd(st, m, true));
+    if (W.fused) {
+      FilterArgs fa;
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      NQ_TRY(nq_msgf_fwd(st, m, fa, true));
+    } else {
+      NQ_TRY(nq_msg_fwd(st, m, true));
+    }
     NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
@@ -415,7 +447,13 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const nq_gra
     m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
     m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
     m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
-    NQ_TRY(nq_msg_rev(st, m, true));
+    if (W.fused) {
+      FilterArgs fa;
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      NQ_TRY(nq_msgf_rev(st, m, fa, true));
+    } else {
+      NQ_TRY(nq_msg_rev(st, m, true));
+    }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
     NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));

@@ -117,7 +117,8 @@ class _EnergyForces(torch.autograd.Function):
         grad_flat = torch.empty_like(flat)
         ge = None if g_energy is None else g_energy.to(torch.float32).contiguous()
         gf = None if (g_forces is None or not ctx.want_forces) else g_forces.to(torch.float32).contiguous()
-        _lib.check(lib.nq_painn_backward(C.byref(model._cfg), _lib.ptr(flat), C.byref(nl.c), _lib.ptr(ctx.ws), ctx.ws_bytes,
+        _lib.check(lib.nq_painn_backward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c),
+                                         _lib.ptr(ctx.ws), ctx.ws_bytes,
                                          _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_flat), _lib.stream_ptr()))
         model._last_grad_flat = grad_flat
         model._release_workspace(ctx.ws)
@@ -283,7 +284,7 @@ class PaiNN(nn.Module):
             return ws
         if not self._ws_busy:
             self._ws_cache = None                                      # drop the old buffer before growing
-            self._ws_cache = torch.empty(int(nbytes * 1.08) + 4096, device=dev, dtype=torch.uint8)
+            self._ws_cache = torch.empty((int(nbytes * 1.08) + 4096) // 256 * 256, device=dev, dtype=torch.uint8)
             self._ws_busy = torch.is_grad_enabled()
             return self._ws_cache
         return torch.empty(nbytes, device=dev, dtype=torch.uint8)     # a second forward before the pending backward

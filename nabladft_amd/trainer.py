@@ -56,7 +56,7 @@ class FusedTrainStep:
         ws_bytes = lib.nq_painn_workspace_bytes(cfg, nl.N, nl.E, nl.B)
         if self._ws is None or self._ws.numel() < ws_bytes:
             self._ws = None                                            # release before growing (27 GB at B=1024)
-            self._ws = torch.empty(int(ws_bytes * 1.08) + 4096, device=dev, dtype=torch.uint8)
+            self._ws = torch.empty((int(ws_bytes * 1.08) + 4096) // 256 * 256, device=dev, dtype=torch.uint8)
         ws = self._ws
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32)
@@ -65,7 +65,8 @@ class FusedTrainStep:
                                         _lib.ptr(energy), _lib.ptr(forces), st))
         _lib.check(lib.nq_loss_l1_l2(_lib.ptr(energy), _lib.ptr(batch.y), nl.B, _lib.ptr(forces), _lib.ptr(batch.forces), nl.N, self.ce, self.cf,
                                      _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
-        _lib.check(lib.nq_painn_backward(cfg, _lib.ptr(flat), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
+        _lib.check(lib.nq_painn_backward(cfg, _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
+                                         _lib.ptr(gE), _lib.ptr(gF),
                                          _lib.ptr(self.grad), st))
         nqdist.allreduce_mean_(self.grad, self.group)
         if update:

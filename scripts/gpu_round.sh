@@ -13,7 +13,7 @@ timeout 1200 python -m pytest tests/test_engine_gpu.py -m gpu -q --tb=short -k "
 echo "== smoke"
 timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -5 | tee gpurun_out/smoke_$TAG.log
 echo "== bench"
-timeout 900 python bench.py --steps 5 --warmup 2 --batch $BATCH 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
+timeout 900 python bench.py --steps 5 --warmup 2 --batch $BATCH $BENCH_EXTRA 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
 echo "== rocprof"
 rm -rf gpurun_out/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o painn -- python bench.py --steps 3 --warmup 1 --batch $BATCH --no-cpu-baseline --no-roofline > gpurun_out/rocprof_$TAG.log 2>&1

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/nablaq.h but not exported by libnablaq.so"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert lib.nq_abi_version() == 1
+    assert lib.nq_abi_version() == _lib.ABI_VERSION
 
 
 def test_param_layout_matches_reference_state_dict(lib):
@@ -60,14 +60,21 @@ def test_workspace_and_lookup(lib):
     assert total > 0 and total % 16 == 0
     off, cnt = C.c_size_t(), C.c_size_t()
     seen = []
-    for name, lay, tan in [("x_in", 0, 0), ("x_in", 2, 1), ("vec_msg", 1, 0), ("phi", 0, 0), ("rho", 0, 1), ("zo", 0, 0), ("gedge", 0, 0)]:
+    for name, lay, tan in [("x_in", 0, 0), ("x_in", 2, 1), ("vec_msg", 1, 0), ("xh", 0, 0), ("rho", 0, 1), ("zo", 0, 0), ("gedge", 0, 0)]:
         assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, name.encode(), lay, tan, C.byref(off), C.byref(cnt)) == 0
         assert (off.value + cnt.value) * 4 <= total and off.value % 4 == 0
         seen.append((off.value, cnt.value))
     assert len(set(seen)) == len(seen)
     assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"nonsense", 0, 0, C.byref(off), C.byref(cnt)) != 0
     assert b"unknown workspace buffer" in lib.nq_last_error()
-    assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 1, C.byref(off), C.byref(cnt)) != 0   # no tangent half
+    assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 0, C.byref(off), C.byref(cnt)) != 0   # fused filter: not materialised
+    os.environ["NQ_NO_FUSED_FILTER"] = "1"
+    try:
+        assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 0, C.byref(off), C.byref(cnt)) == 0
+        assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 1, C.byref(off), C.byref(cnt)) != 0   # no tangent half
+        assert lib.nq_painn_workspace_bytes(cfg, 100, 900, 4) > total
+    finally:
+        del os.environ["NQ_NO_FUSED_FILTER"]
 
 
 def test_unsupported_configs_fail_loudly():
