@@ -102,6 +102,7 @@ struct FilterArgs {
   const float* WRT;   // [R][3F] = rbf_proj.weight^T (written once per forward by k_transpose)
   const float* br;    // [3F]
   const float* mu;    // [R] GaussianSmearing offsets
+  const float* RW;    // [E][32] per-edge 13-tap window record written by k_rbf_window: [0..12] rho, [13] k0 (int bits), [16..28] drho
   int R;
   float inv_cutoff, p, a, b, c, coeff;
 };
@@ -166,7 +167,9 @@ int nq_rbf(hipStream_t, const float4* geom, int E, int R, double cutoff, int env
            float* drho);
 int nq_msg_fwd(hipStream_t, const MsgArgs&, bool tangent);
 bool nq_filter_fits_lds(int F, int R);
-void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, int R, double cutoff, int env_p, float coeff);
+void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,
+                         float coeff);
+int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, float* RW);
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
 int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual);

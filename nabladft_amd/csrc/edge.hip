@@ -203,16 +203,21 @@ __device__ __forceinline__ float bcast_lane(float v, int t) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
 }
 
-// window start and this lane's basis values (lane t <-> basis k0 + t)
-__device__ __forceinline__ void rbf_window(const FilterArgs& fa, float d, int lane, int& k0, int& nwin, float& rl, float& drl) {
-  const float ds = d * fa.inv_cutoff;
+// Per-edge window record, computed ONCE per step (the distances do not change between layers / sweeps):
+// RW[e][0..12] = rho_{k0+t}(d_e), RW[e][13] = k0 (int bits), RW[e][16..28] = d rho_{k0+t} / d d.  128 B per edge.
+#define RW_STRIDE 32
+__global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs fa, float* __restrict__ RW) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = (int)(idx >> 4), t = (int)(idx & 15);
+  if (e >= E) return;
   const int R = fa.R;
-  nwin = R < FWIN ? R : FWIN;
+  const float ds = geom[e].w * fa.inv_cutoff;
+  const int nwin = R < FWIN ? R : FWIN;
   int kc = (int)rintf(ds * (float)(R - 1));
   kc = min(max(kc, 0), R - 1);
-  k0 = min(max(kc - FWIN / 2, 0), R - nwin);
-  rl = 0.f; drl = 0.f;
-  if (lane < nwin) {
+  const int k0 = min(max(kc - FWIN / 2, 0), R - nwin);
+  float rl = 0.f, drl = 0.f;
+  if (t < nwin) {
     float env = 0.f, denv = 0.f;
     if (ds < 1.0f) {
       const float pm1 = powf(ds, fa.p - 1.0f);
@@ -220,29 +225,34 @@ __device__ __forceinline__ void rbf_window(const FilterArgs& fa, float d, int la
       env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
       denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
     }
-    const float diff = ds - fa.mu[k0 + lane];
+    const float diff = ds - fa.mu[k0 + t];
     const float g = expf(fa.coeff * (diff * diff));
     rl = env * g;
     drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
   }
+  float* rw = RW + (long)e * RW_STRIDE;
+  rw[t] = (t == 13) ? __int_as_float(k0) : rl;
+  rw[16 + t] = drl;
 }
 
+// phi (and psi) of the edge at CSR slot sp for this thread's three channels; sp is wave-uniform
 #define FILTER_EVAL(WITH_PSI)                                                                  \
   float pa = bra, pb = brb, pc = brc, qa = 0.f, qb = 0.f, qc = 0.f;                            \
   {                                                                                            \
-    int k0, nwin; float rl, drl;                                                               \
-    rbf_window(fa, gm.w, lane, k0, nwin, rl, drl);                                             \
-    const float* wk = wrt + (long)k0 * F3 + f;                                                 \
-    _Pragma("unroll") for (int t = 0; t < FWIN; ++t) {                                         \
-      if (t < nwin) {                                                                          \
-        const float r = bcast_lane(rl, t);                                                     \
-        const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];             \
-        pa = fmaf(wa, r, pa); pb = fmaf(wb, r, pb); pc = fmaf(wc, r, pc);                      \
-        if (WITH_PSI) {                                                                        \
-          const float dr = bcast_lane(drl, t);                                                 \
-          qa = fmaf(wa, dr, qa); qb = fmaf(wb, dr, qb); qc = fmaf(wc, dr, qc);                 \
-        }                                                                                      \
-      }                                                                                        \
+    const float4* rw4 = reinterpret_cast<const float4*>(fa.RW + (long)sp * RW_STRIDE);        \
+    float rr[16], dd[16];                                                                      \
+    *reinterpret_cast<float4*>(rr) = rw4[0]; *reinterpret_cast<float4*>(rr + 4) = rw4[1];      \
+    *reinterpret_cast<float4*>(rr + 8) = rw4[2]; *reinterpret_cast<float4*>(rr + 12) = rw4[3]; \
+    if (WITH_PSI) {                                                                            \
+      *reinterpret_cast<float4*>(dd) = rw4[4]; *reinterpret_cast<float4*>(dd + 4) = rw4[5];    \
+      *reinterpret_cast<float4*>(dd + 8) = rw4[6]; *reinterpret_cast<float4*>(dd + 12) = rw4[7]; \
+    }                                                                                          \
+    const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rr[13]));                     \
+    const float* wk = wrt + k0 * F3 + f;                                                       \
+    _Pragma("unroll") for (int t = 0; t < FWIN; ++t) { /* always 13 taps: LDS rows >= R are zero, RW taps >= R are zero */ \
+      const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];               \
+      pa = fmaf(wa, rr[t], pa); pb = fmaf(wb, rr[t], pb); pc = fmaf(wc, rr[t], pc);            \
+      if (WITH_PSI) { qa = fmaf(wa, dd[t], qa); qb = fmaf(wb, dd[t], qb); qc = fmaf(wc, dd[t], qc); } \
     }                                                                                          \
   }
 
@@ -250,14 +260,16 @@ __device__ __forceinline__ void rbf_window(const FilterArgs& fa, float d, int la
   extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
   const int F = q.F, F3 = 3 * q.F;                                                             \
   {                                                                                            \
-    const int total4 = (fa.R * F3) >> 2;                                                       \
+    const int total4 = (fa.R * F3) >> 2, padded4 = ((fa.R < FWIN ? FWIN : fa.R) * F3) >> 2;    \
     const float4* src = reinterpret_cast<const float4*>(fa.WRT);                               \
     float4* dst4 = reinterpret_cast<float4*>(wrt);                                             \
-    for (int i = threadIdx.x; i < total4; i += blockDim.x) dst4[i] = src[i];                   \
+    for (int i = threadIdx.x; i < padded4; i += blockDim.x)                                    \
+      dst4[i] = i < total4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);                         \
   }                                                                                            \
   __syncthreads();                                                                             \
-  const int nslots = blockDim.x / F, slot = threadIdx.x / F, f = threadIdx.x % F;              \
-  const int lane = threadIdx.x & 63;                                                           \
+  const int nslots = blockDim.x / F, f = threadIdx.x % F;                                      \
+  const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x / F); /* wave-uniform: F % 64 == 0 */ \
+  const int lane = threadIdx.x & 63; (void)lane;                                               \
   const float bra = fa.br[f], brb = fa.br[F + f], brc = fa.br[2 * F + f];
 
 template <bool TAN>
@@ -498,11 +510,20 @@ int nq_geom_rev(hipStream_t st, const NqGraphView& g, const float4* GEDGE, int n
 // ---- fused-filter launchers ------------------------------------------------------------------
 bool nq_filter_fits_lds(int F, int R) { return (size_t)R * 3 * F * sizeof(float) <= 156 * 1024 && FUSED_THREADS_DUAL / F >= 1; }
 
-void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, int R, double cutoff, int env_p, float coeff) {
+void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,
+                         float coeff) {
   const double p = env_p;
-  fa->WRT = WRT; fa->br = br; fa->mu = mu; fa->R = R; fa->inv_cutoff = (float)(1.0 / cutoff);
+  fa->WRT = WRT; fa->br = br; fa->mu = mu; fa->RW = RW; fa->R = R; fa->inv_cutoff = (float)(1.0 / cutoff);
   fa->p = (float)p; fa->a = (float)(-(p + 1) * (p + 2) / 2); fa->b = (float)(p * (p + 2)); fa->c = (float)(-p * (p + 1) / 2);
   fa->coeff = coeff;
+}
+
+int nq_rbf_window(hipStream_t st, const float4* geom, int E, const FilterArgs& fa, float* RW) {
+  NQ_PROF(st, "rbf_window");
+  if (E <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_rbf_window, dim3(nq_cdiv((long)E * 16, 256)), dim3(256), 0, st, geom, E, fa, RW);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
 }
 
 int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out) {
@@ -515,7 +536,7 @@ int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out
 static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
   const int nslots = max_threads / F;
   *threads = nslots * F;
-  *lds = (size_t)R * 3 * F * sizeof(float);
+  *lds = (size_t)(R < FWIN ? FWIN : R) * 3 * F * sizeof(float);
   int blocks = nq_cdiv(N, nslots);
   return blocks < 256 ? blocks : 256;   // one persistent workgroup per CU (LDS-limited to 1 per CU anyway)
 }

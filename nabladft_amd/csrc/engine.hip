@@ -81,7 +81,7 @@ struct WsLayer {
 struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
-  size_t RHO2, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
+  size_t RHO2, RW, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
   size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
@@ -108,6 +108,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
   }
   W->RHO2 = take(2 * E * R);
+  W->RW = take(W->fused ? E * 32 : 0);
   W->ZO = take(2 * N * H); W->e_atom = take(N); W->te_atom = take(N);
   W->TD = take(E); W->TR = take(3 * E); W->pos_dot = take(3 * N); W->ge = take(N); W->gte = take(N);
   W->GX = take(2 * N * F); W->GVa = take(2 * N * 3 * F); W->GVb = take(2 * N * 3 * F);
@@ -279,6 +280,11 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_HIP(hipMemsetAsync(ws + W.V[0], 0, 6 * NF * sizeof(float), st));
   float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
   NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho));
+  if (W.fused) {
+    FilterArgs fa0;
+    nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+    NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
+  }
 
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
@@ -290,7 +296,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     if (W.fused) {
       FilterArgs fa;
       NQ_TRY(nq_transpose(st, params + mp.Wr, 3 * F, R, ws + y.WRT));
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
       NQ_TRY(nq_msgf_fwd(st, m, fa, false));
     } else {
       NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
@@ -338,7 +344,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
       NQ_TRY(nq_msgf_rev(st, m, fa, false));
     } else {
       NQ_TRY(nq_msg_rev(st, m, false));
@@ -382,7 +388,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     m.TXM = ws + y.XM + NF; m.TVM = ws + y.VM + 3 * NF;
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
       NQ_TRY(nq_msgf_fwd(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_fwd(st, m, true));
@@ -449,7 +455,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
       NQ_TRY(nq_msgf_rev(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_rev(st, m, true));
