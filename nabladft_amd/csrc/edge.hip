@@ -197,7 +197,7 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 // =============================================================================================
 #define FWIN 13
 #define FUSED_THREADS 1024
-#define FUSED_THREADS_DUAL 768   // the dual reverse needs ~150 VGPRs: 12 waves per CU instead of 16, no spills
+#define FUSED_THREADS_DUAL 1024  // window records live in SGPRs (scalar loads), so the dual reverse also fits 16 waves per CU
 
 __device__ __forceinline__ float bcast_lane(float v, int t) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));
@@ -235,26 +235,53 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
   rw[16 + t] = drl;
 }
 
-// phi (and psi) of the edge at CSR slot sp for this thread's three channels; sp is wave-uniform
-#define FILTER_EVAL(WITH_PSI)                                                                  \
-  float pa = bra, pb = brb, pc = brc, qa = 0.f, qb = 0.f, qc = 0.f;                            \
-  {                                                                                            \
-    const float4* rw4 = reinterpret_cast<const float4*>(fa.RW + (long)sp * RW_STRIDE);        \
-    float rr[16], dd[16];                                                                      \
-    *reinterpret_cast<float4*>(rr) = rw4[0]; *reinterpret_cast<float4*>(rr + 4) = rw4[1];      \
-    *reinterpret_cast<float4*>(rr + 8) = rw4[2]; *reinterpret_cast<float4*>(rr + 12) = rw4[3]; \
-    if (WITH_PSI) {                                                                            \
-      *reinterpret_cast<float4*>(dd) = rw4[4]; *reinterpret_cast<float4*>(dd + 4) = rw4[5];    \
-      *reinterpret_cast<float4*>(dd + 8) = rw4[6]; *reinterpret_cast<float4*>(dd + 12) = rw4[7]; \
-    }                                                                                          \
-    const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rr[13]));                     \
-    const float* wk = wrt + k0 * F3 + f;                                                       \
-    _Pragma("unroll") for (int t = 0; t < FWIN; ++t) { /* always 13 taps: LDS rows >= R are zero, RW taps >= R are zero */ \
-      const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];               \
-      pa = fmaf(wa, rr[t], pa); pb = fmaf(wb, rr[t], pb); pc = fmaf(wc, rr[t], pc);            \
-      if (WITH_PSI) { qa = fmaf(wa, dd[t], qa); qb = fmaf(wb, dd[t], qb); qc = fmaf(wc, dd[t], qc); } \
-    }                                                                                          \
+// ---- row preload: lane L of the wavefront holds index / geometry (/ tangents) of the row's edge L ------------
+struct RowRegs { int kk; float gx, gy, gz, td, t0, t1, t2; };
+
+template <bool NEED_T>
+__device__ __forceinline__ void load_row(RowRegs& r, const NqGraphView& g, const float* __restrict__ TD, const float* __restrict__ TR,
+                                         int sp0, int cnt, int lane) {
+  r.kk = 0; r.gx = r.gy = r.gz = 0.f; r.td = r.t0 = r.t1 = r.t2 = 0.f;
+  if (lane < cnt) {
+    const int sp = sp0 + lane;
+    r.kk = g.col[sp];
+    const float4 gm = g.geom[sp];
+    r.gx = gm.x; r.gy = gm.y; r.gz = gm.z;
+    if (NEED_T) { r.td = TD[sp]; r.t0 = TR[3 * (long)sp]; r.t1 = TR[3 * (long)sp + 1]; r.t2 = TR[3 * (long)sp + 2]; }
   }
+}
+__device__ __forceinline__ int bl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ float bl_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+
+// ---- per-edge operand bundles (loaded one edge ahead of their use) -------------------------------------------
+template <bool PSI>
+struct WinRegs { float rr[16]; float dd[PSI ? 16 : 1]; };
+
+template <bool PSI>
+__device__ __forceinline__ void load_win(WinRegs<PSI>& w, const float* __restrict__ RW, int sp) {
+  const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)sp * RW_STRIDE);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&w.rr[4 * v]) = rw4[v];
+  if (PSI) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&w.dd[4 * v]) = rw4[4 + v];
+  }
+}
+
+// phi (and psi) for this thread's three channels from the LDS-resident WrT and the edge's window record
+template <bool PSI>
+__device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* wrt, int F, int F3, int f, float bra, float brb, float brc,
+                                            float& pa, float& pb, float& pc, float& qa, float& qb, float& qc) {
+  pa = bra; pb = brb; pc = brc; qa = qb = qc = 0.f;
+  const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(w.rr[13]));
+  const float* wk = wrt + k0 * F3 + f;
+#pragma unroll
+  for (int t = 0; t < FWIN; ++t) {  // always 13 taps: LDS rows >= R and window taps >= R are zero
+    const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];
+    pa = fmaf(wa, w.rr[t], pa); pb = fmaf(wb, w.rr[t], pb); pc = fmaf(wc, w.rr[t], pc);
+    if (PSI) { qa = fmaf(wa, w.dd[t], qa); qb = fmaf(wb, w.dd[t], qb); qc = fmaf(wc, w.dd[t], qc); }
+  }
+}
 
 #define FUSED_PROLOGUE                                                                          \
   extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
@@ -269,40 +296,66 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
   __syncthreads();                                                                             \
   const int nslots = blockDim.x / F, f = threadIdx.x % F;                                      \
   const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x / F); /* wave-uniform: F % 64 == 0 */ \
-  const int lane = threadIdx.x & 63; (void)lane;                                               \
-  const float bra = fa.br[f], brb = fa.br[F + f], brc = fa.br[2 * F + f];
+  const int lane = threadIdx.x & 63;                                                           \
+  const float bra = fa.br[f], brb = fa.br[F + f], brc = fa.br[2 * F + f];                      \
+  /* contiguous node range per workgroup: a molecule's rows stay in ONE XCD's L2 */            \
+  const int per_wg = (q.g.N + gridDim.x - 1) / gridDim.x;                                      \
+  const int n_lo = blockIdx.x * per_wg, n_hi = min(q.g.N, n_lo + per_wg);
+
+// ---- forward / tangent -------------------------------------------------------------------------------------
+template <bool TAN>
+struct FwdOps { float xa, xb, xc, va, vb, vc, txa, txb, txc, tva, tvb, tvc; WinRegs<TAN> w; };
 
 template <bool TAN>
-__global__ __launch_bounds__(FUSED_THREADS) void k_msgf_fwd(MsgArgs q, FilterArgs fa) {
+__device__ __forceinline__ void load_fwd(FwdOps<TAN>& o, const MsgArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int f) {
+  const float* xh = q.XH + (long)k * F3;
+  const float* vk = q.V + (long)k * F3;
+  o.xa = xh[f]; o.xb = xh[F + f]; o.xc = xh[2 * F + f];
+  o.va = vk[f]; o.vb = vk[F + f]; o.vc = vk[2 * F + f];
+  if (TAN) {
+    const float* txh = q.TXH + (long)k * F3;
+    const float* tvk = q.TV + (long)k * F3;
+    o.txa = txh[f]; o.txb = txh[F + f]; o.txc = txh[2 * F + f];
+    o.tva = tvk[f]; o.tvb = tvk[F + f]; o.tvc = tvk[2 * F + f];
+  }
+  load_win<TAN>(o.w, RW, sp);
+}
+
+template <bool TAN>
+__global__ __launch_bounds__(FUSED_THREADS) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  for (int n = blockIdx.x * nslots + slot; n < q.g.N; n += gridDim.x * nslots) {
-    const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+  for (int n = n_lo + slot; n < n_hi; n += nslots) {
+    const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     float dx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int sp = beg; sp < end; ++sp) {
-      const int k = q.g.col[sp];
-      const float4 gm = q.g.geom[sp];
-      FILTER_EVAL(TAN)
-      const float* xh = q.XH + (long)k * F3;
-      const float* vk = q.V + (long)k * F3;
-      const float xa = xh[f], xb = xh[F + f], xc = xh[2 * F + f];
-      const float mb = xb * pb, mc = xc * pc;
-      if (!TAN) {
-        dx += xa * pa;
-        d0 += vk[f] * mb + mc * gm.x;
-        d1 += vk[F + f] * mb + mc * gm.y;
-        d2 += vk[2 * F + f] * mb + mc * gm.z;
-      } else {
-        const float td = q.TD[sp];
-        const float tr0 = q.TR[3 * (long)sp], tr1 = q.TR[3 * (long)sp + 1], tr2 = q.TR[3 * (long)sp + 2];
-        const float* txh = q.TXH + (long)k * F3;
-        const float* tvk = q.TV + (long)k * F3;
-        const float tma = txh[f] * pa + xa * (qa * td);
-        const float tmb = txh[F + f] * pb + xb * (qb * td);
-        const float tmc = txh[2 * F + f] * pc + xc * (qc * td);
-        dx += tma;
-        d0 += tvk[f] * mb + vk[f] * tmb + tmc * gm.x + mc * tr0;
-        d1 += tvk[F + f] * mb + vk[F + f] * tmb + tmc * gm.y + mc * tr1;
-        d2 += tvk[2 * F + f] * mb + vk[2 * F + f] * tmb + tmc * gm.z + mc * tr2;
+    for (int c0 = beg; c0 < end; c0 += 64) {
+      const int cnt = min(64, end - c0);
+      RowRegs row;
+      load_row<TAN>(row, q.g, q.TD, q.TR, c0, cnt, lane);
+      FwdOps<TAN> cur, nxt;
+      load_fwd<TAN>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, f);
+      nxt = cur;
+      for (int j = 0; j < cnt; ++j) {
+        if (j + 1 < cnt) load_fwd<TAN>(nxt, q, RW, bl_i(row.kk, j + 1), c0 + j + 1, F, F3, f);
+        float pa, pb, pc, qa, qb, qc;
+        filter_eval<TAN>(cur.w, wrt, F, F3, f, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        const float gx = bl_f(row.gx, j), gy = bl_f(row.gy, j), gz = bl_f(row.gz, j);
+        const float mb = cur.xb * pb, mc = cur.xc * pc;
+        if (!TAN) {
+          dx += cur.xa * pa;
+          d0 += cur.va * mb + mc * gx;
+          d1 += cur.vb * mb + mc * gy;
+          d2 += cur.vc * mb + mc * gz;
+        } else {
+          const float td = bl_f(row.td, j), tr0 = bl_f(row.t0, j), tr1 = bl_f(row.t1, j), tr2 = bl_f(row.t2, j);
+          const float tma = cur.txa * pa + cur.xa * (qa * td);
+          const float tmb = cur.txb * pb + cur.xb * (qb * td);
+          const float tmc = cur.txc * pc + cur.xc * (qc * td);
+          dx += tma;
+          d0 += cur.tva * mb + cur.va * tmb + tmc * gx + mc * tr0;
+          d1 += cur.tvb * mb + cur.vb * tmb + tmc * gy + mc * tr1;
+          d2 += cur.tvc * mb + cur.vc * tmb + tmc * gz + mc * tr2;
+        }
+        cur = nxt;
       }
     }
     const long o = (long)n * F, o3 = (long)n * F3;
@@ -316,12 +369,29 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_msgf_fwd(MsgArgs q, FilterArg
   }
 }
 
+// ---- reverse (force adjoint / dual) ----------------------------------------------------------------------------
 template <bool DUAL>
-__global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_msgf_rev(MsgRevArgs q, FilterArgs fa) {
+struct RevOps { float A0, A1, A2, gma, T0, T1, T2, gtma; WinRegs<true> w; };
+
+template <bool DUAL>
+__device__ __forceinline__ void load_rev(RevOps<DUAL>& o, const MsgRevArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int f) {
+  const float* A = q.GV + (long)k * F3;
+  o.A0 = A[f]; o.A1 = A[F + f]; o.A2 = A[2 * F + f];
+  o.gma = q.GX[(long)k * F + f];
+  if (DUAL) {
+    const float* T = q.GTV + (long)k * F3;
+    o.T0 = T[f]; o.T1 = T[F + f]; o.T2 = T[2 * F + f];
+    o.gtma = q.GTX[(long)k * F + f];
+  }
+  load_win<true>(o.w, RW, sp);
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   const int wave_in_slot = (threadIdx.x % F) >> 6;
-  for (int n = blockIdx.x * nslots + slot; n < q.g.N; n += gridDim.x * nslots) {
-    const int beg = q.g.row_ptr[n], end = q.g.row_ptr[n + 1];
+  for (int n = n_lo + slot; n < n_hi; n += nslots) {
+    const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     const long o3 = (long)n * F3;
     const float xa = q.XH[o3 + f], xb = q.XH[o3 + F + f], xc = q.XH[o3 + 2 * F + f];
     const float v0 = q.V[o3 + f], v1 = q.V[o3 + F + f], v2 = q.V[o3 + 2 * F + f];
@@ -333,51 +403,57 @@ __global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_m
     float gxa = 0.f, gxb = 0.f, gxc = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
     float gtxa = 0.f, gtxb = 0.f, gtxc = 0.f, gtv0 = 0.f, gtv1 = 0.f, gtv2 = 0.f;
     float sba = 0.f, sbb = 0.f, sbc = 0.f;
-    for (int sp = beg; sp < end; ++sp) {
-      const int k = q.g.col[sp];
-      const float4 gm = q.g.geom[sp];
-      const float r0 = -gm.x, r1 = -gm.y, r2 = -gm.z;
-      FILTER_EVAL(true)
-      const float* A = q.GV + (long)k * F3;
-      const float A0 = A[f], A1 = A[F + f], A2 = A[2 * F + f];
-      const float gma = q.GX[(long)k * F + f];
-      const float mb = xb * pb, mc = xc * pc;
-      float gmb = A0 * v0 + A1 * v1 + A2 * v2;
-      float gmc = A0 * r0 + A1 * r1 + A2 * r2;
-      gv0 += A0 * mb; gv1 += A1 * mb; gv2 += A2 * mb;
-      if (DUAL) {
-        const float td = q.TD[sp];
-        const float tr0 = -q.TR[3 * (long)sp], tr1 = -q.TR[3 * (long)sp + 1], tr2 = -q.TR[3 * (long)sp + 2];
-        const float tpa = qa * td, tpb = qb * td, tpc = qc * td;
-        const float* T = q.GTV + (long)k * F3;
-        const float T0 = T[f], T1 = T[F + f], T2 = T[2 * F + f];
-        const float gtma = q.GTX[(long)k * F + f];
-        const float tmb = txb * pb + xb * tpb;
-        gmb += T0 * tv0 + T1 * tv1 + T2 * tv2;
-        const float gtmb = T0 * v0 + T1 * v1 + T2 * v2;
-        gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
-        const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
-        gv0 += T0 * tmb; gv1 += T1 * tmb; gv2 += T2 * tmb;
-        gtv0 += T0 * mb; gtv1 += T1 * mb; gtv2 += T2 * mb;
-        gxa += gma * pa + gtma * tpa; gxb += gmb * pb + gtmb * tpb; gxc += gmc * pc + gtmc * tpc;
-        gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
-        float* gp = q.GPHI + (long)sp * F3;
-        float* gs = q.GPSI + (long)sp * F3;
-        const float ga = gma * xa + gtma * txa, gb = gmb * xb + gtmb * txb, gc = gmc * xc + gtmc * txc;
-        gp[f] = ga; gp[F + f] = gb; gp[2 * F + f] = gc;
-        sba += ga; sbb += gb; sbc += gc;
-        gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
-      } else {
-        gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
-        float gd = gma * xa * qa + gmb * xb * qb + gmc * xc * qc;
-        float e0 = A0 * mc, e1 = A1 * mc, e2 = A2 * mc;
-        gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
-        if (lane == 0) {
-          float4* dstp = q.GEDGE + (long)wave_in_slot * q.g.E + sp;
-          float4 acc = *dstp;
-          acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
-          *dstp = acc;
+    for (int c0 = beg; c0 < end; c0 += 64) {
+      const int cnt = min(64, end - c0);
+      RowRegs row;
+      load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
+      RevOps<DUAL> cur, nxt;
+      load_rev<DUAL>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, f);
+      nxt = cur;
+      for (int j = 0; j < cnt; ++j) {
+        const int sp = c0 + j;
+        if (j + 1 < cnt) load_rev<DUAL>(nxt, q, RW, bl_i(row.kk, j + 1), sp + 1, F, F3, f);
+        float pa, pb, pc, qa, qb, qc;
+        filter_eval<true>(cur.w, wrt, F, F3, f, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);  // unit vector of the out-edge (n -> k)
+        const float A0 = cur.A0, A1 = cur.A1, A2 = cur.A2, gma = cur.gma;
+        const float mb = xb * pb, mc = xc * pc;
+        float gmb = A0 * v0 + A1 * v1 + A2 * v2;
+        float gmc = A0 * r0 + A1 * r1 + A2 * r2;
+        gv0 += A0 * mb; gv1 += A1 * mb; gv2 += A2 * mb;
+        if (DUAL) {
+          const float td = bl_f(row.td, j);
+          const float tr0 = -bl_f(row.t0, j), tr1 = -bl_f(row.t1, j), tr2 = -bl_f(row.t2, j);
+          const float tpa = qa * td, tpb = qb * td, tpc = qc * td;
+          const float T0 = cur.T0, T1 = cur.T1, T2 = cur.T2, gtma = cur.gtma;
+          const float tmb = txb * pb + xb * tpb;
+          gmb += T0 * tv0 + T1 * tv1 + T2 * tv2;
+          const float gtmb = T0 * v0 + T1 * v1 + T2 * v2;
+          gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
+          const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
+          gv0 += T0 * tmb; gv1 += T1 * tmb; gv2 += T2 * tmb;
+          gtv0 += T0 * mb; gtv1 += T1 * mb; gtv2 += T2 * mb;
+          gxa += gma * pa + gtma * tpa; gxb += gmb * pb + gtmb * tpb; gxc += gmc * pc + gtmc * tpc;
+          gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
+          float* gp = q.GPHI + (long)sp * F3;
+          float* gs = q.GPSI + (long)sp * F3;
+          const float ga = gma * xa + gtma * txa, gb = gmb * xb + gtmb * txb, gc = gmc * xc + gtmc * txc;
+          gp[f] = ga; gp[F + f] = gb; gp[2 * F + f] = gc;
+          sba += ga; sbb += gb; sbc += gc;
+          gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
+        } else {
+          gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
+          float gd = gma * xa * qa + gmb * xb * qb + gmc * xc * qc;
+          float e0 = A0 * mc, e1 = A1 * mc, e2 = A2 * mc;
+          gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
+          if (lane == 0) {
+            float4* dstp = q.GEDGE + (long)wave_in_slot * q.g.E + sp;
+            float4 acc = *dstp;
+            acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
+            *dstp = acc;
+          }
         }
+        cur = nxt;
       }
     }
     q.GXH[o3 + f] = gxa; q.GXH[o3 + F + f] = gxb; q.GXH[o3 + 2 * F + f] = gxc;
@@ -392,6 +468,58 @@ __global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_m
       q.GTV_out[o3 + 2 * F + f] = q.GTV[o3 + 2 * F + f] + gtv2;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient of rbf_proj.weight with the windowed filter:
+//   gWrT[k][c] = sum_e gphi[e][c] rho_k(d_e) + gpsi[e][c] drho_k(d_e),  k in the 13-tap window of edge e.
+// One workgroup per CU owns an LDS accumulator acc[R][3F] (same 153.6 kB footprint as WrT); thread c owns
+// column c, so every accumulator word is updated by exactly one thread in program order: no atomics, and the
+// result is bitwise reproducible.  Each workgroup walks a contiguous chunk of edges (4 in flight per thread);
+// per-workgroup partial slabs are summed in fixed order by k_reduce_partials and transposed into [3F][R].
+#define GWR_UNROLL 4
+__global__ __launch_bounds__(1024) void k_gwr_accum(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
+                                                    int E, int F3, int R, int chunk, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int rows = R < FWIN ? FWIN : R;
+  for (int i = threadIdx.x; i < rows * F3; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int e0 = blockIdx.x * chunk, e1 = min(E, e0 + chunk);
+  for (int c = threadIdx.x; c < F3; c += blockDim.x) {
+    int e = e0;
+    for (; e + GWR_UNROLL <= e1; e += GWR_UNROLL) {
+      float gp[GWR_UNROLL], gs[GWR_UNROLL], rr[GWR_UNROLL][16], dd[GWR_UNROLL][16];
+#pragma unroll
+      for (int u = 0; u < GWR_UNROLL; ++u) {
+        gp[u] = GPHI[(long)(e + u) * F3 + c];
+        gs[u] = GPSI[(long)(e + u) * F3 + c];
+        const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)(e + u) * RW_STRIDE);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          *reinterpret_cast<float4*>(&rr[u][4 * v]) = rw4[v];
+          *reinterpret_cast<float4*>(&dd[u][4 * v]) = rw4[4 + v];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GWR_UNROLL; ++u) {
+        const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rr[u][13]));
+        float* a = acc + k0 * F3 + c;
+#pragma unroll
+        for (int t = 0; t < FWIN; ++t) a[t * F3] = fmaf(gp[u], rr[u][t], fmaf(gs[u], dd[u][t], a[t * F3]));
+      }
+    }
+    for (; e < e1; ++e) {
+      const float gp1 = GPHI[(long)e * F3 + c], gs1 = GPSI[(long)e * F3 + c];
+      const float* rw = RW + (long)e * RW_STRIDE;
+      const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rw[13]));
+      float* a = acc + k0 * F3 + c;
+#pragma unroll
+      for (int t = 0; t < FWIN; ++t) a[t * F3] = fmaf(gp1, rw[t], fmaf(gs1, rw[16 + t], a[t * F3]));
+    }
+  }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * R * F3;
+  for (int i = threadIdx.x; i < R * F3; i += blockDim.x) out[i] = acc[i];
 }
 
 // out[c][r] = in[r][c]  (rbf_proj.weight [3F][R] -> WrT [R][3F]); 32x32 LDS tile, coalesced both ways
@@ -548,10 +676,10 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
   const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R);
   if (tangent) {
     NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_fwd<true>), dim3(grid), dim3(threads), lds, st, q, fa);
+    hipLaunchKernelGGL((k_msgf_fwd<true>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
   } else {
     NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_fwd<false>), dim3(grid), dim3(threads), lds, st, q, fa);
+    hipLaunchKernelGGL((k_msgf_fwd<false>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
   }
   NQ_LAUNCH_CHECK();
   return NQ_OK;
@@ -564,11 +692,32 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, dual ? FUSED_THREADS_DUAL : FUSED_THREADS);
   if (dual) {
     NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_rev<true>), dim3(grid), dim3(threads), lds, st, q, fa);
+    hipLaunchKernelGGL((k_msgf_rev<true>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
   } else {
     NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_rev<false>), dim3(grid), dim3(threads), lds, st, q, fa);
+    hipLaunchKernelGGL((k_msgf_rev<false>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
   }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+#define GWR_BLOCKS 256
+size_t nq_gwr_scratch_floats(int F, int R) { return (size_t)(GWR_BLOCKS + 1) * R * 3 * F; }
+
+// gWr[3F][R] (overwrites). scratch: nq_gwr_scratch_floats()
+int nq_gwr_accum(hipStream_t st, const float* GPHI, const float* GPSI, const float* RW, int E, int F, int R, float* gWr, float* scratch) {
+  NQ_PROF(st, "gwr_accum");
+  const int F3 = 3 * F;
+  const int blocks = E < GWR_BLOCKS * 8 ? nq_cdiv(E, 8) : GWR_BLOCKS;
+  const int chunk = nq_cdiv(E, blocks);
+  const int threads = F3 <= 1024 ? F3 : 1024;
+  const size_t lds = (size_t)(R < FWIN ? FWIN : R) * F3 * sizeof(float);
+  NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_gwr_accum, dim3(blocks), dim3(threads), lds, st, GPHI, GPSI, RW, E, F3, R, chunk, scratch);
+  NQ_LAUNCH_CHECK();
+  float* gWrT = scratch + (size_t)GWR_BLOCKS * R * F3;
+  NQ_TRY(nq_reduce_partials(st, scratch, blocks, (long)R * F3, (long)R * F3, gWrT));
+  hipLaunchKernelGGL(k_transpose, dim3(nq_cdiv(F3, 32), nq_cdiv(R, 32)), dim3(32, 8), 0, st, gWrT, R, F3, gWr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

