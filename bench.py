@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="conformers per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: nq_set_gemm_variant (bit0 8 waves, bit1 prefetch)")
     args = ap.parse_args()
 
     import nabladft_amd as nq
@@ -119,6 +120,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.gemm_variant is not None:
+        _lib.load().nq_set_gemm_variant(args.gemm_variant)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
     model = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
     step = nq.FusedTrainStep(model, lr=5e-4, weight_decay=0.0, max_grad_norm=5.0)   # painn-oc.yaml optimizer + clip

@@ -122,6 +122,9 @@ int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 void nq_profile_enable(int32_t on);
 int nq_profile_read(char* names_host, int32_t name_stride, double* total_ms_host, int64_t* counts_host, int32_t cap);
 
+/* Tuning hook (process-global): GEMM kernel variant, bit0 = 8 wavefronts per 128x128 tile, bit1 = register prefetch. */
+void nq_set_gemm_variant(int32_t variant);
+
 /* ---- building blocks exported for unit tests ----------------------------------------------- */
 /* C[M,N] = A[M,K] W[N,K]^T (+bias[N]); if C_silu != NULL also writes silu(C). */
 int nq_linear_forward(const float* A, const float* W, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K,

@@ -45,6 +45,7 @@ SYMBOLS = {
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),
     "nq_profile_enable": (None, [_I32]),
     "nq_profile_read": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "nq_set_gemm_variant": (None, [_I32]),
     "nq_linear_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "nq_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32]),

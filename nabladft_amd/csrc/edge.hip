@@ -470,58 +470,6 @@ __global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_m
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Gradient of rbf_proj.weight with the windowed filter:
-//   gWrT[k][c] = sum_e gphi[e][c] rho_k(d_e) + gpsi[e][c] drho_k(d_e),  k in the 13-tap window of edge e.
-// One workgroup per CU owns an LDS accumulator acc[R][3F] (same 153.6 kB footprint as WrT); thread c owns
-// column c, so every accumulator word is updated by exactly one thread in program order: no atomics, and the
-// result is bitwise reproducible.  Each workgroup walks a contiguous chunk of edges (4 in flight per thread);
-// per-workgroup partial slabs are summed in fixed order by k_reduce_partials and transposed into [3F][R].
-#define GWR_UNROLL 4
-__global__ __launch_bounds__(1024) void k_gwr_accum(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
-                                                    int E, int F3, int R, int chunk, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];
-  const int rows = R < FWIN ? FWIN : R;
-  for (int i = threadIdx.x; i < rows * F3; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
-  const int e0 = blockIdx.x * chunk, e1 = min(E, e0 + chunk);
-  for (int c = threadIdx.x; c < F3; c += blockDim.x) {
-    int e = e0;
-    for (; e + GWR_UNROLL <= e1; e += GWR_UNROLL) {
-      float gp[GWR_UNROLL], gs[GWR_UNROLL], rr[GWR_UNROLL][16], dd[GWR_UNROLL][16];
-#pragma unroll
-      for (int u = 0; u < GWR_UNROLL; ++u) {
-        gp[u] = GPHI[(long)(e + u) * F3 + c];
-        gs[u] = GPSI[(long)(e + u) * F3 + c];
-        const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)(e + u) * RW_STRIDE);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          *reinterpret_cast<float4*>(&rr[u][4 * v]) = rw4[v];
-          *reinterpret_cast<float4*>(&dd[u][4 * v]) = rw4[4 + v];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < GWR_UNROLL; ++u) {
-        const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rr[u][13]));
-        float* a = acc + k0 * F3 + c;
-#pragma unroll
-        for (int t = 0; t < FWIN; ++t) a[t * F3] = fmaf(gp[u], rr[u][t], fmaf(gs[u], dd[u][t], a[t * F3]));
-      }
-    }
-    for (; e < e1; ++e) {
-      const float gp1 = GPHI[(long)e * F3 + c], gs1 = GPSI[(long)e * F3 + c];
-      const float* rw = RW + (long)e * RW_STRIDE;
-      const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(rw[13]));
-      float* a = acc + k0 * F3 + c;
-#pragma unroll
-      for (int t = 0; t < FWIN; ++t) a[t * F3] = fmaf(gp1, rw[t], fmaf(gs1, rw[16 + t], a[t * F3]));
-    }
-  }
-  __syncthreads();
-  float* out = part + (long)blockIdx.x * R * F3;
-  for (int i = threadIdx.x; i < R * F3; i += blockDim.x) out[i] = acc[i];
-}
-
 // out[c][r] = in[r][c]  (rbf_proj.weight [3F][R] -> WrT [R][3F]); 32x32 LDS tile, coalesced both ways
 __global__ void k_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
   __shared__ float tile[32][33];
@@ -701,23 +649,3 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   return NQ_OK;
 }
 
-#define GWR_BLOCKS 256
-size_t nq_gwr_scratch_floats(int F, int R) { return (size_t)(GWR_BLOCKS + 1) * R * 3 * F; }
-
-// gWr[3F][R] (overwrites). scratch: nq_gwr_scratch_floats()
-int nq_gwr_accum(hipStream_t st, const float* GPHI, const float* GPSI, const float* RW, int E, int F, int R, float* gWr, float* scratch) {
-  NQ_PROF(st, "gwr_accum");
-  const int F3 = 3 * F;
-  const int blocks = E < GWR_BLOCKS * 8 ? nq_cdiv(E, 8) : GWR_BLOCKS;
-  const int chunk = nq_cdiv(E, blocks);
-  const int threads = F3 <= 1024 ? F3 : 1024;
-  const size_t lds = (size_t)(R < FWIN ? FWIN : R) * F3 * sizeof(float);
-  NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_gwr_accum, dim3(blocks), dim3(threads), lds, st, GPHI, GPSI, RW, E, F3, R, chunk, scratch);
-  NQ_LAUNCH_CHECK();
-  float* gWrT = scratch + (size_t)GWR_BLOCKS * R * F3;
-  NQ_TRY(nq_reduce_partials(st, scratch, blocks, (long)R * F3, (long)R * F3, gWrT));
-  hipLaunchKernelGGL(k_transpose, dim3(nq_cdiv(F3, 32), nq_cdiv(R, 32)), dim3(32, 8), 0, st, gWrT, R, F3, gWr);
-  NQ_LAUNCH_CHECK();
-  return NQ_OK;
-}

@@ -36,60 +36,73 @@ struct GemmArgs {
 // MN-contiguous source (element (k, r) at src[k*ld + r]) -> LDS tile[k][r], stride LDS_MC (16-B aligned rows)
 #define LDS_MC (BM + 4)
 
-template <bool KC>
-__device__ __forceinline__ void load_tile(float* __restrict__ tile, const float* __restrict__ src, int ld, int r0, int R, int k0,
-                                          int Kend, bool vec_ok) {
+// ---- tile staging, split into fetch (global -> registers) and stash (registers -> LDS) so that the fetch of
+// k-tile t+1 can be issued before the MFMAs of k-tile t (the global latency then hides under the matrix pipe).
+// KC source: element (r, k) at src[r*ld + k]; MC source: element (k, r) at src[k*ld + r].  NT = threads per workgroup.
+template <bool KC, int NT>
+__device__ __forceinline__ void fetch_tile(float4 (&v)[1024 / NT], const float* __restrict__ src, int ld, int r0, int R, int k0, int Kend,
+                                           bool vec_ok) {
   const int t = threadIdx.x;
-  if (KC) {
-    // 128 rows x 32 k = 1024 float4, 4 per thread; consecutive lanes walk k (coalesced 128-B rows)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = t + GEMM_THREADS * it;
+  for (int it = 0; it < 1024 / NT; ++it) {
+    const int idx = t + NT * it;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {  // 128 rows x 32 k: consecutive lanes walk k (128-B row segments)
       const int row = idx >> 3, kq = (idx & 7) * 4;
       const int gr = r0 + row, gk = k0 + kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < R) {
         const float* ptr = src + (long)gr * ld + gk;
-        if (vec_ok && gk + 3 < Kend) {
-          v = *reinterpret_cast<const float4*>(ptr);
-        } else {
-          if (gk + 0 < Kend) v.x = ptr[0];
-          if (gk + 1 < Kend) v.y = ptr[1];
-          if (gk + 2 < Kend) v.z = ptr[2];
-          if (gk + 3 < Kend) v.w = ptr[3];
+        if (vec_ok && gk + 3 < Kend) x = *reinterpret_cast<const float4*>(ptr);
+        else {
+          if (gk + 0 < Kend) x.x = ptr[0];
+          if (gk + 1 < Kend) x.y = ptr[1];
+          if (gk + 2 < Kend) x.z = ptr[2];
+          if (gk + 3 < Kend) x.w = ptr[3];
         }
       }
-      tile[(kq + 0) * LDS_KC + row] = v.x;
-      tile[(kq + 1) * LDS_KC + row] = v.y;
-      tile[(kq + 2) * LDS_KC + row] = v.z;
-      tile[(kq + 3) * LDS_KC + row] = v.w;
-    }
-  } else {
-    // 32 k x 128 cols = 1024 float4; consecutive lanes walk the contiguous dimension (512-B rows)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = t + GEMM_THREADS * it;
+    } else {   // 32 k x 128 cols: consecutive lanes walk the contiguous dimension (512-B rows)
       const int k = idx >> 5, rq = (idx & 31) * 4;
       const int gk = k0 + k, gr = r0 + rq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gk < Kend) {
         const float* ptr = src + (long)gk * ld + gr;
-        if (vec_ok && gr + 3 < R) {
-          v = *reinterpret_cast<const float4*>(ptr);
-        } else {
-          if (gr + 0 < R) v.x = ptr[0];
-          if (gr + 1 < R) v.y = ptr[1];
-          if (gr + 2 < R) v.z = ptr[2];
-          if (gr + 3 < R) v.w = ptr[3];
+        if (vec_ok && gr + 3 < R) x = *reinterpret_cast<const float4*>(ptr);
+        else {
+          if (gr + 0 < R) x.x = ptr[0];
+          if (gr + 1 < R) x.y = ptr[1];
+          if (gr + 2 < R) x.z = ptr[2];
+          if (gr + 3 < R) x.w = ptr[3];
         }
       }
-      *reinterpret_cast<float4*>(tile + k * LDS_MC + rq) = v;
+    }
+    v[it] = x;
+  }
+}
+
+template <bool KC, int NT>
+__device__ __forceinline__ void stash_tile(float* __restrict__ tile, const float4 (&v)[1024 / NT]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 1024 / NT; ++it) {
+    const int idx = t + NT * it;
+    if (KC) {
+      const int row = idx >> 3, kq = (idx & 7) * 4;
+      tile[(kq + 0) * LDS_KC + row] = v[it].x;
+      tile[(kq + 1) * LDS_KC + row] = v[it].y;
+      tile[(kq + 2) * LDS_KC + row] = v[it].z;
+      tile[(kq + 3) * LDS_KC + row] = v[it].w;
+    } else {
+      const int k = idx >> 5, rq = (idx & 31) * 4;
+      *reinterpret_cast<float4*>(tile + k * LDS_MC + rq) = v[it];
     }
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
+// NW = wavefronts per 128x128 tile: 4 -> each wave owns 64x64 (2x2 MFMA tiles), 8 -> 64x32 (2x1).
+// PF = register prefetch of the next k-tile (one extra barrier-free overlap of global latency with MFMAs).
+template <bool A_KC, bool B_KC, int EPI, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int TN = NW == 4 ? 2 : 1;
   constexpr int LDA_S = A_KC ? LDS_KC : LDS_MC;
   constexpr int LDB_S = B_KC ? LDS_KC : LDS_MC;
   __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
@@ -102,34 +115,50 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
     kend = min(p.K, kbeg + p.k_per_split);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
+  const int wcol0 = NW == 4 ? wn * 64 : wn * 32;
   const int lr = lane & 31, lk = lane >> 5;
 
   const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
   const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float4 ra[1024 / NT], rb[1024 / NT];
+  if (PF) {
+    fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, a_vec);
+    fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, b_vec);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    load_tile<A_KC>(As, p.A, p.lda, m0, p.M, k0, kend, a_vec);
-    load_tile<B_KC>(Bs, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
+    if (!PF) {
+      fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, a_vec);
+      fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
+    }
+    stash_tile<A_KC, NT>(As, ra);
+    stash_tile<B_KC, NT>(Bs, rb);
     __syncthreads();
+    if (PF && k0 + BK < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
+      fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, a_vec);
+      fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, b_vec);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const float a0 = As[(kk + lk) * LDA_S + wm * 64 + lr];
       const float a1 = As[(kk + lk) * LDA_S + wm * 64 + 32 + lr];
-      const float b0 = Bs[(kk + lk) * LDB_S + wn * 64 + lr];
-      const float b1 = Bs[(kk + lk) * LDB_S + wn * 64 + 32 + lr];
+      const float b0 = Bs[(kk + lk) * LDB_S + wcol0 + lr];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (TN == 2) {
+        const float b1 = Bs[(kk + lk) * LDB_S + wcol0 + 32 + lr];
+        acc[0][TN - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][TN - 1], 0, 0, 0);
+        acc[1][TN - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][TN - 1], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -140,8 +169,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lr;
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wcol0 + j * 32 + lr;
       if (col >= p.N) continue;
       const float bv = (EPI != EPI_PARTIAL && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
@@ -155,6 +184,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs p) {
         if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
       }
     }
+}
+
+// process-global kernel variant (tuning / A-B measurements): bit0 = 8 waves per tile, bit1 = register prefetch
+static int g_gemm_variant = 0;
+extern "C" void nq_set_gemm_variant(int32_t v) { g_gemm_variant = v; }
+
+template <bool A_KC, bool B_KC, int EPI>
+static void launch_gemm(hipStream_t st, dim3 grid, const GemmArgs& p) {
+  switch (g_gemm_variant & 3) {
+    case 0: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, false>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, false>), grid, dim3(512), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, true>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, true>), grid, dim3(512), 0, st, p); break;
+  }
 }
 
 // out[i] = sum_s part[s*stride + i]  (fixed order -> deterministic)
@@ -201,8 +244,8 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0};
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
-  if (C2_silu) hipLaunchKernelGGL((k_gemm<true, true, EPI_SILU>), grid, dim3(GEMM_THREADS), 0, st, p);
-  else hipLaunchKernelGGL((k_gemm<true, true, EPI_STORE>), grid, dim3(GEMM_THREADS), 0, st, p);
+  if (C2_silu) launch_gemm<true, true, EPI_SILU>(st, grid, p);
+  else launch_gemm<true, true, EPI_STORE>(st, grid, p);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -215,8 +258,8 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0};
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
-  if (accumulate) hipLaunchKernelGGL((k_gemm<true, false, EPI_ACC>), grid, dim3(GEMM_THREADS), 0, st, p);
-  else hipLaunchKernelGGL((k_gemm<true, false, EPI_STORE>), grid, dim3(GEMM_THREADS), 0, st, p);
+  if (accumulate) launch_gemm<true, false, EPI_ACC>(st, grid, p);
+  else launch_gemm<true, false, EPI_STORE>(st, grid, p);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -249,7 +292,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   kper = (kper + BK - 1) / BK * BK;
   GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No};
   dim3 grid(nq_cdiv(Mo, BM), nq_cdiv(No, BN), ns);
-  hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL>), grid, dim3(GEMM_THREADS), 0, st, p);
+  launch_gemm<false, false, EPI_PARTIAL>(st, grid, p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
   hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);

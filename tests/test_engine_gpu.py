@@ -174,14 +174,13 @@ def _trace_report(name, model, sw, s2c, tag, lines):
                     e = rel_err(got, ref)
                     worst = max(worst, e)
                     lines.append(f"{name} {tag} {b}_{l:<10d} rel_err {e:.3e}")
-    if os.environ.get("NQ_NO_FUSED_FILTER") == "1":
-        for b, key in (("rho", "rho"), ("rho", "drho")):
-            ref = sw.ws[key][s2c].reshape(-1).numpy()
-            got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
-            e = rel_err(got, ref)
-            worst = max(worst, e)
-            lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
-    else:
+    for b, key in (("rho", "rho"), ("rho", "drho")):
+        ref = sw.ws[key][s2c].reshape(-1).numpy()
+        got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
+        e = rel_err(got, ref)
+        worst = max(worst, e)
+        lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    if os.environ.get("NQ_NO_FUSED_FILTER") != "1":
         # fused filter: per-edge 13-tap window record {rho[13], k0, ., ., drho[13]} must reproduce the full basis row
         rw = model.workspace_view("rw").cpu().view(-1, 32)
         k0 = rw[:, 13].contiguous().view(torch.int32).long()
