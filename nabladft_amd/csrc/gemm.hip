@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 }
 
 // process-global kernel variant (tuning / A-B measurements): bit0 = 8 waves per tile, bit1 = register prefetch
-static int g_gemm_variant = 0;
+static int g_gemm_variant = 1;  // measured best on MI355X (scripts/gemm_bench.py): 8 wavefronts per tile, no prefetch
 extern "C" void nq_set_gemm_variant(int32_t v) { g_gemm_variant = v; }
 
 template <bool A_KC, bool B_KC, int EPI>
