@@ -197,6 +197,8 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 // =============================================================================================
 #define FWIN 13
 #define FUSED_THREADS 1024
+// workgroup size per kernel flavour and channels-per-lane (register budget: 1024 thr -> 128 VGPRs, 768 -> 168, 512 -> 256)
+__host__ __device__ constexpr int fused_threads(bool heavy, int ch) { return ch >= 4 ? 512 : (ch == 2 ? (heavy ? 768 : 1024) : 1024); }
 #define FUSED_THREADS_DUAL 1024  // window records live in SGPRs (scalar loads), so the dual reverse also fits 16 waves per CU
 
 __device__ __forceinline__ float bcast_lane(float v, int t) {
@@ -253,7 +255,33 @@ __device__ __forceinline__ void load_row(RowRegs& r, const NqGraphView& g, const
 __device__ __forceinline__ int bl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 __device__ __forceinline__ float bl_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 
-// ---- per-edge operand bundles (loaded one edge ahead of their use) -------------------------------------------
+// ---- CH consecutive channels per lane: vector loads / stores ---------------------------------------------------
+template <int CH> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+template <int CH>
+__device__ __forceinline__ void ldv(float (&o)[CH], const float* p) {
+  if constexpr (CH == 1) { o[0] = *p; }
+  else {
+    const typename VecOf<CH>::T v = *reinterpret_cast<const typename VecOf<CH>::T*>(p);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) o[c] = v[c];
+  }
+}
+template <int CH>
+__device__ __forceinline__ void stv(float* p, const float (&o)[CH]) {
+  if constexpr (CH == 1) { *p = o[0]; }
+  else {
+    typename VecOf<CH>::T v;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = o[c];
+    *reinterpret_cast<typename VecOf<CH>::T*>(p) = v;
+  }
+}
+
+// ---- per-edge window record (scalar loads: the record address is wave-uniform) -------------------------------
 template <bool PSI>
 struct WinRegs { float rr[16]; float dd[PSI ? 16 : 1]; };
 
@@ -268,21 +296,28 @@ __device__ __forceinline__ void load_win(WinRegs<PSI>& w, const float* __restric
   }
 }
 
-// phi (and psi) for this thread's three channels from the LDS-resident WrT and the edge's window record
-template <bool PSI>
-__device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* wrt, int F, int F3, int f, float bra, float brb, float brc,
-                                            float& pa, float& pb, float& pc, float& qa, float& qb, float& qc) {
-  pa = bra; pb = brb; pc = brc; qa = qb = qc = 0.f;
+// phi (and psi) for this lane's CH channels of each of the three parts, from the LDS-resident WrT
+template <bool PSI, int CH>
+__device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* wrt, int F, int F3, int fb, const float (&bra)[CH],
+                                            const float (&brb)[CH], const float (&brc)[CH], float (&pa)[CH], float (&pb)[CH], float (&pc)[CH],
+                                            float (&qa)[CH], float (&qb)[CH], float (&qc)[CH]) {
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { pa[c] = bra[c]; pb[c] = brb[c]; pc[c] = brc[c]; qa[c] = qb[c] = qc[c] = 0.f; }
   const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(w.rr[13]));
-  const float* wk = wrt + k0 * F3 + f;
+  const float* wk = wrt + k0 * F3 + fb;
 #pragma unroll
   for (int t = 0; t < FWIN; ++t) {  // always 13 taps: LDS rows >= R and window taps >= R are zero
-    const float wa = wk[t * F3], wb = wk[t * F3 + F], wc = wk[t * F3 + 2 * F];
-    pa = fmaf(wa, w.rr[t], pa); pb = fmaf(wb, w.rr[t], pb); pc = fmaf(wc, w.rr[t], pc);
-    if (PSI) { qa = fmaf(wa, w.dd[t], qa); qb = fmaf(wb, w.dd[t], qb); qc = fmaf(wc, w.dd[t], qc); }
+    float wa[CH], wb[CH], wc[CH];
+    ldv<CH>(wa, wk + t * F3); ldv<CH>(wb, wk + t * F3 + F); ldv<CH>(wc, wk + t * F3 + 2 * F);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      pa[c] = fmaf(wa[c], w.rr[t], pa[c]); pb[c] = fmaf(wb[c], w.rr[t], pb[c]); pc[c] = fmaf(wc[c], w.rr[t], pc[c]);
+      if (PSI) { qa[c] = fmaf(wa[c], w.dd[t], qa[c]); qb[c] = fmaf(wb[c], w.dd[t], qb[c]); qc[c] = fmaf(wc[c], w.dd[t], qc[c]); }
+    }
   }
 }
 
+// One wavefront per atom; lane l owns channels [l*CH, (l+1)*CH) of each part (F = 64*CH).
 #define FUSED_PROLOGUE                                                                          \
   extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
   const int F = q.F, F3 = 3 * q.F;                                                             \
@@ -294,160 +329,189 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
       dst4[i] = i < total4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);                         \
   }                                                                                            \
   __syncthreads();                                                                             \
-  const int nslots = blockDim.x / F, f = threadIdx.x % F;                                      \
-  const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x / F); /* wave-uniform: F % 64 == 0 */ \
+  const int nslots = blockDim.x >> 6;                                                          \
+  const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                           \
   const int lane = threadIdx.x & 63;                                                           \
-  const float bra = fa.br[f], brb = fa.br[F + f], brc = fa.br[2 * F + f];                      \
+  const int fb = lane * CH;                                                                    \
+  float bra[CH], brb[CH], brc[CH];                                                             \
+  ldv<CH>(bra, fa.br + fb); ldv<CH>(brb, fa.br + F + fb); ldv<CH>(brc, fa.br + 2 * F + fb);    \
   /* contiguous node range per workgroup: a molecule's rows stay in ONE XCD's L2 */            \
   const int per_wg = (q.g.N + gridDim.x - 1) / gridDim.x;                                      \
   const int n_lo = blockIdx.x * per_wg, n_hi = min(q.g.N, n_lo + per_wg);
 
 // ---- forward / tangent -------------------------------------------------------------------------------------
-template <bool TAN>
-struct FwdOps { float xa, xb, xc, va, vb, vc, txa, txb, txc, tva, tvb, tvc; WinRegs<TAN> w; };
+template <bool TAN, int CH>
+struct FwdOps { float xa[CH], xb[CH], xc[CH], va[CH], vb[CH], vc[CH], txa[CH], txb[CH], txc[CH], tva[CH], tvb[CH], tvc[CH]; WinRegs<TAN> w; };
 
-template <bool TAN>
-__device__ __forceinline__ void load_fwd(FwdOps<TAN>& o, const MsgArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int f) {
-  const float* xh = q.XH + (long)k * F3;
-  const float* vk = q.V + (long)k * F3;
-  o.xa = xh[f]; o.xb = xh[F + f]; o.xc = xh[2 * F + f];
-  o.va = vk[f]; o.vb = vk[F + f]; o.vc = vk[2 * F + f];
+template <bool TAN, int CH>
+__device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int fb) {
+  const float* xh = q.XH + (long)k * F3 + fb;
+  const float* vk = q.V + (long)k * F3 + fb;
+  ldv<CH>(o.xa, xh); ldv<CH>(o.xb, xh + F); ldv<CH>(o.xc, xh + 2 * F);
+  ldv<CH>(o.va, vk); ldv<CH>(o.vb, vk + F); ldv<CH>(o.vc, vk + 2 * F);
   if (TAN) {
-    const float* txh = q.TXH + (long)k * F3;
-    const float* tvk = q.TV + (long)k * F3;
-    o.txa = txh[f]; o.txb = txh[F + f]; o.txc = txh[2 * F + f];
-    o.tva = tvk[f]; o.tvb = tvk[F + f]; o.tvc = tvk[2 * F + f];
+    const float* txh = q.TXH + (long)k * F3 + fb;
+    const float* tvk = q.TV + (long)k * F3 + fb;
+    ldv<CH>(o.txa, txh); ldv<CH>(o.txb, txh + F); ldv<CH>(o.txc, txh + 2 * F);
+    ldv<CH>(o.tva, tvk); ldv<CH>(o.tvb, tvk + F); ldv<CH>(o.tvc, tvk + 2 * F);
   }
   load_win<TAN>(o.w, RW, sp);
 }
 
-template <bool TAN>
-__global__ __launch_bounds__(FUSED_THREADS) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
+template <bool TAN, int CH>
+__global__ __launch_bounds__(fused_threads(TAN, CH)) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   for (int n = n_lo + slot; n < n_hi; n += nslots) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
-    float dx = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    float dx[CH], d0[CH], d1[CH], d2[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) dx[c] = d0[c] = d1[c] = d2[c] = 0.f;
     for (int c0 = beg; c0 < end; c0 += 64) {
       const int cnt = min(64, end - c0);
       RowRegs row;
       load_row<TAN>(row, q.g, q.TD, q.TR, c0, cnt, lane);
-      FwdOps<TAN> cur, nxt;
-      load_fwd<TAN>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, f);
+      FwdOps<TAN, CH> cur, nxt;
+      load_fwd<TAN, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
       nxt = cur;
       for (int j = 0; j < cnt; ++j) {
-        if (j + 1 < cnt) load_fwd<TAN>(nxt, q, RW, bl_i(row.kk, j + 1), c0 + j + 1, F, F3, f);
-        float pa, pb, pc, qa, qb, qc;
-        filter_eval<TAN>(cur.w, wrt, F, F3, f, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        if (j + 1 < cnt) load_fwd<TAN, CH>(nxt, q, RW, bl_i(row.kk, j + 1), c0 + j + 1, F, F3, fb);
+        float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
+        filter_eval<TAN, CH>(cur.w, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
         const float gx = bl_f(row.gx, j), gy = bl_f(row.gy, j), gz = bl_f(row.gz, j);
-        const float mb = cur.xb * pb, mc = cur.xc * pc;
-        if (!TAN) {
-          dx += cur.xa * pa;
-          d0 += cur.va * mb + mc * gx;
-          d1 += cur.vb * mb + mc * gy;
-          d2 += cur.vc * mb + mc * gz;
-        } else {
-          const float td = bl_f(row.td, j), tr0 = bl_f(row.t0, j), tr1 = bl_f(row.t1, j), tr2 = bl_f(row.t2, j);
-          const float tma = cur.txa * pa + cur.xa * (qa * td);
-          const float tmb = cur.txb * pb + cur.xb * (qb * td);
-          const float tmc = cur.txc * pc + cur.xc * (qc * td);
-          dx += tma;
-          d0 += cur.tva * mb + cur.va * tmb + tmc * gx + mc * tr0;
-          d1 += cur.tvb * mb + cur.vb * tmb + tmc * gy + mc * tr1;
-          d2 += cur.tvc * mb + cur.vc * tmb + tmc * gz + mc * tr2;
+        float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
+        if (TAN) { td = bl_f(row.td, j); tr0 = bl_f(row.t0, j); tr1 = bl_f(row.t1, j); tr2 = bl_f(row.t2, j); }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float mb = cur.xb[c] * pb[c], mc = cur.xc[c] * pc[c];
+          if (!TAN) {
+            dx[c] += cur.xa[c] * pa[c];
+            d0[c] += cur.va[c] * mb + mc * gx;
+            d1[c] += cur.vb[c] * mb + mc * gy;
+            d2[c] += cur.vc[c] * mb + mc * gz;
+          } else {
+            const float tma = cur.txa[c] * pa[c] + cur.xa[c] * (qa[c] * td);
+            const float tmb = cur.txb[c] * pb[c] + cur.xb[c] * (qb[c] * td);
+            const float tmc = cur.txc[c] * pc[c] + cur.xc[c] * (qc[c] * td);
+            dx[c] += tma;
+            d0[c] += cur.tva[c] * mb + cur.va[c] * tmb + tmc * gx + mc * tr0;
+            d1[c] += cur.tvb[c] * mb + cur.vb[c] * tmb + tmc * gy + mc * tr1;
+            d2[c] += cur.tvc[c] * mb + cur.vc[c] * tmb + tmc * gz + mc * tr2;
+          }
         }
         cur = nxt;
       }
     }
-    const long o = (long)n * F, o3 = (long)n * F3;
+    const long o = (long)n * F + fb, o3 = (long)n * F3 + fb;
+    float x0[CH], w0[CH], w1[CH], w2[CH];
     if (!TAN) {
-      q.XM[o + f] = q.X[o + f] + dx;
-      q.VM[o3 + f] = q.V[o3 + f] + d0; q.VM[o3 + F + f] = q.V[o3 + F + f] + d1; q.VM[o3 + 2 * F + f] = q.V[o3 + 2 * F + f] + d2;
+      ldv<CH>(x0, q.X + o); ldv<CH>(w0, q.V + o3); ldv<CH>(w1, q.V + o3 + F); ldv<CH>(w2, q.V + o3 + 2 * F);
     } else {
-      q.TXM[o + f] = q.TX[o + f] + dx;
-      q.TVM[o3 + f] = q.TV[o3 + f] + d0; q.TVM[o3 + F + f] = q.TV[o3 + F + f] + d1; q.TVM[o3 + 2 * F + f] = q.TV[o3 + 2 * F + f] + d2;
+      ldv<CH>(x0, q.TX + o); ldv<CH>(w0, q.TV + o3); ldv<CH>(w1, q.TV + o3 + F); ldv<CH>(w2, q.TV + o3 + 2 * F);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { x0[c] += dx[c]; w0[c] += d0[c]; w1[c] += d1[c]; w2[c] += d2[c]; }
+    if (!TAN) {
+      stv<CH>(q.XM + o, x0); stv<CH>(q.VM + o3, w0); stv<CH>(q.VM + o3 + F, w1); stv<CH>(q.VM + o3 + 2 * F, w2);
+    } else {
+      stv<CH>(q.TXM + o, x0); stv<CH>(q.TVM + o3, w0); stv<CH>(q.TVM + o3 + F, w1); stv<CH>(q.TVM + o3 + 2 * F, w2);
     }
   }
 }
 
 // ---- reverse (force adjoint / dual) ----------------------------------------------------------------------------
-template <bool DUAL>
-struct RevOps { float A0, A1, A2, gma, T0, T1, T2, gtma; WinRegs<true> w; };
+template <bool DUAL, int CH>
+struct RevOps { float A0[CH], A1[CH], A2[CH], gma[CH], T0[CH], T1[CH], T2[CH], gtma[CH]; WinRegs<true> w; };
 
-template <bool DUAL>
-__device__ __forceinline__ void load_rev(RevOps<DUAL>& o, const MsgRevArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int f) {
-  const float* A = q.GV + (long)k * F3;
-  o.A0 = A[f]; o.A1 = A[F + f]; o.A2 = A[2 * F + f];
-  o.gma = q.GX[(long)k * F + f];
+template <bool DUAL, int CH>
+__device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int fb) {
+  const float* A = q.GV + (long)k * F3 + fb;
+  ldv<CH>(o.A0, A); ldv<CH>(o.A1, A + F); ldv<CH>(o.A2, A + 2 * F);
+  ldv<CH>(o.gma, q.GX + (long)k * F + fb);
   if (DUAL) {
-    const float* T = q.GTV + (long)k * F3;
-    o.T0 = T[f]; o.T1 = T[F + f]; o.T2 = T[2 * F + f];
-    o.gtma = q.GTX[(long)k * F + f];
+    const float* T = q.GTV + (long)k * F3 + fb;
+    ldv<CH>(o.T0, T); ldv<CH>(o.T1, T + F); ldv<CH>(o.T2, T + 2 * F);
+    ldv<CH>(o.gtma, q.GTX + (long)k * F + fb);
   }
   load_win<true>(o.w, RW, sp);
 }
 
-template <bool DUAL>
-__global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
+template <bool DUAL, int CH>
+__global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  const int wave_in_slot = (threadIdx.x % F) >> 6;
   for (int n = n_lo + slot; n < n_hi; n += nslots) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
-    const long o3 = (long)n * F3;
-    const float xa = q.XH[o3 + f], xb = q.XH[o3 + F + f], xc = q.XH[o3 + 2 * F + f];
-    const float v0 = q.V[o3 + f], v1 = q.V[o3 + F + f], v2 = q.V[o3 + 2 * F + f];
-    float txa = 0.f, txb = 0.f, txc = 0.f, tv0 = 0.f, tv1 = 0.f, tv2 = 0.f;
+    const long o3 = (long)n * F3 + fb;
+    float xa[CH], xb[CH], xc[CH], v0[CH], v1[CH], v2[CH], txa[CH], txb[CH], txc[CH], tv0[CH], tv1[CH], tv2[CH];
+    ldv<CH>(xa, q.XH + o3); ldv<CH>(xb, q.XH + o3 + F); ldv<CH>(xc, q.XH + o3 + 2 * F);
+    ldv<CH>(v0, q.V + o3); ldv<CH>(v1, q.V + o3 + F); ldv<CH>(v2, q.V + o3 + 2 * F);
     if (DUAL) {
-      txa = q.TXH[o3 + f]; txb = q.TXH[o3 + F + f]; txc = q.TXH[o3 + 2 * F + f];
-      tv0 = q.TV[o3 + f]; tv1 = q.TV[o3 + F + f]; tv2 = q.TV[o3 + 2 * F + f];
+      ldv<CH>(txa, q.TXH + o3); ldv<CH>(txb, q.TXH + o3 + F); ldv<CH>(txc, q.TXH + o3 + 2 * F);
+      ldv<CH>(tv0, q.TV + o3); ldv<CH>(tv1, q.TV + o3 + F); ldv<CH>(tv2, q.TV + o3 + 2 * F);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) txa[c] = txb[c] = txc[c] = tv0[c] = tv1[c] = tv2[c] = 0.f;
     }
-    float gxa = 0.f, gxb = 0.f, gxc = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
-    float gtxa = 0.f, gtxb = 0.f, gtxc = 0.f, gtv0 = 0.f, gtv1 = 0.f, gtv2 = 0.f;
-    float sba = 0.f, sbb = 0.f, sbc = 0.f;
+    float gxa[CH], gxb[CH], gxc[CH], gv0[CH], gv1[CH], gv2[CH], gtxa[CH], gtxb[CH], gtxc[CH], gtv0[CH], gtv1[CH], gtv2[CH], sba[CH], sbb[CH], sbc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      gxa[c] = gxb[c] = gxc[c] = gv0[c] = gv1[c] = gv2[c] = 0.f;
+      gtxa[c] = gtxb[c] = gtxc[c] = gtv0[c] = gtv1[c] = gtv2[c] = 0.f;
+      sba[c] = sbb[c] = sbc[c] = 0.f;
+    }
     for (int c0 = beg; c0 < end; c0 += 64) {
       const int cnt = min(64, end - c0);
       RowRegs row;
       load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
-      RevOps<DUAL> cur, nxt;
-      load_rev<DUAL>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, f);
+      RevOps<DUAL, CH> cur, nxt;
+      load_rev<DUAL, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
       nxt = cur;
       for (int j = 0; j < cnt; ++j) {
         const int sp = c0 + j;
-        if (j + 1 < cnt) load_rev<DUAL>(nxt, q, RW, bl_i(row.kk, j + 1), sp + 1, F, F3, f);
-        float pa, pb, pc, qa, qb, qc;
-        filter_eval<true>(cur.w, wrt, F, F3, f, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        if (j + 1 < cnt) load_rev<DUAL, CH>(nxt, q, RW, bl_i(row.kk, j + 1), sp + 1, F, F3, fb);
+        float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
+        filter_eval<true, CH>(cur.w, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
         const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);  // unit vector of the out-edge (n -> k)
-        const float A0 = cur.A0, A1 = cur.A1, A2 = cur.A2, gma = cur.gma;
-        const float mb = xb * pb, mc = xc * pc;
-        float gmb = A0 * v0 + A1 * v1 + A2 * v2;
-        float gmc = A0 * r0 + A1 * r1 + A2 * r2;
-        gv0 += A0 * mb; gv1 += A1 * mb; gv2 += A2 * mb;
+        float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
+        if (DUAL) { td = bl_f(row.td, j); tr0 = -bl_f(row.t0, j); tr1 = -bl_f(row.t1, j); tr2 = -bl_f(row.t2, j); }
+        float gd = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+        float ga[CH], gb[CH], gc[CH], ha[CH], hb[CH], hc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float A0 = cur.A0[c], A1 = cur.A1[c], A2 = cur.A2[c], gma = cur.gma[c];
+          const float mb = xb[c] * pb[c], mc = xc[c] * pc[c];
+          float gmb = A0 * v0[c] + A1 * v1[c] + A2 * v2[c];
+          float gmc = A0 * r0 + A1 * r1 + A2 * r2;
+          gv0[c] += A0 * mb; gv1[c] += A1 * mb; gv2[c] += A2 * mb;
+          if (DUAL) {
+            const float tpa = qa[c] * td, tpb = qb[c] * td, tpc = qc[c] * td;
+            const float T0 = cur.T0[c], T1 = cur.T1[c], T2 = cur.T2[c], gtma = cur.gtma[c];
+            const float tmb = txb[c] * pb[c] + xb[c] * tpb;
+            gmb += T0 * tv0[c] + T1 * tv1[c] + T2 * tv2[c];
+            const float gtmb = T0 * v0[c] + T1 * v1[c] + T2 * v2[c];
+            gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
+            const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
+            gv0[c] += T0 * tmb; gv1[c] += T1 * tmb; gv2[c] += T2 * tmb;
+            gtv0[c] += T0 * mb; gtv1[c] += T1 * mb; gtv2[c] += T2 * mb;
+            gxa[c] += gma * pa[c] + gtma * tpa; gxb[c] += gmb * pb[c] + gtmb * tpb; gxc[c] += gmc * pc[c] + gtmc * tpc;
+            gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c];
+            ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
+            sba[c] += ga[c]; sbb[c] += gb[c]; sbc[c] += gc[c];
+            ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
+          } else {
+            gxa[c] += gma * pa[c]; gxb[c] += gmb * pb[c]; gxc[c] += gmc * pc[c];
+            gd += gma * xa[c] * qa[c] + gmb * xb[c] * qb[c] + gmc * xc[c] * qc[c];
+            e0 += A0 * mc; e1 += A1 * mc; e2 += A2 * mc;
+          }
+        }
         if (DUAL) {
-          const float td = bl_f(row.td, j);
-          const float tr0 = -bl_f(row.t0, j), tr1 = -bl_f(row.t1, j), tr2 = -bl_f(row.t2, j);
-          const float tpa = qa * td, tpb = qb * td, tpc = qc * td;
-          const float T0 = cur.T0, T1 = cur.T1, T2 = cur.T2, gtma = cur.gtma;
-          const float tmb = txb * pb + xb * tpb;
-          gmb += T0 * tv0 + T1 * tv1 + T2 * tv2;
-          const float gtmb = T0 * v0 + T1 * v1 + T2 * v2;
-          gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
-          const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
-          gv0 += T0 * tmb; gv1 += T1 * tmb; gv2 += T2 * tmb;
-          gtv0 += T0 * mb; gtv1 += T1 * mb; gtv2 += T2 * mb;
-          gxa += gma * pa + gtma * tpa; gxb += gmb * pb + gtmb * tpb; gxc += gmc * pc + gtmc * tpc;
-          gtxa += gtma * pa; gtxb += gtmb * pb; gtxc += gtmc * pc;
-          float* gp = q.GPHI + (long)sp * F3;
-          float* gs = q.GPSI + (long)sp * F3;
-          const float ga = gma * xa + gtma * txa, gb = gmb * xb + gtmb * txb, gc = gmc * xc + gtmc * txc;
-          gp[f] = ga; gp[F + f] = gb; gp[2 * F + f] = gc;
-          sba += ga; sbb += gb; sbc += gc;
-          gs[f] = gtma * xa * td; gs[F + f] = gtmb * xb * td; gs[2 * F + f] = gtmc * xc * td;
+          float* gp = q.GPHI + (long)sp * F3 + fb;
+          float* gs = q.GPSI + (long)sp * F3 + fb;
+          stv<CH>(gp, ga); stv<CH>(gp + F, gb); stv<CH>(gp + 2 * F, gc);
+          stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
         } else {
-          gxa += gma * pa; gxb += gmb * pb; gxc += gmc * pc;
-          float gd = gma * xa * qa + gmb * xb * qb + gmc * xc * qc;
-          float e0 = A0 * mc, e1 = A1 * mc, e2 = A2 * mc;
           gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
           if (lane == 0) {
-            float4* dstp = q.GEDGE + (long)wave_in_slot * q.g.E + sp;
+            float4* dstp = q.GEDGE + sp;   // one wavefront covers all F channels: slice 0 only
             float4 acc = *dstp;
             acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
             *dstp = acc;
@@ -456,16 +520,19 @@ __global__ __launch_bounds__(DUAL ? FUSED_THREADS_DUAL : FUSED_THREADS) void k_m
         cur = nxt;
       }
     }
-    q.GXH[o3 + f] = gxa; q.GXH[o3 + F + f] = gxb; q.GXH[o3 + 2 * F + f] = gxc;
-    q.GV_out[o3 + f] = q.GV[o3 + f] + gv0;
-    q.GV_out[o3 + F + f] = q.GV[o3 + F + f] + gv1;
-    q.GV_out[o3 + 2 * F + f] = q.GV[o3 + 2 * F + f] + gv2;
+    float g0[CH], g1[CH], g2[CH];
+    stv<CH>(q.GXH + o3, gxa); stv<CH>(q.GXH + o3 + F, gxb); stv<CH>(q.GXH + o3 + 2 * F, gxc);
+    ldv<CH>(g0, q.GV + o3); ldv<CH>(g1, q.GV + o3 + F); ldv<CH>(g2, q.GV + o3 + 2 * F);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { g0[c] += gv0[c]; g1[c] += gv1[c]; g2[c] += gv2[c]; }
+    stv<CH>(q.GV_out + o3, g0); stv<CH>(q.GV_out + o3 + F, g1); stv<CH>(q.GV_out + o3 + 2 * F, g2);
     if (DUAL) {
-      q.GTXH[o3 + f] = gtxa; q.GTXH[o3 + F + f] = gtxb; q.GTXH[o3 + 2 * F + f] = gtxc;
-      q.GBR[o3 + f] = sba; q.GBR[o3 + F + f] = sbb; q.GBR[o3 + 2 * F + f] = sbc;
-      q.GTV_out[o3 + f] = q.GTV[o3 + f] + gtv0;
-      q.GTV_out[o3 + F + f] = q.GTV[o3 + F + f] + gtv1;
-      q.GTV_out[o3 + 2 * F + f] = q.GTV[o3 + 2 * F + f] + gtv2;
+      stv<CH>(q.GTXH + o3, gtxa); stv<CH>(q.GTXH + o3 + F, gtxb); stv<CH>(q.GTXH + o3 + 2 * F, gtxc);
+      stv<CH>(q.GBR + o3, sba); stv<CH>(q.GBR + o3 + F, sbb); stv<CH>(q.GBR + o3 + 2 * F, sbc);
+      ldv<CH>(g0, q.GTV + o3); ldv<CH>(g1, q.GTV + o3 + F); ldv<CH>(g2, q.GTV + o3 + 2 * F);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { g0[c] += gtv0[c]; g1[c] += gtv1[c]; g2[c] += gtv2[c]; }
+      stv<CH>(q.GTV_out + o3, g0); stv<CH>(q.GTV_out + o3 + F, g1); stv<CH>(q.GTV_out + o3 + 2 * F, g2);
     }
   }
 }
@@ -584,7 +651,9 @@ int nq_geom_rev(hipStream_t st, const NqGraphView& g, const float4* GEDGE, int n
 }
 
 // ---- fused-filter launchers ------------------------------------------------------------------
-bool nq_filter_fits_lds(int F, int R) { return (size_t)R * 3 * F * sizeof(float) <= 156 * 1024 && FUSED_THREADS_DUAL / F >= 1; }
+bool nq_filter_fits_lds(int F, int R) {
+  return (size_t)(R < FWIN ? FWIN : R) * 3 * F * sizeof(float) <= 156 * 1024 && (F == 64 || F == 128 || F == 256);
+}
 
 void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,
                          float coeff) {
@@ -610,25 +679,36 @@ int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out
 }
 
 static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
-  const int nslots = max_threads / F;
-  *threads = nslots * F;
+  const int nslots = max_threads / 64;   // one wavefront per atom
+  *threads = nslots * 64;
   *lds = (size_t)(R < FWIN ? FWIN : R) * 3 * F * sizeof(float);
   int blocks = nq_cdiv(N, nslots);
+  (void)F;
   return blocks < 256 ? blocks : 256;   // one persistent workgroup per CU (LDS-limited to 1 per CU anyway)
 }
+
+#define FUSED_LAUNCH(KERN, FLAG, CHV, Q)                                                                          \
+  do {                                                                                                            \
+    NQ_HIP(hipFuncSetAttribute((const void*)KERN<FLAG, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((KERN<FLAG, CHV>), dim3(grid), dim3(threads), lds, st, Q, fa, fa.RW);                      \
+  } while (0)
+#define FUSED_DISPATCH(KERN, FLAG, Q)                                   \
+  do {                                                                  \
+    switch ((Q).F / 64) {                                               \
+      case 1: FUSED_LAUNCH(KERN, FLAG, 1, Q); break;                    \
+      case 2: FUSED_LAUNCH(KERN, FLAG, 2, Q); break;                    \
+      case 4: FUSED_LAUNCH(KERN, FLAG, 4, Q); break;                    \
+      default: return nq_fail(NQ_ERR_ARG, "fused message kernels need hidden_channels in {64,128,256}"); \
+    }                                                                   \
+  } while (0)
 
 int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tangent) {
   NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R);
-  if (tangent) {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_fwd<true>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
-  } else {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_fwd<false>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
-  }
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(tangent, q.F / 64));
+  if (tangent) FUSED_DISPATCH(k_msgf_fwd, true, q);
+  else FUSED_DISPATCH(k_msgf_fwd, false, q);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -637,15 +717,9 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   NQ_PROF(st, dual ? "msgf_rev_dual" : "msgf_rev_force");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, dual ? FUSED_THREADS_DUAL : FUSED_THREADS);
-  if (dual) {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_rev<true>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
-  } else {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_msgf_rev<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_msgf_rev<false>), dim3(grid), dim3(threads), lds, st, q, fa, fa.RW);
-  }
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(true, q.F / 64));
+  if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
+  else FUSED_DISPATCH(k_msgf_rev, false, q);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
-
