@@ -117,8 +117,9 @@ def main():
     rank, world, local = nqdist.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    local_dev = local % torch.cuda.device_count()   # (>1 rank per device only in the 1-GPU plumbing test, NQ_DIST_BACKEND=gloo)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     if args.gemm_variant is not None:
         _lib.load().nq_set_gemm_variant(args.gemm_variant)
