@@ -171,6 +171,11 @@ void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, cons
                          float coeff);
 int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, float* RW);
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
+size_t nq_k0_sort_scratch_ints(int E, int R);
+int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch);
+size_t nq_gwr_scratch_floats(int E, int F, int R);
+int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
+                  float* scratch);
 int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
 int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual);
 int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);

@@ -81,7 +81,7 @@ struct WsLayer {
 struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
-  size_t RHO2, RW, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
+  size_t RHO2, RW, ORDER, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
   size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
@@ -107,7 +107,8 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     y.XM = take(2 * N * F); y.VM = take(2 * N * 3 * F); y.UU = take(2 * N * 6 * F);
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
   }
-  W->RHO2 = take(2 * E * R);    // full rho / drho rows: B operand of the rbf_proj weight-gradient contraction
+  W->RHO2 = take(2 * EP * R);   // full rho / drho rows only for the materialised-filter path (B operand of the gWr contraction)
+  W->ORDER = take(W->fused ? E : 0);   // int32: CSR slots sorted by window start k0
   W->RW = take(W->fused ? E * 32 : 0);
   W->ZO = take(2 * N * H); W->e_atom = take(N); W->te_atom = take(N);
   W->TD = take(E); W->TR = take(3 * E); W->pos_dot = take(3 * N); W->ge = take(N); W->gte = take(N);
@@ -121,7 +122,8 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   size_t s = 0;
   auto mx = [&](size_t v) { if (v > s) s = v; };
   mx(nq_gemm_tn_scratch_floats(2 * N, 3 * F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, F, 2 * F)); mx(nq_gemm_tn_scratch_floats(6 * N, 2 * F, F));
-  mx(nq_gemm_tn_scratch_floats(2 * E, 3 * F, R));
+  mx(W->fused ? nq_gwr_scratch_floats((int)E, (int)F, (int)R) : nq_gemm_tn_scratch_floats(2 * E, 3 * F, R));
+  if (W->fused) mx(nq_k0_sort_scratch_ints((int)E, (int)R));
   mx(nq_gemm_tn_scratch_floats(2 * N, F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, H, F));
   mx(nq_colsum_scratch_floats(N > E ? N : E, 3 * F));
   mx(nq_embed_grad_scratch_floats((int)N, (int)F, (int)T));
@@ -249,7 +251,14 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
   else if (!strcmp(name, "zq")) { LAYER_OK(L - 1); base = W.lay[l].ZQ; rows = n; w = F; }
   else if (!strcmp(name, "q")) { LAYER_OK(L - 1); base = W.lay[l].Q; rows = n; w = F; }
   else if (!strcmp(name, "y")) { LAYER_OK(L - 1); base = W.lay[l].Y; rows = n; w = 3 * F; }
-  else if (!strcmp(name, "rho")) { base = W.RHO2; rows = e; w = R; }          // tangent=1 -> drho
+  else if (!strcmp(name, "rho")) {                                            // tangent=1 -> drho
+    if (W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'rho' is not materialised (filter is fused into the message kernels)");
+    base = W.RHO2; rows = e; w = R;
+  }
+  else if (!strcmp(name, "order")) {                                          // int32 payload
+    if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'order' exists only with the fused filter");
+    base = W.ORDER; rows = e; w = 1; dual = false;
+  }
   else if (!strcmp(name, "rw")) {
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'rw' exists only with the fused filter");
     base = W.RW; rows = e; w = 32; dual = false;
@@ -284,11 +293,13 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_HIP(hipMemsetAsync(ws + W.X[0] + NF, 0, NF * sizeof(float), st));
   NQ_HIP(hipMemsetAsync(ws + W.V[0], 0, 6 * NF * sizeof(float), st));
   float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
-  NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho));
   if (W.fused) {
     FilterArgs fa0;
     nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
+    NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
+  } else {
+    NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho));
   }
 
   for (int l = 0; l < L; ++l) {
@@ -466,7 +477,8 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
       NQ_TRY(nq_msg_rev(st, m, true));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
+    if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
+    else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
     NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2"));
     NQ_TRY(nq_colsum(st, ws + W.GXH, N, 3 * F, 3 * F, gp + mp.b2, scr));

@@ -174,12 +174,21 @@ def _trace_report(name, model, sw, s2c, tag, lines):
                     e = rel_err(got, ref)
                     worst = max(worst, e)
                     lines.append(f"{name} {tag} {b}_{l:<10d} rel_err {e:.3e}")
-    for b, key in (("rho", "rho"), ("rho", "drho")):
-        ref = sw.ws[key][s2c].reshape(-1).numpy()
-        got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
-        e = rel_err(got, ref)
-        worst = max(worst, e)
-        lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    if os.environ.get("NQ_NO_FUSED_FILTER") == "1":
+        for b, key in (("rho", "rho"), ("rho", "drho")):
+            ref = sw.ws[key][s2c].reshape(-1).numpy()
+            got = model.workspace_view("rho", 0, key == "drho").cpu().numpy()
+            e = rel_err(got, ref)
+            worst = max(worst, e)
+            lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
+    else:
+        # k0-sorted edge order: a stable permutation of the CSR slots, keys non-decreasing
+        order = model.workspace_view("order").cpu().view(torch.int32).long()
+        k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
+        assert torch.equal(torch.sort(order).values, torch.arange(order.numel()))
+        assert bool((k0s[order][1:] >= k0s[order][:-1]).all())
+        same = k0s[order][1:] == k0s[order][:-1]
+        assert bool((order[1:][same] > order[:-1][same]).all()), "sort must be stable"
     if os.environ.get("NQ_NO_FUSED_FILTER") != "1":
         # fused filter: per-edge 13-tap window record {rho[13], k0, ., ., drho[13]} must reproduce the full basis row
         rw = model.workspace_view("rw").cpu().view(-1, 32)
