@@ -566,37 +566,44 @@ __global__ __launch_bounds__(SORT_CHUNK) void k_k0_hist(const float* __restrict_
     atomicAdd(&hist[key], 1);   // integer atomics: order-independent result
   }
   __syncthreads();
-  if (threadIdx.x < nbins) chunk_hist[(long)blockIdx.x * nbins + threadIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < nbins) chunk_hist[(long)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];   // [bin][chunk]
 }
-// pass B (one workgroup): exclusive prefix over (bin-major, chunk-minor); chunk_hist becomes the start offset
-__global__ __launch_bounds__(256) void k_k0_scan(int* __restrict__ chunk_hist, int nchunks, int nbins) {
-  __shared__ int total[256], base[256];
-  const int b = threadIdx.x;
-  if (b < nbins) {
-    int run = 0;
-    for (int c = 0; c < nchunks; ++c) {
-      const int v = chunk_hist[(long)c * nbins + b];
-      chunk_hist[(long)c * nbins + b] = run;
-      run += v;
+// pass B: one wavefront per bin scans that bin's chunk counts (shuffle scan, 64 chunks per step) in place -> exclusive
+// offsets inside the bin; bin totals go to bin_total[].
+__global__ __launch_bounds__(256) void k_k0_scan(int* __restrict__ hist, int nchunks, int nbins, int* __restrict__ bin_total) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nbins) return;
+  int* row = hist + (long)b * nchunks;
+  int carry = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    const int c = c0 + lane;
+    const int v = c < nchunks ? row[c] : 0;
+    int sc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(sc, off, 64);
+      if (lane >= off) sc += t;
     }
-    total[b] = run;
+    if (c < nchunks) row[c] = carry + sc - v;
+    carry += __shfl(sc, 63, 64);
   }
-  __syncthreads();
-  if (b == 0) {
-    int run = 0;
-    for (int i = 0; i < nbins; ++i) { base[i] = run; run += total[i]; }
-  }
-  __syncthreads();
-  if (b < nbins)
-    for (int c = 0; c < nchunks; ++c) chunk_hist[(long)c * nbins + b] += base[b];
+  if (lane == 0) bin_total[b] = carry;
 }
-// pass C: order[position] = edge slot
-__global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restrict__ RW, int E, int nbins, const int* __restrict__ chunk_off,
-                                                           const int* __restrict__ local_rank, int* __restrict__ order) {
+// pass C: order[bin_base + offset_in_bin(chunk) + local_rank] = edge slot
+__global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restrict__ RW, int E, int nbins, const int* __restrict__ hist,
+                                                           const int* __restrict__ bin_total, const int* __restrict__ local_rank,
+                                                           int* __restrict__ order) {
+  __shared__ int base[256];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < nbins; ++i) { base[i] = run; run += bin_total[i]; }
+  }
+  __syncthreads();
   const int e = blockIdx.x * SORT_CHUNK + threadIdx.x;
   if (e >= E) return;
   const int key = __float_as_int(RW[(long)e * RW_STRIDE + 13]);
-  order[chunk_off[(long)blockIdx.x * nbins + key] + local_rank[e]] = e;
+  order[base[key] + hist[(long)key * gridDim.x + blockIdx.x] + local_rank[e]] = e;
 }
 
 template <int CH>
@@ -871,23 +878,23 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
 
 // ---- k0-sorted edge order + register-resident rbf_proj weight gradient ---------------------------------------------
 static int gwr_nbins(int R) { return R - (R < FWIN ? R : FWIN) + 1; }
-static int gwr_chunks(int E) {   // ~2048 wavefronts in flight over 3 column slices
-  int chunk_len = nq_cdiv(E, 680);
+static int gwr_chunks(int E) {   // ~4096 wavefronts (16 per CU) over 3 column slices
+  int chunk_len = nq_cdiv(E, 1360);
   if (chunk_len < 64) chunk_len = 64;
   return nq_cdiv(E, chunk_len);
 }
-size_t nq_k0_sort_scratch_ints(int E, int R) { return (size_t)nq_cdiv(E, SORT_CHUNK) * gwr_nbins(R) + (size_t)E; }
+size_t nq_k0_sort_scratch_ints(int E, int R) { return (size_t)nq_cdiv(E, SORT_CHUNK) * gwr_nbins(R) + (size_t)E + 256; }
 // order[E] <- CSR slots sorted (stably) by window start k0; scratch: nq_k0_sort_scratch_ints() ints
 int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* scratch) {
   NQ_PROF(st, "k0_sort");
   const int nbins = gwr_nbins(R), nchunks = nq_cdiv(E, SORT_CHUNK);
   if (nbins > 256) return nq_fail(NQ_ERR_ARG, "k0 sort supports at most 256 bins (num_rbf <= 268)");
-  int* chunk_hist = scratch; int* local_rank = scratch + (size_t)nchunks * nbins;
+  int* chunk_hist = scratch; int* local_rank = scratch + (size_t)nchunks * nbins; int* bin_total = local_rank + E;
   hipLaunchKernelGGL(k_k0_hist, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_k0_scan, dim3(1), dim3(256), 0, st, chunk_hist, nchunks, nbins);
+  hipLaunchKernelGGL(k_k0_scan, dim3(nq_cdiv(nbins, 4)), dim3(256), 0, st, chunk_hist, nchunks, nbins, bin_total);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank, order);
+  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, bin_total, local_rank, order);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
