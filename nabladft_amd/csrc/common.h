@@ -158,7 +158,7 @@ int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int
                const char* tag = nullptr);
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
 int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
-               const char* tag = nullptr);
+               const char* tag = nullptr, float* bias_out = nullptr, long bias_rows = 0);
 size_t nq_colsum_scratch_floats(long rows, int cols);
 int nq_colsum(hipStream_t, const float* A, long rows, int cols, int lda, float* out, float* scratch);
 int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, long count, float* out);

@@ -676,16 +676,19 @@ __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __re
   if (lane == 0 && blockIdx.y == 0) { chunk_range[2 * chunk] = lo; chunk_range[2 * chunk + 1] = hi; }
 }
 
-// gWr[c][k] = sum over chunks (in chunk order) whose row range covers k
+// gWr[c][k] = sum over chunks (in chunk order) whose row range [lo, hi) covers k.  The edge stream is sorted by k0, so
+// lo and hi are non-decreasing in the chunk index: the covering chunks form one contiguous run found by bisection.
 __global__ void k_gwr_reduce(const float* __restrict__ part, const int* __restrict__ chunk_range, int nchunks, int R, int F3, float* __restrict__ gWr) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * F3) return;
   const int k = idx / F3, c = idx % F3;
+  int a = 0, b = nchunks;          // first chunk with hi > k
+  while (a < b) { const int m = (a + b) >> 1; if (chunk_range[2 * m + 1] > k) b = m; else a = m + 1; }
+  const int first = a;
+  a = first; b = nchunks;          // first chunk with lo > k
+  while (a < b) { const int m = (a + b) >> 1; if (chunk_range[2 * m] > k) b = m; else a = m + 1; }
   float s = 0.f;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int lo = chunk_range[2 * ch], hi = chunk_range[2 * ch + 1];
-    if (k >= lo && k < hi) s += part[((long)ch * R + k) * F3 + c];
-  }
+  for (int ch = first; ch < a; ++ch) s += part[((long)ch * R + k) * F3 + c];
   gWr[(long)c * R + k] = s;
 }
 

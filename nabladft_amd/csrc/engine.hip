@@ -37,12 +37,12 @@ NqProfScope::NqProfScope(hipStream_t s, const char* name) : st(s), slot(-1) {
   else id = it->second;
   ProfRec r; r.name_id = id;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-  hipEventRecord(r.a, st);
+  (void)hipEventRecord(r.a, st);
   slot = (int)g_prof_recs.size();
   g_prof_recs.push_back(r);
 }
 NqProfScope::~NqProfScope() {
-  if (slot >= 0) hipEventRecord(g_prof_recs[slot].b, st);
+  if (slot >= 0) (void)hipEventRecord(g_prof_recs[slot].b, st);
 }
 
 // ---- parameter layout --------------------------------------------------------------------------
@@ -162,13 +162,13 @@ void nq_profile_enable(int32_t on) { nq_profile_on = on; }
 // Synchronises the device, folds all recorded event pairs into per-name totals and clears them.
 // Fills up to `cap` entries; returns the number of distinct names.
 int nq_profile_read(char* names, int32_t name_stride, double* total_ms, int64_t* counts, int32_t cap) {
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   std::vector<double> tot(g_prof_names.size(), 0.0);
   std::vector<long long> cnt(g_prof_names.size(), 0);
   for (auto& r : g_prof_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot[r.name_id] += ms; cnt[r.name_id] += 1; }
-    hipEventDestroy(r.a); hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof_recs.clear();
   int n = (int)g_prof_names.size();
@@ -438,8 +438,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
   NQ_TRY(nq_readout_rev(st, r, true));
   NQ_TRY(nq_colsum(st, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(st, ws + W.ge, N, 1, 1, gp + P.o2, scr));
-  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1"));
-  NQ_TRY(nq_colsum(st, ws + W.GZO, N, H, H, gp + P.o1, scr));
+  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1", gp + P.o1, N));
   NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
@@ -453,12 +452,10 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     u.GY = ws + W.GY; u.GTY = ws + W.GY + 3 * NF; u.GCAT = ws + W.GCAT; u.GTCAT = ws + W.GCAT + 2 * NF;
     u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
     NQ_TRY(nq_upd_rev(st, u, 1, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2"));
-    NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + up.c2, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2"));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1"));
-    NQ_TRY(nq_colsum(st, ws + W.GQ, N, F, F, gp + up.c1, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     NQ_TRY(nq_upd_rev(st, u, 2, true));
     NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
@@ -480,12 +477,10 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
     else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2"));
-    NQ_TRY(nq_colsum(st, ws + W.GXH, N, 3 * F, 3 * F, gp + mp.b2, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1"));
-    NQ_TRY(nq_colsum(st, ws + W.GH, N, F, F, gp + mp.b1, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
   }
   NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));

@@ -29,6 +29,8 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   int k_per_split;       // EPI_PARTIAL: K range per blockIdx.z
   long part_stride;      // EPI_PARTIAL: floats between partial slabs
+  float* bpart;          // EPI_PARTIAL, optional: per-split column sums of A over rows < brows (bias gradient), [splits][M]
+  int brows;
 };
 
 // K-contiguous source (element (r, k) at src[r*ld + k]) -> LDS tile[k][r], stride LDS_KC
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float bsum = 0.f;
   float4 ra[1024 / NT], rb[1024 / NT];
   if (PF) {
     fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, a_vec);
@@ -143,6 +146,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     stash_tile<A_KC, NT>(As, ra);
     stash_tile<B_KC, NT>(Bs, rb);
     __syncthreads();
+    if (EPI == EPI_PARTIAL && !A_KC) {
+      // bias gradient for free: column sums of the A tile (= gy rows) that is already in LDS, primal rows only
+      if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM) {
+        const int kmax = min(BK, p.brows - k0);
+        for (int kk = 0; kk < kmax; ++kk) bsum += As[kk * LDA_S + threadIdx.x];
+      }
+    }
     if (PF && k0 + BK < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
       fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, a_vec);
       fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, b_vec);
@@ -163,6 +173,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     __syncthreads();
   }
 
+  if (EPI == EPI_PARTIAL && !A_KC) {
+    if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M)
+      p.bpart[(long)blockIdx.z * p.M + m0 + threadIdx.x] = bsum;
+  }
   // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* Cout = p.C;
   if (EPI == EPI_PARTIAL) Cout += (long)blockIdx.z * p.part_stride;
@@ -242,7 +256,7 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
-  GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0};
+  GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
   if (C2_silu) launch_gemm<true, true, EPI_SILU>(st, grid, p);
   else launch_gemm<true, true, EPI_STORE>(st, grid, p);
@@ -256,7 +270,7 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
-  GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0};
+  GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
   if (accumulate) launch_gemm<true, false, EPI_ACC>(st, grid, p);
   else launch_gemm<true, false, EPI_STORE>(st, grid, p);
@@ -276,27 +290,33 @@ static int tn_splits(long rows, int Mo, int No) {
   if (s > 512) s = 512;
   return (int)s;
 }
-size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No) * Mo * No; }
+size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No) * ((size_t)Mo * No + Mo); }
 
 int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
-               const char* tag) {
+               const char* tag, float* bias_out, long bias_rows) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_tn:%s[%dx%d]", tag ? tag : "", Mo, No); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (rows <= 0) {
     NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Mo * No, st));
+    if (bias_out) NQ_HIP(hipMemsetAsync(bias_out, 0, sizeof(float) * Mo, st));
     return NQ_OK;
   }
   if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
   const int ns = tn_splits(rows, Mo, No);
   int kper = (int)((rows + ns - 1) / ns);
   kper = (kper + BK - 1) / BK * BK;
-  GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No};
+  float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
+  GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
   dim3 grid(nq_cdiv(Mo, BM), nq_cdiv(No, BN), ns);
   launch_gemm<false, false, EPI_PARTIAL>(st, grid, p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
   hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);
   NQ_LAUNCH_CHECK();
+  if (bias_out) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Mo, 64)), dim3(64), 0, st, bpart, ns, (long)Mo, (long)Mo, bias_out);
+    NQ_LAUNCH_CHECK();
+  }
   return NQ_OK;
 }
 
