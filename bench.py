@@ -75,6 +75,53 @@ def gemm_flops(name, N, E, launches):
     return 2.0 * rows_single * mult * dims[0] * dims[1]
 
 
+# HIP-event launcher class -> rocprofv3 kernel name (for the PMC traffic file) and sweep multiplicity
+_MSG = {"msgf_fwd": ("k_msgf_fwd<false", 1), "msgf_tan": ("k_msgf_fwd<true", 2), "msgf_rev_force": ("k_msgf_rev<false", 1),
+        "msgf_rev_dual": ("k_msgf_rev<true", 2)}
+
+
+def pmc_traffic_bytes(kernel_prefix, batch):
+    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported), only if it was taken at this batch size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("batch") != batch:
+        return None
+    for name, v in rec.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return 1024.0 * (2.0 * v.get("fetch_kb_per_launch", 0.0) + v.get("write_kb_per_launch", 0.0))
+    return None
+
+
+def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
+    """Roofline entry of the dominant launcher class.  Message kernels are HBM-bound: algorithmic bytes per launch =
+    SURVEY 8(d)'s message share of one layer, (8*N*F*4 + 24*E) bytes, x2 for the sweeps that carry (primal, tangent) pairs.
+    GEMM classes are bound by the fp32 matrix cores: flop per launch from the role tag."""
+    if dom in _MSG:
+        prefix, mult = _MSG[dom]
+        nbytes = mult * (8.0 * n_atoms * F * 4 + 24.0 * E)
+        ach = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic_bytes(prefix, batch)
+        return {"kernel": f"{prefix}, {F // 64}>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+    if dom.startswith("gemm"):
+        flops = gemm_flops(dom, n_atoms, E, launches)
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        return {"kernel": f"k_gemm {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+    if dom == "gwr_sorted":
+        flops = 2.0 * 26 * E * 3 * F          # 26 FMAs per (edge, column)
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        return {"kernel": "k_gwr_sorted", "bound": "hbm", "achieved": (2.0 * E * 3 * F * 4) / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (2.0 * E * 3 * F * 4) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_gwr_sorted", batch),
+                "valu_tflops": ach, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+    return {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches_per_step": launches}
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
     timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
@@ -170,19 +217,7 @@ def main():
         dom, dom_ms_step, dom_launches = kernels[0]
         avg_ms = dom_ms_step / max(dom_launches, 1)
         E = n_edges
-        if dom.startswith("gemm"):
-            # dense contraction on the fp32 matrix cores: flop per launch from the role tag (rows: E for rbf_proj, N/3N for node MLPs;
-            # x2 rows in the dual sweep are averaged in through launches_per_step)
-            flops = gemm_flops(dom, n_atoms, E, prof[dom][1] // args.steps)
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            roofline = {"kernel": f"k_gemm {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
-        else:
-            # message kernels: algorithmic bytes per launch: node state read+write 8*N*F*4 B + edge stream 24 B/edge
-            nbytes = 8.0 * n_atoms * F * 4 + 24.0 * E
-            ach = nbytes / (avg_ms * 1e-3) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": dom_launches}
+        roofline = roofline_record(dom, avg_ms, dom_launches, n_atoms, E, args.batch)
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
 
     cpu = None
