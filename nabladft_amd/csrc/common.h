@@ -60,10 +60,17 @@ __device__ __forceinline__ float nq_d2silu(float z) {
   return ds * (2.0f + z * (1.0f - 2.0f * s));
 }
 
+// Sum over the 64 lanes of the wavefront, result broadcast to every lane.  DPP only (no LDS round trips):
+// an inclusive scan inside each 16-lane row (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals
+// upwards, so lane 63 holds the full sum; v_readlane broadcasts it as a scalar.  Fixed order -> deterministic.
 __device__ __forceinline__ float nq_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));  // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));  // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));  // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));  // row_shr:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));  // row_bcast:15 -> rows 1,3
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, true));  // row_bcast:31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // kernels (implemented in the .hip files, launched by engine.hip) ------------------------------
