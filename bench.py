@@ -143,9 +143,28 @@ def cpu_baseline(seconds_budget=25.0):
         Rf.train_step(params, cfg, pos, z, batch, y, ft)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times)) if times else warm
-    return {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms, {ei.shape[1]} edges), PaiNN-OC config, "
-                      f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 without optimizer step"}
+    out = {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+           "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms, {ei.shape[1]} edges), PaiNN-OC config, "
+                     f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 without optimizer step"}
+    # accuracy half of the metric: the HIP path vs this CPU reference on the identical inputs and weights
+    import nabladft_amd as nq
+    e_ref, f_ref, loss_ref, g_ref = Rf.train_step(params, cfg, pos, z, batch, y, ft, ei)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    m = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100)
+    m.load_state_dict(params, strict=False)
+    m.to(dev)
+    fs = nq.FusedTrainStep(m, max_grad_norm=0.0)
+    loss = float(fs(nq.Batch(pos, z, batch, y, ft).to(dev), update=False))
+    e, f = fs.energy.cpu(), fs.forces.cpu()
+    names = [k for k, _ in Rf.param_shapes(cfg)]
+    gref = torch.cat([g_ref[k].reshape(-1) for k in names])
+    parity = {"mae_energy": float((e - e_ref).abs().mean()), "mae_forces": float((f - f_ref).abs().mean()),
+              "max_rel_energy": float((e - e_ref).abs().max() / e_ref.abs().max()),
+              "max_rel_forces": float((f - f_ref).abs().max() / f_ref.abs().max()),
+              "rel_loss": abs(loss - float(loss_ref)) / abs(float(loss_ref)),
+              "max_rel_grad": float((fs.grad.cpu() - gref).abs().max() / gref.abs().max()),
+              "mean_abs_energy_ref": float(e_ref.abs().mean()), "mean_abs_forces_ref": float(f_ref.abs().mean())}
+    return out, parity
 
 
 def main():
@@ -220,13 +239,13 @@ def main():
         roofline = roofline_record(dom, avg_ms, dom_launches, n_atoms, E, args.batch)
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu, parity = cpu_baseline()
 
     if rank == 0:
         out = {
-            "metric": "conformer-steps/sec (fwd+bwd)", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
+            "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces "
@@ -237,6 +256,7 @@ def main():
             "final_loss": float(loss),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "mae_vs_cpu_reference": parity,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},

@@ -1,0 +1,26 @@
+"""Minimal ``_target_`` instantiator (the subset of hydra.utils.instantiate the nablaDFT model configs use:
+``_target_``, ``_partial_``, nested dicts/lists; ``_convert_`` is accepted and ignored).  hydra-core is not a
+dependency of this package; when it is installed, ``hydra.utils.instantiate`` works on the same dicts."""
+import functools
+import importlib
+from typing import Any
+
+
+def _locate(path: str):
+    mod, _, name = path.rpartition(".")
+    return getattr(importlib.import_module(mod), name)
+
+
+def instantiate(cfg: Any, **overrides):
+    if isinstance(cfg, (list, tuple)):
+        return type(cfg)(instantiate(c) for c in cfg)
+    if not isinstance(cfg, dict):
+        return cfg
+    if "_target_" not in cfg:
+        return {k: instantiate(v) for k, v in cfg.items()}
+    kwargs = {k: instantiate(v) for k, v in cfg.items() if k not in ("_target_", "_partial_", "_convert_")}
+    kwargs.update(overrides)
+    fn = _locate(cfg["_target_"])
+    if cfg.get("_partial_", False):
+        return functools.partial(fn, **kwargs)
+    return fn(**kwargs)

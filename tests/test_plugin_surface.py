@@ -1,0 +1,108 @@
+"""Plugin surface: Hydra-style instantiation of the model config, Lightning-shaped step, energy-only
+mode, inference modes.  CPU part checks construction; GPU part checks behaviour against the oracle."""
+import pytest
+import torch
+import yaml
+
+from oracle import painn_ref as R
+from tests.helpers import rel_err
+
+MODEL_YAML = """
+_target_: nabladft_amd.PaiNNLightning
+model_name: "PAINN-OC"
+model:
+  _target_: nabladft_amd.PaiNN
+  hidden_channels: 128
+  num_layers: 6
+  num_rbf: 100
+  cutoff: 5.0
+  max_neighbors: 100
+  rbf: {name: 'gaussian'}
+  envelope: {name: 'polynomial', exponent: 5}
+  regress_forces: true
+  direct_forces: false
+  use_pbc: false
+  otf_graph: true
+  num_elements: 100
+optimizer: {_target_: torch.optim.AdamW, _partial_: true, lr: 5.0e-4, weight_decay: 0}
+lr_scheduler: {_target_: torch.optim.lr_scheduler.ReduceLROnPlateau, _partial_: true, factor: 0.8, patience: 100, min_lr: 1.0e-6}
+losses:
+  energy: {_target_: torch.nn.L1Loss}
+  forces: {_target_: nabladft_amd.L2Loss}
+loss_coefs: {energy: 1.0, forces: 1.0}
+metric: null
+"""
+
+
+def _task():
+    from nabladft_amd.config import instantiate
+    return instantiate(yaml.safe_load(MODEL_YAML))
+
+
+def test_config_instantiates_like_hydra():
+    task = _task()
+    import nabladft_amd as nq
+    assert isinstance(task, nq.PaiNNLightning) and isinstance(task.model, nq.PaiNN)
+    assert task.model.num_params == 1341313
+    out = task.configure_optimizers()
+    assert isinstance(out["optimizer"], torch.optim.AdamW) and out["optimizer"].defaults["lr"] == 5e-4
+    assert out["lr_scheduler"]["monitor"] == "val_loss"
+    # a Lightning checkpoint of the reference stores the model under "model." -- same here
+    assert all(k.startswith("model.") for k in task.state_dict())
+    assert len(task.state_dict()) == 72
+
+
+@pytest.mark.gpu
+def test_lightning_step_and_modes_on_gpu():
+    import nabladft_amd as nq
+    dev = torch.device("cuda:0")
+    task = _task().to(dev)
+    cfg = R.PaiNNConfig()
+    params = R.make_params(cfg, seed=23)
+    task.model.load_state_dict(params, strict=False)
+    pos, z, batch, y, ft = R.gen_conformers(21, 3)
+    b = nq.Batch(pos, z, batch, y, ft).to(dev)
+    e_ref, f_ref, loss_ref, g_ref = R.train_step(params, cfg, pos, z, batch, y, ft)
+    # training_step == reference loss; backward fills .grad of every parameter
+    loss = task.training_step(b, 0)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    loss.backward()
+    worst = max(rel_err(p.grad.cpu().numpy(), g_ref[k[len("model."):]].numpy()) for k, p in task.named_parameters())
+    assert worst < 5e-5, worst
+    # a torch optimizer steps the flat-buffer views in place
+    opt = task.configure_optimizers()["optimizer"]
+    before = task.model.flat_parameters().clone()
+    opt.step()
+    assert task.model.flat_parameters().data_ptr() == before.data_ptr() and not torch.equal(task.model.flat_parameters(), before)
+    task.model.load_state_dict(params, strict=False)
+    # validation/predict: no_grad and inference_mode give the same energies and forces (forces do not need autograd)
+    task.eval()
+    with torch.no_grad():
+        e1, f1 = task(b)
+    with torch.inference_mode():
+        e2, f2 = task.predict_step(b)
+    assert torch.equal(e1, e2) and torch.equal(f1, f2)
+    assert rel_err(e1.cpu().numpy(), e_ref.numpy()) < 1e-5 and rel_err(f1.cpu().numpy(), f_ref.numpy()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_energy_only_model_trains():
+    """regress_forces=False (painn.py:147-148): forward returns the energy only; backward = first-order gradients."""
+    import nabladft_amd as nq
+    dev = torch.device("cuda:0")
+    cfg = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=20)
+    params = R.make_params(cfg, seed=9)
+    m = nq.PaiNN(64, 2, 20, 5.0, 100, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, False, False, False, True, 100)
+    m.load_state_dict(params, strict=False)
+    m.to(dev)
+    pos, z, batch, y, _ = R.gen_conformers(31, 4, size=(6, 18))
+    energy = m(nq.Batch(pos, z, batch).to(dev))
+    assert energy.shape == (4,)
+    (energy * torch.tensor([1.0, -2.0, 0.5, 3.0], device=dev)).sum().backward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ei, _, _ = R.build_graph(pos, batch, cfg.cutoff, cfg.max_neighbors)
+    e_ref = R.painn_energy(Pg, cfg, pos, z, batch, ei)
+    assert rel_err(energy.detach().cpu().numpy(), e_ref.detach().numpy()) < 1e-5
+    g_ref = torch.autograd.grad((e_ref * torch.tensor([1.0, -2.0, 0.5, 3.0])).sum(), list(Pg.values()))
+    for (k, p), g in zip(m.named_parameters(), g_ref):
+        assert rel_err(p.grad.cpu().numpy(), g.numpy()) < 5e-5, k
