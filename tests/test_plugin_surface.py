@@ -71,9 +71,9 @@ def test_lightning_step_and_modes_on_gpu():
     assert worst < 5e-5, worst
     # a torch optimizer steps the flat-buffer views in place
     opt = task.configure_optimizers()["optimizer"]
-    before = task.model.flat_parameters().clone()
+    ptr0, before = task.model.flat_parameters().data_ptr(), task.model.flat_parameters().clone()
     opt.step()
-    assert task.model.flat_parameters().data_ptr() == before.data_ptr() and not torch.equal(task.model.flat_parameters(), before)
+    assert task.model.flat_parameters().data_ptr() == ptr0 and not torch.equal(task.model.flat_parameters(), before)
     task.model.load_state_dict(params, strict=False)
     # validation/predict: no_grad and inference_mode give the same energies and forces (forces do not need autograd)
     task.eval()
