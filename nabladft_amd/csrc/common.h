@@ -180,8 +180,6 @@ int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, 
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 size_t nq_k0_sort_scratch_ints(int E, int R);
 int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch);
-size_t nq_gwr_mol_scratch_floats(int F, int R);
-int nq_gwr_mol(hipStream_t, const MsgRevArgs& m, const float* RW, int R, float* gWr, float* gbr, float* scratch);
 size_t nq_gwr_scratch_floats(int E, int F, int R);
 int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
                   float* scratch);

@@ -504,12 +504,10 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
           }
         }
         if (DUAL) {
-          if (q.GPHI) {   // only for the sorted-stream Wr gradient; k_gwr_mol recomputes these
-            float* gp = q.GPHI + (long)sp * F3 + fb;
-            float* gs = q.GPSI + (long)sp * F3 + fb;
-            stv<CH>(gp, ga); stv<CH>(gp + F, gb); stv<CH>(gp + 2 * F, gc);
-            stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
-          }
+          float* gp = q.GPHI + (long)sp * F3 + fb;
+          float* gs = q.GPSI + (long)sp * F3 + fb;
+          stv<CH>(gp, ga); stv<CH>(gp + F, gb); stv<CH>(gp + 2 * F, gc);
+          stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
         } else {
           gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
           if (lane == 0) {
@@ -692,148 +690,6 @@ __global__ void k_gwr_reduce(const float* __restrict__ part, const int* __restri
   float s = 0.f;
   for (int ch = first; ch < a; ++ch) s += part[((long)ch * R + k) * F3 + c];
   gWr[(long)c * R + k] = s;
-}
-
-
-// =============================================================================================
-// Alternative rbf_proj gradient that never materialises gphi/gpsi: k_gwr_mol<PART, CH>.
-// A workgroup owns one filter part (a, b or c: F columns) and a contiguous atom range (same ranges as the message
-// kernels, so the rows it gathers are the ones just touched by k_msgf_rev), RECOMPUTES
-//   gphi = gm * xh[n] + gtm * t_xh[n],  gpsi = gtm * xh[n] * t_d      (gm, gtm from the adjoint rows of the target atom)
-// per out-edge and accumulates the 13-tap outer product into an LDS accumulator acc[R+1][F].  Two wavefronts split the
-// taps by the PARITY OF THE ROW k (so every accumulator word has exactly one owner lane: no atomics, program-order
-// updates, bitwise reproducible); lanes own CH = F/64 adjacent columns (ds_read/write_b64 at F=128).
-// Per-workgroup partial slabs are summed in fixed order by k_reduce_partials and transposed into [3F][R].
-// =============================================================================================
-struct GwrMolArgs {
-  NqGraphView g; int F, R;
-  const float* XH; const float* TXH; const float* V; const float* TV;     // source-atom rows (layer input side)
-  const float* GX; const float* GTX; const float* GV; const float* GTV;   // adjoint rows at the target atom
-  const float* TD; const float* TR;
-  float* part_w;   // [3][blocks][R][F]
-  float* part_b;   // [3][blocks][F]
-};
-
-template <int PART, int CH>
-struct GwrOps2 { float a0[CH], a1[CH], a2[CH], t0[CH], t1[CH], t2[CH]; float rr[16], dd[16]; };
-
-template <int PART, int CH>
-__device__ __forceinline__ void load_gwr2(GwrOps2<PART, CH>& o, const GwrMolArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int fb) {
-  if (PART == 0) {
-    ldv<CH>(o.a0, q.GX + (long)k * F + fb);
-    ldv<CH>(o.t0, q.GTX + (long)k * F + fb);
-  } else {
-    const float* A = q.GV + (long)k * F3 + fb;
-    const float* T = q.GTV + (long)k * F3 + fb;
-    ldv<CH>(o.a0, A); ldv<CH>(o.a1, A + F); ldv<CH>(o.a2, A + 2 * F);
-    ldv<CH>(o.t0, T); ldv<CH>(o.t1, T + F); ldv<CH>(o.t2, T + 2 * F);
-  }
-  const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)sp * RW_STRIDE);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { *reinterpret_cast<float4*>(&o.rr[4 * v]) = rw4[v]; *reinterpret_cast<float4*>(&o.dd[4 * v]) = rw4[4 + v]; }
-}
-
-template <int PART, int CH>
-__global__ __launch_bounds__(128) void k_gwr_mol(GwrMolArgs q, const float* __restrict__ RW) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // [R+1 (>= 14)][F]
-  const int F = q.F, F3 = 3 * q.F, R = q.R;
-  const int rows = (R < FWIN ? FWIN : R) + 1;
-  for (int i = threadIdx.x; i < rows * F; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
-  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row parity owned by this wavefront
-  const int lane = threadIdx.x & 63, fb = lane * CH;
-  const int per_wg = (q.g.N + gridDim.x - 1) / gridDim.x;
-  const int n_lo = blockIdx.x * per_wg, n_hi = min(q.g.N, n_lo + per_wg);
-  float sb[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) sb[c] = 0.f;
-  for (int n = n_lo; n < n_hi; ++n) {
-    const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);
-    const long o3 = (long)n * F3 + PART * F + fb;
-    float xs[CH], txs[CH], v0[CH], v1[CH], v2[CH], tv0[CH], tv1[CH], tv2[CH];
-    ldv<CH>(xs, q.XH + o3); ldv<CH>(txs, q.TXH + o3);
-    if (PART == 1) {
-      const long ov = (long)n * F3 + fb;
-      ldv<CH>(v0, q.V + ov); ldv<CH>(v1, q.V + ov + F); ldv<CH>(v2, q.V + ov + 2 * F);
-      ldv<CH>(tv0, q.TV + ov); ldv<CH>(tv1, q.TV + ov + F); ldv<CH>(tv2, q.TV + ov + 2 * F);
-    }
-    for (int c0 = beg; c0 < end; c0 += 64) {
-      const int cnt = min(64, end - c0);
-      RowRegs row;
-      load_row<true>(row, q.g, q.TD, q.TR, c0, cnt, lane);
-      GwrOps2<PART, CH> cur, nxt;
-      load_gwr2<PART, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
-      nxt = cur;
-      for (int j = 0; j < cnt; ++j) {
-        if (j + 1 < cnt) load_gwr2<PART, CH>(nxt, q, RW, bl_i(row.kk, j + 1), c0 + j + 1, F, F3, fb);
-        const float td = bl_f(row.td, j);
-        float G[CH], H[CH];
-        if (PART == 0) {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) { G[c] = cur.a0[c] * xs[c] + cur.t0[c] * txs[c]; H[c] = cur.t0[c] * xs[c] * td; }
-        } else if (PART == 1) {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const float gm = cur.a0[c] * v0[c] + cur.a1[c] * v1[c] + cur.a2[c] * v2[c] + cur.t0[c] * tv0[c] + cur.t1[c] * tv1[c] + cur.t2[c] * tv2[c];
-            const float gtm = cur.t0[c] * v0[c] + cur.t1[c] * v1[c] + cur.t2[c] * v2[c];
-            G[c] = gm * xs[c] + gtm * txs[c]; H[c] = gtm * xs[c] * td;
-          }
-        } else {
-          const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);
-          const float s0 = -bl_f(row.t0, j), s1 = -bl_f(row.t1, j), s2 = -bl_f(row.t2, j);
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const float gm = cur.a0[c] * r0 + cur.a1[c] * r1 + cur.a2[c] * r2 + cur.t0[c] * s0 + cur.t1[c] * s1 + cur.t2[c] * s2;
-            const float gtm = cur.t0[c] * r0 + cur.t1[c] * r1 + cur.t2[c] * r2;
-            G[c] = gm * xs[c] + gtm * txs[c]; H[c] = gtm * xs[c] * td;
-          }
-        }
-        if (h == 0) {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) sb[c] += G[c];
-        }
-        const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(cur.rr[13]));
-        const int s = (h + k0) & 1;          // first tap whose row k0+t has this wavefront's parity
-        float* a = acc + (k0 + s) * F + fb;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {         // taps t = 2i + s; t = 13 (i = 6, s = 1) carries zero weights
-          const float rw = s ? (i < 6 ? cur.rr[2 * i + 1] : 0.f) : cur.rr[2 * i];
-          const float dw = s ? (i < 6 ? cur.dd[2 * i + 1] : 0.f) : cur.dd[2 * i];
-          float u[CH];
-          ldv<CH>(u, a + 2 * i * F);
-#pragma unroll
-          for (int c = 0; c < CH; ++c) u[c] = fmaf(G[c], rw, fmaf(H[c], dw, u[c]));
-          stv<CH>(a + 2 * i * F, u);
-        }
-        cur = nxt;
-      }
-    }
-  }
-  __syncthreads();
-  float* out = q.part_w + ((long)PART * gridDim.x + blockIdx.x) * R * F;
-  for (int i = threadIdx.x; i < R * F; i += blockDim.x) out[i] = acc[i];
-  if (h == 0) stv<CH>(q.part_b + ((long)PART * gridDim.x + blockIdx.x) * F + fb, sb);
-}
-
-// gWr[(p*F + f)][k] = sum_blocks part_w[p][blk][k][f];  gbr[p*F + f] = sum_blocks part_b[p][blk][f]   (fixed order)
-__global__ void k_gwr_mol_reduce(const float* __restrict__ part_w, const float* __restrict__ part_b, int nblk, int R, int F, float* __restrict__ gWr,
-                                 float* __restrict__ gbr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 3 * R * F) return;
-  const int p = idx / (R * F), rem = idx % (R * F), k = rem / F, f = rem % F;
-  float s0 = 0.f, s1 = 0.f;
-  int b = 0;
-  for (; b + 1 < nblk; b += 2) {
-    s0 += part_w[(((long)p * nblk + b) * R + k) * F + f];
-    s1 += part_w[(((long)p * nblk + b + 1) * R + k) * F + f];
-  }
-  if (b < nblk) s0 += part_w[(((long)p * nblk + b) * R + k) * F + f];
-  gWr[(long)(p * F + f) * R + k] = s0 + s1;
-  if (k == 0) {
-    float t = 0.f;
-    for (int bb = 0; bb < nblk; ++bb) t += part_b[((long)p * nblk + bb) * F + f];
-    gbr[p * F + f] = t;
-  }
 }
 
 // out[c][r] = in[r][c]  (rbf_proj.weight [3F][R] -> WrT [R][3F]); 32x32 LDS tile, coalesced both ways
@@ -1063,42 +919,6 @@ int nq_gwr_sorted(hipStream_t st, const float* GPHI, const float* GPSI, const fl
   }
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gwr_reduce, dim3(nq_cdiv((long)R * 3 * F, 256)), dim3(256), 0, st, part, chunk_range, nq_cdiv(E, chunk_len), R, 3 * F, gWr);
-  NQ_LAUNCH_CHECK();
-  return NQ_OK;
-}
-
-// ---- per-molecule-range LDS-accumulated rbf_proj gradient (no gphi/gpsi arrays) --------------------------------------
-#define GWRM_BLOCKS 512
-size_t nq_gwr_mol_scratch_floats(int F, int R) { return (size_t)3 * GWRM_BLOCKS * ((size_t)R * F + F); }
-
-template <int PART>
-static int launch_gwr_mol(hipStream_t st, const GwrMolArgs& q, const float* RW, int blocks, size_t lds) {
-  switch (q.F / 64) {
-    case 1: NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_mol<PART, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_gwr_mol<PART, 1>), dim3(blocks), dim3(128), lds, st, q, RW); break;
-    case 2: NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_mol<PART, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_gwr_mol<PART, 2>), dim3(blocks), dim3(128), lds, st, q, RW); break;
-    case 4: NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_mol<PART, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_gwr_mol<PART, 4>), dim3(blocks), dim3(128), lds, st, q, RW); break;
-    default: return nq_fail(NQ_ERR_ARG, "gwr_mol needs hidden_channels in {64,128,256}");
-  }
-  NQ_LAUNCH_CHECK();
-  return NQ_OK;
-}
-
-int nq_gwr_mol(hipStream_t st, const MsgRevArgs& m, const float* RW, int R, float* gWr, float* gbr, float* scratch) {
-  NQ_PROF(st, "gwr_mol");
-  GwrMolArgs q;
-  q.g = m.g; q.F = m.F; q.R = R;
-  q.XH = m.XH; q.TXH = m.TXH; q.V = m.V; q.TV = m.TV; q.GX = m.GX; q.GTX = m.GTX; q.GV = m.GV; q.GTV = m.GTV; q.TD = m.TD; q.TR = m.TR;
-  int blocks = nq_cdiv(m.g.N, 8);
-  if (blocks > GWRM_BLOCKS) blocks = GWRM_BLOCKS;
-  q.part_w = scratch; q.part_b = scratch + (size_t)3 * blocks * R * m.F;
-  const size_t lds = (size_t)((R < FWIN ? FWIN : R) + 1) * m.F * sizeof(float);
-  NQ_TRY(launch_gwr_mol<0>(st, q, RW, blocks, lds));
-  NQ_TRY(launch_gwr_mol<1>(st, q, RW, blocks, lds));
-  NQ_TRY(launch_gwr_mol<2>(st, q, RW, blocks, lds));
-  hipLaunchKernelGGL(k_gwr_mol_reduce, dim3(nq_cdiv(3L * R * m.F, 256)), dim3(256), 0, st, q.part_w, q.part_b, blocks, R, m.F, gWr, gbr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

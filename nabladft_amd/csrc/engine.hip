@@ -85,7 +85,6 @@ struct WsLayout {
   size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
-  bool gwr_mol; // Wr gradient by per-molecule LDS accumulation (no gphi/gpsi arrays) instead of the k0-sorted stream
 };
 static size_t a4(size_t x) { return (x + 3) & ~(size_t)3; }  // keep every buffer 16-byte aligned
 
@@ -97,7 +96,6 @@ static bool use_fused_filter(const nq_painn_cfg* c) {
 static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, WsLayout* W) {
   const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, L = c->num_layers, T = c->num_elements;
   W->fused = use_fused_filter(c);
-  { const char* gm = getenv("NQ_GWR"); W->gwr_mol = W->fused && gm && !strcmp(gm, "mol"); }
   const size_t EP = W->fused ? 0 : E;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += a4(n); return r; };
@@ -126,7 +124,6 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   mx(nq_gemm_tn_scratch_floats(2 * N, 3 * F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, F, 2 * F)); mx(nq_gemm_tn_scratch_floats(6 * N, 2 * F, F));
   mx(W->fused ? nq_gwr_scratch_floats((int)E, (int)F, (int)R) : nq_gemm_tn_scratch_floats(2 * E, 3 * F, R));
   if (W->fused) mx(nq_k0_sort_scratch_ints((int)E, (int)R));
-  if (W->gwr_mol) mx(nq_gwr_mol_scratch_floats((int)F, (int)R));
   mx(nq_gemm_tn_scratch_floats(2 * N, F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, H, F));
   mx(nq_colsum_scratch_floats(N > E ? N : E, 3 * F));
   mx(nq_embed_grad_scratch_floats((int)N, (int)F, (int)T));
@@ -468,7 +465,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
     m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
-    m.GPHI = W.gwr_mol ? nullptr : gphi; m.GPSI = W.gwr_mol ? nullptr : gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
+    m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
@@ -477,14 +474,9 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
       NQ_TRY(nq_msg_rev(st, m, true));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    if (W.gwr_mol) {
-      m.GV = gv_oth; m.GTV = gv_oth + 3 * NF;   // after the swap: gv_oth is the buffer k_msgf_rev READ (adjoint of vec_msg)
-      NQ_TRY(nq_gwr_mol(st, m, ws + W.RW, R, gp + mp.Wr, gp + mp.br, scr));
-    } else {
-      if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
-      else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
-      NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
-    }
+    if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
+    else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
+    NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
     NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));

@@ -213,7 +213,7 @@ def _trace_report(name, model, sw, s2c, tag, lines):
     return worst
 
 
-@pytest.mark.parametrize("fused", ["fused", "fused-gwrmol", "materialised"])
+@pytest.mark.parametrize("fused", ["fused", "materialised"])
 @pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz"])
 def test_engine_matches_reference_golden(name, fused, monkeypatch):
     """fused: radial filter evaluated inside the message kernels (WrT in LDS, 13-Gaussian window);
@@ -222,10 +222,6 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
         monkeypatch.setenv("NQ_NO_FUSED_FILTER", "1")
     else:
         monkeypatch.delenv("NQ_NO_FUSED_FILTER", raising=False)
-    if fused == "fused-gwrmol":
-        monkeypatch.setenv("NQ_GWR", "mol")
-    else:
-        monkeypatch.delenv("NQ_GWR", raising=False)
     name_tag = f"{name}.{fused}"
     dev = _dev()
     fx, cfg, params = load_case(name)
