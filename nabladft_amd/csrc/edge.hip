@@ -465,6 +465,7 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
       RevOps<DUAL, CH> cur, nxt;
       load_rev<DUAL, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
       nxt = cur;
+      float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = 0; j < cnt; ++j) {
         const int sp = c0 + j;
         if (j + 1 < cnt) load_rev<DUAL, CH>(nxt, q, RW, bl_i(row.kk, j + 1), sp + 1, F, F3, fb);
@@ -510,14 +511,17 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
           stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
         } else {
           gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
-          if (lane == 0) {
-            float4* dstp = q.GEDGE + sp;   // one wavefront covers all F channels: slice 0 only
-            float4 acc = *dstp;
-            acc.x += gd; acc.y += e0; acc.z += e1; acc.w += e2;
-            *dstp = acc;
-          }
+          // lane j keeps the four reduced scalars of edge j; one coalesced float4 update per CSR row chunk below
+          const bool mine = lane == j;
+          eacc.x = mine ? gd : eacc.x; eacc.y = mine ? e0 : eacc.y; eacc.z = mine ? e1 : eacc.z; eacc.w = mine ? e2 : eacc.w;
         }
         cur = nxt;
+      }
+      if (!DUAL && lane < cnt) {
+        float4* dstp = q.GEDGE + c0 + lane;   // one wavefront covers all F channels: slice 0 only
+        float4 acc = *dstp;
+        acc.x += eacc.x; acc.y += eacc.y; acc.z += eacc.z; acc.w += eacc.w;
+        *dstp = acc;
       }
     }
     float g0[CH], g1[CH], g2[CH];
