@@ -377,3 +377,62 @@ def test_training_reduces_loss():
     step = nq.FusedTrainStep(model, lr=2e-3)
     losses = [float(step(b)) for _ in range(30)]
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.parametrize("fused", ["fused", "materialised"])
+def test_dense_molecules_long_rows(fused, monkeypatch):
+    """Rows longer than one wavefront (degree up to 99 > 64 -> chunked row loop), K binding (max_neighbors=40 < degree),
+    a 300-atom molecule (5 adjacency words per row) next to a 2-atom one; full train step vs the CPU oracle."""
+    import nabladft_amd as nq
+    if fused == "materialised":
+        monkeypatch.setenv("NQ_NO_FUSED_FILTER", "1")
+    else:
+        monkeypatch.delenv("NQ_NO_FUSED_FILTER", raising=False)
+    dev = _dev()
+    rng = np.random.Generator(np.random.PCG64(77))
+    sizes = [100, 2, 300, 70]
+    pos = np.concatenate([rng.uniform(0, (n ** (1 / 3)) * 1.9 + 1.0, size=(n, 3)) for n in sizes]).astype(np.float32)
+    batch = np.concatenate([np.full(n, i) for i, n in enumerate(sizes)]).astype(np.int64)
+    z = rng.choice([1, 6, 7, 8], size=len(pos)).astype(np.int64)
+    y = rng.normal(size=len(sizes)).astype(np.float32)
+    ft = rng.normal(0, 0.05, size=pos.shape).astype(np.float32)
+    for K in (100, 40):
+        cfg = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=24, cutoff=6.0, max_neighbors=K)
+        params = R.make_params(cfg, seed=4)
+        for k in params:  # keep activations O(1) at degree ~60
+            if "rbf_proj" in k or "x_proj.2" in k:
+                params[k] = params[k] * 0.3
+        tp, tz, tb = torch.tensor(pos), torch.tensor(z), torch.tensor(batch)
+        ei, nb, sw = R.build_graph(tp, tb, cfg.cutoff, cfg.max_neighbors)
+        deg = torch.bincount(ei[1], minlength=len(pos))
+        assert int(deg.max()) > 64 if K == 100 else True
+        model = _model(cfg, params, dev)
+        b = nq.Batch(tp, tz, tb, torch.tensor(y), torch.tensor(ft)).to(dev)
+        gi = model.generate_graph_values(b)
+        assert np.array_equal(gi[0].cpu().numpy(), ei.numpy()) and np.array_equal(gi[1].cpu().numpy(), nb.numpy())
+        e_ref, f_ref, loss_ref, g_ref = R.train_step(params, cfg, tp, tz, tb, torch.tensor(y), torch.tensor(ft), ei)
+        step = nq.FusedTrainStep(model, max_grad_norm=0.0)
+        loss = float(step(b, update=False))
+        assert rel_err(step.energy.cpu().numpy(), e_ref.numpy()) < 1e-5, (K, fused)
+        assert rel_err(step.forces.cpu().numpy(), f_ref.numpy()) < 2e-5, (K, fused)
+        assert abs(loss - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+        for (k, _), (o, n, s) in zip(model.named_parameters(), model._param_slices):
+            assert rel_err(step.grad[o:o + n].view(s).cpu().numpy(), g_ref[k].numpy()) < 1e-4, (K, fused, k)
+
+
+def test_graph_large_molecule_matches_oracle():
+    """Neighbour list of molecules close to the 512-atom LDS limit (8 adjacency words per row) vs the oracle, bit-exact indices."""
+    import nabladft_amd as nq
+    dev = _dev()
+    rng = np.random.Generator(np.random.PCG64(5))
+    sizes = [512, 1, 449, 64, 65]
+    pos = torch.tensor(np.concatenate([rng.uniform(0, 14.0, size=(n, 3)) for n in sizes]).astype(np.float32))
+    batch = torch.tensor(np.concatenate([np.full(n, i) for i, n in enumerate(sizes)]).astype(np.int64))
+    for cutoff, K in ((3.0, 100), (4.5, 7)):
+        ei, nb, sw = R.build_graph(pos, batch, cutoff, K)
+        nl = nq.build_neighbor_list(pos.to(dev), batch.to(dev), None, cutoff, K, canonical=True)
+        assert np.array_equal(nl.edge_index.cpu().numpy(), ei.numpy())
+        assert np.array_equal(nl.neighbors.cpu().numpy(), nb.numpy())
+        assert np.array_equal(nl.id_swap.cpu().numpy(), sw.numpy())
+        d, v = R.edge_geometry(pos, ei)
+        assert _ulp_close(nl.edge_dist.cpu().numpy(), d.numpy(), 1) and _ulp_close(nl.edge_vector.cpu().numpy(), v.numpy(), 2)
