@@ -28,13 +28,20 @@ __device__ __forceinline__ u64 bits_below(int b) {  // mask of bit positions < b
   return (1ull << b) - 1ull;
 }
 
-// squared distance exactly as torch evaluates (x_i - x_j).pow(2).sum(-1): ((dx*dx + dy*dy) + dz*dz), no FMA
+// squared distance exactly as torch evaluates (x_i - x_j).pow(2).sum(-1): ((dx*dx + dy*dy) + dz*dz), one rounding per
+// operation, no FMA, no reassociation.  Written with explicit VALU instructions: with plain C the packed-math SLP pass was
+// observed to emit (dx*dx + dz*dz) + dy*dy (15 % of distances then differ from the reference in the last bit).
 __device__ __forceinline__ float dist2_nofma(const float* a, const float* b) {
-#pragma clang fp contract(off)
-  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-  float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-  float s = xx + yy;
-  return s + zz;
+  float dx, dy, dz, xx, yy, zz, s;
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(a[0]), "v"(b[0]));
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(a[1]), "v"(b[1]));
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(a[2]), "v"(b[2]));
+  asm volatile("v_mul_f32 %0, %1, %1" : "=v"(xx) : "v"(dx));
+  asm volatile("v_mul_f32 %0, %1, %1" : "=v"(yy) : "v"(dy));
+  asm volatile("v_mul_f32 %0, %1, %1" : "=v"(zz) : "v"(dz));
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(s) : "v"(xx), "v"(yy));
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(zz));
+  return s;
 }
 
 // Build in LDS: LK[i][w] = kept lower neighbours (j < i, first K in ascending j) of atom i,
