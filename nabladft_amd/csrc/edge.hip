@@ -846,9 +846,14 @@ static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_th
   return blocks < 256 ? blocks : 256;   // one persistent workgroup per CU (LDS-limited to 1 per CU anyway)
 }
 
+// the >64 KB dynamic-LDS opt-in is sticky per kernel: set it when the requested size grows, not on every launch
 #define FUSED_LAUNCH(KERN, FLAG, CHV, Q)                                                                          \
   do {                                                                                                            \
-    NQ_HIP(hipFuncSetAttribute((const void*)KERN<FLAG, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    static size_t lds_set__ = 0;                                                                                  \
+    if (lds > lds_set__) {                                                                                        \
+      NQ_HIP(hipFuncSetAttribute((const void*)KERN<FLAG, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      lds_set__ = lds;                                                                                            \
+    }                                                                                                             \
     hipLaunchKernelGGL((KERN<FLAG, CHV>), dim3(grid), dim3(threads), lds, st, Q, fa, fa.RW);                      \
   } while (0)
 #define FUSED_DISPATCH(KERN, FLAG, Q)                                   \
