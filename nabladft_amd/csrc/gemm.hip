@@ -206,7 +206,11 @@ extern "C" void nq_set_gemm_variant(int32_t v) { g_gemm_variant = v; }
 
 template <bool A_KC, bool B_KC, int EPI>
 static void launch_gemm(hipStream_t st, dim3 grid, const GemmArgs& p) {
-  switch (g_gemm_variant & 3) {
+  int variant = g_gemm_variant & 3;
+  // latency-bound regime (few workgroups, e.g. batch_size 32): nothing else hides the global-load latency of the serial
+  // K loop, so the register-prefetch form pays there (it is neutral-to-slightly-negative on full grids)
+  if (variant == 1 && (long)grid.x * grid.y * grid.z < 512) variant = 3;
+  switch (variant) {
     case 0: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, false>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, false>), grid, dim3(512), 0, st, p); break;
     case 2: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, true>), grid, dim3(256), 0, st, p); break;
@@ -284,7 +288,7 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 static int tn_splits(long rows, int Mo, int No) {
   const long tiles = (long)nq_cdiv(Mo, BM) * nq_cdiv(No, BN);
   long s = (768 + tiles - 1) / tiles;
-  const long by_rows = (rows + 511) / 512;
+  const long by_rows = (rows + 127) / 128;   // >= 128 rows (4 k-tiles) per split
   if (s > by_rows) s = by_rows;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
