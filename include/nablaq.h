@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 2
+#define NQ_ABI_VERSION 3
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -51,7 +51,9 @@ typedef struct nq_painn_cfg {
   int32_t envelope_exponent; /* PolynomialEnvelope(exponent) */
   double cutoff;             /* Angstrom */
   float rbf_coeff;           /* GaussianSmearing.coeff = -0.5/(offset[1]-offset[0])^2 */
-  int32_t reserved;
+  int32_t filter_mode;       /* 0: painn_pyg  filter = rbf_proj(envelope(d/rc) * gauss(d/rc)) + bias   (layers.py:181-185)
+                              * 1: schnetpack filter = cosine_cutoff(d) * (filter_net(gauss(d)) + bias), Gaussians on the unscaled
+                              *    distance (config/model/painn.yaml:9-16); needs the fused-filter path */
 } nq_painn_cfg;
 
 /* Neighbour list in engine layout (CSR by target atom, sources ascending; symmetric). */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnablaq.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -19,7 +19,7 @@ class NablaqError(RuntimeError):
 class PainnCfg(C.Structure):
     _fields_ = [("hidden_channels", C.c_int32), ("num_layers", C.c_int32), ("num_rbf", C.c_int32),
                 ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
-                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("reserved", C.c_int32)]
+                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("filter_mode", C.c_int32)]
 
 
 class Graph(C.Structure):

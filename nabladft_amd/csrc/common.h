@@ -112,6 +112,8 @@ struct FilterArgs {
   const float* RW;    // [E][32] per-edge 13-tap window record written by k_rbf_window: [0..12] rho, [13] k0 (int bits), [16..28] drho
   int R;
   float inv_cutoff, p, a, b, c, coeff;
+  int mode;           // 0: polynomial envelope inside the projection (painn_pyg); 1: cosine cutoff after the bias, unscaled Gaussians (spk)
+  float cutoff;
 };
 
 struct MsgRevArgs {
@@ -175,7 +177,7 @@ int nq_rbf(hipStream_t, const float4* geom, int E, int R, double cutoff, int env
 int nq_msg_fwd(hipStream_t, const MsgArgs&, bool tangent);
 bool nq_filter_fits_lds(int F, int R);
 void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,
-                         float coeff);
+                         float coeff, int mode = 0);
 int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, float* RW);
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 size_t nq_k0_sort_scratch_ints(int E, int R);

@@ -218,23 +218,38 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
   int kc = (int)rintf(ds * (float)(R - 1));
   kc = min(max(kc, 0), R - 1);
   const int k0 = min(max(kc - FWIN / 2, 0), R - nwin);
-  float rl = 0.f, drl = 0.f;
-  if (t < nwin) {
-    float env = 0.f, denv = 0.f;
-    if (ds < 1.0f) {
-      const float pm1 = powf(ds, fa.p - 1.0f);
-      const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
-      env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
-      denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
+  float rl = 0.f, drl = 0.f, beta = 1.f, dbeta = 0.f;
+  if (fa.mode == 0) {
+    if (t < nwin) {
+      float env = 0.f, denv = 0.f;
+      if (ds < 1.0f) {
+        const float pm1 = powf(ds, fa.p - 1.0f);
+        const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
+        env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
+        denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
+      }
+      const float diff = ds - fa.mu[k0 + t];
+      const float g = expf(fa.coeff * (diff * diff));
+      rl = env * g;
+      drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
     }
-    const float diff = ds - fa.mu[k0 + t];
-    const float g = expf(fa.coeff * (diff * diff));
-    rl = env * g;
-    drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
+  } else {
+    // schnetpack: W_ij = fcut(d) * (filter_net(gauss(d)) + b)  ->  rho = fcut * gauss (unscaled d), bias multiplier beta = fcut
+    const float d = geom[e].w;
+    const float arg = d * (3.14159265358979323846f / fa.cutoff);
+    const bool inside = d < fa.cutoff;
+    beta = inside ? 0.5f * (cosf(arg) + 1.0f) : 0.f;
+    dbeta = inside ? -0.5f * (3.14159265358979323846f / fa.cutoff) * sinf(arg) : 0.f;
+    if (t < nwin) {
+      const float diff = d - fa.mu[k0 + t];
+      const float g = expf(fa.coeff * (diff * diff));
+      rl = beta * g;
+      drl = dbeta * g + beta * g * (2.0f * fa.coeff) * diff;
+    }
   }
   float* rw = RW + (long)e * RW_STRIDE;
-  rw[t] = (t == 13) ? __int_as_float(k0) : rl;
-  rw[16 + t] = drl;
+  rw[t] = (t == 13) ? __int_as_float(k0) : (t == 14 ? beta : rl);    // [14] = bias multiplier, [30] = its derivative
+  rw[16 + t] = (t == 14) ? dbeta : drl;
 }
 
 // ---- row preload: lane L of the wavefront holds index / geometry (/ tangents) of the row's edge L ------------
@@ -302,7 +317,11 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
                                             const float (&brb)[CH], const float (&brc)[CH], float (&pa)[CH], float (&pb)[CH], float (&pc)[CH],
                                             float (&qa)[CH], float (&qb)[CH], float (&qc)[CH]) {
 #pragma unroll
-  for (int c = 0; c < CH; ++c) { pa[c] = bra[c]; pb[c] = brb[c]; pc[c] = brc[c]; qa[c] = qb[c] = qc[c] = 0.f; }
+  for (int c = 0; c < CH; ++c) {   // bias enters as beta*b (phi) and beta'*b (psi); beta = 1, beta' = 0 in painn_pyg mode (exact)
+    pa[c] = bra[c] * w.rr[14]; pb[c] = brb[c] * w.rr[14]; pc[c] = brc[c] * w.rr[14];
+    if (PSI) { qa[c] = bra[c] * w.dd[14]; qb[c] = brb[c] * w.dd[14]; qc[c] = brc[c] * w.dd[14]; }
+    else { qa[c] = qb[c] = qc[c] = 0.f; }
+  }
   const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(w.rr[13]));
   const float* wk = wrt + k0 * F3 + fb;
 #pragma unroll
@@ -496,8 +515,10 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
             gxa[c] += gma * pa[c] + gtma * tpa; gxb[c] += gmb * pb[c] + gtmb * tpb; gxc[c] += gmc * pc[c] + gtmc * tpc;
             gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c];
             ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
-            sba[c] += ga[c]; sbb[c] += gb[c]; sbc[c] += gc[c];
             ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
+            sba[c] += ga[c] * cur.w.rr[14] + ha[c] * cur.w.dd[14];
+            sbb[c] += gb[c] * cur.w.rr[14] + hb[c] * cur.w.dd[14];
+            sbc[c] += gc[c] * cur.w.rr[14] + hc[c] * cur.w.dd[14];
           } else {
             gxa[c] += gma * pa[c]; gxb[c] += gmb * pb[c]; gxc[c] += gmc * pc[c];
             gd += gma * xa[c] * qa[c] + gmb * xb[c] * qb[c] + gmc * xc[c] * qc[c];
@@ -815,11 +836,11 @@ bool nq_filter_fits_lds(int F, int R) {
 }
 
 void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,
-                         float coeff) {
+                         float coeff, int mode) {
   const double p = env_p;
   fa->WRT = WRT; fa->br = br; fa->mu = mu; fa->RW = RW; fa->R = R; fa->inv_cutoff = (float)(1.0 / cutoff);
   fa->p = (float)p; fa->a = (float)(-(p + 1) * (p + 2) / 2); fa->b = (float)(p * (p + 2)); fa->c = (float)(-p * (p + 1) / 2);
-  fa->coeff = coeff;
+  fa->coeff = coeff; fa->mode = mode; fa->cutoff = (float)cutoff;
 }
 
 int nq_rbf_window(hipStream_t st, const float4* geom, int E, const FilterArgs& fa, float* RW) {

@@ -148,6 +148,9 @@ static int check_common(const nq_painn_cfg* cfg, const nq_graph* g, const void* 
   if (g->E <= 0) return nq_fail(NQ_ERR_NO_EDGES, "batch has no edges within the cutoff");
   if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return nq_fail(NQ_ERR_ARG, "workspace must be 16-byte aligned");
   make_ws_layout(cfg, g->N, g->E, g->B, W);
+  if (cfg->filter_mode != 0 && cfg->filter_mode != 1) return nq_fail(NQ_ERR_ARG, "filter_mode must be 0 (painn_pyg) or 1 (schnetpack)");
+  if (cfg->filter_mode == 1 && !W->fused)
+    return nq_fail(NQ_ERR_ARG, "filter_mode 1 (schnetpack) needs the fused-filter path: hidden_channels in {64,128,256} and WrT fitting the LDS");
   if (ws_bytes < W->total_floats * sizeof(float))
     return nq_fail(NQ_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, W->total_floats * sizeof(float));
   return NQ_OK;
@@ -295,7 +298,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
   if (W.fused) {
     FilterArgs fa0;
-    nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+    nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
     NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
   } else {
@@ -312,7 +315,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     if (W.fused) {
       FilterArgs fa;
       NQ_TRY(nq_transpose(st, params + mp.Wr, 3 * F, R, ws + y.WRT));
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       NQ_TRY(nq_msgf_fwd(st, m, fa, false));
     } else {
       NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
@@ -360,7 +363,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       NQ_TRY(nq_msgf_rev(st, m, fa, false));
     } else {
       NQ_TRY(nq_msg_rev(st, m, false));
@@ -404,7 +407,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     m.TXM = ws + y.XM + NF; m.TVM = ws + y.VM + 3 * NF;
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       NQ_TRY(nq_msgf_fwd(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_fwd(st, m, true));
@@ -468,7 +471,7 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
     if (W.fused) {
       FilterArgs fa;
-      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff);
+      nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       NQ_TRY(nq_msgf_rev(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_rev(st, m, true));

@@ -37,6 +37,9 @@ class PaiNNConfig:
     max_neighbors: int = 100
     envelope_exponent: int = 5
     num_elements: int = 100
+    # "pyg": rbf_proj(envelope * gauss(d/rc)) + bias (nablaDFT/painn_pyg).  "spk": cosine_cutoff(d) * (filter(gauss(d)) + bias)
+    # (schnetpack PaiNN, config/model/painn.yaml) -- see oracle/spk_painn_ref.py
+    filter_mode: str = "pyg"
 
 
 # ----------------------------------------------------------------------------------------
@@ -152,11 +155,24 @@ def _scatter_sum(src, index, n):
     return out.index_add_(0, index, src)
 
 
-def message_layer(P, pre, F, x, vec, edge_index, edge_rbf, edge_vector):
-    """painn.py:475-509."""
+def spk_radial(cfg, d):
+    """schnetpack GaussianRBF(n_rbf, cutoff) on the unscaled distance and CosineCutoff(cutoff)."""
+    import math
+    offsets = torch.linspace(0.0, cfg.cutoff, cfg.num_rbf).to(d.dtype)
+    width = (torch.linspace(0.0, cfg.cutoff, cfg.num_rbf)[1]).item()
+    g = torch.exp((-0.5 / width ** 2) * (d[:, None] - offsets[None, :]) ** 2)
+    fcut = 0.5 * (torch.cos(d * math.pi / cfg.cutoff) + 1.0) * (d < cfg.cutoff).to(d.dtype)
+    return g, fcut
+
+
+def message_layer(P, pre, F, x, vec, edge_index, edge_rbf, edge_vector, bias_scale=None):
+    """painn.py:475-509.  bias_scale (spk filter mode): filter = fcut * (W g + b) = W (fcut g) + fcut b."""
     xh = Fn.linear(Fn.silu(Fn.linear(x, P[pre + "x_proj.0.weight"], P[pre + "x_proj.0.bias"])),
                    P[pre + "x_proj.2.weight"], P[pre + "x_proj.2.bias"])
-    rbfh = Fn.linear(edge_rbf, P[pre + "rbf_proj.weight"], P[pre + "rbf_proj.bias"])
+    if bias_scale is None:
+        rbfh = Fn.linear(edge_rbf, P[pre + "rbf_proj.weight"], P[pre + "rbf_proj.bias"])
+    else:
+        rbfh = Fn.linear(edge_rbf, P[pre + "rbf_proj.weight"]) + bias_scale[:, None] * P[pre + "rbf_proj.bias"]
     j, i = edge_index
     m = xh[j] * rbfh
     xa, xh2, xh3 = torch.split(m, F, dim=-1)
@@ -180,11 +196,16 @@ def painn_energy(P, cfg: PaiNNConfig, pos, z, batch, edge_index, trace=None):
     F = cfg.hidden_channels
     B = int(batch.max()) + 1
     edge_dist, edge_vector = edge_geometry(pos, edge_index)
-    edge_rbf = radial_basis(cfg, edge_dist)
+    bias_scale = None
+    if cfg.filter_mode == "spk":
+        g, fcut = spk_radial(cfg, edge_dist)
+        edge_rbf, bias_scale = g * fcut[:, None], fcut
+    else:
+        edge_rbf = radial_basis(cfg, edge_dist)
     x = P["atom_emb.embeddings.weight"][z - 1]
     vec = torch.zeros(x.size(0), 3, F, dtype=x.dtype)
     for l in range(cfg.num_layers):
-        dx, dvec = message_layer(P, f"message_layers.{l}.", F, x, vec, edge_index, edge_rbf, edge_vector)
+        dx, dvec = message_layer(P, f"message_layers.{l}.", F, x, vec, edge_index, edge_rbf, edge_vector, bias_scale)
         x, vec = x + dx, vec + dvec
         if trace is not None:
             trace[f"x_msg{l}"], trace[f"vec_msg{l}"] = x.detach(), vec.detach()

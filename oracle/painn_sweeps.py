@@ -58,6 +58,22 @@ def rbf_and_derivative(cfg: PaiNNConfig, d):
     return rho, drho
 
 
+def spk_rbf_and_derivative(cfg: PaiNNConfig, d):
+    """spk filter mode: rho = fcut(d) * gauss(d) (unscaled Gaussians, cosine cutoff), beta = fcut multiplies the bias."""
+    import math
+    mu = torch.linspace(0.0, cfg.cutoff, cfg.num_rbf).to(d.dtype)
+    width = (torch.linspace(0.0, cfg.cutoff, cfg.num_rbf)[1]).item()
+    coeff = -0.5 / width ** 2
+    diff = d[:, None] - mu[None, :]
+    g = torch.exp(coeff * diff * diff)
+    inside = (d < cfg.cutoff).to(d.dtype)
+    fcut = 0.5 * (torch.cos(d * math.pi / cfg.cutoff) + 1.0) * inside
+    dfcut = -0.5 * math.pi / cfg.cutoff * torch.sin(d * math.pi / cfg.cutoff) * inside
+    rho = fcut[:, None] * g
+    drho = dfcut[:, None] * g + fcut[:, None] * g * (2 * coeff) * diff
+    return rho, drho, fcut, dfcut
+
+
 class Sweeps:
     def __init__(self, P, cfg: PaiNNConfig, pos, z, batch, edge_index):
         self.P, self.cfg = P, cfg
@@ -91,7 +107,11 @@ class Sweeps:
         d = (self.pos[i] - self.pos[j]).pow(2).sum(-1).sqrt()
         c0 = torch.isclose(d, torch.zeros((), dtype=d.dtype), atol=1e-6).to(d.dtype) * 1e-6
         ws["d"], ws["r"] = d, w / (d + c0)[:, None]
-        ws["rho"], ws["drho"] = rbf_and_derivative(self.cfg, d)
+        if self.cfg.filter_mode == "spk":
+            ws["rho"], ws["drho"], ws["beta"], ws["dbeta"] = spk_rbf_and_derivative(self.cfg, d)
+        else:
+            ws["rho"], ws["drho"] = rbf_and_derivative(self.cfg, d)
+            ws["beta"], ws["dbeta"] = torch.ones_like(d), torch.zeros_like(d)
         x = self.P["atom_emb.embeddings.weight"][self.z - 1]
         vec = torch.zeros(self.N, 3, F, dtype=x.dtype)
         ws["x_in0"], ws["vec_in0"] = x, vec
@@ -99,8 +119,8 @@ class Sweeps:
             z1 = x @ self._w(l, "W1").T + self._w(l, "b1")
             h = silu(z1)
             xh = h @ self._w(l, "W2").T + self._w(l, "b2")
-            phi = ws["rho"] @ self._w(l, "Wr").T + self._w(l, "br")
-            psi = ws["drho"] @ self._w(l, "Wr").T
+            phi = ws["rho"] @ self._w(l, "Wr").T + ws["beta"][:, None] * self._w(l, "br")
+            psi = ws["drho"] @ self._w(l, "Wr").T + ws["dbeta"][:, None] * self._w(l, "br")
             m = xh[j] * phi
             ma, mb, mc = m[:, :F], m[:, F:2 * F], m[:, 2 * F:]
             dx = self._scatter(ma, i, self.N)
@@ -301,7 +321,7 @@ class Sweeps:
                 gphi = gphi + gtm * txh[j]
                 gpsi = gtm * xh[j] * t_d[:, None]
                 G[m_ + "rbf_proj.weight"] = gphi.T @ ws["rho"] + gpsi.T @ ws["drho"]
-                G[m_ + "rbf_proj.bias"] = gphi.sum(0)
+                G[m_ + "rbf_proj.bias"] = (gphi * ws["beta"][:, None] + gpsi * ws["dbeta"][:, None]).sum(0)
                 gtxh = self._scatter(gtxh_e, j, self.N)
                 gtvec = gtvec + self._scatter(gtvec_src, j, self.N)
             else:
