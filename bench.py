@@ -122,6 +122,68 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
             "avg_launch_ms": avg_ms, "launches_per_step": launches}
 
 
+WORKLOADS = {
+    "painn-oc": "PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces train step incl. "
+                "neighbour list, L1+L2 loss, grad all-reduce, clip 5.0, AdamW lr 5e-4",
+    "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
+                 "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
+}
+
+
+def build_step(kind, dev):
+    """(model, FusedTrainStep) for a workload with its config's optimiser settings."""
+    import nabladft_amd as nq
+    if kind == "painn-oc":
+        model = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
+        return model, nq.FusedTrainStep(model, lr=5e-4, weight_decay=0.0, max_grad_norm=5.0)     # painn-oc.yaml optimizer + clip
+    from nabladft_amd import spk
+    pot = spk.NeuralNetworkPotential(
+        representation=spk.PaiNN(n_atom_basis=F, n_interactions=L, radial_basis=spk.GaussianRBF(n_rbf=R, cutoff=CUTOFF), cutoff_fn=spk.CosineCutoff(CUTOFF)),
+        input_modules=[spk.PairwiseDistances()], output_modules=[spk.Atomwise(n_in=F, output_key="energy"), spk.Forces()],
+        postprocessors=[spk.AddOffsets("energy", add_mean=True)]).to(dev)
+    return pot, nq.FusedTrainStep(pot, lr=1e-4, weight_decay=0.01, max_grad_norm=0.0)            # config/model/painn.yaml:48-52, config/painn.yaml:18-19
+
+
+def cpu_baseline_spk(seconds_budget=25.0):
+    """Same as cpu_baseline for the schnetpack-style PaiNN: oracle/spk_painn_ref.py (PARITY UNPINNED restatement)."""
+    from oracle import painn_ref as Rf
+    from oracle import spk_painn_ref as S
+    import nabladft_amd as nq
+    from nabladft_amd import spk
+    scfg = S.SpkPaiNNConfig()
+    P = S.make_spk_params(scfg, seed=23)
+    pos, z, batch, y, ft = Rf.gen_conformers(12345, 32)
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    e_ref, f_ref, loss_ref, g_ref = S.spk_train_step(P, scfg, pos, z, batch, y, ft)
+    warm = time.perf_counter() - t0
+    times = []
+    while sum(times) + warm < seconds_budget and len(times) < 5:
+        t0 = time.perf_counter()
+        S.spk_train_step(P, scfg, pos, z, batch, y, ft)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times)) if times else warm
+    out = {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+           "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms), spk-PaiNN restatement (parity unpinned), median of {max(len(times), 1)} "
+                     f"steps incl. O(n^2) neighbour list, torch {torch.__version__} CPU fp32 without optimizer step"}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pot, _ = build_step("painn-spk", dev)
+    pot.load_state_dict(P, strict=False)
+    fs = nq.FusedTrainStep(pot, max_grad_norm=0.0)
+    loss = float(fs(nq.Batch(pos, z, batch, y, ft).to(dev), update=False))
+    e, f = fs.energy.cpu(), fs.forces.cpu()
+    g_spk = torch.zeros(pot._n_spk, dtype=torch.float32).index_add_(0, pot._index.cpu(), fs.grad.cpu())
+    gref = torch.cat([g_ref[k].reshape(-1) for k, _ in S.spk_param_shapes(scfg)])
+    parity = {"mae_energy": float((e - e_ref).abs().mean()), "mae_forces": float((f - f_ref).abs().mean()),
+              "max_rel_energy": float((e - e_ref).abs().max() / e_ref.abs().max()),
+              "max_rel_forces": float((f - f_ref).abs().max() / f_ref.abs().max()),
+              "rel_loss": abs(loss - float(loss_ref)) / abs(float(loss_ref)),
+              "max_rel_grad": float((g_spk - gref).abs().max() / gref.abs().max()),
+              "mean_abs_energy_ref": float(e_ref.abs().mean()), "mean_abs_forces_ref": float(f_ref.abs().mean())}
+    return out, parity
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
     timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
@@ -175,6 +237,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="conformers per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", choices=sorted(WORKLOADS), default="painn-oc",
+                    help="painn-oc: in-tree PaiNN (parity pinned by reference golden vectors); painn-spk: config/painn.yaml (schnetpack PaiNN, unpinned)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: nq_set_gemm_variant (bit0 8 waves, bit1 prefetch)")
     args = ap.parse_args()
 
@@ -190,8 +254,7 @@ def main():
     if args.gemm_variant is not None:
         _lib.load().nq_set_gemm_variant(args.gemm_variant)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
-    model = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
-    step = nq.FusedTrainStep(model, lr=5e-4, weight_decay=0.0, max_grad_norm=5.0)   # painn-oc.yaml optimizer + clip
+    model, step = build_step(args.model, dev)
     batches = make_batches(1 + rank, 4, args.batch, dev)
     n_atoms = sum(b.num_nodes for b in batches) / len(batches)
 
@@ -241,22 +304,38 @@ def main():
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline()
+        cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk()
+
+    other = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # the sibling PaiNN configuration through the same kernels (reported, not `value`)
+        kind2 = "painn-spk" if args.model == "painn-oc" else "painn-oc"
+        del step, model
+        torch.cuda.empty_cache()
+        model2, step2 = build_step(kind2, dev)
+        for i in range(max(args.warmup, 1)):
+            step2(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step2(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        other = {"workload": WORKLOADS[kind2], "value": args.batch * args.steps / dt2, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt2 / args.steps}
 
     if rank == 0:
         out = {
             "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces "
-                                   f"train step incl. neighbour list, L1+L2 loss, grad all-reduce, clip 5.0, AdamW; synthetic ~42-atom "
-                                   f"drug-like conformers, {args.batch} conformers/GPU/step",
+            "config": {"workload": f"{WORKLOADS[args.model]}; synthetic ~42-atom drug-like conformers, {args.batch} conformers/GPU/step",
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
                        "parallelism": f"dp{world}"},
             "final_loss": float(loss),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "mae_vs_cpu_reference": parity,
+            "sibling_config": other,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},

@@ -111,6 +111,10 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
                   float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream);
+/* loss[1] = coef_e * mean (E-y)^2 + coef_f * mean_{i,c} (F_ic - Ft_ic)^2  -- torch.nn.MSELoss on both outputs, the loss of the
+ * schnetpack task (config/model/painn.yaml:30-46, weights loss_weight) */
+int nq_loss_mse(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
+                float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream);
 /* clip_grad_norm_(max_norm) (skipped if max_norm <= 0) + AdamW step over the flat buffers; step >= 1;
  * scratch: f32[512]. */
 int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t count, float max_norm, float lr,

@@ -42,6 +42,7 @@ SYMBOLS = {
     "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
     "nq_painn_ws_lookup": (C.c_int, [C.POINTER(PainnCfg), _I32, _I32, _I32, C.c_char_p, _I32, _I32, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
+    "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),
     "nq_profile_enable": (None, [_I32]),
     "nq_profile_read": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),

@@ -205,6 +205,6 @@ int nq_mol_sum(hipStream_t, const float* e_atom, const int* mol_ptr, int B, floa
 int nq_atom_seeds(hipStream_t, const float* gE, const int* atom_mol, int N, float* ge, float* gte);
 int nq_negate(hipStream_t, const float* in, float* out, long count);
 int nq_loss_impl(hipStream_t, const float* E, const float* y, int B, const float* Fc, const float* Ft, int N, float ce, float cf, float* loss,
-                 float* gE, float* gF);
+                 float* gE, float* gF, bool mse);
 int nq_adamw_impl(hipStream_t, float* p, const float* g, float* m, float* v, long count, float max_norm, float lr, float beta1, float beta2,
                   float eps, float wd, int step, float* scratch);

@@ -494,7 +494,12 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
                   float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream) {
   if (!energy || !y || !forces || !f_target || !loss || !grad_energy || !grad_forces) return nq_fail(NQ_ERR_ARG, "null argument");
-  return nq_loss_impl((hipStream_t)stream, energy, y, B, forces, f_target, N, coef_e, coef_f, loss, grad_energy, grad_forces);
+  return nq_loss_impl((hipStream_t)stream, energy, y, B, forces, f_target, N, coef_e, coef_f, loss, grad_energy, grad_forces, false);
+}
+int nq_loss_mse(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
+                  float coef_f, float* loss, float* grad_energy, float* grad_forces, void* stream) {
+  if (!energy || !y || !forces || !f_target || !loss || !grad_energy || !grad_forces) return nq_fail(NQ_ERR_ARG, "null argument");
+  return nq_loss_impl((hipStream_t)stream, energy, y, B, forces, f_target, N, coef_e, coef_f, loss, grad_energy, grad_forces, true);
 }
 
 int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t count, float max_norm, float lr, float beta1,

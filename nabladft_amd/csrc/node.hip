@@ -244,7 +244,10 @@ __global__ void k_scale_neg(const float* __restrict__ in, float* __restrict__ ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// loss = ce * mean_b |E_b - y_b| + cf * mean_i ||F_i - Ft_i||_2 and its seeds dL/dE, dL/dF   (single workgroup)
+// MSE = false: loss = ce * mean_b |E_b - y_b| + cf * mean_i ||F_i - Ft_i||_2                       (painn.py:741-745)
+// MSE = true : loss = ce * mean_b (E_b - y_b)^2 + cf * mean_{i,c} (F_ic - Ft_ic)^2  (torch.nn.MSELoss, config/model/painn.yaml:30-46)
+// and the seeds dL/dE, dL/dF   (single workgroup)
+template <bool MSE>
 __global__ __launch_bounds__(1024) void k_loss(const float* __restrict__ E, const float* __restrict__ y, int B, const float* __restrict__ Fc,
                                                const float* __restrict__ Ft, int N, float ce, float cf, float* __restrict__ loss,
                                                float* __restrict__ gE, float* __restrict__ gF) {
@@ -252,14 +255,25 @@ __global__ __launch_bounds__(1024) void k_loss(const float* __restrict__ E, cons
   float acc = 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const float d = E[b] - y[b];
-    acc += ce * fabsf(d) / (float)B;
-    gE[b] = ce * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (float)B;
+    if (MSE) {
+      acc += ce * d * d / (float)B;
+      gE[b] = 2.f * ce * d / (float)B;
+    } else {
+      acc += ce * fabsf(d) / (float)B;
+      gE[b] = ce * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (float)B;
+    }
   }
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const float dx = Fc[3 * (long)n] - Ft[3 * (long)n], dy = Fc[3 * (long)n + 1] - Ft[3 * (long)n + 1], dz = Fc[3 * (long)n + 2] - Ft[3 * (long)n + 2];
-    const float nr = sqrtf(dx * dx + dy * dy + dz * dz);
-    acc += cf * nr / (float)N;
-    const float sc = nr > 0.f ? cf / (nr * (float)N) : 0.f;
+    float sc;
+    if (MSE) {
+      acc += cf * (dx * dx + dy * dy + dz * dz) / (3.f * (float)N);
+      sc = 2.f * cf / (3.f * (float)N);
+    } else {
+      const float nr = sqrtf(dx * dx + dy * dy + dz * dz);
+      acc += cf * nr / (float)N;
+      sc = nr > 0.f ? cf / (nr * (float)N) : 0.f;
+    }
     gF[3 * (long)n] = dx * sc; gF[3 * (long)n + 1] = dy * sc; gF[3 * (long)n + 2] = dz * sc;
   }
   acc = nq_wave_sum(acc);
@@ -408,9 +422,10 @@ int nq_negate(hipStream_t st, const float* in, float* out, long count) {
   return NQ_OK;
 }
 int nq_loss_impl(hipStream_t st, const float* E, const float* y, int B, const float* Fc, const float* Ft, int N, float ce, float cf,
-                 float* loss, float* gE, float* gF) {
+                 float* loss, float* gE, float* gF, bool mse) {
   NQ_PROF(st, "loss");
-  hipLaunchKernelGGL(k_loss, dim3(1), dim3(1024), 0, st, E, y, B, Fc, Ft, N, ce, cf, loss, gE, gF);
+  if (mse) hipLaunchKernelGGL(k_loss<true>, dim3(1), dim3(1024), 0, st, E, y, B, Fc, Ft, N, ce, cf, loss, gE, gF);
+  else hipLaunchKernelGGL(k_loss<false>, dim3(1), dim3(1024), 0, st, E, y, B, Fc, Ft, N, ce, cf, loss, gE, gF);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -220,7 +220,9 @@ class NeuralNetworkPotential(nn.Module):
         forces = [m for m in self.output_modules if isinstance(m, Forces)]
         if len(atomwise) != 1 or len(forces) > 1 or len(atomwise) + len(forces) != len(self.output_modules):
             raise NotImplementedError("output_modules must be [Atomwise(...)] or [Atomwise(...), Forces()]")
-        self._atomwise, self._forces = atomwise[0], (forces[0] if forces else None)
+        # plain indices, not attributes: a second reference to the sub-modules would duplicate their state_dict entries
+        self._i_atomwise = [i for i, m in enumerate(self.output_modules) if isinstance(m, Atomwise)][0]
+        self._i_forces = ([i for i, m in enumerate(self.output_modules) if isinstance(m, Forces)] or [None])[0]
         if self._forces is not None and self._forces.energy_key != self._atomwise.output_key:
             raise ValueError("Forces.energy_key must name the Atomwise output")
         self.model_outputs = [k for m in self.output_modules for k in m.model_outputs]
@@ -237,6 +239,14 @@ class NeuralNetworkPotential(nn.Module):
         self._cfg = cfg
         self._index = None
         self._n_spk = 0
+
+    @property
+    def _atomwise(self):
+        return self.output_modules[self._i_atomwise]
+
+    @property
+    def _forces(self):
+        return None if self._i_forces is None else self.output_modules[self._i_forces]
 
     def _engine_params(self):
         rep, aw = self.representation, self._atomwise

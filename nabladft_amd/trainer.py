@@ -8,6 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib, dist as nqdist
+from . import spk
 from .painn import PaiNN, build_neighbor_list
 
 
@@ -27,13 +28,61 @@ class Batch:
         return Batch(mv(self.pos), mv(self.z), mv(self.batch), mv(self.y), mv(self.forces), mv(self.ptr))
 
 
+class _PygEngine:
+    """nabladft_amd.PaiNN: the module's parameters are views of the engine's flat buffer -- nothing to convert."""
+
+    def __init__(self, model: PaiNN):
+        self.model, self.cfg, self.cutoff, self.max_neighbors = model, model._cfg, model.cutoff, model.max_neighbors
+        self.offsets = model.radial_basis.rbf.offset
+
+    def flat(self):
+        return self.model.flat_parameters()
+
+    def writeback(self):
+        pass
+
+
+class _SpkEngine:
+    """nabladft_amd.spk.NeuralNetworkPotential: the step trains an engine-layout copy of the parameters (a permutation of
+    the spk tensors, so clip / AdamW act identically) and ``writeback`` scatters it into the spk-shaped nn.Parameters."""
+
+    def __init__(self, pot: "spk.NeuralNetworkPotential"):
+        rep = pot.representation
+        self.model, self.cfg, self.cutoff, self.max_neighbors = pot, pot._cfg, rep.cutoff, 2 ** 30
+        self.offsets = rep.radial_basis.offsets
+        dev = self.offsets.device
+        pot._index, pot._n_spk = spk._spk_index(rep.n_atom_basis, rep.n_interactions, rep.radial_basis.n_rbf, rep.max_z, dev)
+        with torch.no_grad():
+            self._flat = torch.cat([p.detach().to(torch.float32).reshape(-1) for p in pot._engine_params()]).index_select(0, pot._index)
+
+    def flat(self):
+        return self._flat
+
+    @torch.no_grad()
+    def writeback(self):
+        pot = self.model
+        ps = pot._engine_params()
+        spk_flat = torch.cat([p.detach().reshape(-1) for p in ps]).index_copy_(0, pot._index, self._flat)
+        o = 0
+        for p in ps:
+            p.copy_(spk_flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+
 class FusedTrainStep:
-    def __init__(self, model: PaiNN, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=5.0, coef_energy=1.0,
-                 coef_forces=1.0, group=None):
+    """``loss``: "l1_l2" (painn.py:741-745, the in-tree PaiNN) or "mse" (config/model/painn.yaml:30-46, the schnetpack task);
+    default by model type.  For an spk-shaped model call ``writeback()`` before reading its nn.Parameters / state_dict."""
+
+    def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=5.0, coef_energy=1.0,
+                 coef_forces=1.0, group=None, loss=None):
         self.model, self.group = model, group
+        self._eng = _SpkEngine(model) if isinstance(model, spk.NeuralNetworkPotential) else _PygEngine(model)
+        self.loss_kind = loss or ("mse" if isinstance(self._eng, _SpkEngine) else "l1_l2")
+        if self.loss_kind not in ("l1_l2", "mse"):
+            raise ValueError(f"unknown loss {self.loss_kind!r}")
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.ce, self.cf = coef_energy, coef_forces
-        flat = model.flat_parameters()
+        flat = self._eng.flat()
         nqdist.broadcast_(flat, 0, group)
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
         self.grad = torch.empty_like(flat)
@@ -45,11 +94,11 @@ class FusedTrainStep:
 
     def __call__(self, batch, update=True):
         lib = _lib.load()
-        model = self.model
-        flat = model.flat_parameters()
-        cfg = C.byref(model._cfg)
+        model, eng = self.model, self._eng
+        flat = eng.flat()
+        cfg = C.byref(eng.cfg)
         st = _lib.stream_ptr()
-        nl = build_neighbor_list(batch.pos, batch.batch, batch.z, model.cutoff, model.max_neighbors, batch.ptr)
+        nl = build_neighbor_list(batch.pos, batch.batch, batch.z, eng.cutoff, eng.max_neighbors, batch.ptr)
         if nl.E == 0:
             raise IndexError("batch has no edges within the cutoff")
         dev = flat.device
@@ -61,11 +110,12 @@ class FusedTrainStep:
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32)
         gE, gF = torch.empty_like(energy), torch.empty_like(forces)
-        _lib.check(lib.nq_painn_forward(cfg, _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
+        _lib.check(lib.nq_painn_forward(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
                                         _lib.ptr(energy), _lib.ptr(forces), st))
-        _lib.check(lib.nq_loss_l1_l2(_lib.ptr(energy), _lib.ptr(batch.y), nl.B, _lib.ptr(forces), _lib.ptr(batch.forces), nl.N, self.ce, self.cf,
-                                     _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
-        _lib.check(lib.nq_painn_backward(cfg, _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
+        loss_fn = lib.nq_loss_mse if self.loss_kind == "mse" else lib.nq_loss_l1_l2
+        _lib.check(loss_fn(_lib.ptr(energy), _lib.ptr(batch.y), nl.B, _lib.ptr(forces), _lib.ptr(batch.forces), nl.N, self.ce, self.cf,
+                           _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
+        _lib.check(lib.nq_painn_backward(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
                                          _lib.ptr(gE), _lib.ptr(gF),
                                          _lib.ptr(self.grad), st))
         nqdist.allreduce_mean_(self.grad, self.group)
@@ -77,3 +127,7 @@ class FusedTrainStep:
         self.energy, self.forces = energy, forces
         model._last_ws, model._last_nl = ws, nl
         return self.loss
+
+    def writeback(self):
+        """Make the module's nn.Parameters reflect the trained values (no-op for nabladft_amd.PaiNN)."""
+        self._eng.writeback()

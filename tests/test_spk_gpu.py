@@ -62,3 +62,38 @@ def test_spk_potential_matches_restatement(F, L, R, cutoff, n_mol, size):
     n_atoms = torch.bincount(batch).double()
     assert rel_err(out2["energy"].cpu().numpy(), (e_ref + (-3.5) * n_atoms).numpy()) < 2e-6
     assert torch.equal(out2["forces"], out["forces"].detach())          # same kernels, bitwise deterministic
+
+
+def test_spk_fused_step_equals_autograd_plus_torch_adamw():
+    """FusedTrainStep on the spk-shaped potential (engine-layout training + writeback) == autograd boundary + torch MSE losses +
+    torch.optim.AdamW on the spk-shaped parameters, for two consecutive steps."""
+    import copy
+    import nabladft_amd as nq
+    from oracle import painn_ref as PR
+    from oracle import spk_painn_ref as S
+    scfg = S.SpkPaiNNConfig(n_atom_basis=64, n_interactions=2, n_rbf=20, cutoff=4.0, max_z=20)
+    P = S.make_spk_params(scfg, seed=3)
+    pos, z, batch, y, ft = PR.gen_conformers(77, 6, size=(4, 16))
+    a = _potential(scfg)
+    a.load_state_dict(P, strict=False)
+    a = a.cuda().train()
+    b = copy.deepcopy(a)
+    fs = nq.FusedTrainStep(a, lr=1e-3, weight_decay=0.01, max_grad_norm=0.0)
+    opt = torch.optim.AdamW(b.parameters(), lr=1e-3, weight_decay=0.01)
+    bt = nq.Batch(pos, z, batch, y, ft).to("cuda")
+    for it in range(2):
+        loss_a = float(fs(bt))
+        opt.zero_grad()
+        out = b({"_positions": bt.pos, "_atomic_numbers": bt.z, "_idx_m": bt.batch})
+        loss_b = torch.nn.functional.mse_loss(out["energy"], bt.y) + torch.nn.functional.mse_loss(out["forces"], bt.forces)
+        loss_b.backward()
+        opt.step()
+        assert abs(loss_a - loss_b.item()) <= 1e-5 * abs(loss_b.item()), (it, loss_a, loss_b.item())
+        if it == 0:      # same kernels on the same parameters: bitwise; afterwards the two AdamW implementations differ by rounding
+            assert torch.equal(fs.energy, out["energy"].detach()) and torch.equal(fs.forces, out["forces"].detach())
+        else:
+            assert torch.allclose(fs.energy, out["energy"].detach(), rtol=1e-5, atol=1e-6) and torch.allclose(fs.forces, out["forces"].detach(), rtol=1e-4, atol=1e-6)
+    fs.writeback()
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb
+        assert torch.allclose(pa, pb, rtol=0, atol=2e-6), (na, (pa - pb).abs().max().item())
