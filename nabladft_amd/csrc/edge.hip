@@ -7,6 +7,7 @@
 // order equals the reference's sequential scatter_add order.  In the reverse sweeps the same row
 // is read as the atom's OUT-edges (n -> k): phi/psi/d are symmetric, r and t_r change sign.
 #include "common.h"
+#include <type_traits>
 
 struct RbfArgs {
   const float4* geom; int E; int R; float inv_cutoff; float p, a, b, c; float coeff; const float* mu;
@@ -197,8 +198,18 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 // =============================================================================================
 #define FWIN 13
 #define FUSED_THREADS 1024
+// measured (profiles/r01_fused_tuning.txt): any VGPR spill in these loops costs 1.3-2x, so the two register-hungry flavours trade waves for registers
+#ifndef NQ_DUAL2_THREADS
+#define NQ_DUAL2_THREADS 512    // dual reverse, 2 channels/lane: 251 VGPRs, no spill (768 threads: 31 spilled VGPRs, 8.3 ms vs 5.5-6.4 ms per step)
+#endif
+#ifndef NQ_TAN2_THREADS
+#define NQ_TAN2_THREADS 768     // tangent, 2 channels/lane: 148 VGPRs (1024 threads: 26 spilled, 7.3 ms vs 3.35 ms per step)
+#endif
 // workgroup size per kernel flavour and channels-per-lane (register budget: 1024 thr -> 128 VGPRs, 768 -> 168, 512 -> 256)
-__host__ __device__ constexpr int fused_threads(bool heavy, int ch) { return ch >= 4 ? 512 : (ch == 2 ? (heavy ? 768 : 1024) : 1024); }
+// kind: 0 forward, 1 tangent, 2 force adjoint, 3 dual reverse.  Workgroup size = VGPR budget (one workgroup per CU: LDS holds WrT)
+__host__ __device__ constexpr int fused_threads(int kind, int ch) {
+  return ch >= 4 ? 512 : (ch == 2 ? (kind == 3 ? NQ_DUAL2_THREADS : (kind == 1 ? NQ_TAN2_THREADS : 1024)) : 1024);
+}
 #define FUSED_THREADS_DUAL 1024  // window records live in SGPRs (scalar loads), so the dual reverse also fits 16 waves per CU
 
 __device__ __forceinline__ float bcast_lane(float v, int t) {
@@ -296,6 +307,18 @@ __device__ __forceinline__ void stv(float* p, const float (&o)[CH]) {
   }
 }
 
+// streaming store (gphi / gpsi: written once, read once by the weight-gradient kernel): keep it from evicting the node rows in L2
+template <int CH>
+__device__ __forceinline__ void stv_stream(float* p, const float (&o)[CH]) {
+  if constexpr (CH == 1) { __builtin_nontemporal_store(o[0], p); }
+  else {
+    typename VecOf<CH>::T v;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = o[c];
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<CH>::T*>(p));
+  }
+}
+
 // ---- per-edge window record (scalar loads: the record address is wave-uniform) -------------------------------
 template <bool PSI>
 struct WinRegs { float rr[16]; float dd[PSI ? 16 : 1]; };
@@ -311,29 +334,49 @@ __device__ __forceinline__ void load_win(WinRegs<PSI>& w, const float* __restric
   }
 }
 
-// phi (and psi) for this lane's CH channels of each of the three parts, from the LDS-resident WrT
+// phi (and psi) for this lane's CH channels of each of the three parts, from the LDS-resident WrT.
+// Written on CH-wide vectors so that every FMA pair becomes one v_pk_fma_f32 (the scalar form left the psi half unpacked).
+template <int CH> struct VOps {
+  typedef typename VecOf<CH>::T V;
+  static __device__ __forceinline__ V splat(float x) { V v; for (int c = 0; c < CH; ++c) v[c] = x; return v; }
+  static __device__ __forceinline__ V load(const float* p) { return *reinterpret_cast<const V*>(p); }
+  static __device__ __forceinline__ V from(const float (&a)[CH]) { V v; for (int c = 0; c < CH; ++c) v[c] = a[c]; return v; }
+  static __device__ __forceinline__ void to(float (&a)[CH], V v) { for (int c = 0; c < CH; ++c) a[c] = v[c]; }
+  static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+};
+template <> struct VOps<1> {
+  typedef float V;
+  static __device__ __forceinline__ V splat(float x) { return x; }
+  static __device__ __forceinline__ V load(const float* p) { return *p; }
+  static __device__ __forceinline__ V from(const float (&a)[1]) { return a[0]; }
+  static __device__ __forceinline__ void to(float (&a)[1], V v) { a[0] = v; }
+  static __device__ __forceinline__ V fma(V a, V b, V c) { return fmaf(a, b, c); }
+};
 template <bool PSI, int CH>
 __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* wrt, int F, int F3, int fb, const float (&bra)[CH],
                                             const float (&brb)[CH], const float (&brc)[CH], float (&pa)[CH], float (&pb)[CH], float (&pc)[CH],
                                             float (&qa)[CH], float (&qb)[CH], float (&qc)[CH]) {
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {   // bias enters as beta*b (phi) and beta'*b (psi); beta = 1, beta' = 0 in painn_pyg mode (exact)
-    pa[c] = bra[c] * w.rr[14]; pb[c] = brb[c] * w.rr[14]; pc[c] = brc[c] * w.rr[14];
-    if (PSI) { qa[c] = bra[c] * w.dd[14]; qb[c] = brb[c] * w.dd[14]; qc[c] = brc[c] * w.dd[14]; }
-    else { qa[c] = qb[c] = qc[c] = 0.f; }
-  }
+  typedef VOps<CH> O;
+  typedef typename O::V V;
+  // bias enters as beta*b (phi) and beta'*b (psi); beta = 1, beta' = 0 in painn_pyg mode (exact)
+  const V ba = O::from(bra), bb = O::from(brb), bc = O::from(brc);
+  V va = ba * O::splat(w.rr[14]), vb = bb * O::splat(w.rr[14]), vc = bc * O::splat(w.rr[14]);
+  V ua = O::splat(0.f), ub = ua, uc = ua;
+  if (PSI) { ua = ba * O::splat(w.dd[14]); ub = bb * O::splat(w.dd[14]); uc = bc * O::splat(w.dd[14]); }
   const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(w.rr[13]));
   const float* wk = wrt + k0 * F3 + fb;
 #pragma unroll
   for (int t = 0; t < FWIN; ++t) {  // always 13 taps: LDS rows >= R and window taps >= R are zero
-    float wa[CH], wb[CH], wc[CH];
-    ldv<CH>(wa, wk + t * F3); ldv<CH>(wb, wk + t * F3 + F); ldv<CH>(wc, wk + t * F3 + 2 * F);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      pa[c] = fmaf(wa[c], w.rr[t], pa[c]); pb[c] = fmaf(wb[c], w.rr[t], pb[c]); pc[c] = fmaf(wc[c], w.rr[t], pc[c]);
-      if (PSI) { qa[c] = fmaf(wa[c], w.dd[t], qa[c]); qb[c] = fmaf(wb[c], w.dd[t], qb[c]); qc[c] = fmaf(wc[c], w.dd[t], qc[c]); }
+    const V wa = O::load(wk + t * F3), wb = O::load(wk + t * F3 + F), wc = O::load(wk + t * F3 + 2 * F);
+    const V r = O::splat(w.rr[t]);
+    va = O::fma(wa, r, va); vb = O::fma(wb, r, vb); vc = O::fma(wc, r, vc);
+    if (PSI) {
+      const V d = O::splat(w.dd[t]);
+      ua = O::fma(wa, d, ua); ub = O::fma(wb, d, ub); uc = O::fma(wc, d, uc);
     }
   }
+  O::to(pa, va); O::to(pb, vb); O::to(pc, vc);
+  O::to(qa, ua); O::to(qb, ub); O::to(qc, uc);
 }
 
 // One wavefront per atom; lane l owns channels [l*CH, (l+1)*CH) of each part (F = 64*CH).
@@ -354,16 +397,21 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
   const int fb = lane * CH;                                                                    \
   float bra[CH], brb[CH], brc[CH];                                                             \
   ldv<CH>(bra, fa.br + fb); ldv<CH>(brb, fa.br + F + fb); ldv<CH>(brc, fa.br + 2 * F + fb);    \
-  /* contiguous node range per workgroup: a molecule's rows stay in ONE XCD's L2 */            \
-  const int per_wg = (q.g.N + gridDim.x - 1) / gridDim.x;                                      \
-  const int n_lo = blockIdx.x * per_wg, n_hi = min(q.g.N, n_lo + per_wg);
+  /* XCD-aware sweep: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8).  The workgroups of one XCD walk   \
+     ONE contiguous eighth of the atoms together, wavefront by wavefront, so at any time an XCD works on ~6 molecules  \
+     and their rows are fetched into that XCD's 4 MB L2 once instead of once per molecule-per-CU working set. */       \
+  const int nxcd = (gridDim.x & 7) == 0 ? 8 : 1;                                               \
+  const int per_x = (q.g.N + nxcd - 1) / nxcd;                                                 \
+  const int x_lo = (int)(blockIdx.x % nxcd) * per_x, n_hi = min(q.g.N, x_lo + per_x);          \
+  const int n_first = x_lo + (int)(blockIdx.x / nxcd) * nslots + slot;                         \
+  const int n_step = (int)(gridDim.x / nxcd) * nslots;
 
 // ---- forward / tangent -------------------------------------------------------------------------------------
 template <bool TAN, int CH>
-struct FwdOps { float xa[CH], xb[CH], xc[CH], va[CH], vb[CH], vc[CH], txa[CH], txb[CH], txc[CH], tva[CH], tvb[CH], tvc[CH]; WinRegs<TAN> w; };
+struct FwdOps { float xa[CH], xb[CH], xc[CH], va[CH], vb[CH], vc[CH], txa[CH], txb[CH], txc[CH], tva[CH], tvb[CH], tvc[CH]; };
 
 template <bool TAN, int CH>
-__device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int fb) {
+__device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, int k, int F, int F3, int fb) {
   const float* xh = q.XH + (long)k * F3 + fb;
   const float* vk = q.V + (long)k * F3 + fb;
   ldv<CH>(o.xa, xh); ldv<CH>(o.xb, xh + F); ldv<CH>(o.xc, xh + 2 * F);
@@ -374,13 +422,12 @@ __device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, c
     ldv<CH>(o.txa, txh); ldv<CH>(o.txb, txh + F); ldv<CH>(o.txc, txh + 2 * F);
     ldv<CH>(o.tva, tvk); ldv<CH>(o.tvb, tvk + F); ldv<CH>(o.tvc, tvk + 2 * F);
   }
-  load_win<TAN>(o.w, RW, sp);
 }
 
 template <bool TAN, int CH>
-__global__ __launch_bounds__(fused_threads(TAN, CH)) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
+__global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  for (int n = n_lo + slot; n < n_hi; n += nslots) {
+  for (int n = n_first; n < n_hi; n += n_step) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     float dx[CH], d0[CH], d1[CH], d2[CH];
 #pragma unroll
@@ -389,13 +436,21 @@ __global__ __launch_bounds__(fused_threads(TAN, CH)) void k_msgf_fwd(MsgArgs q, 
       const int cnt = min(64, end - c0);
       RowRegs row;
       load_row<TAN>(row, q.g, q.TD, q.TR, c0, cnt, lane);
-      FwdOps<TAN, CH> cur, nxt;
-      load_fwd<TAN, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
-      nxt = cur;
-      for (int j = 0; j < cnt; ++j) {
-        if (j + 1 < cnt) load_fwd<TAN, CH>(nxt, q, RW, bl_i(row.kk, j + 1), c0 + j + 1, F, F3, fb);
+      // Per edge: issue the NEXT edge's gathers, evaluate the filter of the current one from LDS, only then issue the next
+      // window's scalar loads (SMEM and LDS share lgkmcnt: an outstanding s_load would turn every LDS wait of the filter
+      // into a wait for the scalar cache), then the arithmetic.
+      // Two operand sets in ping-pong (no register copies, so the wait for a gather sits at its first use one edge later).
+      FwdOps<TAN, CH> opA, opB;
+      load_fwd<TAN, CH>(opA, q, bl_i(row.kk, 0), F, F3, fb);
+      WinRegs<TAN> win;               // ONE window register set: it is dead once the filter is evaluated
+      load_win<TAN>(win, RW, c0);
+      auto step = [&](FwdOps<TAN, CH>& cur, FwdOps<TAN, CH>& nxt, int j, auto prefetch) __attribute__((always_inline)) {
+        const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded (keeps the loop one basic block)
+        if (decltype(prefetch)::value) load_fwd<TAN, CH>(nxt, q, bl_i(row.kk, jn), F, F3, fb);
         float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
-        filter_eval<TAN, CH>(cur.w, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        filter_eval<TAN, CH>(win, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(prefetch)::value) load_win<TAN>(win, RW, c0 + jn);
         const float gx = bl_f(row.gx, j), gy = bl_f(row.gy, j), gz = bl_f(row.gz, j);
         float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
         if (TAN) { td = bl_f(row.td, j); tr0 = bl_f(row.t0, j); tr1 = bl_f(row.t1, j); tr2 = bl_f(row.t2, j); }
@@ -417,8 +472,14 @@ __global__ __launch_bounds__(fused_threads(TAN, CH)) void k_msgf_fwd(MsgArgs q, 
             d2[c] += cur.tvc[c] * mb + cur.vc[c] * tmb + tmc * gz + mc * tr2;
           }
         }
-        cur = nxt;
+      };
+      const int pairs = cnt & ~1;
+#pragma nounroll
+      for (int j = 0; j < pairs; j += 2) {
+        step(opA, opB, j, std::true_type());
+        step(opB, opA, j + 1, std::true_type());
       }
+      if (cnt & 1) step(opA, opB, cnt - 1, std::false_type());
     }
     const long o = (long)n * F + fb, o3 = (long)n * F3 + fb;
     float x0[CH], w0[CH], w1[CH], w2[CH];
@@ -438,11 +499,24 @@ __global__ __launch_bounds__(fused_threads(TAN, CH)) void k_msgf_fwd(MsgArgs q, 
 }
 
 // ---- reverse (force adjoint / dual) ----------------------------------------------------------------------------
+#ifndef NQ_ABLATE
+#define NQ_ABLATE 0   // development only (scripts/ablate.sh): 1 no gphi/gpsi stores, 2 no filter evaluation, 3 gathers hit the own row, 4 fixed window
+#endif
+#if NQ_ABLATE == 3
+#define ABL_K(j) n
+#else
+#define ABL_K(j) bl_i(row.kk, j)
+#endif
+#if NQ_ABLATE == 4
+#define ABL_SP(x) 0
+#else
+#define ABL_SP(x) (x)
+#endif
 template <bool DUAL, int CH>
-struct RevOps { float A0[CH], A1[CH], A2[CH], gma[CH], T0[CH], T1[CH], T2[CH], gtma[CH]; WinRegs<true> w; };
+struct RevOps { float A0[CH], A1[CH], A2[CH], gma[CH], T0[CH], T1[CH], T2[CH], gtma[CH]; };
 
 template <bool DUAL, int CH>
-__device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& q, const float* __restrict__ RW, int k, int sp, int F, int F3, int fb) {
+__device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& q, int k, int F, int F3, int fb) {
   const float* A = q.GV + (long)k * F3 + fb;
   ldv<CH>(o.A0, A); ldv<CH>(o.A1, A + F); ldv<CH>(o.A2, A + 2 * F);
   ldv<CH>(o.gma, q.GX + (long)k * F + fb);
@@ -451,13 +525,12 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
     ldv<CH>(o.T0, T); ldv<CH>(o.T1, T + F); ldv<CH>(o.T2, T + 2 * F);
     ldv<CH>(o.gtma, q.GTX + (long)k * F + fb);
   }
-  load_win<true>(o.w, RW, sp);
 }
 
 template <bool DUAL, int CH>
-__global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
+__global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  for (int n = n_lo + slot; n < n_hi; n += nslots) {
+  for (int n = n_first; n < n_hi; n += n_step) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     const long o3 = (long)n * F3 + fb;
     float xa[CH], xb[CH], xc[CH], v0[CH], v1[CH], v2[CH], txa[CH], txb[CH], txc[CH], tv0[CH], tv1[CH], tv2[CH];
@@ -481,15 +554,25 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
       const int cnt = min(64, end - c0);
       RowRegs row;
       load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
-      RevOps<DUAL, CH> cur, nxt;
-      load_rev<DUAL, CH>(cur, q, RW, bl_i(row.kk, 0), c0, F, F3, fb);
-      nxt = cur;
+      RevOps<DUAL, CH> opA, opB;   // ping-pong operands; scalar window loads are issued after the filter's LDS reads (see k_msgf_fwd)
+      load_rev<DUAL, CH>(opA, q, ABL_K(0), F, F3, fb);
+      WinRegs<true> win;
+      load_win<true>(win, RW, ABL_SP(c0));
       float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = 0; j < cnt; ++j) {
+      auto step = [&](RevOps<DUAL, CH>& cur, RevOps<DUAL, CH>& nxt, int j, auto prefetch) __attribute__((always_inline)) {
         const int sp = c0 + j;
-        if (j + 1 < cnt) load_rev<DUAL, CH>(nxt, q, RW, bl_i(row.kk, j + 1), sp + 1, F, F3, fb);
+        const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded
+        if (decltype(prefetch)::value) load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
         float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
-        filter_eval<true, CH>(cur.w, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+#if NQ_ABLATE == 2
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { pa[c] = bra[c] * win.rr[0]; pb[c] = brb[c] * win.rr[1]; pc[c] = brc[c] * win.rr[2]; qa[c] = bra[c] * win.dd[0]; qb[c] = brb[c] * win.dd[1]; qc[c] = brc[c] * win.dd[2]; }
+#else
+        filter_eval<true, CH>(win, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+#endif
+        const float beta = win.rr[14], dbeta = win.dd[14];
+        __builtin_amdgcn_sched_barrier(0);
+        if (decltype(prefetch)::value) load_win<true>(win, RW, ABL_SP(c0 + jn));
         const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);  // unit vector of the out-edge (n -> k)
         float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
         if (DUAL) { td = bl_f(row.td, j); tr0 = -bl_f(row.t0, j); tr1 = -bl_f(row.t1, j); tr2 = -bl_f(row.t2, j); }
@@ -516,28 +599,39 @@ __global__ __launch_bounds__(fused_threads(true, CH)) void k_msgf_rev(MsgRevArgs
             gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c];
             ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
             ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
-            sba[c] += ga[c] * cur.w.rr[14] + ha[c] * cur.w.dd[14];
-            sbb[c] += gb[c] * cur.w.rr[14] + hb[c] * cur.w.dd[14];
-            sbc[c] += gc[c] * cur.w.rr[14] + hc[c] * cur.w.dd[14];
+            sba[c] += ga[c] * beta + ha[c] * dbeta;
+            sbb[c] += gb[c] * beta + hb[c] * dbeta;
+            sbc[c] += gc[c] * beta + hc[c] * dbeta;
           } else {
             gxa[c] += gma * pa[c]; gxb[c] += gmb * pb[c]; gxc[c] += gmc * pc[c];
             gd += gma * xa[c] * qa[c] + gmb * xb[c] * qb[c] + gmc * xc[c] * qc[c];
             e0 += A0 * mc; e1 += A1 * mc; e2 += A2 * mc;
           }
         }
-        if (DUAL) {
+        if (DUAL && NQ_ABLATE != 1) {
           float* gp = q.GPHI + (long)sp * F3 + fb;
           float* gs = q.GPSI + (long)sp * F3 + fb;
+#if NQ_ABLATE == 5
           stv<CH>(gp, ga); stv<CH>(gp + F, gb); stv<CH>(gp + 2 * F, gc);
           stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
-        } else {
+#else
+          stv_stream<CH>(gp, ga); stv_stream<CH>(gp + F, gb); stv_stream<CH>(gp + 2 * F, gc);
+          stv_stream<CH>(gs, ha); stv_stream<CH>(gs + F, hb); stv_stream<CH>(gs + 2 * F, hc);
+#endif
+        } else if (!DUAL) {
           gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
           // lane j keeps the four reduced scalars of edge j; one coalesced float4 update per CSR row chunk below
           const bool mine = lane == j;
           eacc.x = mine ? gd : eacc.x; eacc.y = mine ? e0 : eacc.y; eacc.z = mine ? e1 : eacc.z; eacc.w = mine ? e2 : eacc.w;
         }
-        cur = nxt;
+      };
+      const int pairs = cnt & ~1;
+#pragma nounroll
+      for (int j = 0; j < pairs; j += 2) {
+        step(opA, opB, j, std::true_type());
+        step(opB, opA, j + 1, std::true_type());
       }
+      if (cnt & 1) step(opA, opB, cnt - 1, std::false_type());
       if (!DUAL && lane < cnt) {
         float4* dstp = q.GEDGE + c0 + lane;   // one wavefront covers all F channels: slice 0 only
         float4 acc = *dstp;
@@ -891,7 +985,7 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
   NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(tangent, q.F / 64));
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(tangent ? 1 : 0, q.F / 64));
   if (tangent) FUSED_DISPATCH(k_msgf_fwd, true, q);
   else FUSED_DISPATCH(k_msgf_fwd, false, q);
   NQ_LAUNCH_CHECK();
@@ -902,7 +996,7 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   NQ_PROF(st, dual ? "msgf_rev_dual" : "msgf_rev_force");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(true, q.F / 64));
+  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(dual ? 3 : 2, q.F / 64));
   if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
   else FUSED_DISPATCH(k_msgf_rev, false, q);
   NQ_LAUNCH_CHECK();
