@@ -63,7 +63,7 @@ def gemm_flops(name, N, E, launches):
     kind, rest = name.split(":", 1)
     tag = rest.split("[")[0]
     dims = [int(x) for x in rest.split("[")[1].rstrip("]").replace("n=", "").replace("k=", "").replace("x", ",").split(",")]
-    rows_single = {"Wr": E, "U": 3 * N}.get(tag, N)
+    rows_single = {"Wr": E, "U": 3 * N, "sn:W2": E}.get(tag, N)
     if kind == "gemm_tn":          # weight gradients: always over the stacked (primal+tangent) rows
         return 2.0 * (2 * rows_single) * dims[0] * dims[1]
     # nt / nn: 1x rows in forward / force adjoint / tangent, 2x rows in the dual reverse -> average over the step's launches
@@ -78,6 +78,14 @@ def gemm_flops(name, N, E, launches):
 # HIP-event launcher class -> rocprofv3 kernel name (for the PMC traffic file) and sweep multiplicity
 _MSG = {"msgf_fwd": ("k_msgf_fwd<false", 1), "msgf_tan": ("k_msgf_fwd<true", 2), "msgf_rev_force": ("k_msgf_rev<false", 1),
         "msgf_rev_dual": ("k_msgf_rev<true", 2)}
+
+
+# SchNet streaming kernels: bytes that must cross HBM once per launch (edge arrays [E][F] fp32, 128-B window records, node rows [N][F])
+_SN = {"sn_filter1": lambda N, E: E * (F * 4 + 128.0), "sn_filter1_tan": lambda N, E: E * (F * 4 + 132.0),
+       "sn_filter1_rev_force": lambda N, E: E * (F * 4 + 136.0), "sn_filter1_rev_dual": lambda N, E: E * (4 * F * 4 + 132.0),
+       "sn_conv": lambda N, E: E * F * 4.0 + 2 * N * F * 4.0, "sn_conv_tan": lambda N, E: 2 * E * F * 4.0 + 3 * N * F * 4.0,
+       "sn_conv_dual": lambda N, E: 2 * E * F * 4.0 + 4 * N * F * 4.0, "sn_edge_rev_force": lambda N, E: 2 * E * F * 4.0 + 2 * N * F * 4.0,
+       "sn_edge_rev_dual": lambda N, E: 2 * E * F * 4.0 + 4 * N * F * 4.0}
 
 
 def pmc_traffic_bytes(kernel_prefix, batch):
@@ -112,6 +120,11 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
         ach = flops / (avg_ms * 1e-3) / 1e12
         return {"kernel": f"k_gemm {dom}", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+    if dom in _SN:
+        nbytes = _SN[dom](n_atoms, E)
+        ach = nbytes / (avg_ms * 1e-3) / 1e9
+        return {"kernel": "k_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
     if dom == "gwr_sorted":
         flops = 2.0 * 26 * E * 3 * F          # 26 FMAs per (edge, column)
         ach = flops / (avg_ms * 1e-3) / 1e12
@@ -125,6 +138,8 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
 WORKLOADS = {
     "painn-oc": "PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces train step incl. "
                 "neighbour list, L1+L2 loss, grad all-reduce, clip 5.0, AdamW lr 5e-4",
+    "schnet-spk": "SchNet (config/schnet.yaml -> schnetpack SchNet F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
+                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
     "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
 }
@@ -137,21 +152,27 @@ def build_step(kind, dev):
         model = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
         return model, nq.FusedTrainStep(model, lr=5e-4, weight_decay=0.0, max_grad_norm=5.0)     # painn-oc.yaml optimizer + clip
     from nabladft_amd import spk
+    rep_cls = spk.SchNet if kind == "schnet-spk" else spk.PaiNN
     pot = spk.NeuralNetworkPotential(
-        representation=spk.PaiNN(n_atom_basis=F, n_interactions=L, radial_basis=spk.GaussianRBF(n_rbf=R, cutoff=CUTOFF), cutoff_fn=spk.CosineCutoff(CUTOFF)),
+        representation=rep_cls(n_atom_basis=F, n_interactions=L, radial_basis=spk.GaussianRBF(n_rbf=R, cutoff=CUTOFF), cutoff_fn=spk.CosineCutoff(CUTOFF)),
         input_modules=[spk.PairwiseDistances()], output_modules=[spk.Atomwise(n_in=F, output_key="energy"), spk.Forces()],
         postprocessors=[spk.AddOffsets("energy", add_mean=True)]).to(dev)
     return pot, nq.FusedTrainStep(pot, lr=1e-4, weight_decay=0.01, max_grad_norm=0.0)            # config/model/painn.yaml:48-52, config/painn.yaml:18-19
 
 
-def cpu_baseline_spk(seconds_budget=25.0):
-    """Same as cpu_baseline for the schnetpack-style PaiNN: oracle/spk_painn_ref.py (PARITY UNPINNED restatement)."""
+def cpu_baseline_spk(kind="painn-spk", seconds_budget=25.0):
+    """Same as cpu_baseline for the schnetpack-style models: oracle/spk_painn_ref.py / spk_schnet_ref.py (PARITY UNPINNED restatements)."""
     from oracle import painn_ref as Rf
-    from oracle import spk_painn_ref as S
     import nabladft_amd as nq
-    from nabladft_amd import spk
-    scfg = S.SpkPaiNNConfig()
-    P = S.make_spk_params(scfg, seed=23)
+    if kind == "schnet-spk":
+        from oracle import spk_schnet_ref as S
+        scfg = S.SchNetConfig()
+        P = S.make_schnet_params(scfg, seed=23)
+        S.spk_train_step, S.spk_param_shapes = S.schnet_train_step, S.schnet_param_shapes
+    else:
+        from oracle import spk_painn_ref as S
+        scfg = S.SpkPaiNNConfig()
+        P = S.make_spk_params(scfg, seed=23)
     pos, z, batch, y, ft = Rf.gen_conformers(12345, 32)
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
@@ -165,15 +186,15 @@ def cpu_baseline_spk(seconds_budget=25.0):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times)) if times else warm
     out = {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
-           "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms), spk-PaiNN restatement (parity unpinned), median of {max(len(times), 1)} "
+           "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms), {kind} restatement (parity unpinned), median of {max(len(times), 1)} "
                      f"steps incl. O(n^2) neighbour list, torch {torch.__version__} CPU fp32 without optimizer step"}
     dev = torch.device("cuda", torch.cuda.current_device())
-    pot, _ = build_step("painn-spk", dev)
+    pot, _ = build_step(kind, dev)
     pot.load_state_dict(P, strict=False)
     fs = nq.FusedTrainStep(pot, max_grad_norm=0.0)
     loss = float(fs(nq.Batch(pos, z, batch, y, ft).to(dev), update=False))
     e, f = fs.energy.cpu(), fs.forces.cpu()
-    g_spk = torch.zeros(pot._n_spk, dtype=torch.float32).index_add_(0, pot._index.cpu(), fs.grad.cpu())
+    g_spk = fs.grad.cpu() if pot._index is None else torch.zeros(pot._n_spk, dtype=torch.float32).index_add_(0, pot._index.cpu(), fs.grad.cpu())
     gref = torch.cat([g_ref[k].reshape(-1) for k, _ in S.spk_param_shapes(scfg)])
     parity = {"mae_energy": float((e - e_ref).abs().mean()), "mae_forces": float((f - f_ref).abs().mean()),
               "max_rel_energy": float((e - e_ref).abs().max() / e_ref.abs().max()),
@@ -304,12 +325,15 @@ def main():
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk()
+        cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk(args.model)
 
-    other = None
+    other, kind2 = None, None
     if rank == 0 and world == 1 and not args.no_roofline:
         # the sibling PaiNN configuration through the same kernels (reported, not `value`)
         kind2 = "painn-spk" if args.model == "painn-oc" else "painn-oc"
+        if args.model == "schnet-spk":
+            kind2 = None
+    if rank == 0 and world == 1 and not args.no_roofline and kind2 is not None:
         del step, model
         torch.cuda.empty_cache()
         model2, step2 = build_step(kind2, dev)

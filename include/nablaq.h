@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 3
+#define NQ_ABI_VERSION 4
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -106,6 +106,29 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
  * ("x_msg", 2, tangent=0).  Returns NQ_ERR_ARG for unknown names. */
 int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t layer, int32_t tangent,
                        size_t* offset_floats, size_t* count);
+
+/* ---- SchNet (schnetpack 2.0.4 representation.SchNet + Atomwise + Forces as instantiated by config/model/schnet.yaml:4-28;
+ *      third-party arithmetic, PARITY UNPINNED -- oracle/spk_schnet_ref.py) -------------------------------------------------- */
+typedef struct nq_schnet_cfg {
+  int32_t n_atom_basis;    /* F in {64,128,256} (n_filters = n_atom_basis) */
+  int32_t n_interactions;  /* L */
+  int32_t n_rbf;           /* GaussianRBF(n_rbf, cutoff) */
+  int32_t max_z;           /* rows of representation.embedding.weight (row 0 = padding) */
+  double cutoff;           /* CosineCutoff(cutoff) = GaussianRBF cutoff, Angstrom */
+  float rbf_coeff;         /* -0.5 / width^2, width = offsets[1] - offsets[0] */
+  int32_t reserved;
+} nq_schnet_cfg;
+/* Flat parameter buffer = the tensors in module order: representation.embedding.weight [max_z][F]; per interaction l:
+ * in2f.weight [F][F], filter_network.{0.weight [F][R], 0.bias, 1.weight [F][F], 1.bias}, f2out.{0.weight, 0.bias, 1.weight, 1.bias};
+ * output_modules.0.outnet.{0.weight [F/2][F], 0.bias, 1.weight [1][F/2], 1.bias}. */
+size_t nq_schnet_num_params(const nq_schnet_cfg* cfg);
+size_t nq_schnet_workspace_bytes(const nq_schnet_cfg* cfg, int32_t N, int32_t E, int32_t B);
+/* Same contracts as nq_painn_forward / nq_painn_backward; rbf_offsets = GaussianRBF.offsets f32[n_rbf] (unscaled distances);
+ * the graph is the full list inside the cutoff (nq_graph_count/fill with max_neighbors >= molecule size). */
+int nq_schnet_forward(const nq_schnet_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                      size_t workspace_bytes, float* energy, float* forces, void* stream);
+int nq_schnet_backward(const nq_schnet_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                       size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
 
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */

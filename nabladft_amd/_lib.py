@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -20,6 +20,11 @@ class PainnCfg(C.Structure):
     _fields_ = [("hidden_channels", C.c_int32), ("num_layers", C.c_int32), ("num_rbf", C.c_int32),
                 ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
                 ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("filter_mode", C.c_int32)]
+
+
+class SchnetCfg(C.Structure):
+    _fields_ = [("n_atom_basis", C.c_int32), ("n_interactions", C.c_int32), ("n_rbf", C.c_int32), ("max_z", C.c_int32),
+                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("reserved", C.c_int32)]
 
 
 class Graph(C.Structure):
@@ -41,6 +46,10 @@ SYMBOLS = {
     "nq_painn_forward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
     "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
     "nq_painn_ws_lookup": (C.c_int, [C.POINTER(PainnCfg), _I32, _I32, _I32, C.c_char_p, _I32, _I32, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "nq_schnet_num_params": (_SZ, [C.POINTER(SchnetCfg)]),
+    "nq_schnet_workspace_bytes": (_SZ, [C.POINTER(SchnetCfg), _I32, _I32, _I32]),
+    "nq_schnet_forward": (C.c_int, [C.POINTER(SchnetCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
+    "nq_schnet_backward": (C.c_int, [C.POINTER(SchnetCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

@@ -33,6 +33,7 @@ int nq_fail(int code, const char* fmt, ...);
     if (rc__ != NQ_OK) return rc__; \
   } while (0)
 
+#define NQ_MAX_LAYERS 64
 static inline int nq_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel timing (HIP events on the launch stream; used by bench.py for the roofline) ----
@@ -112,7 +113,8 @@ struct FilterArgs {
   const float* RW;    // [E][32] per-edge 13-tap window record written by k_rbf_window: [0..12] rho, [13] k0 (int bits), [16..28] drho
   int R;
   float inv_cutoff, p, a, b, c, coeff;
-  int mode;           // 0: polynomial envelope inside the projection (painn_pyg); 1: cosine cutoff after the bias, unscaled Gaussians (spk)
+  int mode;           // 0: polynomial envelope inside the projection (painn_pyg); 1: cosine cutoff after the bias, unscaled Gaussians (spk PaiNN);
+                      // 2: bare unscaled Gaussians, record slots 14/30 = fcut, fcut' (spk SchNet)
   float cutoff;
 };
 
@@ -182,9 +184,9 @@ int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, 
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 size_t nq_k0_sort_scratch_ints(int E, int R);
 int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch);
-size_t nq_gwr_scratch_floats(int E, int F, int R);
+size_t nq_gwr_scratch_floats(int E, int F, int R, int parts = 3);
 int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
-                  float* scratch);
+                  float* scratch, int parts = 3);
 int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
 int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual);
 int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);

@@ -8,6 +8,7 @@
 // is read as the atom's OUT-edges (n -> k): phi/psi/d are symmetric, r and t_r change sign.
 #include "common.h"
 #include <type_traits>
+#include "lanes.h"
 
 struct RbfArgs {
   const float4* geom; int E; int R; float inv_cutoff; float p, a, b, c; float coeff; const float* mu;
@@ -196,7 +197,6 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 // and edge), v_readlane broadcasts them as scalars, and each thread reads its WrT column entries with
 // conflict-free ds_read_b32 (consecutive channels -> consecutive banks).
 // =============================================================================================
-#define FWIN 13
 #define FUSED_THREADS 1024
 // measured (profiles/r01_fused_tuning.txt): any VGPR spill in these loops costs 1.3-2x, so the two register-hungry flavours trade waves for registers
 #ifndef NQ_DUAL2_THREADS
@@ -218,7 +218,6 @@ __device__ __forceinline__ float bcast_lane(float v, int t) {
 
 // Per-edge window record, computed ONCE per step (the distances do not change between layers / sweeps):
 // RW[e][0..12] = rho_{k0+t}(d_e), RW[e][13] = k0 (int bits), RW[e][16..28] = d rho_{k0+t} / d d.  128 B per edge.
-#define RW_STRIDE 32
 __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs fa, float* __restrict__ RW) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int e = (int)(idx >> 4), t = (int)(idx & 15);
@@ -254,8 +253,13 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
     if (t < nwin) {
       const float diff = d - fa.mu[k0 + t];
       const float g = expf(fa.coeff * (diff * diff));
-      rl = beta * g;
-      drl = dbeta * g + beta * g * (2.0f * fa.coeff) * diff;
+      if (fa.mode == 2) {   // SchNet: the filter network sees the bare Gaussians; fcut multiplies its OUTPUT (slots 14 / 30 carry fcut, fcut')
+        rl = g;
+        drl = g * (2.0f * fa.coeff) * diff;
+      } else {
+        rl = beta * g;
+        drl = dbeta * g + beta * g * (2.0f * fa.coeff) * diff;
+      }
     }
   }
   float* rw = RW + (long)e * RW_STRIDE;
@@ -278,80 +282,8 @@ __device__ __forceinline__ void load_row(RowRegs& r, const NqGraphView& g, const
     if (NEED_T) { r.td = TD[sp]; r.t0 = TR[3 * (long)sp]; r.t1 = TR[3 * (long)sp + 1]; r.t2 = TR[3 * (long)sp + 2]; }
   }
 }
-__device__ __forceinline__ int bl_i(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
-__device__ __forceinline__ float bl_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
-
-// ---- CH consecutive channels per lane: vector loads / stores ---------------------------------------------------
-template <int CH> struct VecOf;
-template <> struct VecOf<1> { typedef float T; };
-template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
-template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
-
-template <int CH>
-__device__ __forceinline__ void ldv(float (&o)[CH], const float* p) {
-  if constexpr (CH == 1) { o[0] = *p; }
-  else {
-    const typename VecOf<CH>::T v = *reinterpret_cast<const typename VecOf<CH>::T*>(p);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) o[c] = v[c];
-  }
-}
-template <int CH>
-__device__ __forceinline__ void stv(float* p, const float (&o)[CH]) {
-  if constexpr (CH == 1) { *p = o[0]; }
-  else {
-    typename VecOf<CH>::T v;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = o[c];
-    *reinterpret_cast<typename VecOf<CH>::T*>(p) = v;
-  }
-}
-
-// streaming store (gphi / gpsi: written once, read once by the weight-gradient kernel): keep it from evicting the node rows in L2
-template <int CH>
-__device__ __forceinline__ void stv_stream(float* p, const float (&o)[CH]) {
-  if constexpr (CH == 1) { __builtin_nontemporal_store(o[0], p); }
-  else {
-    typename VecOf<CH>::T v;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = o[c];
-    __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<CH>::T*>(p));
-  }
-}
-
-// ---- per-edge window record (scalar loads: the record address is wave-uniform) -------------------------------
-template <bool PSI>
-struct WinRegs { float rr[16]; float dd[PSI ? 16 : 1]; };
-
-template <bool PSI>
-__device__ __forceinline__ void load_win(WinRegs<PSI>& w, const float* __restrict__ RW, int sp) {
-  const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)sp * RW_STRIDE);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&w.rr[4 * v]) = rw4[v];
-  if (PSI) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(&w.dd[4 * v]) = rw4[4 + v];
-  }
-}
-
 // phi (and psi) for this lane's CH channels of each of the three parts, from the LDS-resident WrT.
 // Written on CH-wide vectors so that every FMA pair becomes one v_pk_fma_f32 (the scalar form left the psi half unpacked).
-template <int CH> struct VOps {
-  typedef typename VecOf<CH>::T V;
-  static __device__ __forceinline__ V splat(float x) { V v; for (int c = 0; c < CH; ++c) v[c] = x; return v; }
-  static __device__ __forceinline__ V load(const float* p) { return *reinterpret_cast<const V*>(p); }
-  static __device__ __forceinline__ V from(const float (&a)[CH]) { V v; for (int c = 0; c < CH; ++c) v[c] = a[c]; return v; }
-  static __device__ __forceinline__ void to(float (&a)[CH], V v) { for (int c = 0; c < CH; ++c) a[c] = v[c]; }
-  static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
-};
-template <> struct VOps<1> {
-  typedef float V;
-  static __device__ __forceinline__ V splat(float x) { return x; }
-  static __device__ __forceinline__ V load(const float* p) { return *p; }
-  static __device__ __forceinline__ V from(const float (&a)[1]) { return a[0]; }
-  static __device__ __forceinline__ void to(float (&a)[1], V v) { a[0] = v; }
-  static __device__ __forceinline__ V fma(V a, V b, V c) { return fmaf(a, b, c); }
-};
 template <bool PSI, int CH>
 __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* wrt, int F, int F3, int fb, const float (&bra)[CH],
                                             const float (&brb)[CH], const float (&brc)[CH], float (&pa)[CH], float (&pb)[CH], float (&pc)[CH],
@@ -741,13 +673,13 @@ __device__ __forceinline__ void load_gwr(GwrOps<CH>& o, const float* __restrict_
 #define GWR_WAVES 4
 template <int CH>
 __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
-                                                               const int* __restrict__ order, int E, int F, int R, int chunk_len,
+                                                               const int* __restrict__ order, int E, int F, int F3, int R, int chunk_len,
                                                                float* __restrict__ part, int* __restrict__ chunk_range) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * GWR_WAVES + wave;
   const int r0 = chunk * chunk_len, r1 = min(E, r0 + chunk_len);
   if (r0 >= E) return;   // wave-uniform
-  const int F3 = 3 * F, col = blockIdx.y * F + lane * CH;
+  const int col = blockIdx.y * F + lane * CH;   // F3 = row length of GPHI/GPSI (3F for the PaiNN filter, F for SchNet's first filter layer)
   float acc[16][CH];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
@@ -839,6 +771,7 @@ __global__ void k_geom_tan(NqGraphView g, const int* __restrict__ dst, const flo
   const float td = gm.x * wx + gm.y * wy + gm.z * wz;
   const float inv = 1.0f / gm.w;
   TD[sp] = td;
+  if (!TR) return;   // SchNet: only distances enter the model
   TR[3 * (long)sp] = (wx - gm.x * td) * inv;
   TR[3 * (long)sp + 1] = (wy - gm.y * td) * inv;
   TR[3 * (long)sp + 2] = (wz - gm.z * td) * inv;
@@ -1026,23 +959,24 @@ int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* s
   return NQ_OK;
 }
 
-size_t nq_gwr_scratch_floats(int E, int F, int R) { const size_t nc = gwr_chunks(E); return nc * R * 3 * F + 2 * nc + 16; }
+size_t nq_gwr_scratch_floats(int E, int F, int R, int parts) { const size_t nc = gwr_chunks(E); return nc * R * parts * F + 2 * nc + 16; }
 
 int nq_gwr_sorted(hipStream_t st, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
-                  float* scratch) {
+                  float* scratch, int parts) {
   NQ_PROF(st, "gwr_sorted");
   const int nchunks = gwr_chunks(E), chunk_len = nq_cdiv(E, nchunks);
   float* part = scratch;
-  int* chunk_range = reinterpret_cast<int*>(scratch + (size_t)nchunks * R * 3 * F);
-  dim3 grid(nq_cdiv(nchunks, GWR_WAVES), 3);
+  const int F3 = parts * F;
+  int* chunk_range = reinterpret_cast<int*>(scratch + (size_t)nchunks * R * F3);
+  dim3 grid(nq_cdiv(nchunks, GWR_WAVES), parts);
   switch (F / 64) {
-    case 1: hipLaunchKernelGGL((k_gwr_sorted<1>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, R, chunk_len, part, chunk_range); break;
-    case 2: hipLaunchKernelGGL((k_gwr_sorted<2>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, R, chunk_len, part, chunk_range); break;
-    case 4: hipLaunchKernelGGL((k_gwr_sorted<4>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, R, chunk_len, part, chunk_range); break;
+    case 1: hipLaunchKernelGGL((k_gwr_sorted<1>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
+    case 2: hipLaunchKernelGGL((k_gwr_sorted<2>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
+    case 4: hipLaunchKernelGGL((k_gwr_sorted<4>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
     default: return nq_fail(NQ_ERR_ARG, "gwr_sorted needs hidden_channels in {64,128,256}");
   }
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gwr_reduce, dim3(nq_cdiv((long)R * 3 * F, 256)), dim3(256), 0, st, part, chunk_range, nq_cdiv(E, chunk_len), R, 3 * F, gWr);
+  hipLaunchKernelGGL(k_gwr_reduce, dim3(nq_cdiv((long)R * F3, 256)), dim3(256), 0, st, part, chunk_range, nq_cdiv(E, chunk_len), R, F3, gWr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -12,8 +12,9 @@ installed here; layer definitions, parameter names (``representation.interaction
 ``representation.mixing.{l}.{intraatomic_context_net.{0,1},mu_channel_mix}``, ``representation.filter_net``,
 ``output_modules.0.outnet.{0,1}``) and the train/eval behaviour of post-processors follow SURVEY.md Appendix C (recalled,
 unverified).  Checked against this repo's own restatement only (tests/test_spk_cpu.py, tests/test_spk_gpu.py).
-Not built: trainable / non-Gaussian radial bases, shared_interactions / shared_filters, atomrefs, stress, the
-``AtomisticTask`` wrapper (nablaDFT/ase_model/task.py) and SchNet (its filter network is a per-edge MLP: a different kernel).
+``SchNet`` (config/model/schnet.yaml) runs on its own engine entry points (csrc/schnet.hip; restatement
+oracle/spk_schnet_ref.py).  Not built: trainable / non-Gaussian radial bases, shared_interactions / shared_filters, atomrefs,
+stress and the ``AtomisticTask`` wrapper (nablaDFT/ase_model/task.py).
 """
 import ctypes as C
 import math
@@ -88,6 +89,36 @@ class PaiNN(nn.Module):
         self.filter_net = Dense(radial_basis.n_rbf, n_interactions * 3 * n_atom_basis)
         self.interactions = nn.ModuleList([_Interaction(n_atom_basis) for _ in range(n_interactions)])
         self.mixing = nn.ModuleList([_Mixing(n_atom_basis) for _ in range(n_interactions)])
+
+
+class _SchNetInteraction(nn.Module):
+    """schnetpack.representation.schnet.SchNetInteraction(n_atom_basis, n_rbf, n_filters): parameter holder."""
+
+    def __init__(self, F, R):
+        super().__init__()
+        self.in2f = Dense(F, F, bias=False)
+        self.f2out = nn.Sequential(Dense(F, F, activation="shifted_softplus"), Dense(F, F))
+        self.filter_network = nn.Sequential(Dense(R, F, activation="shifted_softplus"), Dense(F, F))
+
+
+class SchNet(nn.Module):
+    """schnetpack.representation.SchNet(n_atom_basis, n_interactions, radial_basis, cutoff_fn, ...) -- parameter holder
+    (config/model/schnet.yaml:6-16).  PARITY UNPINNED like the rest of this module (oracle/spk_schnet_ref.py)."""
+
+    def __init__(self, n_atom_basis: int, n_interactions: int, radial_basis: nn.Module, cutoff_fn: nn.Module, n_filters: Optional[int] = None,
+                 shared_interactions: bool = False, max_z: int = 101, activation=None):
+        super().__init__()
+        if shared_interactions:
+            raise NotImplementedError("nabladft_amd.spk.SchNet: shared_interactions is not built")
+        if n_filters not in (None, n_atom_basis):
+            raise NotImplementedError("nabladft_amd.spk.SchNet: n_filters must equal n_atom_basis")
+        if not isinstance(radial_basis, GaussianRBF) or not isinstance(cutoff_fn, CosineCutoff):
+            raise NotImplementedError("nabladft_amd.spk.SchNet: needs GaussianRBF + CosineCutoff (config/model/schnet.yaml:9-16)")
+        self.n_atom_basis, self.n_interactions, self.max_z = n_atom_basis, n_interactions, max_z
+        self.radial_basis, self.cutoff_fn = radial_basis, cutoff_fn
+        self.cutoff = float(cutoff_fn.cutoff)
+        self.embedding = nn.Embedding(max_z, n_atom_basis, padding_idx=0)
+        self.interactions = nn.ModuleList([_SchNetInteraction(n_atom_basis, radial_basis.n_rbf) for _ in range(n_interactions)])
 
 
 class PairwiseDistances(nn.Module):
@@ -171,16 +202,18 @@ class _SpkEnergyForces(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pot, nl, want_forces, *params):
         lib = _lib.load()
-        flat_spk = torch.cat([p.detach().to(torch.float32).reshape(-1) for p in params])
-        flat = flat_spk.index_select(0, pot._index)
+        flat = torch.cat([p.detach().to(torch.float32).reshape(-1) for p in params])
+        if pot._index is not None:
+            flat = flat.index_select(0, pot._index)
         dev = flat.device
-        ws_bytes = lib.nq_painn_workspace_bytes(C.byref(pot._cfg), nl.N, nl.E, nl.B)
+        ws_fn, fwd_fn, _ = pot._entry_points(lib)
+        ws_bytes = ws_fn(C.byref(pot._cfg), nl.N, nl.E, nl.B)
         ws = torch.empty((int(ws_bytes) + 255) // 256 * 256, device=dev, dtype=torch.uint8)
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32) if want_forces else None
         offsets = pot.representation.radial_basis.offsets
-        _lib.check(lib.nq_painn_forward(C.byref(pot._cfg), _lib.ptr(flat), _lib.ptr(offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
-                                        _lib.ptr(energy), _lib.ptr(forces), _lib.stream_ptr()))
+        _lib.check(fwd_fn(C.byref(pot._cfg), _lib.ptr(flat), _lib.ptr(offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
+                          _lib.ptr(energy), _lib.ptr(forces), _lib.stream_ptr()))
         ctx.pot, ctx.nl, ctx.ws, ctx.ws_bytes, ctx.flat, ctx.want_forces = pot, nl, ws, ws_bytes, flat, want_forces
         ctx.shapes = [tuple(p.shape) for p in params]
         return (energy, forces) if want_forces else (energy, energy.new_zeros(0))
@@ -192,9 +225,10 @@ class _SpkEnergyForces(torch.autograd.Function):
         grad_engine = torch.empty_like(ctx.flat)
         ge = None if g_energy is None else g_energy.to(torch.float32).contiguous()
         gf = None if (g_forces is None or not ctx.want_forces) else g_forces.to(torch.float32).contiguous()
-        _lib.check(lib.nq_painn_backward(C.byref(pot._cfg), _lib.ptr(ctx.flat), _lib.ptr(pot.representation.radial_basis.offsets), C.byref(nl.c),
-                                         _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_engine), _lib.stream_ptr()))
-        grad_spk = torch.zeros(pot._n_spk, device=grad_engine.device, dtype=torch.float32).index_add_(0, pot._index, grad_engine)
+        _lib.check(pot._entry_points(lib)[2](C.byref(pot._cfg), _lib.ptr(ctx.flat), _lib.ptr(pot.representation.radial_basis.offsets), C.byref(nl.c),
+                                             _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_engine), _lib.stream_ptr()))
+        grad_spk = grad_engine if pot._index is None else \
+            torch.zeros(pot._n_spk, device=grad_engine.device, dtype=torch.float32).index_add_(0, pot._index, grad_engine)
         out, o = [], 0
         for shp in ctx.shapes:
             n = math.prod(shp)
@@ -209,8 +243,8 @@ class NeuralNetworkPotential(nn.Module):
     def __init__(self, representation: nn.Module, input_modules: List[nn.Module] = None, output_modules: List[nn.Module] = None,
                  postprocessors: Optional[List[nn.Module]] = None, input_dtype_str: str = "float32", do_postprocessing: bool = True):
         super().__init__()
-        if not isinstance(representation, PaiNN):
-            raise NotImplementedError("nabladft_amd.spk.NeuralNetworkPotential: representation must be nabladft_amd.spk.PaiNN")
+        if not isinstance(representation, (PaiNN, SchNet)):
+            raise NotImplementedError("nabladft_amd.spk.NeuralNetworkPotential: representation must be nabladft_amd.spk.PaiNN or .SchNet")
         self.representation = representation
         self.input_modules = nn.ModuleList(input_modules or [])
         self.output_modules = nn.ModuleList(output_modules or [])
@@ -230,12 +264,18 @@ class NeuralNetworkPotential(nn.Module):
         F, L, R = rep.n_atom_basis, rep.n_interactions, rep.radial_basis.n_rbf
         if F % 64 != 0 or F not in (64, 128, 256):
             raise ValueError("n_atom_basis must be 64, 128 or 256 (fused-filter engine path)")
-        cfg = _lib.PainnCfg()
-        cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = F, L, R, rep.max_z - 1
-        cfg.max_neighbors, cfg.envelope_exponent = 2 ** 30, 5          # ASE-style list: every pair inside the cutoff
-        cfg.cutoff = float(rep.cutoff)
         width = float((torch.linspace(0.0, rep.cutoff, R)[1]).item())
-        cfg.rbf_coeff, cfg.filter_mode = -0.5 / width ** 2, 1
+        self._kind = "painn" if isinstance(rep, PaiNN) else "schnet"
+        if self._kind == "painn":
+            cfg = _lib.PainnCfg()
+            cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = F, L, R, rep.max_z - 1
+            cfg.max_neighbors, cfg.envelope_exponent = 2 ** 30, 5      # ASE-style list: every pair inside the cutoff
+            cfg.cutoff = float(rep.cutoff)
+            cfg.rbf_coeff, cfg.filter_mode = -0.5 / width ** 2, 1
+        else:
+            cfg = _lib.SchnetCfg()
+            cfg.n_atom_basis, cfg.n_interactions, cfg.n_rbf, cfg.max_z = F, L, R, rep.max_z
+            cfg.cutoff, cfg.rbf_coeff = float(rep.cutoff), -0.5 / width ** 2
         self._cfg = cfg
         self._index = None
         self._n_spk = 0
@@ -248,8 +288,28 @@ class NeuralNetworkPotential(nn.Module):
     def _forces(self):
         return None if self._i_forces is None else self.output_modules[self._i_forces]
 
+    def _entry_points(self, lib):
+        if self._kind == "painn":
+            return lib.nq_painn_workspace_bytes, lib.nq_painn_forward, lib.nq_painn_backward
+        return lib.nq_schnet_workspace_bytes, lib.nq_schnet_forward, lib.nq_schnet_backward
+
+    def _prepare(self, device):
+        """Gather index spk layout -> engine layout (PaiNN: a permutation; SchNet: the engine uses the module order itself)."""
+        rep = self.representation
+        if self._kind == "painn":
+            if self._index is None or self._index.device != device:
+                self._index, self._n_spk = _spk_index(rep.n_atom_basis, rep.n_interactions, rep.radial_basis.n_rbf, rep.max_z, device)
+        else:
+            self._index, self._n_spk = None, sum(p.numel() for p in self._engine_params())
+
     def _engine_params(self):
         rep, aw = self.representation, self._atomwise
+        if self._kind == "schnet":
+            ps = [rep.embedding.weight]
+            for it in rep.interactions:
+                ps += [it.in2f.weight, it.filter_network[0].weight, it.filter_network[0].bias, it.filter_network[1].weight, it.filter_network[1].bias,
+                       it.f2out[0].weight, it.f2out[0].bias, it.f2out[1].weight, it.f2out[1].bias]
+            return ps + [aw.outnet[0].weight, aw.outnet[0].bias, aw.outnet[1].weight, aw.outnet[1].bias]
         ps = [rep.embedding.weight, rep.filter_net.weight, rep.filter_net.bias]
         for it in rep.interactions:
             n = it.interatomic_context_net
@@ -270,8 +330,7 @@ class NeuralNetworkPotential(nn.Module):
         if not R_.is_cuda:
             raise RuntimeError("nabladft_amd.spk runs on MI355X only (no CPU fallback): move the batch to cuda")
         rep = self.representation
-        if self._index is None or self._index.device != R_.device:
-            self._index, self._n_spk = _spk_index(rep.n_atom_basis, rep.n_interactions, rep.radial_basis.n_rbf, rep.max_z, R_.device)
+        self._prepare(R_.device)
         nl = build_neighbor_list(R_, idx_m.long(), Z.long(), rep.cutoff, 2 ** 30)
         if nl.E == 0:
             raise IndexError("batch has no atom pair within the cutoff")

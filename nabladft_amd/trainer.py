@@ -38,6 +38,9 @@ class _PygEngine:
     def flat(self):
         return self.model.flat_parameters()
 
+    def entry_points(self, lib):
+        return lib.nq_painn_workspace_bytes, lib.nq_painn_forward, lib.nq_painn_backward
+
     def writeback(self):
         pass
 
@@ -51,18 +54,23 @@ class _SpkEngine:
         self.model, self.cfg, self.cutoff, self.max_neighbors = pot, pot._cfg, rep.cutoff, 2 ** 30
         self.offsets = rep.radial_basis.offsets
         dev = self.offsets.device
-        pot._index, pot._n_spk = spk._spk_index(rep.n_atom_basis, rep.n_interactions, rep.radial_basis.n_rbf, rep.max_z, dev)
+        pot._prepare(dev)
         with torch.no_grad():
-            self._flat = torch.cat([p.detach().to(torch.float32).reshape(-1) for p in pot._engine_params()]).index_select(0, pot._index)
+            self._flat = torch.cat([p.detach().to(torch.float32).reshape(-1) for p in pot._engine_params()])
+            if pot._index is not None:
+                self._flat = self._flat.index_select(0, pot._index)
 
     def flat(self):
         return self._flat
+
+    def entry_points(self, lib):
+        return self.model._entry_points(lib)
 
     @torch.no_grad()
     def writeback(self):
         pot = self.model
         ps = pot._engine_params()
-        spk_flat = torch.cat([p.detach().reshape(-1) for p in ps]).index_copy_(0, pot._index, self._flat)
+        spk_flat = self._flat if pot._index is None else torch.cat([p.detach().reshape(-1) for p in ps]).index_copy_(0, pot._index, self._flat)
         o = 0
         for p in ps:
             p.copy_(spk_flat[o:o + p.numel()].view_as(p))
@@ -102,7 +110,8 @@ class FusedTrainStep:
         if nl.E == 0:
             raise IndexError("batch has no edges within the cutoff")
         dev = flat.device
-        ws_bytes = lib.nq_painn_workspace_bytes(cfg, nl.N, nl.E, nl.B)
+        ws_fn, fwd_fn, bwd_fn = eng.entry_points(lib)
+        ws_bytes = ws_fn(cfg, nl.N, nl.E, nl.B)
         if self._ws is None or self._ws.numel() < ws_bytes:
             self._ws = None                                            # release before growing (27 GB at B=1024)
             self._ws = torch.empty((int(ws_bytes * 1.08) + 4096) // 256 * 256, device=dev, dtype=torch.uint8)
@@ -110,14 +119,12 @@ class FusedTrainStep:
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32)
         gE, gF = torch.empty_like(energy), torch.empty_like(forces)
-        _lib.check(lib.nq_painn_forward(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
-                                        _lib.ptr(energy), _lib.ptr(forces), st))
+        _lib.check(fwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(energy), _lib.ptr(forces), st))
         loss_fn = lib.nq_loss_mse if self.loss_kind == "mse" else lib.nq_loss_l1_l2
         _lib.check(loss_fn(_lib.ptr(energy), _lib.ptr(batch.y), nl.B, _lib.ptr(forces), _lib.ptr(batch.forces), nl.N, self.ce, self.cf,
                            _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
-        _lib.check(lib.nq_painn_backward(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes,
-                                         _lib.ptr(gE), _lib.ptr(gF),
-                                         _lib.ptr(self.grad), st))
+        _lib.check(bwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
+                          _lib.ptr(self.grad), st))
         nqdist.allreduce_mean_(self.grad, self.group)
         if update:
             self.t += 1
