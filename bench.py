@@ -63,7 +63,7 @@ def gemm_flops(name, N, E, launches):
     kind, rest = name.split(":", 1)
     tag = rest.split("[")[0]
     dims = [int(x) for x in rest.split("[")[1].rstrip("]").replace("n=", "").replace("k=", "").replace("x", ",").split(",")]
-    rows_single = {"Wr": E, "U": 3 * N, "sn:W2": E}.get(tag, N)
+    rows_single = {"Wr": E, "U": 3 * N, "sn:W2": E // 2}.get(tag, N)       # SchNet's filter network runs per undirected pair
     if kind == "gemm_tn":          # weight gradients: always over the stacked (primal+tangent) rows
         return 2.0 * (2 * rows_single) * dims[0] * dims[1]
     # nt / nn: 1x rows in forward / force adjoint / tangent, 2x rows in the dual reverse -> average over the step's launches
@@ -81,11 +81,12 @@ _MSG = {"msgf_fwd": ("k_msgf_fwd<false", 1), "msgf_tan": ("k_msgf_fwd<true", 2),
 
 
 # SchNet streaming kernels: bytes that must cross HBM once per launch (edge arrays [E][F] fp32, 128-B window records, node rows [N][F])
-_SN = {"sn_filter1": lambda N, E: E * (F * 4 + 128.0), "sn_filter1_tan": lambda N, E: E * (F * 4 + 132.0),
-       "sn_filter1_rev_force": lambda N, E: E * (F * 4 + 136.0), "sn_filter1_rev_dual": lambda N, E: E * (4 * F * 4 + 132.0),
-       "sn_conv": lambda N, E: E * F * 4.0 + 2 * N * F * 4.0, "sn_conv_tan": lambda N, E: 2 * E * F * 4.0 + 3 * N * F * 4.0,
-       "sn_conv_dual": lambda N, E: 2 * E * F * 4.0 + 4 * N * F * 4.0, "sn_edge_rev_force": lambda N, E: 2 * E * F * 4.0 + 2 * N * F * 4.0,
-       "sn_edge_rev_dual": lambda N, E: 2 * E * F * 4.0 + 4 * N * F * 4.0}
+# (pair arrays have E/2 rows)
+_SN = {"sn_filter1": lambda N, E: E / 2 * (F * 4 + 128.0), "sn_filter1_tan": lambda N, E: E / 2 * (F * 4 + 132.0),
+       "sn_filter1_rev_force": lambda N, E: E / 2 * (F * 4 + 136.0), "sn_filter1_rev_dual": lambda N, E: E / 2 * (4 * F * 4 + 132.0),
+       "sn_conv": lambda N, E: E / 2 * F * 4.0 + 2 * N * F * 4.0, "sn_conv_tan": lambda N, E: E * F * 4.0 + 3 * N * F * 4.0,
+       "sn_conv_dual": lambda N, E: E * F * 4.0 + 4 * N * F * 4.0, "sn_pair_rev_force": lambda N, E: E * F * 4.0 + 2 * N * F * 4.0,
+       "sn_pair_rev_dual": lambda N, E: E * F * 4.0 + 4 * N * F * 4.0}
 
 
 def pmc_traffic_bytes(kernel_prefix, batch):

@@ -67,6 +67,8 @@ typedef struct nq_graph {
   const float* geom;        /* [E][4] {rx, ry, rz, d}, r = (pos[col]-pos[dst])/d */
   const int32_t* z;         /* [N] atomic numbers */
   const int32_t* atom_mol;  /* [N] molecule of each atom */
+  const int32_t* lowptr;    /* [N+1] prefix count of in-edges with source < target (the first entries of each row); output of
+                             * nq_graph_count.  Numbers the undirected pairs: pair(i <- j, j < i) = lowptr[i] + position in row i. */
 } nq_graph;
 
 int nq_abi_version(void);

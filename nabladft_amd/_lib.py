@@ -30,7 +30,7 @@ class SchnetCfg(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("N", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("reserved", C.c_int32),
                 ("mol_ptr", C.c_void_p), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("dst", C.c_void_p),
-                ("rev", C.c_void_p), ("geom", C.c_void_p), ("z", C.c_void_p), ("atom_mol", C.c_void_p)]
+                ("rev", C.c_void_p), ("geom", C.c_void_p), ("z", C.c_void_p), ("atom_mol", C.c_void_p), ("lowptr", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t

@@ -84,6 +84,7 @@ struct NqGraphView {
   const float4* geom;   // [E]    {rx, ry, rz, d}: r = (pos[col]-pos[row])/d
   const int* z;         // [N]    atomic numbers
   const int* atom_mol;  // [N]
+  const int* lowptr;    // [N+1] prefix count of lower (source < target) in-edges = numbering of the undirected pairs
 };
 
 // ---- kernel argument blocks (shared between the kernel files and engine.hip) ---------------------

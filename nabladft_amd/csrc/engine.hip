@@ -137,7 +137,7 @@ static NqGraphView view_of(const nq_graph* g) {
   NqGraphView v;
   v.N = g->N; v.B = g->B; v.E = g->E;
   v.mol_ptr = g->mol_ptr; v.row_ptr = g->row_ptr; v.col = g->col; v.rev = g->rev;
-  v.geom = reinterpret_cast<const float4*>(g->geom); v.z = g->z; v.atom_mol = g->atom_mol;
+  v.geom = reinterpret_cast<const float4*>(g->geom); v.z = g->z; v.atom_mol = g->atom_mol; v.lowptr = g->lowptr;
   return v;
 }
 

@@ -7,8 +7,12 @@
 //   cfconv           m_i = sum_{e=(i<-j)} y_j * h2_e * fcut(d_e),  y = in2f(x)
 //   f2out            x += W_o2 ssp(W_o1 m + b_o1) + b_o2
 //
-// Every per-edge filter quantity depends on d_e only, so it is identical on an edge and on its reverse edge: all reverse-mode
-// scatters over the source atom are evaluated as gathers over the atom's own CSR row -- no atomics, bitwise reproducible.
+// Every per-edge filter quantity depends on d_e only, so it is identical on an edge and on its reverse edge:
+//   * the filter network (window layer, GEMMs, weight gradients) runs once per undirected PAIR p (P = E/2 rows): pair (i <- j, j < i) is
+//     numbered lowptr[i] + position in row i (the lower neighbours are the first entries of a row), PAIR_OF[slot] maps both directed
+//     slots to it;
+//   * all reverse-mode scatters over the source atom are evaluated as gathers over the atom's own CSR row -- no atomics, bitwise
+//     reproducible.
 // PARITY UNPINNED (schnetpack is not part of the reference tree): checked against this repo's restatement only.
 #include "common.h"
 #include "lanes.h"
@@ -48,6 +52,25 @@ __global__ void k_sn_add(const float* __restrict__ A, const float* __restrict__ 
   if (i < count) O[i] = A[i] + B[i];
 }
 
+// ---- undirected pairs ---------------------------------------------------------------------------------------------------------
+// one thread per CSR slot: PAIR_OF[sp]; the canonical (lower) slot also writes PAIR_SLOT[p] and the pair's geometry record
+__global__ void k_sn_pairs(NqGraphView g, const int* __restrict__ dst, int* __restrict__ PAIR_OF, int* __restrict__ PAIR_SLOT, float4* __restrict__ GEOMP) {
+  const int sp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sp >= g.E) return;
+  const int i = dst[sp], k = g.col[sp];
+  if (k < i) {
+    const int p = g.lowptr[i] + (sp - g.row_ptr[i]);
+    PAIR_OF[sp] = p; PAIR_SLOT[p] = sp; GEOMP[p] = g.geom[sp];
+  } else {
+    const int r = g.rev[sp];                        // slot of (k <- i), a lower entry of row k
+    PAIR_OF[sp] = g.lowptr[k] + (r - g.row_ptr[k]);
+  }
+}
+__global__ void k_sn_gather_f(const float* __restrict__ in, const int* __restrict__ idx, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+
 // ---- first filter layer from the window record ------------------------------------------------------------------------------
 // One wavefront walks a contiguous chunk of edges; lane l owns channels [l*CH, (l+1)*CH).  W1^T [R][F] lives in LDS.
 //   TAN = false:  A1[e]  = ssp(z1_e),                 z1_e = b1 + sum_t rho_t W1T[k0+t]
@@ -67,6 +90,9 @@ __device__ __forceinline__ void sn_filter1(const WinRegs<PSI>& w, const float* w
   O::to(z, vz); O::to(psi, vp);
 }
 
+// 16 wavefronts share one LDS copy of W1^T: the per-edge chain (scalar window load -> LDS taps -> exp/log -> store) is latency-bound,
+// so occupancy (2 workgroups x 16 waves per CU at <= 64 VGPRs) is what hides it.  4 waves per workgroup measured 2.3 ms/step per flavour.
+#define SN_F1_THREADS 1024
 #define SN_F1_PROLOGUE                                                                          \
   extern __shared__ __attribute__((aligned(16))) float wt[];                                   \
   {                                                                                            \
@@ -87,7 +113,7 @@ __device__ __forceinline__ void sn_filter1(const WinRegs<PSI>& w, const float* w
   if (e0 >= e1) return;
 
 template <bool TAN, int CH>
-__global__ __launch_bounds__(256) void k_sn_filter1(const float* __restrict__ RW, const float* __restrict__ W1T, const float* __restrict__ b1,
+__global__ __launch_bounds__(SN_F1_THREADS) void k_sn_filter1(const float* __restrict__ RW, const float* __restrict__ W1T, const float* __restrict__ b1,
                                                     const float* __restrict__ TD, float* __restrict__ OUT, int E, int F, int R) {
   SN_F1_PROLOGUE
   WinRegs<TAN> win;
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(256) void k_sn_filter1(const float* __restrict__ RW
 //   DUAL = true :  GA1[e] <- gz1 = ga1 sig(z1) + gta1 sig'(z1) td psi ;  GTA1[e] <- gtz1 * td = gta1 sig(z1) td   (in place; these are the
 //                  (gphi, gpsi) operands of the k0-sorted weight-gradient kernel)
 template <bool DUAL, int CH>
-__global__ __launch_bounds__(256) void k_sn_filter1_rev(const float* __restrict__ RW, const float* __restrict__ W1T, const float* __restrict__ b1,
+__global__ __launch_bounds__(SN_F1_THREADS) void k_sn_filter1_rev(const float* __restrict__ RW, const float* __restrict__ W1T, const float* __restrict__ b1,
                                                         const float* __restrict__ TD, float* __restrict__ GA1, float* __restrict__ GTA1,
                                                         float* __restrict__ GD, int E, int F, int R) {
   SN_F1_PROLOGUE
@@ -164,23 +190,24 @@ __device__ __forceinline__ int sn_atom_of_wave(int N) {
   return __builtin_amdgcn_readfirstlane(blk * wpb + (int)(threadIdx.x >> 6));
 }
 
-struct SnRow { int kk; float rc, dt; };   // per lane: neighbour, fcut, fcut' * td of edge (c0 + lane)
+struct SnRow { int kk, pp; float rc, dt; };   // per lane: neighbour, pair id, fcut, fcut' * td of edge (c0 + lane)
 template <bool DUAL>
-__device__ __forceinline__ void sn_load_row(SnRow& r, const int* __restrict__ col, const float* __restrict__ RW, const float* __restrict__ TD,
-                                            int c0, int cnt, int lane) {
-  r.kk = 0; r.rc = 0.f; r.dt = 0.f;
+__device__ __forceinline__ void sn_load_row(SnRow& r, const int* __restrict__ col, const int* __restrict__ PAIR_OF, const float* __restrict__ RW,
+                                            const float* __restrict__ TD, int c0, int cnt, int lane) {
+  r.kk = 0; r.pp = 0; r.rc = 0.f; r.dt = 0.f;
   if (lane < cnt) {
     const int sp = c0 + lane;
     r.kk = col[sp];
-    r.rc = RW[(long)sp * RW_STRIDE + 14];
-    if (DUAL) r.dt = RW[(long)sp * RW_STRIDE + 30] * TD[sp];
+    r.pp = PAIR_OF[sp];
+    r.rc = RW[(long)r.pp * RW_STRIDE + 14];
+    if (DUAL) r.dt = RW[(long)r.pp * RW_STRIDE + 30] * TD[r.pp];
   }
 }
 
 // SINGLE (DUAL=false):  O1_i = sum_e A_k w_e                               w  = h2 fcut
 // DUAL              :  O1_i = sum_e A_k w_e + B_k wt_e,  O2_i = sum_e B_k w_e   (O2 optional)      wt = th2 fcut + h2 fcut' td
 template <bool DUAL, int CH>
-__global__ __launch_bounds__(256) void k_sn_conv(NqGraphView g, int F, const float* __restrict__ RW, const float* __restrict__ TD,
+__global__ __launch_bounds__(256) void k_sn_conv(NqGraphView g, int F, const int* __restrict__ PAIR_OF, const float* __restrict__ RW, const float* __restrict__ TD,
                                                  const float* __restrict__ A, const float* __restrict__ Bv, const float* __restrict__ H2,
                                                  const float* __restrict__ TH2, float* __restrict__ O1, float* __restrict__ O2) {
   const int n = sn_atom_of_wave(g.N);
@@ -193,19 +220,19 @@ __global__ __launch_bounds__(256) void k_sn_conv(NqGraphView g, int F, const flo
   for (int c0 = beg; c0 < end; c0 += 64) {
     const int cnt = min(64, end - c0);
     SnRow row;
-    sn_load_row<DUAL>(row, g.col, RW, TD, c0, cnt, lane);
+    sn_load_row<DUAL>(row, g.col, PAIR_OF, RW, TD, c0, cnt, lane);
     float a[CH], b[CH], h[CH], th[CH];
     {
-      const int k = bl_i(row.kk, 0);
-      ldv<CH>(a, A + (long)k * F + fb); ldv<CH>(h, H2 + (long)c0 * F + fb);
-      if (DUAL) { ldv<CH>(b, Bv + (long)k * F + fb); ldv<CH>(th, TH2 + (long)c0 * F + fb); }
+      const int k = bl_i(row.kk, 0), p = bl_i(row.pp, 0);
+      ldv<CH>(a, A + (long)k * F + fb); ldv<CH>(h, H2 + (long)p * F + fb);
+      if (DUAL) { ldv<CH>(b, Bv + (long)k * F + fb); ldv<CH>(th, TH2 + (long)p * F + fb); }
     }
     for (int j = 0; j < cnt; ++j) {
       const int jn = min(j + 1, cnt - 1);
-      const int kn = bl_i(row.kk, jn);
+      const int kn = bl_i(row.kk, jn), pn = bl_i(row.pp, jn);
       float an[CH], bn[CH], hn[CH], thn[CH];
-      ldv<CH>(an, A + (long)kn * F + fb); ldv<CH>(hn, H2 + (long)(c0 + jn) * F + fb);
-      if (DUAL) { ldv<CH>(bn, Bv + (long)kn * F + fb); ldv<CH>(thn, TH2 + (long)(c0 + jn) * F + fb); }
+      ldv<CH>(an, A + (long)kn * F + fb); ldv<CH>(hn, H2 + (long)pn * F + fb);
+      if (DUAL) { ldv<CH>(bn, Bv + (long)kn * F + fb); ldv<CH>(thn, TH2 + (long)pn * F + fb); }
       const float rc = bl_f(row.rc, j);
       const float dt = DUAL ? bl_f(row.dt, j) : 0.f;
 #pragma unroll
@@ -226,78 +253,84 @@ __global__ __launch_bounds__(256) void k_sn_conv(NqGraphView g, int F, const flo
   if (DUAL && O2) stv<CH>(O2 + (long)n * F + fb, o2);
 }
 
-// adjoint of the filter per edge (own gm_i in registers, neighbour's y_k gathered):
-//   DUAL = false:  GH2[e] = gm_i y_k fcut ;  GD[e] = fcut' sum_c gm_i y_k h2_e
-//   DUAL = true :  GH2[e] = gm_i y_k fcut + gtm_i (ty_k fcut + y_k fcut' td) ;  GTH2[e] = gtm_i y_k fcut
+// adjoint of the filter per PAIR: the wavefront of atom i owns the pairs (i, k), k < i (contiguous pair rows lowptr[i]..lowptr[i+1]);
+// its own rows stay in registers, the neighbour's rows are gathered.  Both directed edges of the pair contribute:
+//   DUAL = false:  gW = gm_i y_k + gm_k y_i ;  GH2[p] = gW fcut ;  GD[p] = fcut' sum_c gW h2_p
+//   DUAL = true :  GH2[p] = fcut (gm_i y_k + gm_k y_i + gtm_i ty_k + gtm_k ty_i) + fcut' td (gtm_i y_k + gtm_k y_i)
+//                  GTH2[p] = fcut (gtm_i y_k + gtm_k y_i)
 template <bool DUAL, int CH>
-__global__ __launch_bounds__(256) void k_sn_edge_rev(NqGraphView g, int F, const float* __restrict__ RW, const float* __restrict__ TD,
+__global__ __launch_bounds__(256) void k_sn_pair_rev(NqGraphView g, int F, const float* __restrict__ RW, const float* __restrict__ TD,
                                                      const float* __restrict__ GM, const float* __restrict__ GTM, const float* __restrict__ Y,
                                                      const float* __restrict__ TY, const float* __restrict__ H2, float* __restrict__ GH2,
                                                      float* __restrict__ GTH2, float* __restrict__ GD) {
   const int n = sn_atom_of_wave(g.N);
   if (n >= g.N) return;
   const int lane = threadIdx.x & 63, fb = lane * CH;
-  const int beg = __builtin_amdgcn_readfirstlane(g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(g.row_ptr[n + 1]);
-  float gm[CH], gtm[CH];
-  ldv<CH>(gm, GM + (long)n * F + fb);
-  if (DUAL) ldv<CH>(gtm, GTM + (long)n * F + fb);
-  for (int c0 = beg; c0 < end; c0 += 64) {
-    const int cnt = min(64, end - c0);
-    SnRow row;
-    sn_load_row<DUAL>(row, g.col, RW, TD, c0, cnt, lane);
-    float drc_lane = 0.f;
-    if (!DUAL && lane < cnt) drc_lane = RW[(long)(c0 + lane) * RW_STRIDE + 30];
-    float y[CH], ty[CH], h[CH];
+  const int p_beg = __builtin_amdgcn_readfirstlane(g.lowptr[n]), p_end = __builtin_amdgcn_readfirstlane(g.lowptr[n + 1]);
+  const int s_beg = __builtin_amdgcn_readfirstlane(g.row_ptr[n]);          // the lower neighbours are the first p_end - p_beg slots of the row
+  float gmi[CH], gtmi[CH], yi[CH], tyi[CH];
+  ldv<CH>(gmi, GM + (long)n * F + fb); ldv<CH>(yi, Y + (long)n * F + fb);
+  if (DUAL) { ldv<CH>(gtmi, GTM + (long)n * F + fb); ldv<CH>(tyi, TY + (long)n * F + fb); }
+  for (int q0 = p_beg; q0 < p_end; q0 += 64) {
+    const int cnt = min(64, p_end - q0);
+    int kk = 0; float rcl = 0.f, dtl = 0.f;
+    if (lane < cnt) {
+      const int p = q0 + lane;
+      kk = g.col[s_beg + (p - p_beg)];
+      rcl = RW[(long)p * RW_STRIDE + 14];
+      dtl = RW[(long)p * RW_STRIDE + 30] * (DUAL ? TD[p] : 1.0f);      // force mode: fcut' itself
+    }
+    float y[CH], gm[CH], ty[CH], gtm[CH], h[CH];
     {
-      const int k = bl_i(row.kk, 0);
-      ldv<CH>(y, Y + (long)k * F + fb);
-      if (DUAL) ldv<CH>(ty, TY + (long)k * F + fb); else ldv<CH>(h, H2 + (long)c0 * F + fb);
+      const int k = bl_i(kk, 0);
+      ldv<CH>(y, Y + (long)k * F + fb); ldv<CH>(gm, GM + (long)k * F + fb);
+      if (DUAL) { ldv<CH>(ty, TY + (long)k * F + fb); ldv<CH>(gtm, GTM + (long)k * F + fb); } else ldv<CH>(h, H2 + (long)q0 * F + fb);
     }
     float gd_lane = 0.f;
     for (int j = 0; j < cnt; ++j) {
       const int jn = min(j + 1, cnt - 1);
-      const int kn = bl_i(row.kk, jn);
-      float yn[CH], tyn[CH], hn[CH];
-      ldv<CH>(yn, Y + (long)kn * F + fb);
-      if (DUAL) ldv<CH>(tyn, TY + (long)kn * F + fb); else ldv<CH>(hn, H2 + (long)(c0 + jn) * F + fb);
-      const float rc = bl_f(row.rc, j);
+      const int kn = bl_i(kk, jn);
+      float yn[CH], gmn[CH], tyn[CH], gtmn[CH], hn[CH];
+      ldv<CH>(yn, Y + (long)kn * F + fb); ldv<CH>(gmn, GM + (long)kn * F + fb);
+      if (DUAL) { ldv<CH>(tyn, TY + (long)kn * F + fb); ldv<CH>(gtmn, GTM + (long)kn * F + fb); } else ldv<CH>(hn, H2 + (long)(q0 + jn) * F + fb);
+      const float rc = bl_f(rcl, j), dt = bl_f(dtl, j);
       float o[CH], ot[CH];
       if (DUAL) {
-        const float dt = bl_f(row.dt, j);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          o[c] = gm[c] * y[c] * rc + gtm[c] * (ty[c] * rc + y[c] * dt);
-          ot[c] = gtm[c] * y[c] * rc;
+          const float tw = gtmi[c] * y[c] + gtm[c] * yi[c];
+          o[c] = rc * (gmi[c] * y[c] + gm[c] * yi[c] + gtmi[c] * ty[c] + gtm[c] * tyi[c]) + dt * tw;
+          ot[c] = rc * tw;
         }
-        stv_stream<CH>(GH2 + (long)(c0 + j) * F + fb, o);
-        stv_stream<CH>(GTH2 + (long)(c0 + j) * F + fb, ot);
+        stv_stream<CH>(GH2 + (long)(q0 + j) * F + fb, o);
+        stv_stream<CH>(GTH2 + (long)(q0 + j) * F + fb, ot);
       } else {
-        float s = 0.f;
+        float sacc = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          const float gw = gm[c] * y[c];
+          const float gw = gmi[c] * y[c] + gm[c] * yi[c];
           o[c] = gw * rc;
-          s += gw * h[c];
+          sacc += gw * h[c];
         }
-        stv_stream<CH>(GH2 + (long)(c0 + j) * F + fb, o);
-        s = nq_wave_sum(s);
-        gd_lane = (lane == j) ? s : gd_lane;
+        stv_stream<CH>(GH2 + (long)(q0 + j) * F + fb, o);
+        sacc = nq_wave_sum(sacc);
+        gd_lane = (lane == j) ? sacc * dt : gd_lane;
       }
 #pragma unroll
-      for (int c = 0; c < CH; ++c) { y[c] = yn[c]; if (DUAL) ty[c] = tyn[c]; else h[c] = hn[c]; }
+      for (int c = 0; c < CH; ++c) { y[c] = yn[c]; gm[c] = gmn[c]; if (DUAL) { ty[c] = tyn[c]; gtm[c] = gtmn[c]; } else h[c] = hn[c]; }
     }
-    if (!DUAL && lane < cnt) GD[c0 + lane] = drc_lane * gd_lane;
+    if (!DUAL && lane < cnt) GD[q0 + lane] = gd_lane;
   }
 }
 
-// F_i = -dE/dr_i = sum_{e in row i} u_e (gd_e + gd_rev(e))      (dd_e/dr_i = -u_e on the own row, +u on the reverse edge, u_rev = -u)
-__global__ void k_sn_forces(NqGraphView g, const float* __restrict__ GD, float* __restrict__ forces) {
+// F_i = -dE/dr_i = sum_{e in row i} u_e gd_pair(e)      (gd_pair = dE/dd of the pair = both directed edges; dd/dr_i = -u_e on the own row)
+__global__ void k_sn_forces(NqGraphView g, const int* __restrict__ PAIR_OF, const float* __restrict__ GD, float* __restrict__ forces) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= g.N) return;
   float fx = 0.f, fy = 0.f, fz = 0.f;
   for (int e = g.row_ptr[n]; e < g.row_ptr[n + 1]; ++e) {
     const float4 u = g.geom[e];
-    const float s = GD[e] + GD[g.rev[e]];
+    const float s = GD[PAIR_OF[e]];
     fx += u.x * s; fy += u.y * s; fz += u.z * s;
   }
   forces[3 * (long)n] = fx; forces[3 * (long)n + 1] = fy; forces[3 * (long)n + 2] = fz;
@@ -340,8 +373,8 @@ static int sn_add(hipStream_t st, const float* A, const float* B, float* O, long
 
 static int sn_f1_grid(int E, size_t lds) {
   const int per_cu = (int)((156 * 1024) / (lds ? lds : 1));
-  const int wgs = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
-  const int need = nq_cdiv(E, 4 * 16);   // at least 16 edges per wavefront
+  const int wgs = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  const int need = nq_cdiv(E, (SN_F1_THREADS / 64) * 16);   // at least 16 edges per wavefront
   return need < wgs ? (need < 1 ? 1 : need) : wgs;
 }
 #define SN_F1_LAUNCH(KERN, ...)                                                                                     \
@@ -351,7 +384,7 @@ static int sn_f1_grid(int E, size_t lds) {
       NQ_HIP(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
       lds_set__ = lds;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL(KERN, dim3(grid), dim3(256), lds, st, __VA_ARGS__);                                         \
+    hipLaunchKernelGGL(KERN, dim3(grid), dim3(SN_F1_THREADS), lds, st, __VA_ARGS__);                                         \
   } while (0)
 
 static int sn_filter1(hipStream_t st, const float* RW, const float* W1T, const float* b1, const float* TD, float* OUT, int E, int F, int R, bool tan) {
@@ -380,26 +413,26 @@ static int sn_filter1_rev(hipStream_t st, const float* RW, const float* W1T, con
   return NQ_OK;
 }
 static int sn_atom_grid(int N) { return ((nq_cdiv(N, 4) + 7) / 8) * 8; }
-static int sn_conv(hipStream_t st, const NqGraphView& g, int F, const float* RW, const float* TD, const float* A, const float* B, const float* H2,
-                   const float* TH2, float* O1, float* O2, bool dual, const char* name) {
+static int sn_conv(hipStream_t st, const NqGraphView& g, int F, const int* PAIR_OF, const float* RW, const float* TD, const float* A, const float* B,
+                   const float* H2, const float* TH2, float* O1, float* O2, bool dual, const char* name) {
   NQ_PROF(st, name);
   if (g.N <= 0) return NQ_OK;
   const int grid = sn_atom_grid(g.N);
   SN_CH_SWITCH(F, {
-    if (dual) hipLaunchKernelGGL((k_sn_conv<true, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, A, B, H2, TH2, O1, O2);
-    else hipLaunchKernelGGL((k_sn_conv<false, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, A, B, H2, TH2, O1, O2);
+    if (dual) hipLaunchKernelGGL((k_sn_conv<true, CHV>), dim3(grid), dim3(256), 0, st, g, F, PAIR_OF, RW, TD, A, B, H2, TH2, O1, O2);
+    else hipLaunchKernelGGL((k_sn_conv<false, CHV>), dim3(grid), dim3(256), 0, st, g, F, PAIR_OF, RW, TD, A, B, H2, TH2, O1, O2);
   })
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
-static int sn_edge_rev(hipStream_t st, const NqGraphView& g, int F, const float* RW, const float* TD, const float* GM, const float* GTM,
+static int sn_pair_rev(hipStream_t st, const NqGraphView& g, int F, const float* RW, const float* TD, const float* GM, const float* GTM,
                        const float* Y, const float* TY, const float* H2, float* GH2, float* GTH2, float* GD, bool dual) {
-  NQ_PROF(st, dual ? "sn_edge_rev_dual" : "sn_edge_rev_force");
+  NQ_PROF(st, dual ? "sn_pair_rev_dual" : "sn_pair_rev_force");
   if (g.N <= 0) return NQ_OK;
   const int grid = sn_atom_grid(g.N);
   SN_CH_SWITCH(F, {
-    if (dual) hipLaunchKernelGGL((k_sn_edge_rev<true, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, GM, GTM, Y, TY, H2, GH2, GTH2, GD);
-    else hipLaunchKernelGGL((k_sn_edge_rev<false, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, GM, GTM, Y, TY, H2, GH2, GTH2, GD);
+    if (dual) hipLaunchKernelGGL((k_sn_pair_rev<true, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, GM, GTM, Y, TY, H2, GH2, GTH2, GD);
+    else hipLaunchKernelGGL((k_sn_pair_rev<false, CHV>), dim3(grid), dim3(256), 0, st, g, F, RW, TD, GM, GTM, Y, TY, H2, GH2, GTH2, GD);
   })
   NQ_LAUNCH_CHECK();
   return NQ_OK;
@@ -423,34 +456,36 @@ static void sn_param_layout(const nq_schnet_cfg* c, SnParams* P) {
   P->O1 = o; o += H * F; P->o1 = o; o += H; P->w2 = o; o += H; P->o2 = o; o += 1;
   P->total = o;
 }
-struct SnLayerW { size_t W1T, A1, H2, Y, M, T1, U; };   // A1, H2: [2][E][F] (primal, tangent); Y, M, T1, U: [2][N][F]
+struct SnLayerW { size_t W1T, A1, H2, Y, M, T1, U; };   // A1, H2: [2][P][F] (primal, tangent) per undirected pair; Y, M, T1, U: [2][N][F]
 struct SnWs {
   size_t X[NQ_MAX_LAYERS + 1];                          // [2][N][F]
   SnLayerW lay[NQ_MAX_LAYERS];
-  size_t RW, ORDER, TD, GD, pos_dot, ZO, e_atom, te_atom, ge, gte, GZO, TMPW, GX, GU, GM, GY, V, GH2, GA1, scratch, total;
+  size_t RW, ORDER, TD, TDP, GD, GDT, PAIR_OF, PAIR_SLOT, GEOMP, pos_dot, ZO, e_atom, te_atom, ge, gte, GZO, TMPW, GX, GU, GM, GY, V, GH2, GA1, scratch, total;
 };
 static size_t sn_a4(size_t x) { return (x + 3) & ~(size_t)3; }
 static size_t sn_max(size_t a, size_t b) { return a > b ? a : b; }
 static void sn_ws_layout(const nq_schnet_cfg* c, size_t N, size_t E, size_t B, SnWs* W) {
   const size_t F = c->n_atom_basis, R = c->n_rbf, H = F / 2, L = c->n_interactions;
+  const size_t Pn = E / 2;          // undirected pairs (the edge list is symmetric)
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += sn_a4(n); return at; };
   for (size_t l = 0; l <= L; ++l) W->X[l] = take(2 * N * F);
   for (size_t l = 0; l < L; ++l) {
     SnLayerW& y = W->lay[l];
-    y.W1T = take(R * F); y.A1 = take(2 * E * F); y.H2 = take(2 * E * F);
+    y.W1T = take(R * F); y.A1 = take(2 * Pn * F); y.H2 = take(2 * Pn * F);
     y.Y = take(2 * N * F); y.M = take(2 * N * F); y.T1 = take(2 * N * F); y.U = take(2 * N * F);
   }
-  W->RW = take(E * RW_STRIDE); W->ORDER = take(E); W->TD = take(E); W->GD = take(E); W->pos_dot = take(3 * N);
+  W->RW = take(Pn * RW_STRIDE); W->ORDER = take(Pn); W->TD = take(E); W->TDP = take(Pn); W->GD = take(Pn); W->GDT = take(Pn);
+  W->PAIR_OF = take(E); W->PAIR_SLOT = take(Pn); W->GEOMP = take(4 * Pn); W->pos_dot = take(3 * N);
   W->ZO = take(2 * N * H); W->e_atom = take(N); W->te_atom = take(N); W->ge = take(N); W->gte = take(N);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
   W->GX = take(2 * N * F); W->GU = take(2 * N * F); W->GM = take(2 * N * F); W->GY = take(2 * N * F); W->V = take(2 * N * F);
-  W->GH2 = take(2 * E * F); W->GA1 = take(2 * E * F);
-  size_t s = nq_gemm_tn_scratch_floats(2 * (long)E, (int)F, (int)F);
+  W->GH2 = take(2 * Pn * F); W->GA1 = take(2 * Pn * F);
+  size_t s = nq_gemm_tn_scratch_floats(2 * (long)Pn, (int)F, (int)F);
   s = sn_max(s, nq_gemm_tn_scratch_floats(2 * (long)N, (int)F, (int)F));
-  s = sn_max(s, nq_gwr_scratch_floats((int)E, (int)F, (int)R, 1));
-  s = sn_max(s, nq_colsum_scratch_floats((long)E, (int)F));
-  s = sn_max(s, nq_k0_sort_scratch_ints((int)E, (int)R));
+  s = sn_max(s, nq_gwr_scratch_floats((int)Pn, (int)F, (int)R, 1));
+  s = sn_max(s, nq_colsum_scratch_floats((long)Pn, (int)F));
+  s = sn_max(s, nq_k0_sort_scratch_ints((int)Pn, (int)R));
   s = sn_max(s, nq_embed_grad_scratch_floats((int)N, (int)F, c->max_z - 1));
   W->scratch = take(s + 64);
   W->total = o;
@@ -459,7 +494,7 @@ static void sn_ws_layout(const nq_schnet_cfg* c, size_t N, size_t E, size_t B, S
 static NqGraphView sn_view(const nq_graph* g) {
   NqGraphView v;
   v.N = g->N; v.B = g->B; v.E = g->E; v.mol_ptr = g->mol_ptr; v.row_ptr = g->row_ptr; v.col = g->col; v.rev = g->rev;
-  v.geom = reinterpret_cast<const float4*>(g->geom); v.z = g->z; v.atom_mol = g->atom_mol;
+  v.geom = reinterpret_cast<const float4*>(g->geom); v.z = g->z; v.atom_mol = g->atom_mol; v.lowptr = g->lowptr;
   return v;
 }
 static int sn_check(const nq_schnet_cfg* c, const nq_graph* g, const void* ws, size_t ws_bytes, SnWs* W, SnParams* P) {
@@ -470,6 +505,7 @@ static int sn_check(const nq_schnet_cfg* c, const nq_graph* g, const void* ws, s
   if (c->n_rbf < 2 || (size_t)(c->n_rbf < FWIN ? FWIN : c->n_rbf) * F * sizeof(float) > 156 * 1024) return nq_fail(NQ_ERR_ARG, "n_rbf * n_atom_basis does not fit LDS");
   if (c->max_z < 2) return nq_fail(NQ_ERR_ARG, "max_z");
   if (g->N <= 0 || g->E <= 0 || g->B <= 0) return nq_fail(NQ_ERR_ARG, "empty graph");
+  if ((g->E & 1) || !g->lowptr || !g->dst) return nq_fail(NQ_ERR_ARG, "SchNet needs the symmetric edge list with lowptr (nq_graph_count / nq_graph_fill)");
   sn_param_layout(c, P);
   sn_ws_layout(c, g->N, g->E, g->B, W);
   if (ws_bytes < W->total * sizeof(float)) return nq_fail(NQ_ERR_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, W->total * sizeof(float));
@@ -497,22 +533,29 @@ int nq_schnet_forward(const nq_schnet_cfg* cfg, const float* params, const float
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const NqGraphView g = sn_view(graph);
-  const int N = g.N, E = g.E, F = cfg->n_atom_basis, R = cfg->n_rbf, H = F / 2, L = cfg->n_interactions;
-  const size_t NF = (size_t)N * F, EF = (size_t)E * F;
+  const int N = g.N, E = g.E, Pn = E / 2, F = cfg->n_atom_basis, R = cfg->n_rbf, H = F / 2, L = cfg->n_interactions;
+  const size_t NF = (size_t)N * F;
   const float* RW = ws + W.RW;
+  const int* PAIR_OF = reinterpret_cast<const int*>(ws + W.PAIR_OF);
 
   NQ_TRY(nq_embed(st, g.z, params + P.emb + F, N, F, ws + W.X[0]));       // table indexed by Z (row 0 = padding): shift by one row
+  {
+    NQ_PROF(st, "sn_pairs");
+    hipLaunchKernelGGL(k_sn_pairs, sn_grid1d(E, 256), dim3(256), 0, st, g, graph->dst, reinterpret_cast<int*>(ws + W.PAIR_OF),
+                       reinterpret_cast<int*>(ws + W.PAIR_SLOT), reinterpret_cast<float4*>(ws + W.GEOMP));
+    NQ_LAUNCH_CHECK();
+  }
   FilterArgs fa;
   nq_make_filter_args(&fa, nullptr, nullptr, rbf_offsets, RW, R, cfg->cutoff, 5, cfg->rbf_coeff, 2);
-  NQ_TRY(nq_rbf_window(st, g.geom, E, fa, ws + W.RW));
-  NQ_TRY(nq_k0_sort(st, RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
+  NQ_TRY(nq_rbf_window(st, reinterpret_cast<const float4*>(ws + W.GEOMP), Pn, fa, ws + W.RW));
+  NQ_TRY(nq_k0_sort(st, RW, Pn, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
   for (int l = 0; l < L; ++l) {
     const SnLayerW& y = W.lay[l]; const SnLayerP& p = P.lay[l];
     NQ_TRY(nq_transpose(st, params + p.W1, F, R, ws + y.W1T));
-    NQ_TRY(sn_filter1(st, RW, ws + y.W1T, params + p.b1, nullptr, ws + y.A1, E, F, R, false));
-    NQ_TRY(nq_gemm_nt(st, ws + y.A1, params + p.W2, ws + y.H2, params + p.b2, nullptr, E, F, F, F, F, F, "sn:W2"));
+    NQ_TRY(sn_filter1(st, RW, ws + y.W1T, params + p.b1, nullptr, ws + y.A1, Pn, F, R, false));
+    NQ_TRY(nq_gemm_nt(st, ws + y.A1, params + p.W2, ws + y.H2, params + p.b2, nullptr, Pn, F, F, F, F, F, "sn:W2"));
     NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + p.Win, ws + y.Y, nullptr, nullptr, N, F, F, F, F, F, "sn:in2f"));
-    NQ_TRY(sn_conv(st, g, F, RW, nullptr, ws + y.Y, nullptr, ws + y.H2, nullptr, ws + y.M, nullptr, false, "sn_conv"));
+    NQ_TRY(sn_conv(st, g, F, PAIR_OF, RW, nullptr, ws + y.Y, nullptr, ws + y.H2, nullptr, ws + y.M, nullptr, false, "sn_conv"));
     NQ_TRY(nq_gemm_nt(st, ws + y.M, params + p.Wo1, ws + y.T1, params + p.bo1, nullptr, N, F, F, F, F, F, "sn:f2out0"));
     NQ_TRY(sn_ssp(st, ws + y.T1, ws + y.U, (long)NF));
     NQ_TRY(nq_gemm_nt(st, ws + y.U, params + p.Wo2, ws + W.V, params + p.bo2, nullptr, N, F, F, F, F, F, "sn:f2out1"));
@@ -525,31 +568,30 @@ int nq_schnet_forward(const nq_schnet_cfg* cfg, const float* params, const float
   NQ_TRY(nq_mol_sum(st, ws + W.e_atom, g.mol_ptr, g.B, energy));
   if (!forces) return NQ_OK;
 
-  // ---- force adjoint: seeds dE_tot/d eps_i = 1 -> gd[e] -> forces -----------------------------------------------------
+  // ---- force adjoint: seeds dE_tot/d eps_i = 1 -> gd[pair] -> forces --------------------------------------------------
   NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.ge, nullptr));
   r.ge = ws + W.ge; r.GZO = ws + W.GZO;
   NQ_TRY(nq_readout_rev(st, r, false));
   NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, N, H, F, H, F, F, 0, "O1"));
-  NQ_HIP(hipMemsetAsync(ws + W.TD, 0, (size_t)E * sizeof(float), st));   // TD doubles as the running total of gd over the layers
-  float* gd_total = ws + W.TD;
+  float* gd_total = ws + W.GDT;
+  NQ_HIP(hipMemsetAsync(gd_total, 0, (size_t)Pn * sizeof(float), st));
   for (int l = L - 1; l >= 0; --l) {
     const SnLayerW& y = W.lay[l]; const SnLayerP& p = P.lay[l];
     NQ_TRY(nq_gemm_nn(st, ws + W.GX, params + p.Wo2, ws + W.GU, N, F, F, F, F, F, 0, "sn:f2out1"));
     NQ_TRY(sn_ssp_rev(st, ws + y.T1, nullptr, ws + W.GU, nullptr, (long)NF, false));
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + p.Wo1, ws + W.GM, N, F, F, F, F, F, 0, "sn:f2out0"));
-    NQ_TRY(sn_edge_rev(st, g, F, RW, nullptr, ws + W.GM, nullptr, ws + y.Y, nullptr, ws + y.H2, ws + W.GH2, nullptr, ws + W.GD, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH2, params + p.W2, ws + W.GA1, E, F, F, F, F, F, 0, "sn:W2"));
-    NQ_TRY(sn_filter1_rev(st, RW, ws + y.W1T, params + p.b1, nullptr, ws + W.GA1, nullptr, ws + W.GD, E, F, R, false));
-    NQ_TRY(sn_add(st, gd_total, ws + W.GD, gd_total, (long)E));
-    NQ_TRY(sn_conv(st, g, F, RW, nullptr, ws + W.GM, nullptr, ws + y.H2, nullptr, ws + W.GY, nullptr, false, "sn_conv"));
+    NQ_TRY(sn_pair_rev(st, g, F, RW, nullptr, ws + W.GM, nullptr, ws + y.Y, nullptr, ws + y.H2, ws + W.GH2, nullptr, ws + W.GD, false));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH2, params + p.W2, ws + W.GA1, Pn, F, F, F, F, F, 0, "sn:W2"));
+    NQ_TRY(sn_filter1_rev(st, RW, ws + y.W1T, params + p.b1, nullptr, ws + W.GA1, nullptr, ws + W.GD, Pn, F, R, false));
+    NQ_TRY(sn_add(st, gd_total, ws + W.GD, gd_total, (long)Pn));
+    NQ_TRY(sn_conv(st, g, F, PAIR_OF, RW, nullptr, ws + W.GM, nullptr, ws + y.H2, nullptr, ws + W.GY, nullptr, false, "sn_conv"));
     NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + p.Win, ws + W.GX, N, F, F, F, F, F, 1, "sn:in2f"));
   }
   {
     NQ_PROF(st, "sn_forces");
-    hipLaunchKernelGGL(k_sn_forces, sn_grid1d(N, 128), dim3(128), 0, st, g, gd_total, forces);
+    hipLaunchKernelGGL(k_sn_forces, sn_grid1d(N, 128), dim3(128), 0, st, g, PAIR_OF, gd_total, forces);
     NQ_LAUNCH_CHECK();
   }
-  (void)EF;
   return NQ_OK;
 }
 
@@ -563,22 +605,25 @@ int nq_schnet_backward(const nq_schnet_cfg* cfg, const float* params, const floa
   float* gp = grad_params;
   float* scr = ws + W.scratch;
   const NqGraphView g = sn_view(graph);
-  const int N = g.N, E = g.E, F = cfg->n_atom_basis, R = cfg->n_rbf, H = F / 2, L = cfg->n_interactions;
-  const size_t NF = (size_t)N * F, EF = (size_t)E * F, NH = (size_t)N * H;
+  const int N = g.N, E = g.E, Pn = E / 2, F = cfg->n_atom_basis, R = cfg->n_rbf, H = F / 2, L = cfg->n_interactions;
+  const size_t NF = (size_t)N * F, EF = (size_t)Pn * F, NH = (size_t)N * H;   // EF: stride between the primal and tangent halves of a pair array
   const float* RW = ws + W.RW;
-  const float* TD = ws + W.TD;
+  const float* TD = ws + W.TDP;                                              // tangent distances per pair
+  const int* PAIR_OF = reinterpret_cast<const int*>(ws + W.PAIR_OF);
 
   // ---- tangent forward along pos_dot = -dL/dF ---------------------------------------------------------------------------
   if (grad_forces) NQ_TRY(nq_negate(st, grad_forces, ws + W.pos_dot, 3L * N));
   else NQ_HIP(hipMemsetAsync(ws + W.pos_dot, 0, 3 * (size_t)N * sizeof(float), st));
   NQ_TRY(nq_geom_tan(st, g, graph->dst, ws + W.pos_dot, ws + W.TD, nullptr));
+  hipLaunchKernelGGL(k_sn_gather_f, sn_grid1d(Pn, 256), dim3(256), 0, st, ws + W.TD, reinterpret_cast<const int*>(ws + W.PAIR_SLOT), Pn, ws + W.TDP);
+  NQ_LAUNCH_CHECK();
   NQ_HIP(hipMemsetAsync(ws + W.X[0] + NF, 0, NF * sizeof(float), st));
   for (int l = 0; l < L; ++l) {
     const SnLayerW& y = W.lay[l]; const SnLayerP& p = P.lay[l];
-    NQ_TRY(sn_filter1(st, RW, ws + y.W1T, params + p.b1, TD, ws + y.A1 + EF, E, F, R, true));
-    NQ_TRY(nq_gemm_nt(st, ws + y.A1 + EF, params + p.W2, ws + y.H2 + EF, nullptr, nullptr, E, F, F, F, F, F, "sn:W2"));
+    NQ_TRY(sn_filter1(st, RW, ws + y.W1T, params + p.b1, TD, ws + y.A1 + EF, Pn, F, R, true));
+    NQ_TRY(nq_gemm_nt(st, ws + y.A1 + EF, params + p.W2, ws + y.H2 + EF, nullptr, nullptr, Pn, F, F, F, F, F, "sn:W2"));
     NQ_TRY(nq_gemm_nt(st, ws + W.X[l] + NF, params + p.Win, ws + y.Y + NF, nullptr, nullptr, N, F, F, F, F, F, "sn:in2f"));
-    NQ_TRY(sn_conv(st, g, F, RW, TD, ws + y.Y + NF, ws + y.Y, ws + y.H2, ws + y.H2 + EF, ws + y.M + NF, nullptr, true, "sn_conv_tan"));
+    NQ_TRY(sn_conv(st, g, F, PAIR_OF, RW, TD, ws + y.Y + NF, ws + y.Y, ws + y.H2, ws + y.H2 + EF, ws + y.M + NF, nullptr, true, "sn_conv_tan"));
     NQ_TRY(nq_gemm_nt(st, ws + y.M + NF, params + p.Wo1, ws + y.T1 + NF, nullptr, nullptr, N, F, F, F, F, F, "sn:f2out0"));
     NQ_TRY(sn_ssp_tan(st, ws + y.T1, ws + y.T1 + NF, ws + y.U + NF, (long)NF));
     NQ_TRY(nq_gemm_nt(st, ws + y.U + NF, params + p.Wo2, ws + W.V, nullptr, nullptr, N, F, F, F, F, F, "sn:f2out1"));
@@ -611,14 +656,14 @@ int nq_schnet_backward(const nq_schnet_cfg* cfg, const float* params, const floa
     NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.M, gp + p.Wo1, 2L * N, F, F, F, F, scr, "sn:f2out0", gp + p.bo1, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + p.Wo1, ws + W.GM, 2 * N, F, F, F, F, F, 0, "sn:f2out0"));
     // continuous-filter convolution
-    NQ_TRY(sn_edge_rev(st, g, F, RW, TD, ws + W.GM, ws + W.GM + NF, ws + y.Y, ws + y.Y + NF, nullptr, ws + W.GH2, ws + W.GH2 + EF, nullptr, true));
-    NQ_TRY(sn_conv(st, g, F, RW, TD, ws + W.GM, ws + W.GM + NF, ws + y.H2, ws + y.H2 + EF, ws + W.GY, ws + W.GY + NF, true, "sn_conv_dual"));
+    NQ_TRY(sn_pair_rev(st, g, F, RW, TD, ws + W.GM, ws + W.GM + NF, ws + y.Y, ws + y.Y + NF, nullptr, ws + W.GH2, ws + W.GH2 + EF, nullptr, true));
+    NQ_TRY(sn_conv(st, g, F, PAIR_OF, RW, TD, ws + W.GM, ws + W.GM + NF, ws + y.H2, ws + y.H2 + EF, ws + W.GY, ws + W.GY + NF, true, "sn_conv_dual"));
     // filter network
-    NQ_TRY(nq_gemm_tn(st, ws + W.GH2, ws + y.A1, gp + p.W2, 2L * E, F, F, F, F, scr, "sn:W2", gp + p.b2, E));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH2, params + p.W2, ws + W.GA1, 2 * E, F, F, F, F, F, 0, "sn:W2"));
-    NQ_TRY(sn_filter1_rev(st, RW, ws + y.W1T, params + p.b1, TD, ws + W.GA1, ws + W.GA1 + EF, nullptr, E, F, R, true));
-    NQ_TRY(nq_gwr_sorted(st, ws + W.GA1, ws + W.GA1 + EF, RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + p.W1, scr, 1));
-    NQ_TRY(nq_colsum(st, ws + W.GA1, E, F, F, gp + p.b1, scr));
+    NQ_TRY(nq_gemm_tn(st, ws + W.GH2, ws + y.A1, gp + p.W2, 2L * Pn, F, F, F, F, scr, "sn:W2", gp + p.b2, Pn));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH2, params + p.W2, ws + W.GA1, 2 * Pn, F, F, F, F, F, 0, "sn:W2"));
+    NQ_TRY(sn_filter1_rev(st, RW, ws + y.W1T, params + p.b1, TD, ws + W.GA1, ws + W.GA1 + EF, nullptr, Pn, F, R, true));
+    NQ_TRY(nq_gwr_sorted(st, ws + W.GA1, ws + W.GA1 + EF, RW, reinterpret_cast<const int*>(ws + W.ORDER), Pn, F, R, gp + p.W1, scr, 1));
+    NQ_TRY(nq_colsum(st, ws + W.GA1, Pn, F, F, gp + p.b1, scr));
     // in2f and the residual stream
     NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + W.X[l], gp + p.Win, 2L * N, F, F, F, F, scr, "sn:in2f"));
     NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + p.Win, ws + W.GX, 2 * N, F, F, F, F, F, 1, "sn:in2f"));

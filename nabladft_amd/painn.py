@@ -84,6 +84,7 @@ def build_neighbor_list(pos: torch.Tensor, batch: torch.Tensor, z: Optional[torc
     g.mol_ptr, g.row_ptr, g.col, g.dst = mol_ptr.data_ptr(), row_ptr.data_ptr(), col.data_ptr(), dst.data_ptr()
     g.rev, g.geom, g.atom_mol = rev.data_ptr(), geom.data_ptr(), atom_mol.data_ptr()
     g.z = z32.data_ptr() if z32 is not None else None
+    g.lowptr = lowptr.data_ptr()
     nl.c = g
     return nl
 
