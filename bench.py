@@ -328,6 +328,32 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk(args.model)
 
+    host_feed = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # PCIe-inclusive rate: the same steps fed from a pinned host arena through the overlapped loader (nabladft_amd/data.py);
+        # reported next to `value`, never as `value` (inputs of the timed region above are HBM-resident)
+        from nabladft_amd import data as nqdata
+        hb = [b.to("cpu") for b in batches]
+        arena = nqdata.ConformerArena(torch.cat([b.pos for b in hb]), torch.cat([b.z for b in hb]), torch.cat([b.y for b in hb]),
+                                      torch.cat([b.forces for b in hb]),
+                                      torch.cat([torch.zeros(1, dtype=torch.long)] + [b.ptr[1:] + sum(int(x.ptr[-1]) for x in hb[:i]) for i, b in enumerate(hb)]))
+        loader = nqdata.ArenaLoader(arena, args.batch, dev, shuffle=True, seed=1)
+        done = 0
+        for bt in loader:                      # warm-up epoch (pins the arena, sizes the staging buffers)
+            step(bt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while done < args.steps:
+            for bt in loader:
+                step(bt)
+                done += 1
+                if done >= args.steps:
+                    break
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t0
+        host_feed = {"value": args.batch * done / dth, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dth / done,
+                     "what": "same step, batches collated from a pinned host arena and copied on a side stream (PCIe-inclusive)"}
+
     other, kind2 = None, None
     if rank == 0 and world == 1 and not args.no_roofline:
         # the sibling PaiNN configuration through the same kernels (reported, not `value`)
@@ -361,6 +387,7 @@ def main():
             "cpu_baseline": cpu,
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
+            "host_feed": host_feed,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},

@@ -16,6 +16,11 @@ test database tests/data/raw/test_database.db (geometry blobs only).  Outputs wr
                          empty-neighbour molecules
   real_conformers.npz    numbers/positions of the first 16 conformers of the test DB (data file
                          held by the reference's tests) for real-geometry runs on the GPU box
+  energy_db_30.db        the first 30 rows of that data file, blobs verbatim, same `systems` table (ASE sqlite format): fixture
+                         for the database reader (nabladft_amd/data.py); energy_db_30.npz = the arrays the reference's
+                         PyGNablaDFT.process would build from it (decoded here with struct/json, no ase), cross-checked against
+                         the reference tests' known answers (tests/dataset/test_pyg_datasets.py:21-28: 40 atoms in sample 0,
+                         610 atoms in samples 15:30)
 """
 import os
 import sqlite3
@@ -42,6 +47,39 @@ def read_conformers(n):
         pp = np.frombuffer(pb, dtype=np.float64).reshape(-1, 3)
         pos.append(pp), z.append(zz), batch.append(np.full(len(zz), m))
     return (np.concatenate(pos).astype(np.float32), np.concatenate(z), np.concatenate(batch).astype(np.int64))
+
+
+def write_db_fixture(n):
+    import json
+    import struct
+    src = sqlite3.connect(f"file:{DB}?mode=ro", uri=True)
+    (create_sql,) = src.execute("select sql from sqlite_master where type='table' and name='systems'").fetchone()
+    rows = src.execute("select * from systems order by id limit ?", (n,)).fetchall()
+    cols = [d[0] for d in src.execute("select * from systems limit 1").description]
+    out = os.path.join(OUT, "energy_db_30.db")
+    if os.path.exists(out):
+        os.remove(out)
+    dst = sqlite3.connect(out)
+    dst.execute(create_sql)
+    dst.executemany(f"insert into systems values ({','.join('?' * len(cols))})", rows)
+    dst.commit()
+    dst.execute("vacuum")
+    dst.close()
+    pos, z, y, f, sizes = [], [], [], [], []
+    ci = {c: i for i, c in enumerate(cols)}
+    for r in rows:
+        numbers, positions, blob = r[ci["numbers"]], r[ci["positions"]], r[ci["data"]]
+        zz = np.frombuffer(numbers, dtype=np.int32)
+        pp = np.frombuffer(positions, dtype=np.float64).reshape(-1, 3)
+        (off,) = struct.unpack_from("<q", blob, 0)
+        doc = json.loads(blob[off:])
+        shape, dtype, offset = doc["forces"]["__ndarray__"]
+        ff = np.frombuffer(blob, dtype=dtype, count=int(np.prod(shape)), offset=offset).reshape(shape)
+        pos.append(pp.astype(np.float32)), z.append(zz.astype(np.int64)), f.append(ff.astype(np.float32))
+        y.append(np.float32(doc["energy"][0])), sizes.append(len(zz))
+    assert sizes[0] == 40 and sum(sizes[15:30]) == 610      # the reference's own known answers for this file
+    np.savez_compressed(os.path.join(OUT, "energy_db_30.npz"), pos=np.concatenate(pos), z=np.concatenate(z), y=np.array(y, dtype=np.float32),
+                        forces=np.concatenate(f), ptr=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64))
 
 
 def build_reference_model(ref, cfg, params):
@@ -103,6 +141,9 @@ def main():
     # ---- data file held by the reference tests ------------------------------------------------
     pos16, z16, b16 = read_conformers(16)
     np.savez_compressed(os.path.join(OUT, "real_conformers.npz"), pos=pos16, z=z16, batch=b16)
+    write_db_fixture(30)
+    if os.environ.get("NQ_GOLDEN_ONLY") == "db":
+        return
 
     # ---- full config on 4 real conformers -------------------------------------------------------
     cfg = R.PaiNNConfig()

@@ -1,0 +1,88 @@
+"""CPU: the step before the hot path: ASE-sqlite energy database -> packed arena -> batches.
+Fixture: tests/golden/energy_db_30.db = 30 verbatim rows of the data file the reference's dataset tests use, with the reference
+tests' own known answers (tests/dataset/test_pyg_datasets.py:13-28) and the arrays PyGNablaDFT.process would build."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nabladft_amd import data as D
+from tests.helpers import GOLDEN
+
+DB = os.path.join(GOLDEN, "energy_db_30.db")
+
+
+def test_energy_database_reader_known_answers_and_arrays():
+    arena = D.read_energy_database(DB)
+    fx = np.load(os.path.join(GOLDEN, "energy_db_30.npz"))
+    assert len(arena) == 30
+    # the reference's own assertions on this file: sample 0 and the slice 15:30
+    b0 = arena.batch([0])
+    assert b0.y.shape == (1,) and b0.z.shape == (40,) and b0.pos.shape == b0.forces.shape == (40, 3)
+    assert b0.z.dtype == torch.long and b0.pos.dtype == b0.forces.dtype == b0.y.dtype == torch.float32
+    bs = arena.batch(range(15, 30))
+    assert bs.y.shape == (15,) and bs.pos.shape == bs.forces.shape == (610, 3) and bs.z.shape == (610,)
+    for k in ("pos", "z", "y", "forces", "ptr"):
+        assert np.array_equal(getattr(arena, k).numpy(), fx[k]), k
+    sub = D.read_energy_database(DB, indices=[3, 7])
+    assert torch.equal(sub.pos, arena.batch([3, 7]).pos)
+    with pytest.raises(sqlite3_error()):
+        D.read_energy_database(os.path.join(GOLDEN, "does_not_exist.db"))
+
+
+def sqlite3_error():
+    import sqlite3
+    return sqlite3.OperationalError
+
+
+def test_arena_batch_equals_naive_collate_and_staging():
+    arena = D.read_energy_database(DB)
+    sel = [5, 0, 29, 12, 12]
+    b = arena.batch(sel)
+    pos = torch.cat([arena.pos[arena.ptr[i]:arena.ptr[i + 1]] for i in sel])
+    z = torch.cat([arena.z[arena.ptr[i]:arena.ptr[i + 1]] for i in sel])
+    f = torch.cat([arena.forces[arena.ptr[i]:arena.ptr[i + 1]] for i in sel])
+    batch = torch.cat([torch.full((int(arena.sizes[i]),), m) for m, i in enumerate(sel)])
+    assert torch.equal(b.pos, pos) and torch.equal(b.z, z) and torch.equal(b.forces, f) and torch.equal(b.batch, batch)
+    assert torch.equal(b.y, arena.y[sel]) and torch.equal(b.ptr, torch.tensor([0] + list(np.cumsum([int(arena.sizes[i]) for i in sel]))))
+    st = D._Staging(pin=False)
+    b2 = arena.batch(sel, out=st)
+    for k in ("pos", "z", "batch", "y", "forces", "ptr"):
+        assert torch.equal(getattr(b2, k), getattr(b, k)), k
+    b3 = arena.batch([1], out=st)                       # staging is reused (grow-only)
+    assert b3.pos.shape[0] == int(arena.sizes[1]) and b3.pos.data_ptr() == st.pos.data_ptr()
+
+
+def test_epoch_plan_covers_split_and_balances_ranks():
+    arena = D.read_energy_database(DB)
+    for world in (1, 2, 4):
+        seen = []
+        per_rank_steps = set()
+        for rank in range(world):
+            plan = D.epoch_plan(arena.sizes, 4, True, 7, 0, rank, world)
+            per_rank_steps.add(len(plan))
+            seen += [int(i) for s in plan for i in s]
+        assert len(per_rank_steps) == 1                                   # same number of steps on every rank (collective safety)
+        assert len(seen) == len(set(seen))                                # disjoint
+        assert len(seen) >= 30 - 30 % world - (4 * world - 1) or len(seen) == 30
+    p0 = D.epoch_plan(arena.sizes, 8, True, 7, 0)
+    p1 = D.epoch_plan(arena.sizes, 8, True, 7, 1)
+    assert sorted(int(i) for s in p0 for i in s) == list(range(30)) and any(not torch.equal(a, b) for a, b in zip(p0, p1))
+    # cost balance at world 2: |cost_0 - cost_1| is at most one largest molecule
+    a = D.epoch_plan(arena.sizes, 15, False, 0, 0, 0, 2)[0]
+    b = D.epoch_plan(arena.sizes, 15, False, 0, 0, 1, 2)[0]
+    ca, cb = (arena.sizes[a] ** 2).sum(), (arena.sizes[b] ** 2).sum()
+    assert abs(int(ca) - int(cb)) <= int(arena.sizes.max()) ** 2
+
+
+def test_loader_on_cpu_yields_the_plan():
+    arena = D.read_energy_database(DB)
+    ld = D.ArenaLoader(arena, 7, "cpu", shuffle=True, seed=3)
+    plan = D.epoch_plan(arena.sizes, 7, True, 3, 0)
+    got = list(ld)
+    assert len(got) == len(plan) == len(ld) == 5
+    for bt, sel in zip(got, plan):
+        ref = arena.batch(sel)
+        assert torch.equal(bt.pos, ref.pos) and torch.equal(bt.y, ref.y) and torch.equal(bt.ptr, ref.ptr)
+    assert not torch.equal(next(iter(ld)).y, got[0].y)                    # next epoch: new permutation
