@@ -132,6 +132,36 @@ int nq_schnet_forward(const nq_schnet_cfg* cfg, const float* params, const float
 int nq_schnet_backward(const nq_schnet_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                        size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
 
+/* ---- Hamiltonian block assembly (QHNet.build_final_matrix, qhnet/qhnet.py:293-321; + H + H^T, qhnet.py:237; HamiltonianLoss,
+ *      qhnet/loss.py:9-16).  Packed result layout: molecule after molecule, M_b x M_b row-major, M_b = orbitals of molecule b;
+ *      pack_ptr[b] = sum_{b' < b} M_b'^2, mol_orb_ptr[b] = sum_{b' < b} M_b'.  All index arrays are device pointers. ------------- */
+/* Tables for one batch: orb_atom / orb_slot [sum M_b] (global orbital -> atom, slot of the padded S x S block = mask[Z][t], the table
+ * of QHNet._get_mask, qhnet.py:323-342), look [sum_b n_b^2] (ordered atom pair -> index into the pair-block array; e_dst = row 0 and
+ * e_src = row 1 of data.full_edge_index, qhnet.py:296).  orb_ptr [N+1]: prefix of mask_count[z]; pair_base [B]: prefix of n_b^2.
+ * err_flag (device int32) becomes non-zero if a pair joins two molecules (1) or, later, a needed pair is missing (2). */
+int nq_hblock_tables(const int32_t* z, const int32_t* atom_mol, const int32_t* mol_ptr, int32_t N, int32_t B, const int64_t* orb_ptr,
+                     const int64_t* pair_base, const int64_t* e_dst, const int64_t* e_src, int64_t P, const int32_t* mask_table,
+                     const int32_t* mask_count, int32_t S, int32_t* orb_atom, int32_t* orb_slot, int32_t* look, int64_t look_count,
+                     int32_t* err_flag, void* stream);
+/* out_packed[total]: block (dst rows, src columns) = diag[atom] or nondiag[pair(dst, src)] on the atoms' orbital slots; symmetrize != 0
+ * adds the transposed element (H + H^T). */
+int nq_hblock_assemble(const float* diag, const float* nondiag, const int32_t* mol_ptr, const int64_t* pair_base, const int64_t* pack_ptr,
+                       const int64_t* mol_orb_ptr, const int32_t* orb_atom, const int32_t* orb_slot, const int32_t* look, int32_t B, int32_t S,
+                       int32_t symmetrize, int64_t total, float* out_packed, int32_t* err_flag, void* stream);
+/* Reverse of nq_hblock_assemble: grad_diag [N][S][S], grad_nondiag [P][S][S] (unused slots get 0).  inv_table [Zt][S]: slot -> local
+ * orbital of that atom type or -1. */
+int nq_hblock_assemble_backward(const float* grad_packed, const int32_t* z, const int32_t* atom_mol, const int64_t* orb_ptr, const int64_t* pack_ptr,
+                                const int64_t* mol_orb_ptr, const int32_t* inv_table, const int64_t* e_dst, const int64_t* e_src, int32_t N,
+                                int64_t P, int32_t S, int32_t symmetrize, float* grad_diag, float* grad_nondiag, void* stream);
+/* to_dense != 0: dense [m_total][m_total] = block_diag of the packed blocks (zero elsewhere; what the reference returns);
+ * to_dense == 0: packed <- the diagonal blocks of dense. */
+int nq_hblock_packed_dense(float* packed, float* dense, const int64_t* pack_ptr, const int64_t* mol_orb_ptr, int32_t B, int64_t total, int64_t m_total,
+                           int32_t to_dense, void* stream);
+/* stats3 = {loss = sqrt(sum d^2 / total) + sum|d| / total, rmse, sum|d|} (mask.sum() == total for block-diagonal targets);
+ * grad_packed (nullable) = grad_scale * dloss/dpred.  scratch: 512 doubles. */
+int nq_hamiltonian_loss(const float* pred_packed, const float* target_packed, int64_t total, float grad_scale, float* stats3, float* grad_packed,
+                        double* scratch, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,
