@@ -162,6 +162,22 @@ int nq_hblock_packed_dense(float* packed, float* dense, const int64_t* pack_ptr,
 int nq_hamiltonian_loss(const float* pred_packed, const float* target_packed, int64_t total, float grad_scale, float* stats3, float* grad_packed,
                         double* scratch, void* stream);
 
+/* ---- SO(3) Clebsch-Gordan mixing (PhiSNet PairMixing / SelfMixing contraction: phisnet/nn/modules/pair_mixing.py:47-69,
+ *      self_mixing.py:55-83).  x1 [rows][(order1+1)^2][F], x2 [rows][(order2+1)^2][F], y [rows][(order_out+1)^2][F], orders <= 4,
+ *      components of all orders concatenated (offset l*l + m + l).  path_index_host: HOST int8[65], for every path (l1,l2,L) in the
+ *      loop order of PairMixing.forward over orders 4/4/4 the index of its coefficient among the enabled paths, or -1.
+ *      coeff [rows][n_enabled][F] (coeff_row_stride = n_enabled*F) or [n_enabled][F] shared by all rows (coeff_row_stride = 0).
+ *      keep (nullable) [keep_orders][F]: y_L += keep_L * x1_L.  The kernels use the canonical tensors of nabladft_amd/cg.py; a model's
+ *      own sign convention is folded into coeff by the caller. ------------------------------------------------------------------ */
+int nq_so3_mix_forward(const float* x1, const float* x2, const float* coeff, const float* keep, int64_t rows, int32_t F, int32_t order1,
+                       int32_t order2, int32_t order_out, const int8_t* path_index_host, int64_t coeff_row_stride, int32_t keep_orders, float* y,
+                       void* stream);
+/* grad_coeff_rows [rows][n_enabled][F] and grad_keep_rows [rows][keep_orders][F] are per-row contributions (sum over rows for shared
+ * coefficients); grad_x1 / grad_x2 have the shapes of x1 / x2 (for x1 == x2 add them). */
+int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, const float* keep, const float* grad_y, int64_t rows, int32_t F,
+                        int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int64_t coeff_row_stride,
+                        int32_t keep_orders, float* grad_x1, float* grad_x2, float* grad_coeff_rows, float* grad_keep_rows, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

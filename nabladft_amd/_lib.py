@@ -55,6 +55,8 @@ SYMBOLS = {
     "nq_hblock_assemble_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _P]),
     "nq_hblock_packed_dense": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _I32, _P]),
     "nq_hamiltonian_loss": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
+    "nq_so3_mix_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P]),
+    "nq_so3_mix_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

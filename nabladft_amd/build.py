@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnablaq.so")
-SOURCES = ["graph.hip", "gemm.hip", "edge.hip", "node.hip", "schnet.hip", "hblock.hip", "engine.hip"]
+SOURCES = ["graph.hip", "gemm.hip", "edge.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 
@@ -28,7 +28,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "lanes.h"), os.path.join(os.path.dirname(HERE), "include", "nablaq.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "lanes.h"), os.path.join(CSRC, "cg_l4.inc"), os.path.join(os.path.dirname(HERE), "include", "nablaq.h")]
     objs, procs = [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))

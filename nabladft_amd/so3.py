@@ -1,0 +1,191 @@
+"""PhiSNet's SO(3) mixing modules on MI355X: same constructors, parameter names and list-of-orders
+call convention as
+  nablaDFT.phisnet.nn.modules.pair_mixing.PairMixing   (pair_mixing.py:10-69)
+  nablaDFT.phisnet.nn.modules.self_mixing.SelfMixing   (self_mixing.py:10-83)
+so they drop into InteractionBlock / ResidualBlock unchanged (state_dict compatible).  The Clebsch-Gordan contraction runs in one
+register-resident kernel per call (csrc/so3.hip), the distance-dependent coefficients of PairMixing in one MFMA GEMM over all paths.
+``clebsch_gordan`` is the model's own provider (``ClebschGordan()`` module or any callable (l1, l2, L) -> tensor); only its per-path
+signs are used -- the values are checked against tensors computed from scratch (nabladft_amd/cg.py).  GPU only, orders <= 4.
+"""
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, cg
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T through the engine's fp32 MFMA GEMMs (nq_linear_*)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        lib = _lib.load()
+        x = x.to(torch.float32).contiguous()
+        W = W.to(torch.float32).contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(y), None, M, N, K, _lib.stream_ptr()))
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        gx = torch.empty_like(x)
+        _lib.check(lib.nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(gx), M, N, K, 0, _lib.stream_ptr()))
+        scr = torch.empty(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, device=x.device, dtype=torch.float32)
+        gW = torch.empty_like(W)
+        _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
+        return gx, gW
+
+
+class _MixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, coeff, keep, spec):
+        lib = _lib.load()
+        o1, o2, oy, pidx, per_row, keep_orders, same = spec
+        rows, _, F = x1.shape
+        y = torch.empty(rows, (oy + 1) ** 2, F, device=x1.device, dtype=torch.float32)
+        stride = coeff.shape[-2] * F if per_row else 0
+        _lib.check(lib.nq_so3_mix_forward(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(coeff), _lib.ptr(keep), rows, F, o1, o2, oy, pidx, stride, keep_orders,
+                                          _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(x1, x2, coeff, keep if keep is not None else x1.new_zeros(0))
+        ctx.spec = spec
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x1, x2, coeff, keep = ctx.saved_tensors
+        o1, o2, oy, pidx, per_row, keep_orders, same = ctx.spec
+        keep = keep if keep.numel() else None
+        rows, _, F = x1.shape
+        gy = gy.to(torch.float32).contiguous()
+        n_en = coeff.shape[-2]
+        gx1, gx2 = torch.empty_like(x1), torch.empty_like(x2)
+        gc_rows = torch.empty(rows, n_en, F, device=x1.device, dtype=torch.float32)
+        gk_rows = torch.empty(rows, keep_orders, F, device=x1.device, dtype=torch.float32) if keep is not None else None
+        stride = n_en * F if per_row else 0
+        _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, o1, o2, oy, pidx, stride,
+                                           keep_orders, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_rows), _lib.ptr(gk_rows), _lib.stream_ptr()))
+        gc = gc_rows if per_row else gc_rows.sum(0)
+        gk = None if keep is None else gk_rows.sum(0)
+        return gx1, gx2, gc, gk, None
+
+
+def _pack(xs: List[torch.Tensor], order: int, F: int):
+    lead = xs[0].shape[:-2]
+    x = torch.cat([xs[l].reshape(-1, 2 * l + 1, F) for l in range(order + 1)], dim=1).to(torch.float32).contiguous()
+    return x, lead
+
+
+def _unpack(y: torch.Tensor, order: int, lead, F: int):
+    return [y[:, L * L:(L + 1) * (L + 1), :].reshape(*lead, 2 * L + 1, F) for L in range(order + 1)]
+
+
+def _path_index(enabled):
+    arr = (C.c_int8 * len(cg.ALL_PATHS))(*([-1] * len(cg.ALL_PATHS)))
+    for i, p in enumerate(enabled):
+        arr[cg.PATH_ID[p]] = i
+    return arr
+
+
+def _signs(clebsch_gordan, which):
+    table = lambda a, b, c: clebsch_gordan(a, b, c).detach().cpu().numpy()
+    return cg.path_signs(table, which)
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("nabladft_amd.so3 runs on MI355X only (no CPU fallback): move the tensors to cuda")
+
+
+class PairMixing(nn.Module):
+    def __init__(self, order_in1, order_in2, order_out, num_basis_functions, num_features, clebsch_gordan):
+        super().__init__()
+        if max(order_in1, order_in2, order_out) > cg.LMAX:
+            raise NotImplementedError(f"nabladft_amd.so3: orders up to {cg.LMAX} are built")
+        self.order_in1, self.order_in2, self.order_out = order_in1, order_in2, order_out
+        self.num_basis_functions, self.num_features = num_basis_functions, num_features
+        self.clebsch_gordan = clebsch_gordan
+        self._paths = cg.paths(order_in1, order_in2, order_out)
+        for (l1, l2, L) in self._paths:
+            self.add_module("coeff_{}_{}_{}".format(l1, l2, L), nn.Linear(num_basis_functions, num_features, bias=False))
+        self.reset_parameters()
+        self.register_buffer("_sign", torch.tensor(_signs(clebsch_gordan, self._paths), dtype=torch.float32), persistent=False)
+        self._pidx = _path_index(self._paths)
+
+    def reset_parameters(self):
+        for (l1, l2, L) in self._paths:
+            nn.init.orthogonal_(self.coeff(l1, l2, L).weight)
+
+    def coeff(self, l1, l2, L):
+        return getattr(self, "coeff_{}_{}_{}".format(l1, l2, L))
+
+    def forward(self, x1s, x2s, rbf):
+        _require_gpu(rbf)
+        F = self.num_features
+        x1, lead = _pack(x1s, self.order_in1, F)
+        x2, _ = _pack(x2s, self.order_in2, F)
+        rows = x1.shape[0]
+        rbf2 = rbf.expand(*lead, 1, self.num_basis_functions).reshape(rows, self.num_basis_functions)
+        W = torch.cat([self.coeff(*p).weight * s for p, s in zip(self._paths, self._sign)], dim=0)       # [n_paths * F, K], CG sign convention folded in
+        coeff = _LinearFn.apply(rbf2, W).view(rows, len(self._paths), F)
+        y = _MixFn.apply(x1, x2, coeff, None, (self.order_in1, self.order_in2, self.order_out, self._pidx, True, 0, False))
+        return _unpack(y, self.order_out, lead, F)
+
+
+class SelfMixing(nn.Module):
+    def __init__(self, order_in, order_out, num_features, clebsch_gordan):
+        super().__init__()
+        if max(order_in, order_out) > cg.LMAX:
+            raise NotImplementedError(f"nabladft_amd.so3: orders up to {cg.LMAX} are built")
+        self.order_in, self.order_out, self.num_features = order_in, order_out, num_features
+        self.clebsch_gordan = clebsch_gordan
+        self._paths = [(l1, l2, L) for l1 in range(order_in + 1) for l2 in range(l1 + 1, order_in + 1)
+                       for L in range(abs(l1 - l2), min(l1 + l2, order_out) + 1)]
+        for (l1, l2, L) in self._paths:
+            self.register_parameter("mixcoeff_{}_{}_{}".format(l1, l2, L), nn.Parameter(torch.Tensor(num_features)))
+        self._keep = min(order_in, order_out) + 1
+        for L in range(self._keep):
+            self.register_parameter("keepcoeff_{}".format(L), nn.Parameter(torch.Tensor(num_features)))
+        self.reset_parameters()
+        self.register_buffer("_sign", torch.tensor(_signs(clebsch_gordan, self._paths), dtype=torch.float32).view(-1, 1), persistent=False)
+        self._pidx = _path_index(self._paths)
+
+    def reset_parameters(self):
+        count = [0 for _ in range(self.order_out + 1)]
+        for L in range(self._keep):
+            count[L] += 1
+        for (_, _, L) in self._paths:
+            count[L] += 1
+        for L in range(self._keep):
+            nn.init.uniform_(self.keepcoeff(L), a=-np.sqrt(3 / count[L]), b=np.sqrt(3 / count[L]))
+        for (l1, l2, L) in self._paths:
+            nn.init.uniform_(self.mixcoeff(l1, l2, L), a=-np.sqrt(3 / count[L]), b=np.sqrt(3 / count[L]))
+
+    def keepcoeff(self, L):
+        return getattr(self, "keepcoeff_{}".format(L))
+
+    def mixcoeff(self, l1, l2, L):
+        return getattr(self, "mixcoeff_{}_{}_{}".format(l1, l2, L))
+
+    def forward(self, xs):
+        _require_gpu(xs[0])
+        F = self.num_features
+        x, lead = _pack(xs, self.order_in, F)
+        if self._paths:
+            coeff = torch.stack([self.mixcoeff(*p) for p in self._paths]) * self._sign                 # [n_paths, F]
+        else:
+            coeff = x.new_zeros(1, F)
+        keep = torch.stack([self.keepcoeff(L) for L in range(self._keep)]).contiguous()
+        y = _MixFn.apply(x, x, coeff.contiguous(), keep, (self.order_in, self.order_in, self.order_out, self._pidx, False, self._keep, True))
+        return _unpack(y, self.order_out, lead, F)

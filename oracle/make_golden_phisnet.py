@@ -1,0 +1,70 @@
+"""TEST INFRASTRUCTURE (container-only): golden vectors for the SO(3) mixing modules, produced by the REAL reference modules
+nablaDFT/phisnet/nn/modules/{pair_mixing,self_mixing,clebsch_gordan}.py (pure torch; loaded file by file, the package __init__ chain
+is not executed).  Writes tests/golden/phisnet_mixing.npz (inputs, seeded parameters, outputs, gradients) and
+tests/golden/phisnet_cg_l4.npz (the reference's Clebsch-Gordan table restricted to l <= 4: data held by the reference's module).
+    python oracle/make_golden_phisnet.py"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+MOD = "/root/reference/nablaDFT/phisnet/nn/modules"
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location("ref_phisnet_" + name, os.path.join(MOD, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    torch.manual_seed(0)
+    CG = _load("clebsch_gordan").ClebschGordan()
+    PairMixing = _load("pair_mixing").PairMixing
+    SelfMixing = _load("self_mixing").SelfMixing
+    raw = np.load(os.path.join(MOD, "clebsch_gordan_coefficients_L10.npz"), allow_pickle=True)["cg"][()]
+    np.savez_compressed(os.path.join(OUT, "phisnet_cg_l4.npz"), **{"cg_%d_%d_%d" % k: v for k, v in raw.items() if max(k) <= 4})
+    fx = {}
+    rng = np.random.Generator(np.random.PCG64(3))
+    for tag, (o1, o2, oy, K, F, rows) in {"pm222": (2, 2, 2, 8, 64, 10), "pm444": (4, 4, 4, 16, 64, 6), "pm214": (2, 1, 3, 8, 64, 5)}.items():
+        m = PairMixing(o1, o2, oy, K, F, CG)
+        x1s = [torch.tensor(rng.normal(size=(1, rows, 2 * l + 1, F)).astype(np.float32), requires_grad=True) for l in range(o1 + 1)]
+        x2s = [torch.tensor(rng.normal(size=(1, rows, 2 * l + 1, F)).astype(np.float32), requires_grad=True) for l in range(o2 + 1)]
+        rbf = torch.tensor(rng.normal(size=(1, rows, 1, K)).astype(np.float32), requires_grad=True)
+        ys = m(x1s, x2s, rbf)
+        ws = [torch.tensor(rng.normal(size=tuple(y.shape)).astype(np.float32)) for y in ys]
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        fx[tag + ":cfg"] = np.array([o1, o2, oy, K, F, rows])
+        for l, t in enumerate(x1s):
+            fx[f"{tag}:x1_{l}"], fx[f"{tag}:gx1_{l}"] = t.detach().numpy(), t.grad.numpy()
+        for l, t in enumerate(x2s):
+            fx[f"{tag}:x2_{l}"], fx[f"{tag}:gx2_{l}"] = t.detach().numpy(), t.grad.numpy()
+        fx[f"{tag}:rbf"], fx[f"{tag}:grbf"] = rbf.detach().numpy(), rbf.grad.numpy()
+        for L, (y, w) in enumerate(zip(ys, ws)):
+            fx[f"{tag}:y_{L}"], fx[f"{tag}:w_{L}"] = y.detach().numpy(), w.numpy()
+        for n, p in m.named_parameters():
+            fx[f"{tag}:p:{n}"], fx[f"{tag}:g:{n}"] = p.detach().numpy(), p.grad.numpy()
+    for tag, (oi, oo, F, rows) in {"sm44": (4, 4, 64, 7), "sm23": (2, 3, 64, 5), "sm31": (3, 1, 64, 4)}.items():
+        m = SelfMixing(oi, oo, F, CG)
+        xs = [torch.tensor(rng.normal(size=(1, rows, 2 * l + 1, F)).astype(np.float32), requires_grad=True) for l in range(oi + 1)]
+        ys = m(xs)
+        ws = [torch.tensor(rng.normal(size=tuple(y.shape)).astype(np.float32)) for y in ys]
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        fx[tag + ":cfg"] = np.array([oi, oo, F, rows])
+        for l, t in enumerate(xs):
+            fx[f"{tag}:x_{l}"], fx[f"{tag}:gx_{l}"] = t.detach().numpy(), t.grad.numpy()
+        for L, (y, w) in enumerate(zip(ys, ws)):
+            fx[f"{tag}:y_{L}"], fx[f"{tag}:w_{L}"] = y.detach().numpy(), w.numpy()
+        for n, p in m.named_parameters():
+            fx[f"{tag}:p:{n}"], fx[f"{tag}:g:{n}"] = p.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "phisnet_mixing.npz"), **fx)
+    print("phisnet_mixing.npz:", len(fx), "arrays")
+
+
+if __name__ == "__main__":
+    main()
