@@ -178,6 +178,17 @@ int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, co
                         int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int64_t coeff_row_stride,
                         int32_t keep_orders, float* grad_x1, float* grad_x2, float* grad_coeff_rows, float* grad_keep_rows, void* stream);
 
+/* ---- geometry bases of the Hamiltonian models --------------------------------------------------------------------------------- */
+/* out [P][(order+1)^2]: real spherical harmonics Y_0..Y_order (order <= 4) of unit vectors [P][3], PhiSNet convention
+ * (phisnet/nn/spherical_harmonics/spherical_harmonics.py:10-25: no 1/sqrt(4 pi), Condon-Shortley, m = -l..l). */
+int nq_sph_harm(const float* unit_vectors, int64_t P, int32_t order, float* out, void* stream);
+/* out [P][K] = cutoff_function(r) * exp(logc_k + n_k x + v_k log(1 - e^x)), x = -alpha r  (ExponentialBernsteinRadialBasisFunctions.forward,
+ * phisnet/nn/modules/exponential_bernstein_radial_basis_functions.py:36-41 == qhnet/layers.py:115-120); alpha = softplus(_alpha). */
+int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n, const float* v, float* out,
+                     void* stream);
+int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
+                                const float* v, float* galpha_rows, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

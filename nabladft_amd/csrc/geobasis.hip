@@ -1,0 +1,112 @@
+// Geometry bases of the Hamiltonian models (SURVEY.md section 8, row a25 and the radial part of a13):
+//   real spherical harmonics Y_0..Y_4 of unit vectors  -- closed forms of phisnet/nn/spherical_harmonics/spherical_harmonics_any_order.py:11-100
+//     (no 1/sqrt(4 pi), Condon-Shortley phase, m = -l..l, Y_1 = sqrt(3) (y, z, x))
+//   exponential Bernstein radial basis with the smooth cutoff  -- phisnet/nn/modules/exponential_bernstein_radial_basis_functions.py:13-41,
+//     qhnet/layers.py:86-120:  rbf_k(r) = fc(r) exp(logC_k + n_k x + v_k log(1 - e^x)),  x = -softplus(_alpha) r,  fc = exp(-r^2 / ((c - r)(c + r)))
+// One thread per output element; both are bandwidth-trivial next to the tensor products they feed.
+#include "common.h"
+#include "../../include/nablaq.h"
+
+__global__ void k_sph_harm(const float* __restrict__ u, long P, int L, float* __restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int nc = (L + 1) * (L + 1);
+  float* o = out + p * nc;
+  const float x = u[3 * p], y = u[3 * p + 1], z = u[3 * p + 2];
+  o[0] = 1.0f;
+  if (L < 1) return;
+  const float s3 = 1.7320508075688772f;
+  o[1] = s3 * y; o[2] = s3 * z; o[3] = s3 * x;
+  if (L < 2) return;
+  const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, yz = y * z, xz = x * z;
+  const float x2my2 = x2 - y2, t3z2m1 = 3.0f * z2 - 1.0f;
+  const float s15 = 3.872983346207417f, s5o2 = 1.118033988749895f, s15o2 = 1.9364916731037085f;
+  o[4] = s15 * xy; o[5] = s15 * yz; o[6] = s5o2 * t3z2m1; o[7] = s15 * xz; o[8] = s15o2 * x2my2;
+  if (L < 3) return;
+  const float xyz = xy * z, t3x2my2 = 3.0f * x2 - y2, x2m3y2 = x2 - 3.0f * y2;
+  const float s70o4 = 2.091650066335189f, s105 = 10.246950765959598f, s42o4 = 1.620185174601965f, s7o2 = 1.3228756555322954f, s105o2 = 5.123475382979799f;
+  const float t5z2 = 5.0f * z2, t5z2m1 = t5z2 - 1.0f;
+  o[9] = s70o4 * y * t3x2my2; o[10] = s105 * xyz; o[11] = s42o4 * y * t5z2m1; o[12] = s7o2 * z * (t5z2 - 3.0f);
+  o[13] = s42o4 * x * t5z2m1; o[14] = s105o2 * z * x2my2; o[15] = s70o4 * x * x2m3y2;
+  if (L < 4) return;
+  const float x4 = x2 * x2, y4 = y2 * y2, x2y2 = x2 * y2;
+  const float a = 8.874119674649425f /* sqrt(35)*3/2 */, b = 18.824850597016705f /* sqrt(70)*9/4 */, c = 3.3541019662496847f /* sqrt(45)/2 */,
+              d = 2.3717082451262845f /* sqrt(10)*3/4 */, e = 1.6770509831248424f /* sqrt(45)/4 */, f = 6.274950199005566f /* sqrt(70)*3/4 */,
+              g = 2.2185299186623562f /* sqrt(35)*3/8 */;
+  const float t7z2 = 7.0f * z2, t7z2m1 = t7z2 - 1.0f, t7z2m3 = t7z2 - 3.0f;
+  o[16] = a * xy * x2my2; o[17] = b * yz * (x2 - y2 / 3.0f); o[18] = c * xy * t7z2m1; o[19] = d * yz * t7z2m3;
+  o[20] = 0.125f * (z2 * (105.0f * z2 - 90.0f) + 9.0f);
+  o[21] = d * xz * t7z2m3; o[22] = e * t7z2m1 * x2my2; o[23] = f * xz * x2m3y2; o[24] = g * (x4 - 6.0f * x2y2 + y4);
+}
+
+// rbf[p][k] and (optionally) the integrand of d/d alpha:  drbf/dalpha = rbf * (-r) * (n_k - v_k e^x / (1 - e^x))
+template <bool GRAD>
+__global__ void k_bernstein_rbf(const float* __restrict__ r, long P, int K, float alpha, float cutoff, const float* __restrict__ logc,
+                                const float* __restrict__ nk, const float* __restrict__ vk, float* __restrict__ out,
+                                const float* __restrict__ gout, float* __restrict__ galpha_rows) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * (GRAD ? 1 : K)) return;
+  if (!GRAD) {
+    const long p = idx / K; const int k = (int)(idx % K);
+    const float rr = r[p];
+    float val = 0.f;
+    if (rr < cutoff) {
+      const float x = -alpha * rr;
+      const float fc = expf(-(rr * rr) / ((cutoff - rr) * (cutoff + rr)));
+      val = fc * expf(logc[k] + nk[k] * x + vk[k] * logf(-expm1f(x)));
+    }
+    out[idx] = val;
+  } else {
+    const long p = idx;
+    const float rr = r[p];
+    float acc = 0.f;
+    if (rr < cutoff) {
+      const float x = -alpha * rr;
+      const float fc = expf(-(rr * rr) / ((cutoff - rr) * (cutoff + rr)));
+      const float om = -expm1f(x);                 // 1 - e^x
+      const float ratio = (1.0f - om) / om;        // e^x / (1 - e^x)
+      const float lg = logf(om);
+      for (int k = 0; k < K; ++k) {
+        const float val = fc * expf(logc[k] + nk[k] * x + vk[k] * lg);
+        acc = fmaf(gout[p * K + k] * val, -rr * (nk[k] - vk[k] * ratio), acc);
+      }
+    }
+    galpha_rows[p] = acc;
+  }
+}
+
+extern "C" {
+
+int nq_sph_harm(const float* unit_vectors, int64_t P, int32_t order, float* out, void* stream) {
+  if (!unit_vectors || !out || order < 0 || order > 4 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument (orders 0..4)");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "sph_harm");
+  if (P > 0) hipLaunchKernelGGL(k_sph_harm, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, unit_vectors, (long)P, order, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n, const float* v, float* out,
+                     void* stream) {
+  if (!r || !logc || !n || !v || !out || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bernstein_rbf");
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
+                                out, nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* galpha_rows[p] = sum_k grad_out[p][k] * d rbf[p][k] / d alpha  (alpha = softplus(_alpha); the caller sums over p and applies sigmoid(_alpha)) */
+int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
+                                const float* v, float* galpha_rows, void* stream) {
+  if (!r || !grad_out || !logc || !n || !v || !galpha_rows || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bernstein_rbf_grad");
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
+                                nullptr, grad_out, galpha_rows);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+}  // extern "C"

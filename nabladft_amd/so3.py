@@ -189,3 +189,76 @@ class SelfMixing(nn.Module):
         keep = torch.stack([self.keepcoeff(L) for L in range(self._keep)]).contiguous()
         y = _MixFn.apply(x, x, coeff.contiguous(), keep, (self.order_in, self.order_in, self.order_out, self._pidx, False, self._keep, True))
         return _unpack(y, self.order_out, lead, F)
+
+
+# ---- geometry bases (radial part of a13) --------------------------------------------------------------------
+def spherical_harmonics(L: int, u: torch.Tensor) -> List[torch.Tensor]:
+    """List over l = 0..L of [..., 2l+1]: same call and conventions as phisnet/nn/spherical_harmonics/spherical_harmonics.py:28-64
+    (unit vectors in, no 1/sqrt(4 pi), Condon-Shortley phase, m = -l..l).  L <= 4 on the GPU path."""
+    _require_gpu(u)
+    if L > cg.LMAX:
+        raise NotImplementedError(f"nabladft_amd.so3.spherical_harmonics: orders up to {cg.LMAX} are built")
+    lib = _lib.load()
+    lead = u.shape[:-1]
+    u2 = u.detach().to(torch.float32).reshape(-1, 3).contiguous()
+    out = torch.empty(u2.shape[0], (L + 1) ** 2, device=u.device, dtype=torch.float32)
+    _lib.check(lib.nq_sph_harm(_lib.ptr(u2), u2.shape[0], L, _lib.ptr(out), _lib.stream_ptr()))
+    return [out[:, l * l:(l + 1) * (l + 1)].reshape(*lead, 2 * l + 1) for l in range(L + 1)]
+
+
+class _BernsteinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, raw_alpha, mod):
+        lib = _lib.load()
+        r2 = r.detach().to(torch.float32).reshape(-1).contiguous()
+        alpha = float(torch.nn.functional.softplus(raw_alpha.detach().double()))
+        K = mod.num_basis_functions
+        out = torch.empty(r2.shape[0], K, device=r.device, dtype=torch.float32)
+        logc, n, v = (t.to(device=r.device, dtype=torch.float32).contiguous() for t in (mod.logc, mod.n, mod.v))
+        _lib.check(lib.nq_bernstein_rbf(_lib.ptr(r2), r2.shape[0], K, alpha, float(mod.cutoff), _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v), _lib.ptr(out),
+                                        _lib.stream_ptr()))
+        ctx.save_for_backward(r2, raw_alpha, logc, n, v)
+        ctx.meta = (alpha, float(mod.cutoff), K, r.shape)
+        return out.view(*r.shape[:-1], K) if r.shape[-1] == 1 else out.view(*r.shape, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        r2, raw_alpha, logc, n, v = ctx.saved_tensors
+        alpha, cutoff, K, _ = ctx.meta
+        g2 = g.to(torch.float32).reshape(-1, K).contiguous()
+        rows = torch.empty(r2.shape[0], device=r2.device, dtype=torch.float32)
+        _lib.check(lib.nq_bernstein_rbf_grad_alpha(_lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, alpha, cutoff, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v),
+                                                   _lib.ptr(rows), _lib.stream_ptr()))
+        g_raw = rows.double().sum() * torch.sigmoid(raw_alpha.detach().double())       # d softplus
+        return None, g_raw.to(raw_alpha.dtype).reshape(raw_alpha.shape), None
+
+
+class ExponentialBernsteinRadialBasisFunctions(nn.Module):
+    """Same constructor, buffers (cutoff, logc, n, v) and parameter (_alpha) as the reference classes of that name
+    (phisnet/nn/modules/exponential_bernstein_radial_basis_functions.py:13-41, qhnet/layers.py:92-120).  forward(r [..., 1]) -> [..., K].
+    Gradient: w.r.t. ``_alpha`` only (distances are inputs of the Hamiltonian models, not differentiated)."""
+
+    def __init__(self, num_basis_functions, cutoff, ini_alpha=0.5, dtype=torch.float32):
+        super().__init__()
+        self.num_basis_functions, self.ini_alpha = num_basis_functions, ini_alpha
+        logfactorial = np.zeros(num_basis_functions)
+        for i in range(2, num_basis_functions):
+            logfactorial[i] = logfactorial[i - 1] + np.log(i)
+        v = np.arange(0, num_basis_functions)
+        n = (num_basis_functions - 1) - v
+        logbinomial = logfactorial[-1] - logfactorial[v] - logfactorial[n]
+        self.register_buffer("cutoff", torch.tensor(cutoff, dtype=dtype))
+        self.register_buffer("logc", torch.tensor(logbinomial, dtype=dtype))
+        self.register_buffer("n", torch.tensor(n, dtype=dtype))
+        self.register_buffer("v", torch.tensor(v, dtype=dtype))
+        self.register_parameter("_alpha", nn.Parameter(torch.tensor(1.0, dtype=dtype)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        x = torch.tensor(float(self.ini_alpha), dtype=torch.float64)
+        nn.init.constant_(self._alpha, float(x + torch.log(-torch.expm1(-x))))          # softplus_inverse (phisnet/nn/functional.py)
+
+    def forward(self, r):
+        _require_gpu(r)
+        return _BernsteinFn.apply(r, self._alpha, self)

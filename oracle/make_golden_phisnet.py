@@ -66,5 +66,53 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--bases" not in sys.argv:
     main()
+
+
+def geometry_bases():
+    """Spherical harmonics and exponential-Bernstein radial bases from the real reference code (PhiSNet: fp64 buffers cast with .float();
+    QHNet's fp32 copy of the same class via oracle/qhnet_import.py)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import types
+    # phisnet/nn/spherical_harmonics is a plain package of two files
+    pkg = types.ModuleType("ref_sh")
+    pkg.__path__ = ["/root/reference/nablaDFT/phisnet/nn/spherical_harmonics"]
+    sys.modules["ref_sh"] = pkg
+    sh = importlib.import_module("ref_sh.spherical_harmonics")
+    fpkg = types.ModuleType("ref_phisnet_nn")
+    fpkg.__path__ = ["/root/reference/nablaDFT/phisnet/nn"]
+    sys.modules["ref_phisnet_nn"] = fpkg
+    mpkg = types.ModuleType("ref_phisnet_nn.modules")
+    mpkg.__path__ = [MOD]
+    sys.modules["ref_phisnet_nn.modules"] = mpkg
+    rbf_mod = importlib.import_module("ref_phisnet_nn.modules.exponential_bernstein_radial_basis_functions")
+    from oracle.qhnet_import import load_qhnet
+    qlayers = sys.modules.get("nablaDFT.qhnet.layers") or (load_qhnet() and sys.modules["nablaDFT.qhnet.layers"])
+    rng = np.random.Generator(np.random.PCG64(17))
+    fx = {}
+    u = rng.normal(size=(37, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    u[0] = [0, 0, 1]
+    ut = torch.tensor(u.astype(np.float32))
+    fx["u"] = ut.numpy()
+    for l, y in enumerate(sh.spherical_harmonics(4, ut)):
+        fx[f"Y_{l}"] = y.numpy()
+    for tag, (cls, K, cutoff, ini) in {"phisnet128": (rbf_mod.ExponentialBernsteinRadialBasisFunctions, 128, 15.0, 0.5),
+                                      "qhnet32": (qlayers.ExponentialBernsteinRadialBasisFunctions, 32, 12.0, 0.5),
+                                      "small": (qlayers.ExponentialBernsteinRadialBasisFunctions, 8, 5.0, 1.3)}.items():
+        m = cls(K, cutoff, ini).float()
+        r = torch.tensor(np.concatenate([rng.uniform(0.3, cutoff * 0.999, size=29), [cutoff * 0.9999, cutoff, cutoff * 1.2]]).astype(np.float32)).view(-1, 1)
+        out = m(r)
+        w = torch.tensor(rng.normal(size=tuple(out.shape)).astype(np.float32))
+        (out * w).sum().backward()
+        fx[f"{tag}:cfg"] = np.array([K, cutoff, ini])
+        fx[f"{tag}:r"], fx[f"{tag}:rbf"], fx[f"{tag}:w"] = r.numpy(), out.detach().numpy(), w.numpy()
+        fx[f"{tag}:g_alpha"], fx[f"{tag}:_alpha"] = m._alpha.grad.numpy(), m._alpha.detach().numpy()
+        fx[f"{tag}:logc"] = m.logc.numpy()
+    np.savez_compressed(os.path.join(OUT, "geometry_bases.npz"), **fx)
+    print("geometry_bases.npz:", len(fx), "arrays")
+
+
+if __name__ == "__main__" and "--bases" in sys.argv:
+    geometry_bases()

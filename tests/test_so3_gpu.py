@@ -77,3 +77,23 @@ def test_pair_mixing_throughput_on_a_phisnet_sized_call():
     flops = rows * F * 2052 * 2 * (1 + 3)          # forward (mul + fma per non-zero) and ~3x that in the reverse kernel
     print(f"PairMixing order 4, {rows} pairs, F={F}, K={K}: fwd+bwd {ms:.2f} ms  (CG contraction ~{flops / ms / 1e9:.1f} TFLOP/s incl. GEMMs and packing)")
     assert all(torch.isfinite(y).all() for y in ys)
+
+
+def test_spherical_harmonics_and_bernstein_rbf_match_reference():
+    """Golden vectors from the real reference code: PhiSNet spherical_harmonics(4, u); ExponentialBernsteinRadialBasisFunctions of PhiSNet
+    (K = 128, cutoff 15) and QHNet (K = 32, cutoff 12), values at / beyond the cutoff included, gradient w.r.t. _alpha."""
+    from nabladft_amd import so3
+    fx = np.load(os.path.join(GOLDEN, "geometry_bases.npz"))
+    ys = so3.spherical_harmonics(4, torch.tensor(fx["u"]).cuda())
+    for l, y in enumerate(ys):
+        assert y.shape == fx[f"Y_{l}"].shape and np.abs(y.cpu().numpy() - fx[f"Y_{l}"]).max() < 5e-6, l
+    for tag in ("phisnet128", "qhnet32", "small"):
+        K, cutoff, ini = fx[f"{tag}:cfg"]
+        m = so3.ExponentialBernsteinRadialBasisFunctions(int(K), float(cutoff), float(ini)).cuda()
+        assert abs(float(m._alpha) - float(fx[f"{tag}:_alpha"])) < 1e-6 and np.allclose(m.logc.cpu().numpy(), fx[f"{tag}:logc"], rtol=1e-6, atol=1e-5)
+        out = m(torch.tensor(fx[f"{tag}:r"]).cuda())
+        assert out.shape == fx[f"{tag}:rbf"].shape
+        assert rel_err(out.detach().cpu().numpy(), fx[f"{tag}:rbf"]) < 2e-5, tag
+        assert float(out[-1].abs().max()) == 0.0 and float(out[-2].abs().max()) == 0.0          # r >= cutoff -> exactly 0
+        (out * torch.tensor(fx[f"{tag}:w"]).cuda()).sum().backward()
+        assert abs(float(m._alpha.grad) - float(fx[f"{tag}:g_alpha"])) < 5e-5 * max(1.0, abs(float(fx[f"{tag}:g_alpha"]))), tag
