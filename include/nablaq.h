@@ -189,6 +189,12 @@ int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cu
 int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
                                 const float* v, float* galpha_rows, void* stream);
 
+/* Learnable feature-wise activations of PhiSNet on [rows][F]: kind 0 = Swish (swish.py:23-24), kind 1 = ShiftedSoftplus
+ * (shifted_softplus.py:26-32).  Backward writes grad_x and per-element partials of dL/dalpha, dL/dbeta ([rows][F], sum over rows). */
+int nq_feature_act(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t F, int32_t kind, float* y, void* stream);
+int nq_feature_act_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t F, int32_t kind,
+                            float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

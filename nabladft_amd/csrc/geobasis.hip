@@ -110,3 +110,63 @@ int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P
 }
 
 }  // extern "C"
+
+// ---- learnable feature-wise activations of PhiSNet (phisnet/nn/modules/swish.py:10-24, shifted_softplus.py:14-32) --------------------------
+//   kind 0: swish  y = alpha_f x sigmoid(beta_f x)          kind 1: ssp  y = alpha_f (softplus(beta_f x) - ln 2) / beta_f   (0.5 alpha x if beta = 0)
+// backward: gx in place of a fresh buffer, and per-row partials of dL/dalpha, dL/dbeta (summed over rows by the caller).
+__device__ __forceinline__ float act_sig(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_softplus(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+template <bool BWD>
+__global__ void k_feature_act(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta, long rows, int F, int kind,
+                              float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, float* __restrict__ ga_rows,
+                              float* __restrict__ gb_rows) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * F) return;
+  const int f = (int)(idx % F);
+  const float xv = x[idx], a = alpha[f], b = beta[f];
+  const float ln2 = 0.69314718055994530942f;
+  if (kind == 0) {
+    const float s = act_sig(b * xv);
+    if (!BWD) { y[idx] = a * xv * s; return; }
+    const float g = gy[idx];
+    gx[idx] = g * a * (s + xv * b * s * (1.0f - s));
+    ga_rows[idx] = g * xv * s;
+    gb_rows[idx] = g * a * xv * xv * s * (1.0f - s);
+  } else {
+    if (b != 0.f) {
+      const float sp = act_softplus(b * xv) - ln2;
+      if (!BWD) { y[idx] = a * sp / b; return; }
+      const float g = gy[idx], s = act_sig(b * xv);
+      gx[idx] = g * a * s;
+      ga_rows[idx] = g * sp / b;
+      gb_rows[idx] = g * a * (xv * s / b - sp / (b * b));
+    } else {
+      if (!BWD) { y[idx] = 0.5f * a * xv; return; }
+      const float g = gy[idx];
+      gx[idx] = g * 0.5f * a; ga_rows[idx] = g * 0.5f * xv; gb_rows[idx] = g * a * xv * xv * 0.125f;   // limit beta -> 0 of the derivative
+    }
+  }
+}
+
+extern "C" {
+int nq_feature_act(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t F, int32_t kind, float* y, void* stream) {
+  if (!x || !alpha || !beta || !y || F <= 0 || rows < 0 || kind < 0 || kind > 1) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "feature_act");
+  if (rows > 0) hipLaunchKernelGGL((k_feature_act<false>), dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, x, alpha, beta, (long)rows, F, kind, y,
+                                   nullptr, nullptr, nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_feature_act_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t F, int32_t kind,
+                            float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream) {
+  if (!x || !alpha || !beta || !grad_y || !grad_x || !grad_alpha_rows || !grad_beta_rows || F <= 0 || rows < 0 || kind < 0 || kind > 1)
+    return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "feature_act_bwd");
+  if (rows > 0) hipLaunchKernelGGL((k_feature_act<true>), dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, x, alpha, beta, (long)rows, F, kind, nullptr,
+                                   grad_y, grad_x, grad_alpha_rows, grad_beta_rows);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+}  // extern "C"

@@ -66,7 +66,7 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__" and "--bases" not in sys.argv:
+if __name__ == "__main__" and "--bases" not in sys.argv and "--blocks" not in sys.argv:
     main()
 
 
@@ -116,3 +116,46 @@ def geometry_bases():
 
 if __name__ == "__main__" and "--bases" in sys.argv:
     geometry_bases()
+
+
+def blocks():
+    """ModularBlock (residual stacks + InteractionBlock) of the real reference on a small full graph, seeded non-trivial parameters (the
+    reference zero-initialises the second linear of every residual block, which would hide half of the graph), outputs + all gradients."""
+    mpkg = __import__("types").ModuleType("ref_pm")
+    mpkg.__path__ = [MOD]
+    sys.modules["ref_pm"] = mpkg
+    mb = importlib.import_module("ref_pm.modular_block")
+    CG = importlib.import_module("ref_pm.clebsch_gordan").ClebschGordan().float()
+    torch.manual_seed(1)
+    rng = np.random.Generator(np.random.PCG64(23))
+    fx = {}
+    for tag, (order, F, K, N, act) in {"mb2": (2, 32, 8, 5, "swish"), "mb1ssp": (1, 32, 6, 4, "ssp")}.items():
+        m = mb.ModularBlock(order, F, K, 1, 1, 1, 1, 1, 1, CG, True, act)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.abs().max() == 0 or n.endswith("alpha") or n.endswith("beta"):
+                    p.add_(torch.tensor(rng.normal(0, 0.3, size=tuple(p.shape)).astype(np.float32)))
+        ii, jj = zip(*[(i, j) for i in range(N) for j in range(N) if i != j])
+        idx_i, idx_j = torch.tensor(ii), torch.tensor(jj)
+        P = len(ii)
+        xs = [torch.tensor(rng.normal(0, 0.7, size=(1, N, 2 * l + 1, F)).astype(np.float32), requires_grad=True) for l in range(order + 1)]
+        rbf = torch.tensor(rng.uniform(0, 1, size=(1, P, 1, K)).astype(np.float32), requires_grad=True)
+        sph = [torch.tensor(rng.normal(size=(1, P, 2 * l + 1, 1)).astype(np.float32)) for l in range(order + 1)]
+        xo, yo = m(xs, rbf, sph, idx_i, idx_j)
+        ws = [torch.tensor(rng.normal(size=tuple(t.shape)).astype(np.float32)) for t in xo + yo]
+        sum((t * w).sum() for t, w in zip(xo + yo, ws)).backward()
+        fx[tag + ":cfg"] = np.array([order, F, K, N, 0 if act == "swish" else 1])
+        fx[tag + ":idx_i"], fx[tag + ":idx_j"] = idx_i.numpy(), idx_j.numpy()
+        for l in range(order + 1):
+            fx[f"{tag}:x_{l}"], fx[f"{tag}:gx_{l}"], fx[f"{tag}:sph_{l}"] = xs[l].detach().numpy(), xs[l].grad.numpy(), sph[l].numpy()
+            fx[f"{tag}:xo_{l}"], fx[f"{tag}:yo_{l}"] = xo[l].detach().numpy(), yo[l].detach().numpy()
+            fx[f"{tag}:wx_{l}"], fx[f"{tag}:wy_{l}"] = ws[l].numpy(), ws[order + 1 + l].numpy()
+        fx[tag + ":rbf"], fx[tag + ":grbf"] = rbf.detach().numpy(), rbf.grad.numpy()
+        for n, p in m.named_parameters():
+            fx[f"{tag}:p:{n}"], fx[f"{tag}:g:{n}"] = p.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "phisnet_blocks.npz"), **fx)
+    print("phisnet_blocks.npz:", len(fx), "arrays")
+
+
+if __name__ == "__main__" and "--blocks" in sys.argv:
+    blocks()
