@@ -256,7 +256,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="conformers per GPU per step (weak scaling)")
+    ap.add_argument("--batch", type=int, default=2048, help="conformers per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", choices=sorted(WORKLOADS), default="painn-oc",
