@@ -208,7 +208,7 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 // workgroup size per kernel flavour and channels-per-lane (register budget: 1024 thr -> 128 VGPRs, 768 -> 168, 512 -> 256)
 // kind: 0 forward, 1 tangent, 2 force adjoint, 3 dual reverse.  Workgroup size = VGPR budget (one workgroup per CU: LDS holds WrT)
 __host__ __device__ constexpr int fused_threads(int kind, int ch) {
-  return ch >= 4 ? 512 : (ch == 2 ? (kind == 3 ? NQ_DUAL2_THREADS : (kind == 1 ? NQ_TAN2_THREADS : 1024)) : 1024);
+  return ch >= 4 ? 512 : (ch == 2 ? (kind == 3 ? NQ_DUAL2_THREADS : (kind == 1 ? NQ_TAN2_THREADS : 1024)) : (kind == 3 ? 768 : 1024));
 }
 #define FUSED_THREADS_DUAL 1024  // window records live in SGPRs (scalar loads), so the dual reverse also fits 16 waves per CU
 
@@ -315,28 +315,35 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
 #define FUSED_PROLOGUE                                                                          \
   extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
   const int F = q.F, F3 = 3 * q.F;                                                             \
-  {                                                                                            \
-    const int total4 = (fa.R * F3) >> 2, padded4 = ((fa.R < FWIN ? FWIN : fa.R) * F3) >> 2;    \
-    const float4* src = reinterpret_cast<const float4*>(fa.WRT);                               \
+  constexpr int FL = 64 * CH;                  /* channels of one slice = one wavefront */      \
+  const int nslices = F / FL;                                                                  \
+  /* blocks are dealt round-robin to the 8 XCDs (blockIdx % 8); inside an XCD consecutive blocks take the slices of one atom group */ \
+  const int nxcd = (gridDim.x % (8 * nslices)) == 0 ? 8 : 1;                                   \
+  const int bx = (int)(blockIdx.x / nxcd);                                                     \
+  const int slice = bx % nslices, wg = bx / nslices;                                           \
+  {   /* LDS copy of this slice's columns of WrT: [Rpad][3][FL] */                              \
+    const int Rp = fa.R < FWIN ? FWIN : fa.R;                                                  \
+    const int per_row4 = (3 * FL) >> 2, fl4 = FL >> 2;                                         \
     float4* dst4 = reinterpret_cast<float4*>(wrt);                                             \
-    for (int i = threadIdx.x; i < padded4; i += blockDim.x)                                    \
-      dst4[i] = i < total4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);                         \
+    for (int i = threadIdx.x; i < Rp * per_row4; i += blockDim.x) {                            \
+      const int r = i / per_row4, c4 = i % per_row4, part = c4 / fl4, cc = c4 % fl4;           \
+      dst4[i] = r < fa.R ? reinterpret_cast<const float4*>(fa.WRT + (long)r * F3 + part * F + slice * FL)[cc] : make_float4(0.f, 0.f, 0.f, 0.f); \
+    }                                                                                          \
   }                                                                                            \
   __syncthreads();                                                                             \
   const int nslots = blockDim.x >> 6;                                                          \
   const int slot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                           \
   const int lane = threadIdx.x & 63;                                                           \
-  const int fb = lane * CH;                                                                    \
+  const int lfb = lane * CH;                   /* channel offset inside the LDS slice */        \
+  const int fb = slice * FL + lfb;             /* channel offset in the global rows */           \
   float bra[CH], brb[CH], brc[CH];                                                             \
   ldv<CH>(bra, fa.br + fb); ldv<CH>(brb, fa.br + F + fb); ldv<CH>(brc, fa.br + 2 * F + fb);    \
-  /* XCD-aware sweep: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8).  The workgroups of one XCD walk   \
-     ONE contiguous eighth of the atoms together, wavefront by wavefront, so at any time an XCD works on ~6 molecules  \
-     and their rows are fetched into that XCD's 4 MB L2 once instead of once per molecule-per-CU working set. */       \
-  const int nxcd = (gridDim.x & 7) == 0 ? 8 : 1;                                               \
+  /* XCD-aware sweep: the workgroups of one XCD walk ONE contiguous eighth of the atoms together, wavefront by wavefront, so at     \
+     any time an XCD works on ~6 molecules and their rows are fetched into that XCD's 4 MB L2 once. */                              \
   const int per_x = (q.g.N + nxcd - 1) / nxcd;                                                 \
   const int x_lo = (int)(blockIdx.x % nxcd) * per_x, n_hi = min(q.g.N, x_lo + per_x);          \
-  const int n_first = x_lo + (int)(blockIdx.x / nxcd) * nslots + slot;                         \
-  const int n_step = (int)(gridDim.x / nxcd) * nslots;
+  const int n_first = x_lo + wg * nslots + slot;                                               \
+  const int n_step = (int)(gridDim.x / nxcd / nslices) * nslots;
 
 // ---- forward / tangent -------------------------------------------------------------------------------------
 template <bool TAN, int CH>
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(Msg
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded (keeps the loop one basic block)
         if (decltype(prefetch)::value) load_fwd<TAN, CH>(nxt, q, bl_i(row.kk, jn), F, F3, fb);
         float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
-        filter_eval<TAN, CH>(win, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        filter_eval<TAN, CH>(win, wrt, FL, 3 * FL, lfb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
         __builtin_amdgcn_sched_barrier(0);
         if (decltype(prefetch)::value) load_win<TAN>(win, RW, c0 + jn);
         const float gx = bl_f(row.gx, j), gy = bl_f(row.gy, j), gz = bl_f(row.gz, j);
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
 #pragma unroll
         for (int c = 0; c < CH; ++c) { pa[c] = bra[c] * win.rr[0]; pb[c] = brb[c] * win.rr[1]; pc[c] = brc[c] * win.rr[2]; qa[c] = bra[c] * win.dd[0]; qb[c] = brb[c] * win.dd[1]; qc[c] = brc[c] * win.dd[2]; }
 #else
-        filter_eval<true, CH>(win, wrt, F, F3, fb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
+        filter_eval<true, CH>(win, wrt, FL, 3 * FL, lfb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
 #endif
         const float beta = win.rr[14], dbeta = win.dd[14];
         __builtin_amdgcn_sched_barrier(0);
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
       }
       if (cnt & 1) step(opA, opB, cnt - 1, std::false_type());
       if (!DUAL && lane < cnt) {
-        float4* dstp = q.GEDGE + c0 + lane;   // one wavefront covers all F channels: slice 0 only
+        float4* dstp = q.GEDGE + (long)slice * q.g.E + c0 + lane;   // one accumulator plane per channel slice (summed by k_geom_rev)
         float4 acc = *dstp;
         acc.x += eacc.x; acc.y += eacc.y; acc.z += eacc.z; acc.w += eacc.w;
         *dstp = acc;
@@ -885,13 +892,40 @@ int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out
   return NQ_OK;
 }
 
-static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
-  const int nslots = max_threads / 64;   // one wavefront per atom
+// Channels per lane of each kernel flavour (kind: 0 forward, 1 tangent, 2 force adjoint, 3 dual reverse).  A wavefront covers a SLICE of
+// 64*CH channels; F/(64*CH) slices of one atom run as separate wavefronts in separate workgroups, each with only its slice of WrT in
+// LDS (R*3*64*CH*4 bytes) -- fewer channels per lane = fewer VGPRs and a smaller LDS copy = more wavefronts per CU to hide the gathers,
+// at the price of repeating the per-edge scalar work per slice.  Defaults from profiles/r01_fused_tuning.txt; -DNQ_CH_<kind>=n overrides.
+#ifndef NQ_CH_FWD
+#define NQ_CH_FWD 0
+#endif
+#ifndef NQ_CH_TAN
+#define NQ_CH_TAN 0
+#endif
+#ifndef NQ_CH_FORCE
+#define NQ_CH_FORCE 0
+#endif
+#ifndef NQ_CH_DUAL
+#define NQ_CH_DUAL 0
+#endif
+static int fused_ch(int kind, int F) {
+  const int forced = kind == 0 ? NQ_CH_FWD : (kind == 1 ? NQ_CH_TAN : (kind == 2 ? NQ_CH_FORCE : NQ_CH_DUAL));
+  const int full = F / 64;                       // one slice: the whole row in one wavefront
+  if (forced > 0 && forced <= full && full % forced == 0) return forced;
+  return full;
+}
+static int fused_grid(int N, int F, int ch, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
+  const int nslots = max_threads / 64;   // one wavefront per (atom, slice)
+  const int nslices = F / (64 * ch);
   *threads = nslots * 64;
-  *lds = (size_t)(R < FWIN ? FWIN : R) * 3 * F * sizeof(float);
-  int blocks = nq_cdiv(N, nslots);
-  (void)F;
-  return blocks < 256 ? blocks : 256;   // one persistent workgroup per CU (LDS-limited to 1 per CU anyway)
+  *lds = (size_t)(R < FWIN ? FWIN : R) * 3 * 64 * ch * sizeof(float);
+  int per_cu = (int)((156 * 1024) / *lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  int groups = 256 * per_cu / nslices;           // atom groups (one workgroup per slice each)
+  groups = groups < 8 ? 8 : (groups / 8) * 8;    // multiple of 8 -> the XCD-aware sweep applies
+  const int need = nq_cdiv(N, nslots);
+  if (need < groups) groups = need;              // small batches: plain interleave
+  return groups * nslices;
 }
 
 // the >64 KB dynamic-LDS opt-in is sticky per kernel: set it when the requested size grows, not on every launch
@@ -906,7 +940,7 @@ static int fused_grid(int N, int F, int* threads, size_t* lds, int R, int max_th
   } while (0)
 #define FUSED_DISPATCH(KERN, FLAG, Q)                                   \
   do {                                                                  \
-    switch ((Q).F / 64) {                                               \
+    switch (ch) {                                                       \
       case 1: FUSED_LAUNCH(KERN, FLAG, 1, Q); break;                    \
       case 2: FUSED_LAUNCH(KERN, FLAG, 2, Q); break;                    \
       case 4: FUSED_LAUNCH(KERN, FLAG, 4, Q); break;                    \
@@ -918,7 +952,8 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
   NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(tangent ? 1 : 0, q.F / 64));
+  const int ch = fused_ch(tangent ? 1 : 0, q.F);
+  const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(tangent ? 1 : 0, ch));
   if (tangent) FUSED_DISPATCH(k_msgf_fwd, true, q);
   else FUSED_DISPATCH(k_msgf_fwd, false, q);
   NQ_LAUNCH_CHECK();
@@ -929,7 +964,8 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   NQ_PROF(st, dual ? "msgf_rev_dual" : "msgf_rev_force");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int grid = fused_grid(q.g.N, q.F, &threads, &lds, fa.R, fused_threads(dual ? 3 : 2, q.F / 64));
+  const int ch = fused_ch(dual ? 3 : 2, q.F);
+  const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(dual ? 3 : 2, ch));
   if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
   else FUSED_DISPATCH(k_msgf_rev, false, q);
   NQ_LAUNCH_CHECK();

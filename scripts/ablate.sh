@@ -13,11 +13,13 @@ if [ "$1" = build ]; then
     [ $k = 7 ] && X="-DNQ_DUAL2_THREADS=1024"     # dual reverse with 16 waves per CU
     [ $k = 8 ] && X="-DNQ_DUAL2_THREADS=512 -DNQ_TAN2_THREADS=768"
     [ $k = 9 ] && X="-DNQ_DUAL2_THREADS=512 -DNQ_TAN2_THREADS=512"
+    [ $k = 10 ] && X="-DNQ_CH_FWD=1 -DNQ_CH_TAN=1 -DNQ_CH_FORCE=1 -DNQ_CH_DUAL=1"   # two 64-channel slices per atom at F=128
+    [ $k = 11 ] && X="-DNQ_CH_FWD=1"
     /opt/rocm/bin/hipcc $FLAGS $X -c nabladft_amd/csrc/edge.hip -o $D/edge_$k.o &
   done
   wait
   for k in ${ABLATIONS:-1 2 3 4}; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libnablaq_$k.so nabladft_amd/csrc/_obj/graph.o nabladft_amd/csrc/_obj/gemm.o $D/edge_$k.o nabladft_amd/csrc/_obj/node.o nabladft_amd/csrc/_obj/engine.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libnablaq_$k.so nabladft_amd/csrc/_obj/graph.o nabladft_amd/csrc/_obj/gemm.o $D/edge_$k.o nabladft_amd/csrc/_obj/node.o nabladft_amd/csrc/_obj/schnet.o nabladft_amd/csrc/_obj/hblock.o nabladft_amd/csrc/_obj/so3.o nabladft_amd/csrc/_obj/geobasis.o nabladft_amd/csrc/_obj/engine.o
   done
   ls -la $D/*.so
 else
