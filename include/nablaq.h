@@ -195,6 +195,12 @@ int nq_feature_act(const float* x, const float* alpha, const float* beta, int64_
 int nq_feature_act_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t F, int32_t kind,
                             float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream);
 
+/* Pair <-> atom data movement of the interaction blocks (interaction_block.py:135-142).  Rows of C floats.
+ * nq_gather_rows: out[p] = x[idx[p]].  nq_segment_sum: out[n] = base[n] (nullable) + sum_{q in [seg_ptr[n], seg_ptr[n+1])} rows[order ? order[q] : q]
+ * -- fixed summation order, no atomics (the reference's index_add on a GPU is not reproducible). */
+int nq_gather_rows(const float* x, const int64_t* idx, int64_t P, int32_t C, float* out, void* stream);
+int nq_segment_sum(const float* rows, const int64_t* order, const int64_t* seg_ptr, const float* base, int64_t N, int32_t C, float* out, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

@@ -62,6 +62,8 @@ SYMBOLS = {
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_feature_act": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_feature_act_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "nq_gather_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "nq_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

@@ -170,3 +170,59 @@ int nq_feature_act_backward(const float* x, const float* alpha, const float* bet
   return NQ_OK;
 }
 }  // extern "C"
+
+// ---- pair <-> atom data movement for the interaction blocks (interaction_block.py:135-142: torch.gather over idx_j, index_add over idx_i) -----
+// rows are [C] floats (C = (2l+1) * F); seg_ptr [N+1] delimits the contiguous pair rows of every atom (pairs sorted by centre atom), so the
+// sum is a fixed-order loop per output element: deterministic, no atomics.
+__global__ void k_gather_rows(const float* __restrict__ x, const long long* __restrict__ idx, long P, int C, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * C) return;
+  const long p = i / C; const int c = (int)(i % C);
+  out[i] = x[idx[p] * C + c];
+}
+__global__ void k_segment_sum(const float* __restrict__ rows, const long long* __restrict__ seg_ptr, const float* __restrict__ base, long N, int C,
+                              float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const long n = i / C; const int c = (int)(i % C);
+  float s = base ? base[i] : 0.f;
+  for (long long p = seg_ptr[n]; p < seg_ptr[n + 1]; ++p) s += rows[p * C + c];
+  out[i] = s;
+}
+// reverse of the gather with an arbitrary index: out[n] = sum over the rows p with idx[p] == n, rows listed per n in (order, ptr)
+__global__ void k_segment_sum_perm(const float* __restrict__ rows, const long long* __restrict__ order, const long long* __restrict__ seg_ptr, long N, int C,
+                                   float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const long n = i / C; const int c = (int)(i % C);
+  float s = 0.f;
+  for (long long q = seg_ptr[n]; q < seg_ptr[n + 1]; ++q) s += rows[order[q] * C + c];
+  out[i] = s;
+}
+
+extern "C" {
+int nq_gather_rows(const float* x, const int64_t* idx, int64_t P, int32_t C, float* out, void* stream) {
+  if (!x || !idx || !out || C <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "gather_rows");
+  if (P > 0) hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, st, x, (const long long*)idx, (long)P, C, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+/* out[n] = base[n] (nullable) + sum of rows[seg_ptr[n] .. seg_ptr[n+1]) ; with `order` != NULL the rows are taken through it (rows[order[q]]) */
+int nq_segment_sum(const float* rows, const int64_t* order, const int64_t* seg_ptr, const float* base, int64_t N, int32_t C, float* out, void* stream) {
+  if (!rows || !seg_ptr || !out || C <= 0 || N < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "segment_sum");
+  if (N > 0) {
+    if (order) {
+      if (base) return nq_fail(NQ_ERR_ARG, "base is not supported together with order");
+      hipLaunchKernelGGL(k_segment_sum_perm, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, st, rows, (const long long*)order, (const long long*)seg_ptr, (long)N, C, out);
+    } else {
+      hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, st, rows, (const long long*)seg_ptr, base, (long)N, C, out);
+    }
+  }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+}  // extern "C"

@@ -6,8 +6,9 @@
   ModularBlock                 modular_block.py:11-80
 with the reference constructors, attribute / parameter names (state_dict compatible) and list-of-orders tensors
 ``xs[l]: [1, N, 2l+1, F]``.  The arithmetic runs in HIP kernels: Clebsch-Gordan mixing (csrc/so3.hip), fp32 MFMA GEMMs for every
-Linear (csrc/gemm.hip), feature-wise activations (csrc/geobasis.hip).  torch is used for autograd plumbing, residual adds, the
-neighbour gather and the ``index_add`` over pairs (next to move into a segment-sum kernel).  GPU only.
+Linear (csrc/gemm.hip), feature-wise activations, the neighbour gather and the fixed-order segment sum over pairs (csrc/geobasis.hip:
+deterministic, unlike ``index_add`` on a GPU).  torch is used for autograd plumbing and residual adds.  GPU only.
+``idx_i`` may be a ``PairIndex`` (built once per batch) instead of a tensor.
 """
 from typing import List
 
@@ -16,6 +17,71 @@ from torch import nn
 
 from . import _lib
 from .so3 import PairMixing, SelfMixing, _LinearFn, _require_gpu
+
+
+class PairIndex:
+    """Index tables of one batch of pairs for the deterministic gather / segment-sum kernels: ``idx_i`` must be sorted (PhiSNet's fill_idx and
+    QHNet's full graph are); the reverse of the neighbour gather needs the pairs grouped by ``idx_j`` (a stable argsort, once per batch)."""
+
+    def __init__(self, idx_i: torch.Tensor, idx_j: torch.Tensor, num_atoms: int):
+        self.idx_i, self.idx_j, self.N = idx_i.long().contiguous(), idx_j.long().contiguous(), int(num_atoms)
+        if self.idx_i.numel() > 1 and bool((self.idx_i[1:] < self.idx_i[:-1]).any()):
+            raise ValueError("pairs must be sorted by the centre atom idx_i")
+        cnt_i = torch.bincount(self.idx_i, minlength=self.N)
+        self.ptr_i = torch.cat([cnt_i.new_zeros(1), cnt_i.cumsum(0)]).contiguous()
+        self.order_j = torch.argsort(self.idx_j, stable=True).contiguous()
+        cnt_j = torch.bincount(self.idx_j, minlength=self.N)
+        self.ptr_j = torch.cat([cnt_j.new_zeros(1), cnt_j.cumsum(0)]).contiguous()
+
+
+class _GatherFn(torch.autograd.Function):
+    """x [1, N, m, F] -> [1, P, m, F] rows of idx_j; reverse = segment sum over the pairs of each j."""
+
+    @staticmethod
+    def forward(ctx, x, pidx):
+        lib = _lib.load()
+        x2 = x.to(torch.float32).contiguous()
+        Cw = x2.shape[-2] * x2.shape[-1]
+        P = pidx.idx_j.numel()
+        out = torch.empty(1, P, x2.shape[-2], x2.shape[-1], device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_gather_rows(_lib.ptr(x2), _lib.ptr(pidx.idx_j), P, Cw, _lib.ptr(out), _lib.stream_ptr()))
+        ctx.pidx, ctx.shape = pidx, x2.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pidx = ctx.pidx
+        g = g.to(torch.float32).contiguous()
+        Cw = ctx.shape[-2] * ctx.shape[-1]
+        out = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _lib.check(lib.nq_segment_sum(_lib.ptr(g), _lib.ptr(pidx.order_j), _lib.ptr(pidx.ptr_j), None, pidx.N, Cw, _lib.ptr(out), _lib.stream_ptr()))
+        return out, None
+
+
+class _SegmentAddFn(torch.autograd.Function):
+    """base [1, N, m, F] + sum over the pair rows of every centre atom (index_add over sorted idx_i); reverse = identity + gather by idx_i."""
+
+    @staticmethod
+    def forward(ctx, base, rows, pidx):
+        lib = _lib.load()
+        b2, r2 = base.to(torch.float32).contiguous(), rows.to(torch.float32).contiguous()
+        Cw = b2.shape[-2] * b2.shape[-1]
+        out = torch.empty_like(b2)
+        _lib.check(lib.nq_segment_sum(_lib.ptr(r2), None, _lib.ptr(pidx.ptr_i), _lib.ptr(b2), pidx.N, Cw, _lib.ptr(out), _lib.stream_ptr()))
+        ctx.pidx = pidx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pidx = ctx.pidx
+        g = g.to(torch.float32).contiguous()
+        Cw = g.shape[-2] * g.shape[-1]
+        P = pidx.idx_i.numel()
+        grows = torch.empty(1, P, g.shape[-2], g.shape[-1], device=g.device, dtype=torch.float32)
+        _lib.check(lib.nq_gather_rows(_lib.ptr(g), _lib.ptr(pidx.idx_i), P, Cw, _lib.ptr(grows), _lib.stream_ptr()))
+        return g, grows, None
 
 
 class _ActFn(torch.autograd.Function):
@@ -173,10 +239,11 @@ class InteractionBlock(nn.Module):
         yj = self.residual_pre_vj(xs)
         yj[0] = self.activation_j(yj[0])
         yj = self.linear_j(yj)
-        yj = [y.index_select(1, idx_j) for y in yj]                                   # neighbour gather (interaction_block.py:135-137)
+        pidx = idx_i if isinstance(idx_i, PairIndex) else PairIndex(idx_i, idx_j, xs[0].shape[1])
+        yj = [_GatherFn.apply(y, pidx) for y in yj]                                   # neighbour gather (interaction_block.py:135-137)
         vs = self.mixing(yj, self.angular_fn1(sph), rbf)
         a = self.angular_fn2(sph)
-        vs = [yi[L].index_add(1, idx_i, vs[L] + _linear(rbf, self.radial_fn[L]) * a[L] * yj[0]) for L in range(self.order + 1)]
+        vs = [_SegmentAddFn.apply(yi[L], vs[L] + _linear(rbf, self.radial_fn[L]) * a[L] * yj[0], pidx) for L in range(self.order + 1)]
         vs = self.residual_post_v(vs)
         vs[0] = self.activation_v(vs[0])
         vs = self.linear_v(vs)
