@@ -48,7 +48,7 @@ typedef struct nq_painn_cfg {
   int32_t num_rbf;           /* R */
   int32_t num_elements;      /* rows of atom_emb.embeddings.weight */
   int32_t max_neighbors;     /* K of radius_graph */
-  int32_t envelope_exponent; /* PolynomialEnvelope(exponent) */
+  int32_t envelope_exponent; /* PolynomialEnvelope(exponent) (layers.py:14-33); 0 selects ExponentialEnvelope (layers.py:36-48) */
   double cutoff;             /* Angstrom */
   float rbf_coeff;           /* GaussianSmearing.coeff = -0.5/(offset[1]-offset[0])^2 */
   int32_t filter_mode;       /* 0: painn_pyg  filter = rbf_proj(envelope(d/rc) * gauss(d/rc)) + bias   (layers.py:181-185)

@@ -24,10 +24,16 @@ __global__ void k_rbf(RbfArgs q) {
   const float ds = d * q.inv_cutoff;
   float env = 0.f, denv = 0.f;
   if (ds < 1.0f) {
-    const float pm1 = powf(ds, q.p - 1.0f);
-    const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
-    env = 1.0f + q.a * p0 + q.b * p1 + q.c * p2;
-    denv = q.a * q.p * pm1 + q.b * (q.p + 1.0f) * p0 + q.c * (q.p + 2.0f) * p1;
+    if (q.p > 0.f) {   // PolynomialEnvelope(exponent p)  (layers.py:14-33)
+      const float pm1 = powf(ds, q.p - 1.0f);
+      const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
+      env = 1.0f + q.a * p0 + q.b * p1 + q.c * p2;
+      denv = q.a * q.p * pm1 + q.b * (q.p + 1.0f) * p0 + q.c * (q.p + 2.0f) * p1;
+    } else {           // ExponentialEnvelope: exp(-ds^2 / ((1 - ds)(1 + ds)))  (layers.py:36-48), encoded as exponent 0
+      const float om = (1.0f - ds) * (1.0f + ds);
+      env = expf(-(ds * ds) / om);
+      denv = -env * 2.0f * ds / (om * om);
+    }
   }
   // same rounding order as GaussianSmearing: exp(coeff * (ds - mu_k)^2), mu = the module's fp32 offset buffer
   const float diff = ds - q.mu[k];
@@ -233,10 +239,16 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
     if (t < nwin) {
       float env = 0.f, denv = 0.f;
       if (ds < 1.0f) {
-        const float pm1 = powf(ds, fa.p - 1.0f);
-        const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
-        env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
-        denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
+        if (fa.p > 0.f) {
+          const float pm1 = powf(ds, fa.p - 1.0f);
+          const float p0 = pm1 * ds, p1 = p0 * ds, p2 = p1 * ds;
+          env = 1.0f + fa.a * p0 + fa.b * p1 + fa.c * p2;
+          denv = fa.a * fa.p * pm1 + fa.b * (fa.p + 1.0f) * p0 + fa.c * (fa.p + 2.0f) * p1;
+        } else {   // ExponentialEnvelope (exponent 0, see k_rbf)
+          const float om = (1.0f - ds) * (1.0f + ds);
+          env = expf(-(ds * ds) / om);
+          denv = -env * 2.0f * ds / (om * om);
+        }
       }
       const float diff = ds - fa.mu[k0 + t];
       const float g = expf(fa.coeff * (diff * diff));

@@ -143,10 +143,16 @@ class _RadialBasis(nn.Module):
     def __init__(self, num_radial, cutoff, rbf, envelope):
         super().__init__()
         env = dict(envelope)
-        if env.pop("name").lower() != "polynomial":
-            raise NotImplementedError("nabladft_amd: only envelope {'name': 'polynomial'} is implemented (layers.py:160-165)")
-        self.exponent = int(env.get("exponent", 5))
-        assert self.exponent > 0
+        name = env.pop("name").lower()
+        if name == "polynomial":
+            self.exponent = int(env.get("exponent", 5))
+            assert self.exponent > 0
+        elif name == "exponential":                     # ExponentialEnvelope (layers.py:36-48); exponent 0 in the C ABI
+            if env:
+                raise TypeError(f"ExponentialEnvelope takes no hyper-parameters, got {env}")
+            self.exponent = 0
+        else:
+            raise ValueError(f"Unknown envelope function '{name}'.")
         rb = dict(rbf)
         if rb.pop("name").lower() != "gaussian":
             raise NotImplementedError("nabladft_amd: only rbf {'name': 'gaussian'} is implemented (layers.py:172-179)")

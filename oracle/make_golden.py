@@ -84,7 +84,8 @@ def write_db_fixture(n):
 
 def build_reference_model(ref, cfg, params):
     m = ref["painn"].PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors,
-                           {"name": "gaussian"}, {"name": "polynomial", "exponent": cfg.envelope_exponent},
+                           {"name": "gaussian"},
+                           {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
                            True, False, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
     assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected, (missing, unexpected)
@@ -143,6 +144,29 @@ def main():
     np.savez_compressed(os.path.join(OUT, "real_conformers.npz"), pos=pos16, z=z16, batch=b16)
     write_db_fixture(30)
     if os.environ.get("NQ_GOLDEN_ONLY") == "db":
+        return
+
+    # ---- exponential envelope (layers.py:36-48; row a4b), small config on ragged molecules -------------------------------
+    rng_e = np.random.Generator(np.random.PCG64(71))
+    cfg_e = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=20, cutoff=4.0, max_neighbors=100, envelope_exponent=0, num_elements=100)
+    params_e = R.make_params(cfg_e, seed=6)
+    pp, zz, bb = [], [], []
+    for m, n in enumerate([9, 2, 17, 5]):
+        p, zc, _, _, _ = R.gen_conformers(300 + m, 1, size=n)
+        pp.append(p.numpy()), zz.append(zc.numpy()), bb.append(np.full(n, m, dtype=np.int64))
+    pos_e, z_e, batch_e = np.concatenate(pp), np.concatenate(zz), np.concatenate(bb)
+    y_e = rng_e.normal(0, 1, size=4).astype(np.float32)
+    ft_e = rng_e.normal(0, 0.05, size=pos_e.shape).astype(np.float32)
+    out_e, grads_e = run_reference(ref, cfg_e, params_e, pos_e, z_e, batch_e, y_e, ft_e)
+    fx_e = dict(cfg=np.array([cfg_e.hidden_channels, cfg_e.num_layers, cfg_e.num_rbf, cfg_e.max_neighbors, cfg_e.envelope_exponent,
+                              cfg_e.num_elements]), cutoff=np.float64(cfg_e.cutoff), param_seed=np.int64(6), pos=pos_e, z=z_e, batch=batch_e,
+                y=y_e, f_target=ft_e)
+    fx_e.update(out_e)
+    for k, gnp in grads_e.items():
+        fx_e["grad:" + k] = gnp
+    np.savez_compressed(os.path.join(OUT, "painn_small_expenv.npz"), **fx_e)
+    print("small_expenv: E", out_e["energy"], "loss", out_e["loss"], "edges", out_e["edge_index"].shape)
+    if os.environ.get("NQ_GOLDEN_ONLY") == "expenv":
         return
 
     # ---- full config on 4 real conformers -------------------------------------------------------

@@ -139,7 +139,10 @@ def radial_basis(cfg: PaiNNConfig, d):
     p = float(cfg.envelope_exponent)
     a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
     ds = d * (1 / cfg.cutoff)
-    env = 1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)
+    if cfg.envelope_exponent == 0:                    # ExponentialEnvelope (layers.py:36-48)
+        env = torch.exp(-(ds**2) / ((1 - ds) * (1 + ds)))
+    else:
+        env = 1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)
     env = torch.where(ds < 1, env, torch.zeros_like(ds))
     offset = torch.linspace(0.0, 1.0, cfg.num_rbf).to(d.dtype)
     coeff = -0.5 / (torch.linspace(0.0, 1.0, cfg.num_rbf)[1] - 0.0).item() ** 2

@@ -47,8 +47,14 @@ def rbf_and_derivative(cfg: PaiNNConfig, d):
     inv = 1.0 / cfg.cutoff
     ds = d * inv
     inside = (ds < 1).to(d.dtype)
-    env = (1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)) * inside
-    denv = (a * p * ds ** (p - 1) + b * (p + 1) * ds**p + c * (p + 2) * ds ** (p + 1)) * inside
+    if cfg.envelope_exponent == 0:                    # ExponentialEnvelope
+        dsc = torch.where(ds < 1, ds, torch.zeros_like(ds))
+        om = (1 - dsc) * (1 + dsc)
+        env = torch.exp(-(dsc**2) / om) * inside
+        denv = -env * 2 * dsc / (om * om)
+    else:
+        env = (1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)) * inside
+        denv = (a * p * ds ** (p - 1) + b * (p + 1) * ds**p + c * (p + 2) * ds ** (p + 1)) * inside
     mu = torch.linspace(0.0, 1.0, cfg.num_rbf).to(d.dtype)
     coeff = -0.5 / (torch.linspace(0.0, 1.0, cfg.num_rbf)[1]).item() ** 2
     diff = ds[:, None] - mu[None, :]

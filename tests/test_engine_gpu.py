@@ -56,7 +56,8 @@ def _dev():
 def _model(cfg, params, dev):
     import nabladft_amd as nq
     m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": "gaussian"},
-                 {"name": "polynomial", "exponent": cfg.envelope_exponent}, True, False, False, True, cfg.num_elements)
+                 {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
+                 True, False, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
     assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected
     return m.to(dev)
@@ -231,7 +232,7 @@ def _trace_report(name, model, sw, s2c, tag, lines):
 
 
 @pytest.mark.parametrize("fused", ["fused", "materialised"])
-@pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz"])
+@pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz", "painn_small_expenv.npz"])
 def test_engine_matches_reference_golden(name, fused, monkeypatch):
     """fused: radial filter evaluated inside the message kernels (WrT in LDS, 13-Gaussian window);
     materialised: fallback path (phi/psi through the GEMM) used when WrT does not fit the LDS."""
