@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 4
+#define NQ_ABI_VERSION 5
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -54,6 +54,11 @@ typedef struct nq_painn_cfg {
   int32_t filter_mode;       /* 0: painn_pyg  filter = rbf_proj(envelope(d/rc) * gauss(d/rc)) + bias   (layers.py:181-185)
                               * 1: schnetpack filter = cosine_cutoff(d) * (filter_net(gauss(d)) + bias), Gaussians on the unscaled
                               *    distance (config/model/painn.yaml:9-16); needs the fused-filter path */
+  int32_t rbf_type;          /* RadialBasis(rbf=...) (layers.py:168-179): 0 gaussian; 1 spherical_bessel (learnable frequencies [R]);
+                              * 2 bernstein (learnable pregamma).  1 and 2 use the materialised-filter path; their parameters sit in the
+                              * flat buffer right after atom_emb.embeddings.weight (state_dict order); for 2 `rbf_offsets` carries the
+                              * BernsteinBasis.prefactor buffer (binomial coefficients). */
+  int32_t reserved;
 } nq_painn_cfg;
 
 /* Neighbour list in engine layout (CSR by target atom, sources ascending; symmetric). */

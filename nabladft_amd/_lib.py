@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -19,7 +19,7 @@ class NablaqError(RuntimeError):
 class PainnCfg(C.Structure):
     _fields_ = [("hidden_channels", C.c_int32), ("num_layers", C.c_int32), ("num_rbf", C.c_int32),
                 ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
-                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("filter_mode", C.c_int32)]
+                ("cutoff", C.c_double), ("rbf_coeff", C.c_float), ("filter_mode", C.c_int32), ("rbf_type", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SchnetCfg(C.Structure):

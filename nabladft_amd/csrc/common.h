@@ -176,7 +176,9 @@ int nq_colsum(hipStream_t, const float* A, long rows, int cols, int lda, float* 
 int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, long count, float* out);
 
 int nq_rbf(hipStream_t, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets, float* rho,
-           float* drho);
+           float* drho, int type = 0, const float* theta = nullptr);
+int nq_rbf_param_grad(hipStream_t, const float4* geom, int E, int R, double cutoff, int env_p, const float* offsets, int type, const float* theta,
+                      const float* grho, float* contrib);
 int nq_msg_fwd(hipStream_t, const MsgArgs&, bool tangent);
 bool nq_filter_fits_lds(int F, int R);
 void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, const float* mu, const float* RW, int R, double cutoff, int env_p,

@@ -13,16 +13,15 @@
 struct RbfArgs {
   const float4* geom; int E; int R; float inv_cutoff; float p, a, b, c; float coeff; const float* mu;
   float* rho; float* drho;
+  int type;                 // 0 GaussianSmearing(0,1,R), 1 SphericalBesselBasis (layers.py:51-80), 2 BernsteinBasis (layers.py:83-126)
+  const float* theta;       // learnable basis parameters: frequencies [R] (1) / pregamma [1] (2)
+  float norm_const;         // Bessel: sqrt(2 / cutoff^3)
+  const float* grho;        // parameter-gradient mode: adjoints of rho and drho, [2][E][R]
+  float* contrib;           // parameter-gradient mode: per-(edge, k) contribution to dL/dtheta, [E][R]
 };
 
-// rho[e,k] = env(d/rc) * exp(coeff (d/rc - mu_k)^2) and d rho/d d  (oracle: rbf_and_derivative)
-__global__ void k_rbf(RbfArgs q) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)q.E * q.R) return;
-  const int e = (int)(idx / q.R), k = (int)(idx % q.R);
-  const float d = q.geom[e].w;
-  const float ds = d * q.inv_cutoff;
-  float env = 0.f, denv = 0.f;
+__device__ __forceinline__ void rbf_envelope(const RbfArgs& q, float ds, float& env, float& denv) {
+  env = 0.f; denv = 0.f;
   if (ds < 1.0f) {
     if (q.p > 0.f) {   // PolynomialEnvelope(exponent p)  (layers.py:14-33)
       const float pm1 = powf(ds, q.p - 1.0f);
@@ -35,11 +34,61 @@ __global__ void k_rbf(RbfArgs q) {
       denv = -env * 2.0f * ds / (om * om);
     }
   }
-  // same rounding order as GaussianSmearing: exp(coeff * (ds - mu_k)^2), mu = the module's fp32 offset buffer
-  const float diff = ds - q.mu[k];
-  const float g = expf(q.coeff * (diff * diff));
-  q.rho[idx] = env * g;
-  q.drho[idx] = q.inv_cutoff * g * (denv + env * (2.0f * q.coeff) * diff);
+}
+__device__ __forceinline__ float ipow(float x, int e) {   // x^e for integer e >= 0 (torch.pow with an integer exponent), 0^0 = 1
+  float r = 1.f, b = x;
+  for (int n = e; n > 0; n >>= 1) { if (n & 1) r *= b; b *= b; }
+  return r;
+}
+
+// rho[e,k] = env(d/rc) * basis_k(d/rc) and d rho/d d  (oracle: painn_ref.radial_basis, painn_sweeps.rbf_and_derivative);
+// GRAD = true: contrib[e,k] = grho * d rho/d theta + gdrho * d (d rho/d d)/d theta for the learnable basis parameter(s)
+template <bool GRAD>
+__global__ void k_rbf(RbfArgs q) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)q.E * q.R) return;
+  const int e = (int)(idx / q.R), k = (int)(idx % q.R);
+  const float d = q.geom[e].w;
+  const float ds = d * q.inv_cutoff;
+  float env, denv;
+  rbf_envelope(q, ds, env, denv);
+  if (q.type == 0) {
+    // same rounding order as GaussianSmearing: exp(coeff * (ds - mu_k)^2), mu = the module's fp32 offset buffer
+    const float diff = ds - q.mu[k];
+    const float g = expf(q.coeff * (diff * diff));
+    if (!GRAD) { q.rho[idx] = env * g; q.drho[idx] = q.inv_cutoff * g * (denv + env * (2.0f * q.coeff) * diff); }
+  } else if (q.type == 1) {
+    const float f = q.theta[k], nc = q.norm_const;
+    float sn, cs;
+    sincosf(f * ds, &sn, &cs);
+    if (!GRAD) {
+      q.rho[idx] = env * (nc / ds * sn);
+      q.drho[idx] = q.inv_cutoff * (denv * nc / ds * sn + env * nc * (f * cs / ds - sn / (ds * ds)));
+    } else {
+      const long ER = (long)q.E * q.R;
+      q.contrib[idx] = q.grho[idx] * env * nc * cs + q.grho[ER + idx] * q.inv_cutoff * nc * (denv * cs - env * f * sn);
+    }
+  } else {
+    const float pg = q.theta[0];
+    const float gam = fmaxf(pg, 0.f) + log1pf(expf(-fabsf(pg)));       // softplus
+    const float x = expf(-gam * ds), y = 1.0f - x;
+    const int m = q.R - 1, a = k, b = m - k;
+    const float C = q.mu[k];                                            // binom(R-1, k): the module's `prefactor` buffer
+    const float B = C * ipow(x, a) * ipow(y, b);
+    const float dB = C * ((a > 0 ? a * ipow(x, a - 1) * ipow(y, b) : 0.f) - (b > 0 ? b * ipow(x, a) * ipow(y, b - 1) : 0.f));
+    if (!GRAD) {
+      q.rho[idx] = env * B;
+      q.drho[idx] = q.inv_cutoff * (denv * B + env * dB * (-gam * x));
+    } else {
+      const float d2B = C * ((a > 1 ? a * (a - 1) * ipow(x, a - 2) * ipow(y, b) : 0.f) - (a > 0 && b > 0 ? 2.f * a * b * ipow(x, a - 1) * ipow(y, b - 1) : 0.f)
+                             + (b > 1 ? b * (b - 1) * ipow(x, a) * ipow(y, b - 2) : 0.f));
+      const float dsx = ds * x, sig = 1.0f / (1.0f + expf(-pg));
+      const float drho_dg = env * dB * (-dsx);
+      const float ddrho_dg = q.inv_cutoff * (denv * dB * (-dsx) + env * (-x * dB + gam * dsx * (dB + x * d2B)));
+      const long ER = (long)q.E * q.R;
+      q.contrib[idx] = (q.grho[idx] * drho_dg + q.grho[ER + idx] * ddrho_dg) * sig;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -827,18 +876,36 @@ __global__ void k_geom_rev(NqGraphView g, const float4* __restrict__ GEDGE, int 
 }
 
 // ---- host launchers ------------------------------------------------------------------------
+static void rbf_fill(RbfArgs* q, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets, int type,
+                     const float* theta) {
+  q->geom = geom; q->E = E; q->R = R; q->inv_cutoff = (float)(1.0 / cutoff);
+  const double p = env_p;
+  q->p = (float)p; q->a = (float)(-(p + 1) * (p + 2) / 2); q->b = (float)(p * (p + 2)); q->c = (float)(-p * (p + 1) / 2);
+  q->mu = offsets;   // type 0: GaussianSmearing(0, 1, R).offset (buffer radial_basis.rbf.offset); type 2: BernsteinBasis.prefactor
+  q->coeff = coeff;  // -0.5 / (offset[1]-offset[0])^2, computed by the host exactly as PyG does
+  q->type = type; q->theta = theta; q->norm_const = (float)sqrt(2.0 / (cutoff * cutoff * cutoff));
+  q->rho = nullptr; q->drho = nullptr; q->grho = nullptr; q->contrib = nullptr;
+}
 int nq_rbf(hipStream_t st, const float4* geom, int E, int R, double cutoff, int env_p, float coeff, const float* offsets,
-           float* rho, float* drho) {
+           float* rho, float* drho, int type, const float* theta) {
   NQ_PROF(st, "rbf");
   if (E <= 0) return NQ_OK;
   RbfArgs q;
-  q.geom = geom; q.E = E; q.R = R; q.inv_cutoff = (float)(1.0 / cutoff);
-  const double p = env_p;
-  q.p = (float)p; q.a = (float)(-(p + 1) * (p + 2) / 2); q.b = (float)(p * (p + 2)); q.c = (float)(-p * (p + 1) / 2);
-  q.mu = offsets;   // GaussianSmearing(0, 1, R).offset (state_dict buffer radial_basis.rbf.offset)
-  q.coeff = coeff;  // -0.5 / (offset[1]-offset[0])^2, computed by the host exactly as PyG does
+  rbf_fill(&q, geom, E, R, cutoff, env_p, coeff, offsets, type, theta);
   q.rho = rho; q.drho = drho;
-  hipLaunchKernelGGL(k_rbf, dim3(nq_cdiv((long)E * R, 256)), dim3(256), 0, st, q);
+  hipLaunchKernelGGL((k_rbf<false>), dim3(nq_cdiv((long)E * R, 256)), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+// contrib [E][R] (see k_rbf<true>); the caller reduces it over edges (per k for the Bessel frequencies, over everything for pregamma)
+int nq_rbf_param_grad(hipStream_t st, const float4* geom, int E, int R, double cutoff, int env_p, const float* offsets, int type, const float* theta,
+                      const float* grho, float* contrib) {
+  NQ_PROF(st, "rbf_param_grad");
+  if (E <= 0 || type == 0) return NQ_OK;
+  RbfArgs q;
+  rbf_fill(&q, geom, E, R, cutoff, env_p, 0.f, offsets, type, theta);
+  q.grho = grho; q.contrib = contrib;
+  hipLaunchKernelGGL((k_rbf<true>), dim3(nq_cdiv((long)E * R, 256)), dim3(256), 0, st, q);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

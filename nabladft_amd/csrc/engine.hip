@@ -49,17 +49,20 @@ NqProfScope::~NqProfScope() {
 struct MsgP { size_t W1, b1, W2, b2, Wr, br; };
 struct UpdP { size_t U, V1, c1, V2, c2; };
 struct ParamLayout {
-  size_t emb, O1, o1, w2, o2, total;
+  size_t emb, basis, n_basis, O1, o1, w2, o2, total;
   MsgP msg[64];
   UpdP upd[64];
 };
 static int make_param_layout(const nq_painn_cfg* c, ParamLayout* P) {
   const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, T = c->num_elements;
   if (c->num_layers < 1 || c->num_layers > 64) return nq_fail(NQ_ERR_ARG, "num_layers=%d out of range [1,64]", c->num_layers);
+  if (c->rbf_type < 0 || c->rbf_type > 2) return nq_fail(NQ_ERR_ARG, "rbf_type=%d unknown", c->rbf_type);
+  if (c->rbf_type != 0 && c->filter_mode != 0) return nq_fail(NQ_ERR_ARG, "learnable bases are built for filter_mode 0 only");
   if (F % 64 != 0 || F < 64 || F > 1024) return nq_fail(NQ_ERR_ARG, "hidden_channels=%zu must be a multiple of 64 in [64,1024]", F);
   if (R < 1 || T < 1) return nq_fail(NQ_ERR_ARG, "num_rbf / num_elements must be positive");
   size_t o = 0;
   P->emb = o; o += T * F;
+  P->basis = o; P->n_basis = c->rbf_type == 1 ? R : (c->rbf_type == 2 ? 1 : 0); o += P->n_basis;   // radial_basis.rbf.{frequencies | pregamma}
   for (int l = 0; l < c->num_layers; ++l) {
     MsgP& m = P->msg[l];
     m.W1 = o; o += F * F; m.b1 = o; o += F; m.W2 = o; o += 3 * F * F; m.b2 = o; o += 3 * F; m.Wr = o; o += 3 * F * R; m.br = o; o += 3 * F;
@@ -82,7 +85,7 @@ struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
   size_t RHO2, RW, ORDER, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
-  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, scratch;
+  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
 };
@@ -90,7 +93,7 @@ static size_t a4(size_t x) { return (x + 3) & ~(size_t)3; }  // keep every buffe
 
 static bool use_fused_filter(const nq_painn_cfg* c) {
   const char* off = getenv("NQ_NO_FUSED_FILTER");
-  return nq_filter_fits_lds(c->hidden_channels, c->num_rbf) && !(off && off[0] == '1');
+  return c->rbf_type == 0 && nq_filter_fits_lds(c->hidden_channels, c->num_rbf) && !(off && off[0] == '1');   // the window needs compact Gaussians
 }
 
 static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, WsLayout* W) {
@@ -118,6 +121,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GPHI2 = take(2 * E * 3 * F);
   W->GEDGE = take((F / 64) * E * 4);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
+  W->GRHO = take(c->rbf_type ? 2 * E * R : 0); W->BCON = take(c->rbf_type ? E * R : 0);   // learnable bases: adjoints of rho / drho, per-edge contributions
   // scratch for split-K partials / column sums / embedding partials: max over all uses
   size_t s = 0;
   auto mx = [&](size_t v) { if (v > s) s = v; };
@@ -126,6 +130,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   if (W->fused) mx(nq_k0_sort_scratch_ints((int)E, (int)R));
   mx(nq_gemm_tn_scratch_floats(2 * N, F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, H, F));
   mx(nq_colsum_scratch_floats(N > E ? N : E, 3 * F));
+  if (c->rbf_type) { mx(nq_colsum_scratch_floats(E, R)); mx(nq_colsum_scratch_floats(E * R, 1)); }
   mx(nq_embed_grad_scratch_floats((int)N, (int)F, (int)T));
   W->scratch_floats = s;
   W->scratch = take(s);
@@ -302,7 +307,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
     NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
   } else {
-    NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho));
+    NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho, cfg->rbf_type, params + P.basis));
   }
 
   for (int l = 0; l < L; ++l) {
@@ -479,6 +484,8 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
     if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
     else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
+    if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
+      NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));
     NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
     NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
@@ -487,6 +494,11 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
   }
   NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));
+  if (cfg->rbf_type) {   // dL/d(frequencies) [R] or dL/d(pregamma) [1]
+    NQ_TRY(nq_rbf_param_grad(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, rbf_offsets, cfg->rbf_type, params + P.basis, ws + W.GRHO, ws + W.BCON));
+    if (cfg->rbf_type == 1) NQ_TRY(nq_colsum(st, ws + W.BCON, E, R, R, gp + P.basis, scr));
+    else NQ_TRY(nq_colsum(st, ws + W.BCON, (long)E * R, 1, 1, gp + P.basis, scr));
+  }
   return NQ_OK;
 }
 

@@ -102,7 +102,7 @@ class _EnergyForces(torch.autograd.Function):
         ws = model._take_workspace(ws_bytes, dev)
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32) if want_forces else None
-        _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c),
+        _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
                                         _lib.ptr(ws), ws_bytes, _lib.ptr(energy), _lib.ptr(forces), _lib.stream_ptr()))
         ctx.model, ctx.nl, ctx.ws, ctx.ws_bytes, ctx.want_forces = model, nl, ws, ws_bytes, want_forces
         model._last_ws, model._last_nl = ws, nl
@@ -118,7 +118,7 @@ class _EnergyForces(torch.autograd.Function):
         grad_flat = torch.empty_like(flat)
         ge = None if g_energy is None else g_energy.to(torch.float32).contiguous()
         gf = None if (g_forces is None or not ctx.want_forces) else g_forces.to(torch.float32).contiguous()
-        _lib.check(lib.nq_painn_backward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.rbf.offset), C.byref(nl.c),
+        _lib.check(lib.nq_painn_backward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
                                          _lib.ptr(ctx.ws), ctx.ws_bytes,
                                          _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_flat), _lib.stream_ptr()))
         model._last_grad_flat = grad_flat
@@ -154,10 +154,45 @@ class _RadialBasis(nn.Module):
         else:
             raise ValueError(f"Unknown envelope function '{name}'.")
         rb = dict(rbf)
-        if rb.pop("name").lower() != "gaussian":
-            raise NotImplementedError("nabladft_amd: only rbf {'name': 'gaussian'} is implemented (layers.py:172-179)")
+        rbf_name = rb.pop("name").lower()
         self.inv_cutoff = 1 / cutoff
-        self.rbf = _GaussianSmearing(start=0, stop=1, num_gaussians=num_radial, **rb)
+        if rbf_name == "gaussian":
+            self.rbf_type = 0
+            self.rbf = _GaussianSmearing(start=0, stop=1, num_gaussians=num_radial, **rb)
+        elif rbf_name == "spherical_bessel":
+            self.rbf_type = 1
+            self.rbf = _SphericalBesselBasis(num_radial=num_radial, cutoff=cutoff, **rb)
+        elif rbf_name == "bernstein":
+            self.rbf_type = 2
+            self.rbf = _BernsteinBasis(num_radial=num_radial, **rb)
+        else:
+            raise ValueError(f"Unknown radial basis function '{rbf_name}'.")
+
+    def engine_buffer(self):
+        """The fp32 buffer the C ABI takes as ``rbf_offsets``: Gaussian offsets / Bernstein binomial prefactors / (Bessel: unused)."""
+        return self.rbf.offset if self.rbf_type == 0 else (self.rbf.prefactor if self.rbf_type == 2 else self.rbf.frequencies.detach())
+
+
+class _SphericalBesselBasis(nn.Module):
+    """Parameter holder of SphericalBesselBasis (layers.py:51-80): learnable ``frequencies`` at k*pi."""
+
+    def __init__(self, num_radial, cutoff):
+        super().__init__()
+        import math
+        self.norm_const = math.sqrt(2 / (cutoff ** 3))
+        self.coeff = 0.0
+        self.frequencies = nn.Parameter(torch.pi * torch.arange(1, num_radial + 1, dtype=torch.float32))
+
+
+class _BernsteinBasis(nn.Module):
+    """Parameter holder of BernsteinBasis (layers.py:83-126): learnable ``pregamma``; ``prefactor`` = binomial coefficients (non-persistent)."""
+
+    def __init__(self, num_radial, pregamma_initial: float = 0.45264):
+        super().__init__()
+        import math
+        self.coeff = 0.0
+        self.register_buffer("prefactor", torch.tensor([math.comb(num_radial - 1, k) for k in range(num_radial)], dtype=torch.float), persistent=False)
+        self.pregamma = nn.Parameter(torch.tensor(pregamma_initial, dtype=torch.float))
 
 
 class _AtomEmbedding(nn.Module):
@@ -243,6 +278,7 @@ class PaiNN(nn.Module):
         cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = hidden_channels, num_layers, num_rbf, num_elements
         cfg.max_neighbors, cfg.envelope_exponent = max_neighbors, self.radial_basis.exponent
         cfg.cutoff, cfg.rbf_coeff = float(cutoff), float(self.radial_basis.rbf.coeff)
+        cfg.rbf_type = self.radial_basis.rbf_type
         self._cfg = cfg
 
     def reset_parameters(self) -> None:

@@ -33,7 +33,7 @@ class _PygEngine:
 
     def __init__(self, model: PaiNN):
         self.model, self.cfg, self.cutoff, self.max_neighbors = model, model._cfg, model.cutoff, model.max_neighbors
-        self.offsets = model.radial_basis.rbf.offset
+        self.offsets = model.radial_basis.engine_buffer()
 
     def flat(self):
         return self.model.flat_parameters()

@@ -84,11 +84,11 @@ def write_db_fixture(n):
 
 def build_reference_model(ref, cfg, params):
     m = ref["painn"].PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors,
-                           {"name": "gaussian"},
+                           {"name": cfg.rbf},
                            {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
                            True, False, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
-    assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected, (missing, unexpected)
+    assert list(missing) == (["radial_basis.rbf.offset"] if cfg.rbf == "gaussian" else []) and not unexpected, (missing, unexpected)
     assert [k for k, _ in m.named_parameters()] == [k for k, _ in R.param_shapes(cfg)]
     return m
 
@@ -167,6 +167,23 @@ def main():
     np.savez_compressed(os.path.join(OUT, "painn_small_expenv.npz"), **fx_e)
     print("small_expenv: E", out_e["energy"], "loss", out_e["loss"], "edges", out_e["edge_index"].shape)
     if os.environ.get("NQ_GOLDEN_ONLY") == "expenv":
+        return
+
+    # ---- learnable non-Gaussian bases (layers.py:51-126; row a4b): same molecules -------------------------------------------
+    for rbf_name, tag in (("spherical_bessel", "bessel"), ("bernstein", "bernstein")):
+        cfg_b = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=12, cutoff=4.0, max_neighbors=100, envelope_exponent=5, num_elements=100,
+                              rbf=rbf_name)
+        params_b = R.make_params(cfg_b, seed=8)
+        out_b, grads_b = run_reference(ref, cfg_b, params_b, pos_e, z_e, batch_e, y_e, ft_e)
+        fx_b = dict(cfg=np.array([cfg_b.hidden_channels, cfg_b.num_layers, cfg_b.num_rbf, cfg_b.max_neighbors, cfg_b.envelope_exponent,
+                                  cfg_b.num_elements]), cutoff=np.float64(cfg_b.cutoff), param_seed=np.int64(8), pos=pos_e, z=z_e, batch=batch_e,
+                    y=y_e, f_target=ft_e, rbf=np.array(rbf_name))
+        fx_b.update(out_b)
+        for k, gnp in grads_b.items():
+            fx_b["grad:" + k] = gnp
+        np.savez_compressed(os.path.join(OUT, f"painn_small_{tag}.npz"), **fx_b)
+        print(f"small_{tag}: E", out_b["energy"], "loss", out_b["loss"])
+    if os.environ.get("NQ_GOLDEN_ONLY") == "bases":
         return
 
     # ---- full config on 4 real conformers -------------------------------------------------------

@@ -40,6 +40,8 @@ class PaiNNConfig:
     # "pyg": rbf_proj(envelope * gauss(d/rc)) + bias (nablaDFT/painn_pyg).  "spk": cosine_cutoff(d) * (filter(gauss(d)) + bias)
     # (schnetpack PaiNN, config/model/painn.yaml) -- see oracle/spk_painn_ref.py
     filter_mode: str = "pyg"
+    # radial basis of RadialBasis (layers.py:168-179): "gaussian" | "spherical_bessel" (learnable frequencies [R]) | "bernstein" (learnable pregamma)
+    rbf: str = "gaussian"
 
 
 # ----------------------------------------------------------------------------------------
@@ -49,6 +51,10 @@ def param_shapes(cfg: PaiNNConfig):
     """state_dict layout of the reference PaiNN (painn.py:63-87)."""
     F, R = cfg.hidden_channels, cfg.num_rbf
     shapes = [("atom_emb.embeddings.weight", (cfg.num_elements, F))]
+    if cfg.rbf == "spherical_bessel":
+        shapes += [("radial_basis.rbf.frequencies", (R,))]
+    elif cfg.rbf == "bernstein":
+        shapes += [("radial_basis.rbf.pregamma", ())]
     for i in range(cfg.num_layers):
         p = f"message_layers.{i}."
         shapes += [(p + "x_proj.0.weight", (F, F)), (p + "x_proj.0.bias", (F,)),
@@ -71,7 +77,11 @@ def make_params(cfg: PaiNNConfig, seed: int, dtype=torch.float32):
     rng = np.random.Generator(np.random.PCG64(seed))
     out = {}
     for name, shape in param_shapes(cfg):
-        if name.endswith("embeddings.weight"):
+        if name.endswith("rbf.frequencies"):
+            a = np.pi * np.arange(1, shape[0] + 1) + rng.normal(0, 0.05, size=shape)       # layers.py:71-74 canonical positions, perturbed
+        elif name.endswith("rbf.pregamma"):
+            a = np.array(0.45264 + rng.normal(0, 0.05))                                    # layers.py:104
+        elif name.endswith("embeddings.weight"):
             a = rng.uniform(-np.sqrt(3.0), np.sqrt(3.0), size=shape)
         elif name.endswith("weight"):
             bound = np.sqrt(6.0 / (shape[0] + shape[1]))
@@ -134,8 +144,9 @@ def edge_geometry(pos, edge_index):
     return edge_dist, edge_vector
 
 
-def radial_basis(cfg: PaiNNConfig, d):
-    """layers.py:181-185 with PolynomialEnvelope (:23-33) and GaussianSmearing(0,1,R)."""
+def radial_basis(cfg: PaiNNConfig, d, P=None):
+    """layers.py:181-185 with PolynomialEnvelope (:23-33) / ExponentialEnvelope (:36-48) and GaussianSmearing(0,1,R) /
+    SphericalBesselBasis (:51-80) / BernsteinBasis (:83-126; needs the parameter dict P for the learnable basis parameters)."""
     p = float(cfg.envelope_exponent)
     a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
     ds = d * (1 / cfg.cutoff)
@@ -144,6 +155,18 @@ def radial_basis(cfg: PaiNNConfig, d):
     else:
         env = 1 + a * ds**p + b * ds ** (p + 1) + c * ds ** (p + 2)
     env = torch.where(ds < 1, env, torch.zeros_like(ds))
+    if cfg.rbf == "spherical_bessel":
+        import math
+        norm_const = math.sqrt(2 / (cfg.cutoff ** 3))
+        return env[:, None] * (norm_const / ds[:, None] * torch.sin(P["radial_basis.rbf.frequencies"] * ds[:, None]))
+    if cfg.rbf == "bernstein":
+        from scipy.special import binom
+        R_ = cfg.num_rbf
+        prefactor = torch.tensor(binom(R_ - 1, np.arange(R_)), dtype=torch.float).to(d.dtype)
+        gamma = Fn.softplus(P["radial_basis.rbf.pregamma"])
+        exp_d = torch.exp(-gamma * ds)[:, None]
+        exp1 = torch.arange(R_)[None, :]
+        return env[:, None] * (prefactor * (exp_d ** exp1) * ((1 - exp_d) ** (R_ - 1 - exp1)))
     offset = torch.linspace(0.0, 1.0, cfg.num_rbf).to(d.dtype)
     coeff = -0.5 / (torch.linspace(0.0, 1.0, cfg.num_rbf)[1] - 0.0).item() ** 2
     g = torch.exp(coeff * (ds.view(-1, 1) - offset.view(1, -1)).pow(2))
@@ -204,7 +227,7 @@ def painn_energy(P, cfg: PaiNNConfig, pos, z, batch, edge_index, trace=None):
         g, fcut = spk_radial(cfg, edge_dist)
         edge_rbf, bias_scale = g * fcut[:, None], fcut
     else:
-        edge_rbf = radial_basis(cfg, edge_dist)
+        edge_rbf = radial_basis(cfg, edge_dist, P)
     x = P["atom_emb.embeddings.weight"][z - 1]
     vec = torch.zeros(x.size(0), 3, F, dtype=x.dtype)
     for l in range(cfg.num_layers):

@@ -13,7 +13,8 @@ def load_case(name):
     fx = dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
     c = fx["cfg"]
     cfg = R.PaiNNConfig(hidden_channels=int(c[0]), num_layers=int(c[1]), num_rbf=int(c[2]), cutoff=float(fx["cutoff"]),
-                        max_neighbors=int(c[3]), envelope_exponent=int(c[4]), num_elements=int(c[5]))
+                        max_neighbors=int(c[3]), envelope_exponent=int(c[4]), num_elements=int(c[5]),
+                        rbf=str(fx["rbf"]) if "rbf" in fx else "gaussian")
     params = R.make_params(cfg, int(fx["param_seed"]))
     return fx, cfg, params
 

@@ -83,8 +83,16 @@ def test_unsupported_configs_fail_loudly():
               use_pbc=False, otf_graph=True, num_elements=100)
     with pytest.raises(ValueError):
         nq.PaiNN(100, 6, 100, 5.0, 100, **kw)                # hidden_channels not a multiple of 64
-    with pytest.raises(NotImplementedError):
-        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "rbf": {"name": "spherical_bessel"}})
+    with pytest.raises(ValueError):                           # unknown names fail like the reference (layers.py:166,179)
+        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "rbf": {"name": "chebyshev"}})
+    with pytest.raises(ValueError):
+        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "envelope": {"name": "cosine"}})
+    # every RadialBasis option of the reference is built: parameter surface of the learnable bases
+    mb = nq.PaiNN(64, 1, 12, 4.0, 100, **{**kw, "rbf": {"name": "spherical_bessel"}})
+    assert tuple(mb.state_dict()["radial_basis.rbf.frequencies"].shape) == (12,) and "radial_basis.rbf.offset" not in mb.state_dict()
+    mn = nq.PaiNN(64, 1, 12, 4.0, 100, **{**kw, "rbf": {"name": "bernstein"}, "envelope": {"name": "exponential"}})
+    assert tuple(mn.state_dict()["radial_basis.rbf.pregamma"].shape) == () and "radial_basis.rbf.prefactor" not in mn.state_dict()
+    assert [n for n, _ in mn.named_parameters()][:2] == ["atom_emb.embeddings.weight", "radial_basis.rbf.pregamma"]
     with pytest.raises(NotImplementedError):
         nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "use_pbc": True})
     with pytest.raises(NotImplementedError):

@@ -55,11 +55,11 @@ def _dev():
 
 def _model(cfg, params, dev):
     import nabladft_amd as nq
-    m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": "gaussian"},
+    m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": cfg.rbf},
                  {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
                  True, False, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
-    assert list(missing) == ["radial_basis.rbf.offset"] and not unexpected
+    assert list(missing) == (["radial_basis.rbf.offset"] if cfg.rbf == "gaussian" else []) and not unexpected
     return m.to(dev)
 
 
@@ -456,3 +456,27 @@ def test_graph_large_molecule_matches_oracle():
         assert np.array_equal(nl.edge_dist.cpu().numpy(), d) and np.array_equal(nl.edge_vector.cpu().numpy(), v)   # bit-exact IEEE
         dt, vt = R.edge_geometry(pos, ei)                                                                            # torch CPU: faithful
         assert _ulp_close(nl.edge_dist.cpu().numpy(), dt.numpy(), 1, 0.5) and _ulp_close(nl.edge_vector.cpu().numpy(), vt.numpy(), 2, 0.5)
+
+
+@pytest.mark.parametrize("name", ["painn_small_bessel.npz", "painn_small_bernstein.npz"])
+def test_engine_learnable_bases_match_reference(name):
+    """SphericalBesselBasis / BernsteinBasis (layers.py:51-126, row a4b): non-compact, learnable bases run on the materialised-filter
+    path; golden vectors from the real reference incl. the gradients of the basis parameters (frequencies [R] / pregamma)."""
+    from nabladft_amd import L2Loss
+    dev = _dev()
+    fx, cfg, params = load_case(name)
+    model = _model(cfg, params, dev)
+    batch = _batch(fx, dev)
+    model.train()
+    energy, forces = model(batch)
+    e_err, f_err = rel_err(energy.detach().cpu().numpy(), fx["energy"]), rel_err(forces.detach().cpu().numpy(), fx["forces"])
+    assert e_err < 2e-6 and f_err < 2e-5, (e_err, f_err)
+    loss = torch.nn.L1Loss()(energy, batch.y) + L2Loss()(forces, batch.forces)
+    loss.backward()
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    basis = [k for k in grads if k.startswith("radial_basis.rbf.")]
+    assert len(basis) == 1 and "grad:" + basis[0] in fx
+    worst = check_grads(fx, grads, 1e-4, name)
+    print(f"{name}: energy {e_err:.2e} forces {f_err:.2e} worst grad {worst[0]:.2e} ({worst[1]}); d{basis[0]}: "
+          f"{rel_err(grads[basis[0]], fx['grad:' + basis[0]]):.2e}")
