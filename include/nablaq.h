@@ -109,6 +109,21 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
  * Must follow nq_painn_forward (with forces) on the same workspace and graph. */
 int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                       size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
+/* First-order reverse for the direct-force model (direct_forces=True, painn.py:130-133; the PaiNNOutput head itself, painn.py:551-620, is
+ * evaluated by the caller on the final node state "x_in"/"vec_in" at layer L of the workspace): given dL/dE[B] and the adjoints of the
+ * final x [N][F] and vec [N][3][F] (any may be NULL) writes dL/dparams.  Must follow nq_painn_forward (forces == NULL) on the same workspace. */
+int nq_painn_backward_seeded(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                             size_t workspace_bytes, const float* grad_energy, const float* grad_x, const float* grad_vec, float* grad_params,
+                             void* stream);
+/* Elementwise pieces of GatedEquivariantBlock (painn.py:583-620), the GEMMs in between are nq_linear_*:
+ * nq_scaled_silu: out = silu(z)/0.6 (grad_y == NULL) or grad_y * dsilu(z)/0.6;  nq_geb_cat: cat[N][2h] = [x | ||v1||_xyz], v1 [N][3][h];
+ * nq_geb_gate: (xo | gate) = split(o2 [N][2o]); xout = ScaledSiLU(xo), vout [N][3][o] = gate * v2. */
+int nq_scaled_silu(const float* z, const float* grad_y, float* out, int64_t count, void* stream);
+int nq_geb_cat(const float* x, const float* v1, int64_t N, int32_t h, float* cat, void* stream);
+int nq_geb_cat_backward(const float* grad_cat, const float* v1, int64_t N, int32_t h, float* grad_x, float* grad_v1, void* stream);
+int nq_geb_gate(const float* o2, const float* v2, int64_t N, int32_t o, float* xout, float* vout, void* stream);
+int nq_geb_gate_backward(const float* o2, const float* v2, const float* grad_xout, const float* grad_vout, int64_t N, int32_t o, float* grad_o2,
+                         float* grad_v2, void* stream);
 /* Test/inspection hook: offset (in floats) and element count of a named workspace buffer, e.g.
  * ("x_msg", 2, tangent=0).  Returns NQ_ERR_ARG for unknown names. */
 int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t layer, int32_t tangent,

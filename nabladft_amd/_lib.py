@@ -45,6 +45,12 @@ SYMBOLS = {
     "nq_painn_workspace_bytes": (_SZ, [C.POINTER(PainnCfg), _I32, _I32, _I32]),
     "nq_painn_forward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
     "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
+    "nq_painn_backward_seeded": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P, _P]),
+    "nq_scaled_silu": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "nq_geb_cat": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "nq_geb_cat_backward": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "nq_geb_gate": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "nq_geb_gate_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "nq_painn_ws_lookup": (C.c_int, [C.POINTER(PainnCfg), _I32, _I32, _I32, C.c_char_p, _I32, _I32, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "nq_schnet_num_params": (_SZ, [C.POINTER(SchnetCfg)]),
     "nq_schnet_workspace_bytes": (_SZ, [C.POINTER(SchnetCfg), _I32, _I32, _I32]),

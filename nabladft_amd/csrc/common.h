@@ -209,6 +209,7 @@ int nq_readout_rev(hipStream_t, const ReadoutArgs&, bool dual);
 int nq_mol_sum(hipStream_t, const float* e_atom, const int* mol_ptr, int B, float* out);
 int nq_atom_seeds(hipStream_t, const float* gE, const int* atom_mol, int N, float* ge, float* gte);
 int nq_negate(hipStream_t, const float* in, float* out, long count);
+int nq_axpy(hipStream_t, const float* x, float* y, long count);   // y += x
 int nq_loss_impl(hipStream_t, const float* E, const float* y, int B, const float* Fc, const float* Ft, int N, float ce, float cf, float* loss,
                  float* gE, float* gF, bool mse);
 int nq_adamw_impl(hipStream_t, float* p, const float* g, float* m, float* v, long count, float max_norm, float lr, float beta1, float beta2,

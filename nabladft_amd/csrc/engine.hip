@@ -383,8 +383,12 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
-                      size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
+// seeded = true: first-order reverse for the direct-force model (painn.py:130-133): no tangent sweep; the tangent halves of every
+// stacked buffer are zeroed so that the dual-reverse kernels reduce to the plain reverse, and the adjoints of the final node state
+// (from the PaiNNOutput head, evaluated by the caller) are added to the seeds.
+static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                               size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream,
+                               bool seeded, const float* seed_x, const float* seed_vec) {
   WsLayout W; ParamLayout P;
   NQ_TRY(check_common(cfg, graph, workspace, workspace_bytes, &W, &P));
   if (!params || !grad_params || !rbf_offsets) return nq_fail(NQ_ERR_ARG, "null argument");
@@ -396,6 +400,22 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers, T = cfg->num_elements;
   const size_t NF = (size_t)N * F;
 
+  const size_t NH = (size_t)N * H;
+  ReadoutArgs r{};
+  r.N = N; r.H = H; r.ZO = ws + W.ZO; r.TZO = ws + W.ZO + NH; r.w2 = params + P.w2; r.o2 = params + P.o2;
+  r.e_atom = ws + W.e_atom; r.te_atom = ws + W.te_atom;
+  if (seeded) {
+    // zero every tangent half (the forward sweep filled the primal halves only)
+    auto zero = [&](size_t off, size_t n) { return hipMemsetAsync(ws + off, 0, n * sizeof(float), st); };
+    for (int l = 0; l <= L; ++l) { NQ_HIP(zero(W.X[l] + NF, NF)); NQ_HIP(zero(W.V[l] + 3 * NF, 3 * NF)); }
+    for (int l = 0; l < L; ++l) {
+      const WsLayer& y = W.lay[l];
+      NQ_HIP(zero(y.Z1 + NF, NF)); NQ_HIP(zero(y.Hh + NF, NF)); NQ_HIP(zero(y.XH + 3 * NF, 3 * NF)); NQ_HIP(zero(y.XM + NF, NF));
+      NQ_HIP(zero(y.VM + 3 * NF, 3 * NF)); NQ_HIP(zero(y.UU + 6 * NF, 6 * NF)); NQ_HIP(zero(y.S + NF, NF)); NQ_HIP(zero(y.CAT + 2 * NF, 2 * NF));
+      NQ_HIP(zero(y.ZQ + NF, NF)); NQ_HIP(zero(y.Q + NF, NF)); NQ_HIP(zero(y.Y + 3 * NF, 3 * NF));
+    }
+    NQ_HIP(zero(W.TD, E)); NQ_HIP(zero(W.TR, 3 * (size_t)E)); NQ_HIP(zero(W.ZO + (size_t)N * H, (size_t)N * H)); NQ_HIP(zero(W.te_atom, N));
+  } else {
   // ---- tangent forward along pos_dot = -dL/dF --------------------------------------------------
   if (grad_forces) NQ_TRY(nq_negate(st, grad_forces, ws + W.pos_dot, 3L * N));
   else NQ_HIP(hipMemsetAsync(ws + W.pos_dot, 0, 3 * (size_t)N * sizeof(float), st));
@@ -429,19 +449,19 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
     NQ_TRY(nq_upd_b(st, u, true));
   }
-  const size_t NH = (size_t)N * H;
   NQ_TRY(nq_gemm_nt(st, ws + W.X[L] + NF, params + P.O1, ws + W.ZO + NH, nullptr, nullptr, N, H, F, F, F, H, "O1"));
-  ReadoutArgs r{};
   r.N = N; r.H = H; r.ZO = ws + W.ZO; r.TZO = ws + W.ZO + NH; r.w2 = params + P.w2; r.o2 = params + P.o2;
   r.e_atom = ws + W.e_atom; r.te_atom = ws + W.te_atom;
   NQ_TRY(nq_readout(st, r, 1));
 
+  }
   // ---- dual reverse: seeds (dL/dE_b, 1) on (E_b, Edot) -----------------------------------------
   if (grad_energy) NQ_TRY(nq_atom_seeds(st, grad_energy, g.atom_mol, N, ws + W.ge, ws + W.gte));
   else {
     NQ_HIP(hipMemsetAsync(ws + W.ge, 0, (size_t)N * sizeof(float), st));
     NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.gte, nullptr));  // gte = 1
   }
+  if (seeded) NQ_HIP(hipMemsetAsync(ws + W.gte, 0, (size_t)N * sizeof(float), st));   // no Edot term
   r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
   NQ_TRY(nq_readout_rev(st, r, true));
   NQ_TRY(nq_colsum(st, ws + W.TMPW, N, H, H, gp + P.w2, scr));
@@ -450,6 +470,10 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
   NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
+  if (seeded) {   // adjoints of the final (x, vec) coming from the force head
+    if (seed_x) NQ_TRY(nq_axpy(st, seed_x, ws + W.GX, (long)NF));
+    if (seed_vec) NQ_HIP(hipMemcpyAsync(gv_cur, seed_vec, 3 * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
@@ -500,6 +524,18 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
     else NQ_TRY(nq_colsum(st, ws + W.BCON, (long)E * R, 1, 1, gp + P.basis, scr));
   }
   return NQ_OK;
+}
+
+int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                      size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
+  return painn_backward_impl(cfg, params, rbf_offsets, graph, workspace, workspace_bytes, grad_energy, grad_forces, grad_params, stream, false, nullptr,
+                             nullptr);
+}
+int nq_painn_backward_seeded(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                             size_t workspace_bytes, const float* grad_energy, const float* grad_x, const float* grad_vec, float* grad_params,
+                             void* stream) {
+  return painn_backward_impl(cfg, params, rbf_offsets, graph, workspace, workspace_bytes, grad_energy, nullptr, grad_params, stream, true, grad_x,
+                             grad_vec);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -416,6 +416,15 @@ int nq_atom_seeds(hipStream_t st, const float* gE, const int* atom_mol, int N, f
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
+__global__ void k_axpy(const float* __restrict__ x, float* __restrict__ y, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) y[i] += x[i];
+}
+int nq_axpy(hipStream_t st, const float* x, float* y, long count) {
+  hipLaunchKernelGGL(k_axpy, grid1d(count, 256), dim3(256), 0, st, x, y, count);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
 int nq_negate(hipStream_t st, const float* in, float* out, long count) {
   hipLaunchKernelGGL(k_scale_neg, grid1d(count, 256), dim3(256), 0, st, in, out, count);
   NQ_LAUNCH_CHECK();
@@ -443,3 +452,94 @@ int nq_adamw_impl(hipStream_t st, float* p, const float* g, float* m, float* v, 
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
+
+// ---- GatedEquivariantBlock pieces of the direct-force head (painn.py:583-620); GEMMs in between via nq_linear_* ---------------------------
+// ScaledSiLU(x) = silu(x) / 0.6 (layers.py:188-195)
+__global__ void k_scaled_silu(const float* __restrict__ z, const float* __restrict__ gy, float* __restrict__ out, long count, int bwd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float s = 1.0f / 0.6f;
+  out[i] = bwd ? gy[i] * nq_dsilu(z[i]) * s : nq_silu(z[i]) * s;
+}
+// cat[n] = [x[n] | ||v1[n]||_xyz]     v1: [N][3][h]
+__global__ void k_geb_cat(const float* __restrict__ x, const float* __restrict__ v1, long N, int h, float* __restrict__ cat) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * h) return;
+  const long n = i / h; const int c = (int)(i % h);
+  const float a = v1[(n * 3) * h + c], b = v1[(n * 3 + 1) * h + c], d = v1[(n * 3 + 2) * h + c];
+  cat[n * 2 * h + c] = x[i];
+  cat[n * 2 * h + h + c] = sqrtf(a * a + b * b + d * d);
+}
+__global__ void k_geb_cat_rev(const float* __restrict__ gcat, const float* __restrict__ v1, long N, int h, float* __restrict__ gx, float* __restrict__ gv1) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * h) return;
+  const long n = i / h; const int c = (int)(i % h);
+  gx[i] = gcat[n * 2 * h + c];
+  const float a = v1[(n * 3) * h + c], b = v1[(n * 3 + 1) * h + c], d = v1[(n * 3 + 2) * h + c];
+  const float nr = sqrtf(a * a + b * b + d * d);
+  const float sc = nr > 0.f ? gcat[n * 2 * h + h + c] / nr : 0.f;
+  gv1[(n * 3) * h + c] = sc * a; gv1[(n * 3 + 1) * h + c] = sc * b; gv1[(n * 3 + 2) * h + c] = sc * d;
+}
+// (xo | gate) = split(o2);  xout = ScaledSiLU(xo);  vout[n][xyz][j] = gate[n][j] * v2[n][xyz][j]
+__global__ void k_geb_gate(const float* __restrict__ o2, const float* __restrict__ v2, long N, int o, float* __restrict__ xout, float* __restrict__ vout) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * o) return;
+  const long n = i / o; const int j = (int)(i % o);
+  xout[i] = nq_silu(o2[n * 2 * o + j]) * (1.0f / 0.6f);
+  const float gate = o2[n * 2 * o + o + j];
+  for (int c = 0; c < 3; ++c) vout[(n * 3 + c) * o + j] = gate * v2[(n * 3 + c) * o + j];
+}
+__global__ void k_geb_gate_rev(const float* __restrict__ o2, const float* __restrict__ v2, const float* __restrict__ gxout, const float* __restrict__ gvout,
+                               long N, int o, float* __restrict__ go2, float* __restrict__ gv2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * o) return;
+  const long n = i / o; const int j = (int)(i % o);
+  go2[n * 2 * o + j] = gxout[i] * nq_dsilu(o2[n * 2 * o + j]) * (1.0f / 0.6f);
+  const float gate = o2[n * 2 * o + o + j];
+  float gg = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float gv = gvout[(n * 3 + c) * o + j];
+    gg += gv * v2[(n * 3 + c) * o + j];
+    gv2[(n * 3 + c) * o + j] = gv * gate;
+  }
+  go2[n * 2 * o + o + j] = gg;
+}
+
+extern "C" {
+int nq_scaled_silu(const float* z, const float* grad_y, float* out, int64_t count, void* stream) {
+  if (!z || !out || count < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (count > 0) hipLaunchKernelGGL(k_scaled_silu, grid1d(count, 256), dim3(256), 0, st, z, grad_y, out, (long)count, grad_y ? 1 : 0);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_geb_cat(const float* x, const float* v1, int64_t N, int32_t h, float* cat, void* stream) {
+  if (!x || !v1 || !cat || h <= 0 || N < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0) hipLaunchKernelGGL(k_geb_cat, grid1d(N * h, 256), dim3(256), 0, st, x, v1, (long)N, h, cat);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_geb_cat_backward(const float* grad_cat, const float* v1, int64_t N, int32_t h, float* grad_x, float* grad_v1, void* stream) {
+  if (!grad_cat || !v1 || !grad_x || !grad_v1 || h <= 0 || N < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0) hipLaunchKernelGGL(k_geb_cat_rev, grid1d(N * h, 256), dim3(256), 0, st, grad_cat, v1, (long)N, h, grad_x, grad_v1);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_geb_gate(const float* o2, const float* v2, int64_t N, int32_t o, float* xout, float* vout, void* stream) {
+  if (!o2 || !v2 || !xout || !vout || o <= 0 || N < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0) hipLaunchKernelGGL(k_geb_gate, grid1d(N * o, 256), dim3(256), 0, st, o2, v2, (long)N, o, xout, vout);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_geb_gate_backward(const float* o2, const float* v2, const float* grad_xout, const float* grad_vout, int64_t N, int32_t o, float* grad_o2,
+                         float* grad_v2, void* stream) {
+  if (!o2 || !v2 || !grad_xout || !grad_vout || !grad_o2 || !grad_v2 || o <= 0 || N < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0) hipLaunchKernelGGL(k_geb_gate_rev, grid1d(N * o, 256), dim3(256), 0, st, o2, v2, grad_xout, grad_vout, (long)N, o, grad_o2, grad_v2);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+}  // extern "C"

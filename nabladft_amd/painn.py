@@ -127,6 +127,175 @@ class _EnergyForces(torch.autograd.Function):
         return (None, None, None) + grads
 
 
+class _EnergyBackbone(torch.autograd.Function):
+    """direct_forces=True (painn.py:130-133): (energy, x_L, vec_L) = f(params); backward = first-order reverse of the engine seeded with
+    dL/dE and the adjoints of the final node state coming from the PaiNNOutput head."""
+
+    @staticmethod
+    def forward(ctx, model, nl, *params):
+        lib = _lib.load()
+        flat = model._flat
+        dev = flat.device
+        ws_bytes = lib.nq_painn_workspace_bytes(C.byref(model._cfg), nl.N, nl.E, nl.B)
+        ws = model._take_workspace(ws_bytes, dev)
+        energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
+        _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
+                                        _lib.ptr(ws), ws_bytes, _lib.ptr(energy), None, _lib.stream_ptr()))
+        model._last_ws, model._last_nl = ws, nl
+        F, L = model.hidden_channels, model.num_layers
+        x = model.workspace_view("x_in", L).view(nl.N, F).clone()
+        vec = model.workspace_view("vec_in", L).view(nl.N, 3, F).clone()
+        ctx.model, ctx.nl, ctx.ws, ctx.ws_bytes = model, nl, ws, ws_bytes
+        return energy, x, vec
+
+    @staticmethod
+    def backward(ctx, g_energy, g_x, g_vec):
+        lib = _lib.load()
+        model, nl = ctx.model, ctx.nl
+        flat = model._flat
+        grad_flat = torch.zeros_like(flat)                       # the head's own parameters (tail of the buffer) get theirs from autograd
+        cont = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        _lib.check(lib.nq_painn_backward_seeded(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
+                                                _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.ptr(cont(g_energy)), _lib.ptr(cont(g_x)), _lib.ptr(cont(g_vec)),
+                                                _lib.ptr(grad_flat), _lib.stream_ptr()))
+        model._last_grad_flat = grad_flat
+        model._release_workspace(ctx.ws)
+        n_engine = model._n_engine_params
+        grads = tuple((grad_flat[o:o + n].view(s) if o < n_engine else None) for (o, n, s) in model._param_slices)
+        return (None, None) + grads
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T (+ b) through the engine's fp32 MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        lib = _lib.load()
+        x, W = x.to(torch.float32).contiguous(), W.to(torch.float32).contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_linear_forward(_lib.ptr(x), _lib.ptr(W), _lib.ptr(None if b is None else b.to(torch.float32).contiguous()), _lib.ptr(y), None, M, N, K,
+                                         _lib.stream_ptr()))
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        gx, gW = torch.empty_like(x), torch.empty_like(W)
+        _lib.check(lib.nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(gx), M, N, K, 0, _lib.stream_ptr()))
+        scr = torch.empty(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
+        return gx, gW, (g.sum(0) if ctx.has_bias else None)
+
+
+class _ScaledSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        out = torch.empty_like(z)
+        _lib.check(_lib.load().nq_scaled_silu(_lib.ptr(z), None, _lib.ptr(out), z.numel(), _lib.stream_ptr()))
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(z)
+        _lib.check(_lib.load().nq_scaled_silu(_lib.ptr(z), _lib.ptr(g), _lib.ptr(out), z.numel(), _lib.stream_ptr()))
+        return out
+
+
+class _GebCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v1):
+        x, v1 = x.contiguous(), v1.contiguous()
+        N, h = x.shape
+        cat = torch.empty(N, 2 * h, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().nq_geb_cat(_lib.ptr(x), _lib.ptr(v1), N, h, _lib.ptr(cat), _lib.stream_ptr()))
+        ctx.save_for_backward(v1)
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        (v1,) = ctx.saved_tensors
+        N, _, h = v1.shape
+        g = g.contiguous()
+        gx, gv1 = torch.empty(N, h, device=g.device, dtype=torch.float32), torch.empty_like(v1)
+        _lib.check(_lib.load().nq_geb_cat_backward(_lib.ptr(g), _lib.ptr(v1), N, h, _lib.ptr(gx), _lib.ptr(gv1), _lib.stream_ptr()))
+        return gx, gv1
+
+
+class _GebGateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o2, v2):
+        o2, v2 = o2.contiguous(), v2.contiguous()
+        N, _, o = v2.shape
+        xout, vout = torch.empty(N, o, device=o2.device, dtype=torch.float32), torch.empty_like(v2)
+        _lib.check(_lib.load().nq_geb_gate(_lib.ptr(o2), _lib.ptr(v2), N, o, _lib.ptr(xout), _lib.ptr(vout), _lib.stream_ptr()))
+        ctx.save_for_backward(o2, v2)
+        return xout, vout
+
+    @staticmethod
+    def backward(ctx, gx, gv):
+        o2, v2 = ctx.saved_tensors
+        N, _, o = v2.shape
+        go2, gv2 = torch.empty_like(o2), torch.empty_like(v2)
+        _lib.check(_lib.load().nq_geb_gate_backward(_lib.ptr(o2), _lib.ptr(v2), _lib.ptr(gx.contiguous()), _lib.ptr(gv.contiguous()), N, o, _lib.ptr(go2),
+                                                    _lib.ptr(gv2), _lib.stream_ptr()))
+        return go2, gv2
+
+
+class _GatedEquivariantBlock(nn.Module):
+    """Parameter holder + HIP evaluation of GatedEquivariantBlock (painn.py:583-620)."""
+
+    def __init__(self, hidden_channels, out_channels):
+        super().__init__()
+        self.out_channels = out_channels
+        self.vec1_proj = nn.Linear(hidden_channels, hidden_channels, bias=False)
+        self.vec2_proj = nn.Linear(hidden_channels, out_channels, bias=False)
+        self.update_net = nn.Sequential(nn.Linear(hidden_channels * 2, hidden_channels), nn.Identity(), nn.Linear(hidden_channels, out_channels * 2))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.vec1_proj.weight)
+        nn.init.xavier_uniform_(self.vec2_proj.weight)
+        nn.init.xavier_uniform_(self.update_net[0].weight)
+        self.update_net[0].bias.data.fill_(0)
+        nn.init.xavier_uniform_(self.update_net[2].weight)
+        self.update_net[2].bias.data.fill_(0)
+
+    def forward(self, x, v):
+        N, _, h = v.shape
+        v1 = _LinearFn.apply(v.reshape(3 * N, h), self.vec1_proj.weight, None).view(N, 3, h)
+        v2 = _LinearFn.apply(v.reshape(3 * N, h), self.vec2_proj.weight, None).view(N, 3, self.out_channels)
+        u = _ScaledSiluFn.apply(_LinearFn.apply(_GebCatFn.apply(x, v1), self.update_net[0].weight, self.update_net[0].bias))
+        o2 = _LinearFn.apply(u, self.update_net[2].weight, self.update_net[2].bias)
+        return _GebGateFn.apply(o2, v2)
+
+
+class _PaiNNOutput(nn.Module):
+    """PaiNNOutput (painn.py:551-579): two gated equivariant blocks hidden -> hidden/2 -> 1; returns forces [N, 3]."""
+
+    def __init__(self, hidden_channels):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.output_network = nn.ModuleList([_GatedEquivariantBlock(hidden_channels, hidden_channels // 2),
+                                             _GatedEquivariantBlock(hidden_channels // 2, 1)])
+
+    def forward(self, x, vec):
+        for layer in self.output_network:
+            x, vec = layer(x, vec)
+        return vec.squeeze(-1)
+
+
 class _GaussianSmearing(nn.Module):
     """Holds the ``offset`` buffer / ``coeff`` exactly as torch_geometric's GaussianSmearing(start, stop, n)."""
 
@@ -246,9 +415,6 @@ class PaiNN(nn.Module):
         if use_pbc:
             raise NotImplementedError("nabladft_amd: use_pbc=True (radius_graph_pbc, utils.py) is outside the nablaDFT hot path "
                                       "(config/model/painn-oc.yaml:18 sets use_pbc: false)")
-        if regress_forces and direct_forces:
-            raise NotImplementedError("nabladft_amd: direct_forces=True (PaiNNOutput head, painn.py:551-620) is not built yet "
-                                      "(config/model/painn-oc.yaml:17 sets direct_forces: false)")
         if hidden_channels % 64 != 0 or not (64 <= hidden_channels <= 1024):
             raise ValueError("hidden_channels must be a multiple of 64 in [64, 1024] (one thread per channel, wavefront = 64)")
         self.hidden_channels = hidden_channels
@@ -268,9 +434,12 @@ class PaiNN(nn.Module):
         self.update_layers = nn.ModuleList([_Update(hidden_channels) for _ in range(num_layers)])
         self.out_energy = nn.Sequential(nn.Linear(hidden_channels, hidden_channels // 2), nn.SiLU(),
                                         nn.Linear(hidden_channels // 2, 1))
+        if self.regress_forces is True and self.direct_forces is True:
+            self.out_forces = _PaiNNOutput(hidden_channels)        # painn.py:84-85; its parameters follow the engine's in the flat buffer
         self.reset_parameters()
 
         self._flat = None
+        self._n_engine_params = None
         self._param_slices = None
         self._last_ws = self._last_nl = self._last_grad_flat = None
         self._ws_cache, self._ws_busy = None, False
@@ -289,7 +458,7 @@ class PaiNN(nn.Module):
     def __getstate__(self):
         # transient engine handles (device pointers) are rebuilt lazily; keep copies/pickles clean
         state = self.__dict__.copy()
-        for k in ("_flat", "_param_slices", "_last_ws", "_last_nl", "_last_grad_flat", "_ws_cache"):
+        for k in ("_flat", "_param_slices", "_last_ws", "_last_nl", "_last_grad_flat", "_ws_cache", "_n_engine_params"):
             state[k] = None
         state["_ws_busy"] = False
         return state
@@ -314,8 +483,10 @@ class PaiNN(nn.Module):
                 p.data = flat[o:o + n].view(p.shape)
                 o += n
             expect = _lib.load().nq_painn_num_params(C.byref(self._cfg))
-            if o != expect:
-                raise RuntimeError(f"parameter count {o} != engine layout {expect}")
+            head = sum(p.numel() for p in self.out_forces.parameters()) if hasattr(self, "out_forces") else 0
+            if o != expect + head:
+                raise RuntimeError(f"parameter count {o} != engine layout {expect} (+ {head} force-head parameters)")
+            self._n_engine_params = expect
             self._flat, self._param_slices = flat, slices
         return self._flat
 
@@ -360,6 +531,9 @@ class PaiNN(nn.Module):
         self.flat_parameters()
         nl = build_neighbor_list(pos, batch, z, self.cutoff, self.max_neighbors, getattr(data, "ptr", None))
         self._check_neighbors(nl)
+        if self.regress_forces and self.direct_forces:              # painn.py:130-133
+            energy, x, vec = _EnergyBackbone.apply(self, nl, *self.parameters())
+            return energy, self.out_forces(x, vec)
         energy, forces = _EnergyForces.apply(self, nl, bool(self.regress_forces), *self.parameters())
         if self.regress_forces:
             return energy, forces

@@ -32,6 +32,8 @@ class _PygEngine:
     """nabladft_amd.PaiNN: the module's parameters are views of the engine's flat buffer -- nothing to convert."""
 
     def __init__(self, model: PaiNN):
+        if getattr(model, "direct_forces", False) and getattr(model, "regress_forces", False):
+            raise NotImplementedError("FusedTrainStep covers the autograd-force model; train direct_forces=True models through the autograd boundary")
         self.model, self.cfg, self.cutoff, self.max_neighbors = model, model._cfg, model.cutoff, model.max_neighbors
         self.offsets = model.radial_basis.engine_buffer()
 

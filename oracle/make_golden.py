@@ -86,7 +86,7 @@ def build_reference_model(ref, cfg, params):
     m = ref["painn"].PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors,
                            {"name": cfg.rbf},
                            {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
-                           True, False, False, True, cfg.num_elements)
+                           True, cfg.direct_forces, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
     assert list(missing) == (["radial_basis.rbf.offset"] if cfg.rbf == "gaussian" else []) and not unexpected, (missing, unexpected)
     assert [k for k, _ in m.named_parameters()] == [k for k, _ in R.param_shapes(cfg)]
@@ -184,6 +184,22 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"painn_small_{tag}.npz"), **fx_b)
         print(f"small_{tag}: E", out_b["energy"], "loss", out_b["loss"])
     if os.environ.get("NQ_GOLDEN_ONLY") == "bases":
+        return
+
+    # ---- direct-force head (PaiNNOutput, painn.py:551-620; row a10): same molecules ------------------------------------------
+    cfg_d = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=20, cutoff=4.0, max_neighbors=100, envelope_exponent=5, num_elements=100,
+                          direct_forces=True)
+    params_d = R.make_params(cfg_d, seed=12)
+    out_d, grads_d = run_reference(ref, cfg_d, params_d, pos_e, z_e, batch_e, y_e, ft_e)
+    fx_d = dict(cfg=np.array([cfg_d.hidden_channels, cfg_d.num_layers, cfg_d.num_rbf, cfg_d.max_neighbors, cfg_d.envelope_exponent,
+                              cfg_d.num_elements]), cutoff=np.float64(cfg_d.cutoff), param_seed=np.int64(12), pos=pos_e, z=z_e, batch=batch_e,
+                y=y_e, f_target=ft_e, direct_forces=np.array(True))
+    fx_d.update(out_d)
+    for k, gnp in grads_d.items():
+        fx_d["grad:" + k] = gnp
+    np.savez_compressed(os.path.join(OUT, "painn_small_direct.npz"), **fx_d)
+    print("small_direct: E", out_d["energy"], "loss", out_d["loss"], "F[0]", out_d["forces"][0])
+    if os.environ.get("NQ_GOLDEN_ONLY") == "direct":
         return
 
     # ---- full config on 4 real conformers -------------------------------------------------------

@@ -42,6 +42,8 @@ class PaiNNConfig:
     filter_mode: str = "pyg"
     # radial basis of RadialBasis (layers.py:168-179): "gaussian" | "spherical_bessel" (learnable frequencies [R]) | "bernstein" (learnable pregamma)
     rbf: str = "gaussian"
+    # direct_forces=True: forces from the PaiNNOutput head (painn.py:551-620) instead of -dE/dpos
+    direct_forces: bool = False
 
 
 # ----------------------------------------------------------------------------------------
@@ -67,6 +69,12 @@ def param_shapes(cfg: PaiNNConfig):
                    (p + "xvec_proj.2.weight", (3 * F, F)), (p + "xvec_proj.2.bias", (3 * F,))]
     shapes += [("out_energy.0.weight", (F // 2, F)), ("out_energy.0.bias", (F // 2,)),
                ("out_energy.2.weight", (1, F // 2)), ("out_energy.2.bias", (1,))]
+    if cfg.direct_forces:
+        for i, (h, o) in enumerate(((F, F // 2), (F // 2, 1))):
+            p = f"out_forces.output_network.{i}."
+            shapes += [(p + "vec1_proj.weight", (h, h)), (p + "vec2_proj.weight", (o, h)),
+                       (p + "update_net.0.weight", (h, 2 * h)), (p + "update_net.0.bias", (h,)),
+                       (p + "update_net.2.weight", (2 * o, h)), (p + "update_net.2.bias", (2 * o,))]
     return shapes
 
 
@@ -217,6 +225,25 @@ def update_layer(P, pre, F, x, vec):
     return xvec1 + xvec2 * vec_dot, xvec3.unsqueeze(1) * vec1
 
 
+def scaled_silu(x):
+    return Fn.silu(x) * (1 / 0.6)                       # layers.py:188-195
+
+
+def painn_output_head(P, cfg: PaiNNConfig, x, vec):
+    """PaiNNOutput = two GatedEquivariantBlocks (painn.py:551-620): returns forces [N, 3]."""
+    F = cfg.hidden_channels
+    for i, (h, o) in enumerate(((F, F // 2), (F // 2, 1))):
+        p = f"out_forces.output_network.{i}."
+        vec1 = torch.norm(Fn.linear(vec, P[p + "vec1_proj.weight"]), dim=-2)
+        vec2 = Fn.linear(vec, P[p + "vec2_proj.weight"])
+        u = scaled_silu(Fn.linear(torch.cat([x, vec1], dim=-1), P[p + "update_net.0.weight"], P[p + "update_net.0.bias"]))
+        o2 = Fn.linear(u, P[p + "update_net.2.weight"], P[p + "update_net.2.bias"])
+        xo, gate = torch.split(o2, o, dim=-1)
+        vec = gate.unsqueeze(1) * vec2
+        x = scaled_silu(xo)
+    return vec.squeeze(-1)
+
+
 def painn_energy(P, cfg: PaiNNConfig, pos, z, batch, edge_index, trace=None):
     """painn.py:89-128 (energy only; forces are taken by autograd in energy_forces)."""
     F = cfg.hidden_channels
@@ -244,6 +271,8 @@ def painn_energy(P, cfg: PaiNNConfig, pos, z, batch, edge_index, trace=None):
     if trace is not None:
         trace["edge_dist"], trace["edge_vector"] = edge_dist.detach(), edge_vector.detach()
         trace["edge_rbf"] = edge_rbf.detach()
+    if cfg.direct_forces:
+        return _scatter_sum(per_atom, batch, B), painn_output_head(P, cfg, x, vec)
     return _scatter_sum(per_atom, batch, B)
 
 
@@ -252,6 +281,10 @@ def energy_forces(P, cfg, pos, z, batch, edge_index=None, create_graph=False, tr
     pos = pos.detach().clone().requires_grad_(True)
     if edge_index is None:
         edge_index, _, _ = build_graph(pos, batch, cfg.cutoff, cfg.max_neighbors)
+    if cfg.direct_forces:                                 # painn.py:131-133: no autograd forces
+        with torch.enable_grad():
+            energy, forces = painn_energy(P, cfg, pos.detach(), z, batch, edge_index, trace)
+        return (energy, forces) if create_graph else (energy.detach(), forces.detach())
     with torch.enable_grad():
         energy = painn_energy(P, cfg, pos, z, batch, edge_index, trace)
         forces = -torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy),

@@ -14,7 +14,7 @@ def load_case(name):
     c = fx["cfg"]
     cfg = R.PaiNNConfig(hidden_channels=int(c[0]), num_layers=int(c[1]), num_rbf=int(c[2]), cutoff=float(fx["cutoff"]),
                         max_neighbors=int(c[3]), envelope_exponent=int(c[4]), num_elements=int(c[5]),
-                        rbf=str(fx["rbf"]) if "rbf" in fx else "gaussian")
+                        rbf=str(fx["rbf"]) if "rbf" in fx else "gaussian", direct_forces=bool(fx["direct_forces"]) if "direct_forces" in fx else False)
     params = R.make_params(cfg, int(fx["param_seed"]))
     return fx, cfg, params
 

@@ -95,8 +95,9 @@ def test_unsupported_configs_fail_loudly():
     assert [n for n, _ in mn.named_parameters()][:2] == ["atom_emb.embeddings.weight", "radial_basis.rbf.pregamma"]
     with pytest.raises(NotImplementedError):
         nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "use_pbc": True})
-    with pytest.raises(NotImplementedError):
-        nq.PaiNN(128, 6, 100, 5.0, 100, **{**kw, "direct_forces": True})
+    md = nq.PaiNN(64, 2, 20, 4.0, 100, **{**kw, "direct_forces": True})        # direct-force head: reference parameter surface
+    cfg_d = R.PaiNNConfig(hidden_channels=64, num_layers=2, num_rbf=20, cutoff=4.0, direct_forces=True)
+    assert [(n, tuple(p.shape)) for n, p in md.named_parameters()] == R.param_shapes(cfg_d)
     m = nq.PaiNN(128, 1, 100, 5.0, 100, **kw)
     pos, z, batch, _, _ = R.gen_conformers(0, 1, size=5)
     with pytest.raises(RuntimeError, match="MI355X only"):      # no CPU fallback

@@ -57,7 +57,7 @@ def _model(cfg, params, dev):
     import nabladft_amd as nq
     m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": cfg.rbf},
                  {"name": "polynomial", "exponent": cfg.envelope_exponent} if cfg.envelope_exponent > 0 else {"name": "exponential"},
-                 True, False, False, True, cfg.num_elements)
+                 True, cfg.direct_forces, False, True, cfg.num_elements)
     missing, unexpected = m.load_state_dict(params, strict=False)
     assert list(missing) == (["radial_basis.rbf.offset"] if cfg.rbf == "gaussian" else []) and not unexpected
     return m.to(dev)
@@ -78,7 +78,8 @@ def test_library_is_loaded_native():
         assert "libnablaq.so" in f.read()
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 384, 100), (1000, 128, 128), (257, 64, 128), (129, 384, 20), (4096, 256, 128), (77, 128, 256)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 100), (1000, 128, 128), (257, 64, 128), (129, 384, 20), (4096, 256, 128), (77, 128, 256),
+                                   (500, 1, 64), (501, 2, 64), (333, 64, 64), (1000, 3, 128)])
 def test_gemm_forward_and_grads(M, N, K):
     from nabladft_amd import _lib
     lib, dev = _lib.load(), _dev()
@@ -480,3 +481,30 @@ def test_engine_learnable_bases_match_reference(name):
     worst = check_grads(fx, grads, 1e-4, name)
     print(f"{name}: energy {e_err:.2e} forces {f_err:.2e} worst grad {worst[0]:.2e} ({worst[1]}); d{basis[0]}: "
           f"{rel_err(grads[basis[0]], fx['grad:' + basis[0]]):.2e}")
+
+
+def test_engine_direct_forces_match_reference():
+    """direct_forces=True (row a10): forces from the PaiNNOutput head (two gated equivariant blocks, painn.py:551-620) on the engine's final
+    node state, first-order backward seeded with the head's adjoints; golden vectors from the real reference."""
+    from nabladft_amd import L2Loss
+    dev = _dev()
+    fx, cfg, params = load_case("painn_small_direct.npz")
+    assert cfg.direct_forces
+    model = _model(cfg, params, dev)
+    assert [n for n, _ in model.named_parameters()] == [k for k, _ in R.param_shapes(cfg)]
+    batch = _batch(fx, dev)
+    model.train()
+    energy, forces = model(batch)
+    assert forces.shape == (batch.pos.shape[0], 3)
+    e_err, f_err = rel_err(energy.detach().cpu().numpy(), fx["energy"]), rel_err(forces.detach().cpu().numpy(), fx["forces"])
+    assert e_err < 2e-6 and f_err < 2e-5, (e_err, f_err)
+    loss = torch.nn.L1Loss()(energy, batch.y) + L2Loss()(forces, batch.forces)
+    loss.backward()
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+    worst = check_grads(fx, grads, 1e-4, "direct")
+    print(f"direct forces: energy {e_err:.2e} forces {f_err:.2e} worst grad {worst[0]:.2e} ({worst[1]})")
+    model.eval()                                   # inference: same outputs, no graph
+    with torch.no_grad():
+        e2, f2 = model(batch)
+    assert torch.equal(e2, energy.detach()) and torch.equal(f2, forces.detach())

@@ -32,7 +32,7 @@ def test_six_atom_known_answer():
     assert np.array_equal(sw, np.concatenate([np.arange(h) + h, np.arange(h)]))
 
 
-@pytest.mark.parametrize("name,tol", [("painn_small_ragged.npz", 2e-5), ("painn_full_real4.npz", 2e-5), ("painn_small_expenv.npz", 2e-5), ("painn_small_bessel.npz", 2e-5), ("painn_small_bernstein.npz", 2e-5)])
+@pytest.mark.parametrize("name,tol", [("painn_small_ragged.npz", 2e-5), ("painn_full_real4.npz", 2e-5), ("painn_small_expenv.npz", 2e-5), ("painn_small_bessel.npz", 2e-5), ("painn_small_bernstein.npz", 2e-5), ("painn_small_direct.npz", 2e-5)])
 def test_train_step_matches_reference(name, tol):
     fx, cfg, params = load_case(name)
     pos, z, batch = torch.tensor(fx["pos"]), torch.tensor(fx["z"]), torch.tensor(fx["batch"])
