@@ -177,6 +177,22 @@ int nq_hblock_assemble_backward(const float* grad_packed, const int32_t* z, cons
  * to_dense == 0: packed <- the diagonal blocks of dense. */
 int nq_hblock_packed_dense(float* packed, float* dense, const int64_t* pack_ptr, const int64_t* mol_orb_ptr, int32_t B, int64_t total, int64_t m_total,
                            int32_t to_dense, void* stream);
+/* PhiSNet irreps -> matrix (NeuralNetwork.matrix_block / generate_matrix_from_irreps + the collection loops of forward,
+ * phisnet/nn/neural_network.py:636-706, 859-918): packed result as above; block(i,j)[(n_i,m_i),(n_j,m_j)] =
+ * sum_L sum_M cg_table[l_i][l_j][L][m_i][m_j][M] * f[row][L*L+M][idx(type_i, type_j, n_i, n_j, L)], f = f_ii[atom] or f_ij[pair(i, j)]
+ * ([rows][ncomp][Fo]); cg_table [3][3][5][5][5][9] = sqrt(2L+1) * the model's Clebsch-Gordan tensors; shell tables [T][32]; idx_ii
+ * [T][S][S][5], idx_ij [T][T][S][S][5] (-1 = absent).  orb_local: local orbital index inside its atom (nq_hblock_tables with identity masks).
+ * unit_diagonal: overlap matrices (diagonal = 1, neural_network.py:964-965).  Backward: inv_ii [T][5][Fo], inv_ij [T][T][5][Fo] = n_i*S+n_j or -1. */
+int nq_irreps_assemble(const float* f_ii, const float* f_ij, const int32_t* z, const int32_t* mol_ptr, const int64_t* pair_base, const int64_t* pack_ptr,
+                       const int64_t* mol_orb_ptr, const int64_t* orb_ptr, const int32_t* orb_atom, const int32_t* orb_local, const int32_t* look,
+                       int32_t B, int32_t ncomp, int32_t Fo, const int32_t* tz, const int32_t* sh_n, const int32_t* sh_l, const int32_t* sh_m,
+                       const int32_t* sh_off, const int32_t* idx_ii, const int32_t* idx_ij, const float* cg_table, int32_t T, int32_t S,
+                       int32_t symmetrize, int32_t unit_diagonal, int64_t total, float* out_packed, int32_t* err_flag, void* stream);
+int nq_irreps_assemble_backward(const float* grad_packed, const int32_t* z, const int32_t* atom_mol, const int64_t* e_i, const int64_t* e_j,
+                                const int64_t* pack_ptr, const int64_t* mol_orb_ptr, const int64_t* orb_ptr, const int32_t* inv_ii, const int32_t* inv_ij,
+                                int64_t N, int64_t P, int32_t ncomp, int32_t Fo, const int32_t* tz, const int32_t* sh_n, const int32_t* sh_l,
+                                const int32_t* sh_m, const int32_t* sh_off, const float* cg_table, int32_t T, int32_t S, int32_t symmetrize,
+                                int32_t unit_diagonal, float* grad_f_ii, float* grad_f_ij, void* stream);
 /* stats3 = {loss = sqrt(sum d^2 / total) + sum|d| / total, rmse, sum|d|} (mask.sum() == total for block-diagonal targets);
  * grad_packed (nullable) = grad_scale * dloss/dpred.  scratch: 512 doubles. */
 int nq_hamiltonian_loss(const float* pred_packed, const float* target_packed, int64_t total, float grad_scale, float* stats3, float* grad_packed,

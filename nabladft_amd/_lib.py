@@ -60,6 +60,8 @@ SYMBOLS = {
     "nq_hblock_assemble": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P]),
     "nq_hblock_assemble_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _P, _P, _P]),
     "nq_hblock_packed_dense": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _I32, _P]),
+    "nq_irreps_assemble": (C.c_int, [_P] * 11 + [_I32, _I32, _I32] + [_P] * 8 + [_I32, _I32, _I32, _I32, _I64, _P, _P, _P]),
+    "nq_irreps_assemble_backward": (C.c_int, [_P] * 10 + [_I64, _I64, _I32, _I32] + [_P] * 6 + [_I32, _I32, _I32, _I32, _P, _P, _P]),
     "nq_hamiltonian_loss": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "nq_so3_mix_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P]),
     "nq_so3_mix_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P]),

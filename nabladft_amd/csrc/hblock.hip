@@ -224,3 +224,158 @@ int nq_hamiltonian_loss(const float* pred_packed, const float* target_packed, in
 }
 
 }  // extern "C"
+
+// =====================================================================================================================================
+// PhiSNet: irreducible representations -> matrix blocks (NeuralNetwork.matrix_block / generate_matrix_from_irreps,
+// /root/reference/nablaDFT/phisnet/nn/neural_network.py:636-706, and the irreps collection loops of forward, :859-918):
+//   block(i, j)[(n_i, m_i), (n_j, m_j)] = sum_L sqrt(2L+1) sum_M CG(l_i m_i, l_j m_j | L M) * f_L[row(i, j)][M][idx(z_i, z_j, n_i, n_j, L)]
+// with f = features of the atom (diagonal block) or of the ordered pair (off-diagonal block).  The reference walks atoms x atoms x shells
+// x shells x L in Python and stacks per-element-pair tensors; here one thread per packed matrix element evaluates the sum from tables.
+// Same packed layout and per-batch tables (orbital -> atom / local orbital, ordered pair -> pair row) as the QHNet assembly above.
+// =====================================================================================================================================
+#define IR_MAXORB 32      // orbitals per atom (table stride)
+#define IR_LMAX 2         // highest shell angular momentum (s, p, d)
+#define IR_NL (2 * IR_LMAX + 1)
+struct IrTables {
+  const int* tz;            // [Zt] element -> type index or -1
+  const int* sh_n; const int* sh_l; const int* sh_m;     // [T][IR_MAXORB] local orbital -> shell number, l, m + l
+  const int* sh_off;        // [T][IR_MAXORB] shell number -> first local orbital of that shell
+  const int* idx_ii;        // [T][S][S][IR_NL] feature index or -1 (S = IR_MAXORB shells max)
+  const int* idx_ij;        // [T][T][S][S][IR_NL]
+  const float* cgt;         // [3][3][IR_NL][5][5][9] sqrt(2L+1) * CG(l_i, l_j, L)[m_i][m_j][M] (model's sign convention)
+  int T, S;
+};
+struct IrArgs {
+  const float* f_ii; const float* f_ij;        // [N][ncomp][Fo], [P][ncomp][Fo]
+  const int* z; const int* mol_ptr; const long long* pair_base; const long long* pack_ptr; const long long* mol_orb_ptr; const long long* orb_ptr;
+  const int* ORB_ATOM; const int* ORB_SLOT; const int* LOOK;
+  int B, ncomp, Fo, symmetrize, unit_diagonal;
+};
+__device__ __forceinline__ long ir_cg_index(int li, int lj, int L, int mi, int mj, int M) { return ((((long)(li * 3 + lj) * IR_NL + L) * 5 + mi) * 5 + mj) * 9 + M; }
+
+__device__ __forceinline__ float ir_elem(const IrArgs& a, const IrTables& t, int b, int ai, int aj, int ti, int tj, int* err) {
+  const int tzi = t.tz[a.z[ai]], tzj = t.tz[a.z[aj]];
+  const int ni = t.sh_n[tzi * IR_MAXORB + ti], li = t.sh_l[tzi * IR_MAXORB + ti], mi = t.sh_m[tzi * IR_MAXORB + ti];
+  const int nj = t.sh_n[tzj * IR_MAXORB + tj], lj = t.sh_l[tzj * IR_MAXORB + tj], mj = t.sh_m[tzj * IR_MAXORB + tj];
+  const float* frow; const int* idx;
+  if (ai == aj) {
+    frow = a.f_ii + (long)ai * a.ncomp * a.Fo;
+    idx = t.idx_ii + (((long)tzi * t.S + ni) * t.S + nj) * IR_NL;
+  } else {
+    const int a0 = a.mol_ptr[b], n = a.mol_ptr[b + 1] - a0;
+    const int e = a.LOOK[a.pair_base[b] + (long)(ai - a0) * n + (aj - a0)];
+    if (e < 0) { atomicOr(err, 2); return 0.f; }
+    frow = a.f_ij + (long)e * a.ncomp * a.Fo;
+    idx = t.idx_ij + ((((long)tzi * t.T + tzj) * t.S + ni) * t.S + nj) * IR_NL;
+  }
+  float val = 0.f;
+  const int Lmin = li > lj ? li - lj : lj - li;
+  for (int L = Lmin; L <= li + lj; ++L) {
+    const int fi = idx[L];
+    if (fi < 0) { atomicOr(err, 4); continue; }      // the model has no irrep for this (element pair, shells, L)
+    const float* cg = t.cgt + ir_cg_index(li, lj, L, mi, mj, 0);
+    for (int M = 0; M < 2 * L + 1; ++M) val = fmaf(cg[M], frow[(long)(L * L + M) * a.Fo + fi], val);
+  }
+  return val;
+}
+
+__global__ void k_ir_assemble(IrArgs a, IrTables t, long long total, float* __restrict__ out, int* __restrict__ err) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= total) return;
+  const int b = hb_find_mol(a.pack_ptr, a.B, q);
+  const long long o0 = a.mol_orb_ptr[b];
+  const int M = (int)(a.mol_orb_ptr[b + 1] - o0);
+  const long long loc = q - a.pack_ptr[b];
+  const int r = (int)(loc / M), c = (int)(loc % M);
+  if (a.unit_diagonal && r == c) { out[q] = 1.0f; return; }                    // overlap matrix: diagonal = 1 (neural_network.py:964-965)
+  const int ai = a.ORB_ATOM[o0 + r], aj = a.ORB_ATOM[o0 + c], ti = a.ORB_SLOT[o0 + r], tj = a.ORB_SLOT[o0 + c];
+  float val = ir_elem(a, t, b, ai, aj, ti, tj, err);
+  if (a.symmetrize) val += ir_elem(a, t, b, aj, ai, tj, ti, err);              // matrix + matrix^T (neural_network.py:931)
+  out[q] = val;
+}
+
+// reverse: one thread per feature element (row, component (L, M), feature index).  inv tables: [T][IR_NL][Fo] / [T][T][IR_NL][Fo] -> n_i * S + n_j or -1
+struct IrRevArgs {
+  const float* G; const int* z; const int* atom_mol; const long long* e_i; const long long* e_j;
+  const long long* pack_ptr; const long long* mol_orb_ptr; const long long* orb_ptr;
+  const int* inv_ii; const int* inv_ij;
+  long long N, P; int ncomp, Fo, symmetrize, unit_diagonal;
+};
+__global__ void k_ir_assemble_rev(IrRevArgs a, IrTables t, float* __restrict__ g_ii, float* __restrict__ g_ij) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)a.ncomp * a.Fo, nii = a.N * per, total = nii + a.P * per;
+  if (idx >= total) return;
+  const bool diag = idx < nii;
+  const long long k = diag ? idx : idx - nii;
+  const long long row = k / per; const int comp = (int)((k % per) / a.Fo), fo = (int)(k % a.Fo);
+  int L = 0;
+  while ((L + 1) * (L + 1) <= comp) ++L;
+  const int M = comp - L * L;
+  float* dst = diag ? g_ii + k : g_ij + k;
+  if (L >= IR_NL) { *dst = 0.f; return; }
+  const int ai = diag ? (int)row : (int)a.e_i[row], aj = diag ? (int)row : (int)a.e_j[row];
+  const int tzi = t.tz[a.z[ai]], tzj = t.tz[a.z[aj]];
+  const int code = diag ? a.inv_ii[((long)tzi * IR_NL + L) * a.Fo + fo] : a.inv_ij[(((long)tzi * t.T + tzj) * IR_NL + L) * a.Fo + fo];
+  if (code < 0) { *dst = 0.f; return; }
+  const int ni = code / t.S, nj = code % t.S;
+  const int oi = t.sh_off[tzi * IR_MAXORB + ni], oj = t.sh_off[tzj * IR_MAXORB + nj];
+  const int li = t.sh_l[tzi * IR_MAXORB + oi], lj = t.sh_l[tzj * IR_MAXORB + oj];
+  const int b = a.atom_mol[ai];
+  const long long o0 = a.mol_orb_ptr[b];
+  const int Mo = (int)(a.mol_orb_ptr[b + 1] - o0);
+  const int r0 = (int)(a.orb_ptr[ai] - o0) + oi, c0 = (int)(a.orb_ptr[aj] - o0) + oj;
+  const float* Gm = a.G + a.pack_ptr[b];
+  float g = 0.f;
+  for (int mi = 0; mi < 2 * li + 1; ++mi)
+    for (int mj = 0; mj < 2 * lj + 1; ++mj) {
+      const int r = r0 + mi, c = c0 + mj;
+      if (a.unit_diagonal && r == c) continue;
+      float gg = Gm[(long long)r * Mo + c];
+      if (a.symmetrize) gg += Gm[(long long)c * Mo + r];
+      g = fmaf(t.cgt[ir_cg_index(li, lj, L, mi, mj, M)], gg, g);
+    }
+  *dst = g;
+}
+
+extern "C" {
+
+int nq_irreps_assemble(const float* f_ii, const float* f_ij, const int32_t* z, const int32_t* mol_ptr, const int64_t* pair_base, const int64_t* pack_ptr,
+                       const int64_t* mol_orb_ptr, const int64_t* orb_ptr, const int32_t* orb_atom, const int32_t* orb_local, const int32_t* look,
+                       int32_t B, int32_t ncomp, int32_t Fo, const int32_t* tz, const int32_t* sh_n, const int32_t* sh_l, const int32_t* sh_m,
+                       const int32_t* sh_off, const int32_t* idx_ii, const int32_t* idx_ij, const float* cg_table, int32_t T, int32_t S,
+                       int32_t symmetrize, int32_t unit_diagonal, int64_t total, float* out_packed, int32_t* err_flag, void* stream) {
+  if (!f_ii || !z || !mol_ptr || !pair_base || !pack_ptr || !mol_orb_ptr || !orb_ptr || !orb_atom || !orb_local || !look || !tz || !sh_n || !sh_l ||
+      !sh_m || !sh_off || !idx_ii || !idx_ij || !cg_table || !out_packed || !err_flag)
+    return nq_fail(NQ_ERR_ARG, "null argument");
+  if (S > IR_MAXORB) return nq_fail(NQ_ERR_ARG, "more than %d shells per atom", IR_MAXORB);
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "irreps_assemble");
+  if (total <= 0) return NQ_OK;
+  IrArgs a{f_ii, f_ij, z, mol_ptr, (const long long*)pair_base, (const long long*)pack_ptr, (const long long*)mol_orb_ptr, (const long long*)orb_ptr,
+           orb_atom, orb_local, look, B, ncomp, Fo, symmetrize, unit_diagonal};
+  IrTables t{tz, sh_n, sh_l, sh_m, sh_off, idx_ii, idx_ij, cg_table, T, S};
+  hipLaunchKernelGGL(k_ir_assemble, hb_grid(total, 256), dim3(256), 0, st, a, t, (long long)total, out_packed, err_flag);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_irreps_assemble_backward(const float* grad_packed, const int32_t* z, const int32_t* atom_mol, const int64_t* e_i, const int64_t* e_j,
+                                const int64_t* pack_ptr, const int64_t* mol_orb_ptr, const int64_t* orb_ptr, const int32_t* inv_ii, const int32_t* inv_ij,
+                                int64_t N, int64_t P, int32_t ncomp, int32_t Fo, const int32_t* tz, const int32_t* sh_n, const int32_t* sh_l,
+                                const int32_t* sh_m, const int32_t* sh_off, const float* cg_table, int32_t T, int32_t S, int32_t symmetrize,
+                                int32_t unit_diagonal, float* grad_f_ii, float* grad_f_ij, void* stream) {
+  if (!grad_packed || !z || !atom_mol || !pack_ptr || !mol_orb_ptr || !orb_ptr || !inv_ii || !inv_ij || !tz || !sh_n || !sh_l || !sh_m || !sh_off ||
+      !cg_table || !grad_f_ii)
+    return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "irreps_assemble_rev");
+  IrRevArgs a{grad_packed, z, atom_mol, (const long long*)e_i, (const long long*)e_j, (const long long*)pack_ptr, (const long long*)mol_orb_ptr,
+              (const long long*)orb_ptr, inv_ii, inv_ij, (long long)N, (long long)P, ncomp, Fo, symmetrize, unit_diagonal};
+  IrTables t{tz, sh_n, sh_l, sh_m, sh_off, nullptr, nullptr, cg_table, T, S};
+  const long long total = ((long long)N + P) * ncomp * Fo;
+  if (total > 0) hipLaunchKernelGGL(k_ir_assemble_rev, hb_grid(total, 256), dim3(256), 0, st, a, t, grad_f_ii, grad_f_ij);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+}  // extern "C"

@@ -237,3 +237,154 @@ def masked_mae(pred_packed: torch.Tensor, target_packed: torch.Tensor) -> torch.
     scratch = torch.empty(512, device=p.device, dtype=torch.float64)
     _lib.check(lib.nq_hamiltonian_loss(_lib.ptr(p), _lib.ptr(t), p.numel(), 1.0, _lib.ptr(stats), None, _lib.ptr(scratch), _lib.stream_ptr()))
     return stats[2] / torch.count_nonzero(t)
+
+
+# ---- PhiSNet: irreducible representations -> matrix (the assembly part) -----------------------------------------
+def compute_matrix_irreps(orbitals_i, orbitals_j, irreps, number_L):
+    """Same contract as NeuralNetwork.compute_matrix_irreps (phisnet/nn/neural_network.py:610-621): assigns the next free feature index of
+    order L to every new key (z_i, z_j, n_i, n_j, L)."""
+    for n_i, (z_i, l_i) in enumerate(orbitals_i):
+        for n_j, (z_j, l_j) in enumerate(orbitals_j):
+            for L in range(abs(l_i - l_j), l_i + l_j + 1):
+                key = (z_i, z_j, n_i, n_j, L)
+                if key not in irreps:
+                    irreps[key] = number_L[L]
+                    number_L[L] += 1
+    return irreps, number_L
+
+
+class _IrAssemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, asm, plan, symmetrize, unit_diagonal, f_ii, f_ij):
+        lib = _lib.load()
+        dev = f_ii.device
+        a, b = f_ii.detach().to(torch.float32).contiguous(), f_ij.detach().to(torch.float32).contiguous()
+        t = asm._tables(dev)
+        out = torch.empty(plan.total, device=dev, dtype=torch.float32)
+        _lib.check(lib.nq_irreps_assemble(
+            _lib.ptr(a), _lib.ptr(b), _lib.ptr(plan.z), _lib.ptr(plan.mol_ptr), _lib.ptr(plan.pair_base), _lib.ptr(plan.pack_ptr), _lib.ptr(plan.mol_orb_ptr),
+            _lib.ptr(plan.orb_ptr), _lib.ptr(plan.orb_atom), _lib.ptr(plan.orb_slot), _lib.ptr(plan.look), plan.B, a.shape[1], a.shape[2],
+            _lib.ptr(t["tz"]), _lib.ptr(t["sh_n"]), _lib.ptr(t["sh_l"]), _lib.ptr(t["sh_m"]), _lib.ptr(t["sh_off"]), _lib.ptr(t["idx_ii"]), _lib.ptr(t["idx_ij"]),
+            _lib.ptr(t["cgt"]), asm.T, asm.S, int(symmetrize), int(unit_diagonal), plan.total, _lib.ptr(out), _lib.ptr(plan.err), _lib.stream_ptr()))
+        ctx.asm, ctx.plan, ctx.flags, ctx.shapes = asm, plan, (symmetrize, unit_diagonal), (f_ii.shape, f_ij.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        asm, plan = ctx.asm, ctx.plan
+        t = asm._tables(g.device)
+        g = g.to(torch.float32).contiguous()
+        g_ii = torch.empty(ctx.shapes[0], device=g.device, dtype=torch.float32)
+        g_ij = torch.empty(ctx.shapes[1], device=g.device, dtype=torch.float32)
+        inv_ii, inv_ij = asm._inverse(ctx.shapes[0][2], g.device)
+        _lib.check(lib.nq_irreps_assemble_backward(
+            _lib.ptr(g), _lib.ptr(plan.z), _lib.ptr(plan.atom_mol), _lib.ptr(plan.e_dst), _lib.ptr(plan.e_src), _lib.ptr(plan.pack_ptr), _lib.ptr(plan.mol_orb_ptr),
+            _lib.ptr(plan.orb_ptr), _lib.ptr(inv_ii), _lib.ptr(inv_ij), plan.N, plan.P, ctx.shapes[0][1], ctx.shapes[0][2], _lib.ptr(t["tz"]), _lib.ptr(t["sh_n"]),
+            _lib.ptr(t["sh_l"]), _lib.ptr(t["sh_m"]), _lib.ptr(t["sh_off"]), _lib.ptr(t["cgt"]), asm.T, asm.S, int(ctx.flags[0]), int(ctx.flags[1]),
+            _lib.ptr(g_ii), _lib.ptr(g_ij), _lib.stream_ptr()))
+        return None, None, None, None, g_ii, g_ij
+
+
+class IrrepsAssembler:
+    """Builds Hamiltonian / overlap matrices from PhiSNet's irreducible-representation features (the loops of NeuralNetwork.forward at
+    phisnet/nn/neural_network.py:859-918 + generate_matrix_from_irreps / matrix_block, :636-706) in one kernel launch.
+
+    ``atom2orbitals``: {Z: ((Z, l), ...)} shells of every element (l <= 2);  ``irreps_ii`` / ``irreps_ij``: the model's index dictionaries
+    {(z_i, z_j, n_i, n_j, L): feature index} (``compute_matrix_irreps``);  ``clebsch_gordan``: the model's CG provider (its sign convention is
+    used as is).  Features: f_ii [N, (Lout+1)^2, Fo] per atom, f_ij [P, (Lout+1)^2, Fo] per ordered pair (idx_i, idx_j) -- the concatenation
+    over L of the reference's lists ``fii_*[L]`` / ``fij_*[L]``.  Result: packed block-diagonal matrix (see BlockAssembler)."""
+
+    MAXORB, NL = 32, 5
+
+    def __init__(self, atom2orbitals, irreps_ii, irreps_ij, clebsch_gordan):
+        self.types = sorted(int(zz) for zz in atom2orbitals)
+        self.T = len(self.types)
+        tindex = {zz: i for i, zz in enumerate(self.types)}
+        self.S = max(len(v) for v in atom2orbitals.values())
+        if self.S > self.MAXORB or max(l for v in atom2orbitals.values() for _, l in v) > 2:
+            raise NotImplementedError("IrrepsAssembler: up to 32 shells per atom with l <= 2 are built")
+        zt = max(self.types) + 1
+        tz = torch.full((zt,), -1, dtype=torch.int32)
+        sh_n = torch.zeros(self.T, self.MAXORB, dtype=torch.int32)
+        sh_l, sh_m, sh_off = torch.zeros_like(sh_n), torch.zeros_like(sh_n), torch.zeros_like(sh_n)
+        self.norb = {}
+        count = torch.zeros(zt, dtype=torch.int32)
+        for zz, shells in atom2orbitals.items():
+            ti = tindex[int(zz)]
+            tz[int(zz)] = ti
+            o = 0
+            for n, (_, l) in enumerate(shells):
+                sh_off[ti, n] = o
+                for m in range(2 * l + 1):
+                    if o >= self.MAXORB:
+                        raise NotImplementedError("IrrepsAssembler: more than 32 orbitals per atom")
+                    sh_n[ti, o], sh_l[ti, o], sh_m[ti, o] = n, l, m
+                    o += 1
+            self.norb[int(zz)] = o
+            count[int(zz)] = o
+        idx_ii = torch.full((self.T, self.S, self.S, self.NL), -1, dtype=torch.int32)
+        idx_ij = torch.full((self.T, self.T, self.S, self.S, self.NL), -1, dtype=torch.int32)
+        for (zi, zj, ni, nj, L), v in irreps_ii.items():
+            if zi == zj and int(zi) in tindex:
+                idx_ii[tindex[int(zi)], ni, nj, L] = v
+        for (zi, zj, ni, nj, L), v in irreps_ij.items():
+            if int(zi) in tindex and int(zj) in tindex:
+                idx_ij[tindex[int(zi)], tindex[int(zj)], ni, nj, L] = v
+        cgt = torch.zeros(3, 3, self.NL, 5, 5, 9, dtype=torch.float32)
+        for li in range(3):
+            for lj in range(3):
+                for L in range(abs(li - lj), li + lj + 1):
+                    c = torch.as_tensor(clebsch_gordan(li, lj, L)).detach().to(torch.float32).cpu() * (2 * L + 1) ** 0.5
+                    cgt[li, lj, L, :2 * li + 1, :2 * lj + 1, :2 * L + 1] = c
+        self._host = dict(tz=tz, sh_n=sh_n, sh_l=sh_l, sh_m=sh_m, sh_off=sh_off, idx_ii=idx_ii, idx_ij=idx_ij, cgt=cgt)
+        self._count = count
+        self._identity = torch.arange(self.MAXORB, dtype=torch.int32).repeat(zt, 1)
+        self._dev, self._inv = {}, {}
+        # the per-batch tables (orbital -> atom / local orbital, pair lookup) are those of the QHNet assembler with identity "masks"
+        self._plan_helper = BlockAssembler.__new__(BlockAssembler)
+        self._plan_helper.S = self.MAXORB
+        self._plan_helper._host = (self._identity, count, torch.full((zt, self.MAXORB), -1, dtype=torch.int32))
+        self._plan_helper._dev = {}
+
+    def _tables(self, device):
+        if device not in self._dev:
+            self._dev[device] = {k: v.to(device).contiguous() for k, v in self._host.items()}
+        return self._dev[device]
+
+    def _inverse(self, Fo, device):
+        key = (Fo, device)
+        if key not in self._inv:
+            inv_ii = torch.full((self.T, self.NL, Fo), -1, dtype=torch.int32)
+            inv_ij = torch.full((self.T, self.T, self.NL, Fo), -1, dtype=torch.int32)
+            ii, ij = self._host["idx_ii"], self._host["idx_ij"]
+            for t in range(self.T):
+                for ni in range(self.S):
+                    for nj in range(self.S):
+                        for L in range(self.NL):
+                            v = int(ii[t, ni, nj, L])
+                            if 0 <= v < Fo:
+                                inv_ii[t, L, v] = ni * self.S + nj
+                            for t2 in range(self.T):
+                                w = int(ij[t, t2, ni, nj, L])
+                                if 0 <= w < Fo:
+                                    inv_ij[t, t2, L, w] = ni * self.S + nj
+            self._inv[key] = (inv_ii.to(device), inv_ij.to(device))
+        return self._inv[key]
+
+    def plan(self, z, ptr, idx_i, idx_j):
+        """Per-batch tables; (idx_i, idx_j) = the ordered pairs whose features are the rows of f_ij (fill_idx, neural_network.py:515-547)."""
+        return self._plan_helper.plan(z, ptr, torch.stack([idx_i, idx_j]))
+
+    def assemble(self, plan, f_ii, f_ij, symmetrize=True, unit_diagonal=False):
+        return _IrAssemble.apply(self, plan, symmetrize, unit_diagonal, f_ii, f_ij)
+
+    def check(self, plan):
+        code = int(plan.err.item())
+        if code & 4:
+            raise KeyError("an (element pair, shells, L) combination has no entry in irreps_ii / irreps_ij")       # the reference raises KeyError
+        if code:
+            raise IndexError("the pair list does not hold every ordered atom pair of every molecule" if code & 2 else "a pair joins two molecules")
+
+    to_dense = BlockAssembler.to_dense
+    from_dense = BlockAssembler.from_dense

@@ -66,7 +66,7 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__" and "--bases" not in sys.argv and "--blocks" not in sys.argv:
+if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix"} & set(sys.argv)):
     main()
 
 
@@ -159,3 +159,89 @@ def blocks():
 
 if __name__ == "__main__" and "--blocks" in sys.argv:
     blocks()
+
+
+def matrix_assembly():
+    """irreps -> matrix with the REAL NeuralNetwork.compute_matrix_irreps / matrix_block / generate_matrix_from_irreps (called unbound on a
+    stand-in ``self`` that carries only the real ClebschGordan table); the irreps-collection loops of forward (neural_network.py:859-918) are
+    inline code there and are restated here (which feature row / index an irrep is read from)."""
+    import types
+    from collections import defaultdict
+    pkg = types.ModuleType("ref_phisnet_nn3")
+    pkg.__path__ = ["/root/reference/nablaDFT/phisnet/nn"]
+    sys.modules["ref_phisnet_nn3"] = pkg
+    NN = importlib.import_module("ref_phisnet_nn3.neural_network").NeuralNetwork
+    CG = importlib.import_module("ref_phisnet_nn3.modules.clebsch_gordan").ClebschGordan().float()
+    fake = types.SimpleNamespace(clebsch_gordan=CG)
+    fake.matrix_block = types.MethodType(NN.matrix_block, fake)
+    rng = np.random.Generator(np.random.PCG64(31))
+    atom2orb = {1: ((1, 0), (1, 0), (1, 1)), 6: ((6, 0), (6, 0), (6, 0), (6, 1), (6, 1), (6, 2)), 8: ((8, 0), (8, 0), (8, 0), (8, 1), (8, 1), (8, 2))}
+    elements = sorted(atom2orb)
+    # index dictionaries exactly as NeuralNetwork.__init__ builds them (neural_network.py:368-417) from the per-element orbital lists
+    number_L = [0] * 5
+    irreps_ii = {}
+    for zz in elements:
+        irreps_ii, number_L = NN.compute_matrix_irreps(atom2orb[zz], atom2orb[zz], irreps_ii, number_L)
+    n_ii = max(number_L)
+    number_L = [0] * 5
+    irreps_ij = {}
+    for za in elements:
+        for zb in elements:
+            irreps_ij, number_L = NN.compute_matrix_irreps(atom2orb[za], atom2orb[zb], irreps_ij, number_L)    # incl. same-element pairs
+    n_ij = max(number_L)
+    Fo = max(n_ii, n_ij)
+    sizes = [3, 1, 4]
+    zs = np.array([8, 1, 1, 6, 6, 1, 8, 1])
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    N = int(ptr[-1])
+    orbitals = [atom2orb[int(a)] for a in zs]
+    idx_i, idx_j = [], []
+    for b in range(len(sizes)):
+        for i in range(ptr[b], ptr[b + 1]):
+            for j in range(ptr[b], ptr[b + 1]):
+                if i != j:
+                    idx_i.append(i), idx_j.append(j)
+    P = len(idx_i)
+    f_ii = [torch.tensor(rng.normal(size=(1, N, 2 * L + 1, Fo)).astype(np.float32), requires_grad=True) for L in range(5)]
+    f_ij = [torch.tensor(rng.normal(size=(1, P, 2 * L + 1, Fo)).astype(np.float32), requires_grad=True) for L in range(5)]
+    begin, end, Norb = {}, {}, 0
+    for i in range(N):
+        begin[i] = Norb
+        Norb += sum(2 * l + 1 for _, l in orbitals[i])
+        end[i] = Norb
+    mask = torch.block_diag(*(torch.ones(s, s) for s in sizes))
+    irreps = defaultdict(list)
+    idx = 0
+    for i in range(N):                                                     # restated collection loops (neural_network.py:859-918)
+        for j in range(N):
+            cur = []
+            if i != j and not mask[i, j]:
+                continue
+            for n_i, (z_i, l_i) in enumerate(orbitals[i]):
+                for n_j, (z_j, l_j) in enumerate(orbitals[j]):
+                    for L in range(abs(l_i - l_j), l_i + l_j + 1):
+                        if i == j:
+                            cur.append(f_ii[L][:, i, :, irreps_ii[(z_i, z_j, n_i, n_j, L)]])
+                        else:
+                            cur.append(f_ij[L][:, idx, :, irreps_ij[(z_i, z_j, n_i, n_j, L)]])
+            if i != j:
+                idx += 1
+            irreps[(orbitals[i][0][0], orbitals[j][0][0])].append((cur, i, j))
+    H0 = NN.generate_matrix_from_irreps(fake, irreps, Norb, atom2orb, begin, end, 1, "cpu", torch.float32)
+    H = H0 + H0.transpose(-2, -1)
+    w = torch.tensor(rng.normal(size=tuple(H.shape)).astype(np.float32))
+    (H * w).sum().backward()
+    eye = torch.eye(Norb).unsqueeze(0)
+    S = (1 - eye) * H + eye
+    fx = dict(z=zs, ptr=ptr, idx_i=np.array(idx_i), idx_j=np.array(idx_j), Fo=np.int64(Fo), H_unsym=H0[0].detach().numpy(), H=H[0].detach().numpy(),
+              overlap=S[0].detach().numpy(), w=w[0].numpy(),
+              f_ii=np.concatenate([t.detach().numpy()[0] for t in f_ii], axis=1), f_ij=np.concatenate([t.detach().numpy()[0] for t in f_ij], axis=1),
+              g_ii=np.concatenate([t.grad.numpy()[0] for t in f_ii], axis=1), g_ij=np.concatenate([t.grad.numpy()[0] for t in f_ij], axis=1),
+              ii_keys=np.array(list(irreps_ii.keys())), ii_vals=np.array(list(irreps_ii.values())),
+              ij_keys=np.array(list(irreps_ij.keys())), ij_vals=np.array(list(irreps_ij.values())))
+    np.savez_compressed(os.path.join(OUT, "phisnet_matrix.npz"), **fx)
+    print("phisnet_matrix.npz: Norb", Norb, "pairs", P, "features", Fo, "irreps", len(irreps_ii), len(irreps_ij))
+
+
+if __name__ == "__main__" and "--matrix" in sys.argv:
+    matrix_assembly()

@@ -76,3 +76,36 @@ def test_assembly_matches_restatement_on_a_drug_sized_batch_and_is_fast():
     cpu_ms = (time.perf_counter() - t0) * 1e3
     assert torch.equal(asm.to_dense(plan, packed).cpu(), Href)
     print(f"hblock: {N} atoms, {P} pairs, {plan.m_total} orbitals: GPU plan+assemble {gpu_ms:.3f} ms, CPU restatement {cpu_ms:.0f} ms")
+
+
+def test_phisnet_irreps_to_matrix_matches_reference():
+    """PhiSNet irreps -> Hamiltonian / overlap matrix (row a24, assembly part): golden vectors from the REAL compute_matrix_irreps /
+    matrix_block / generate_matrix_from_irreps with the reference's Clebsch-Gordan table (oracle/make_golden_phisnet.py --matrix)."""
+    from nabladft_amd import hamiltonian as HM
+    from tests.so3_helpers import FixtureCG
+    fx = dict(np.load(os.path.join(GOLDEN, "phisnet_matrix.npz")))
+    atom2orb = {1: ((1, 0), (1, 0), (1, 1)), 6: ((6, 0), (6, 0), (6, 0), (6, 1), (6, 1), (6, 2)), 8: ((8, 0), (8, 0), (8, 0), (8, 1), (8, 1), (8, 2))}
+    # the index dictionaries are the model's; the host mirror of compute_matrix_irreps rebuilds them identically
+    number_L, irreps_ii = [0] * 5, {}
+    for zz in sorted(atom2orb):
+        irreps_ii, number_L = HM.compute_matrix_irreps(atom2orb[zz], atom2orb[zz], irreps_ii, number_L)
+    number_L, irreps_ij = [0] * 5, {}
+    for za in sorted(atom2orb):
+        for zb in sorted(atom2orb):
+            irreps_ij, number_L = HM.compute_matrix_irreps(atom2orb[za], atom2orb[zb], irreps_ij, number_L)
+    assert {tuple(int(v) for v in k): int(x) for k, x in zip(fx["ii_keys"], fx["ii_vals"])} == irreps_ii
+    assert {tuple(int(v) for v in k): int(x) for k, x in zip(fx["ij_keys"], fx["ij_vals"])} == irreps_ij
+    asm = HM.IrrepsAssembler(atom2orb, irreps_ii, irreps_ij, FixtureCG())
+    z, ptr = torch.tensor(fx["z"]).cuda(), torch.tensor(fx["ptr"]).cuda()
+    plan = asm.plan(z, ptr, torch.tensor(fx["idx_i"]).cuda(), torch.tensor(fx["idx_j"]).cuda())
+    f_ii = torch.tensor(fx["f_ii"]).cuda().requires_grad_(True)
+    f_ij = torch.tensor(fx["f_ij"]).cuda().requires_grad_(True)
+    H0 = asm.to_dense(plan, asm.assemble(plan, f_ii, f_ij, symmetrize=False).detach())
+    asm.check(plan)
+    packed = asm.assemble(plan, f_ii, f_ij, symmetrize=True)
+    H = asm.to_dense(plan, packed.detach())
+    S = asm.to_dense(plan, asm.assemble(plan, f_ii, f_ij, symmetrize=True, unit_diagonal=True).detach())
+    assert rel_err(H0.cpu().numpy(), fx["H_unsym"]) < 2e-6 and rel_err(H.cpu().numpy(), fx["H"]) < 2e-6 and rel_err(S.cpu().numpy(), fx["overlap"]) < 2e-6
+    (packed * asm.from_dense(plan, torch.tensor(fx["w"]).cuda())).sum().backward()
+    # the reference's dense weights also cover the zero off-molecule region; only the in-molecule part of w matters
+    assert rel_err(f_ii.grad.cpu().numpy(), fx["g_ii"]) < 2e-6 and rel_err(f_ij.grad.cpu().numpy(), fx["g_ij"]) < 2e-6
