@@ -267,3 +267,320 @@ class ModularBlock(nn.Module):
         xs = self.residual_post_x(xs)
         ys = self.residual_out(xs)
         return xs, ys
+
+
+# ---- embeddings (phisnet/nn/modules/embedding.py:13-34, spherical_embedding.py:11-27) ------------------------------------------------------------
+def electron_configuration_table(zmax: int = 87) -> torch.Tensor:
+    """[zmax, 16] ground-state electron configurations scaled to [0, 1]: column 0 = Z / 86, then the occupations of 1s 2s 2p 3s 3p 3d 4s 4p 4d 4f 5s 5p
+    5d 6s 6p divided by the shell capacities (aufbau filling with the usual d/f exceptions).  It is the DEFAULT of the ``electron_config``
+    buffer only: the buffer is part of the state_dict, so a reference checkpoint brings the reference's own table."""
+    fill = [("1s", 2), ("2s", 2), ("2p", 6), ("3s", 2), ("3p", 6), ("4s", 2), ("3d", 10), ("4p", 6), ("5s", 2), ("4d", 10), ("5p", 6), ("6s", 2), ("4f", 14),
+            ("5d", 10), ("6p", 6)]                                                               # Madelung filling order
+    order = sorted(fill, key=lambda t: (int(t[0][0]), "spdf".index(t[0][1])))                    # column order: by shell, then subshell
+    exceptions = {24: {"4s": 1, "3d": 5}, 29: {"4s": 1, "3d": 10}, 41: {"5s": 1, "4d": 4}, 42: {"5s": 1, "4d": 5}, 44: {"5s": 1, "4d": 7}, 45: {"5s": 1, "4d": 8},
+                  46: {"5s": 0, "4d": 10}, 47: {"5s": 1, "4d": 10}, 57: {"4f": 0, "5d": 1}, 58: {"4f": 1, "5d": 1}, 64: {"4f": 7, "5d": 1}, 78: {"6s": 1, "5d": 9},
+                  79: {"6s": 1, "5d": 10}}
+    table = torch.zeros(zmax, 16)
+    for Z in range(1, zmax):
+        left, occ = Z, {}
+        for name, cap in fill:
+            occ[name] = min(cap, left)
+            left -= occ[name]
+        occ.update(exceptions.get(Z, {}))
+        table[Z, 0] = Z / 86.0
+        for c, (name, cap) in enumerate(order):
+            table[Z, 1 + c] = occ[name] / cap
+    return table
+
+
+class Embedding(nn.Module):
+    def __init__(self, num_features, Zmax=87, electron_config=None):
+        super().__init__()
+        self.num_features, self.Zmax = num_features, Zmax
+        ec = electron_configuration_table(Zmax) if electron_config is None else torch.as_tensor(electron_config, dtype=torch.float32)
+        self.register_buffer("electron_config", ec)
+        self.register_parameter("element_embedding", nn.Parameter(torch.Tensor(Zmax, num_features)))
+        self.config_linear = nn.Linear(ec.size(1), num_features, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.element_embedding, -3 ** 0.5, 3 ** 0.5)
+        nn.init.orthogonal_(self.config_linear.weight)
+
+    def forward(self, Z):
+        table = self.element_embedding + _linear(self.electron_config, self.config_linear)          # [Zmax, F]
+        return table.index_select(0, Z.reshape(-1)).view(*Z.shape, self.num_features)
+
+
+class SphericalEmbedding(nn.Module):
+    def __init__(self, order, num_features, Zmax=87, electron_config=None):
+        super().__init__()
+        self.order, self.num_features, self.Zmax = order, num_features, Zmax
+        self.embedding = Embedding(num_features, Zmax, electron_config)
+
+    def forward(self, Z):
+        x0 = self.embedding(Z).unsqueeze(-2)                                                          # [..., 1, F]
+        return [x0] + [x0.new_zeros(*x0.shape[:-2], 2 * L + 1, self.num_features) for L in range(1, self.order + 1)]
+
+
+class _SegmentMeanFn(torch.autograd.Function):
+    """rows [R, C] grouped in consecutive segments (ptr [B+1]) -> per-segment mean [B, C] (fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, rows, ptr):
+        lib = _lib.load()
+        r2 = rows.to(torch.float32).contiguous()
+        B, Cw = ptr.numel() - 1, r2.shape[-1]
+        out = torch.empty(B, Cw, device=rows.device, dtype=torch.float32)
+        _lib.check(lib.nq_segment_sum(_lib.ptr(r2), None, _lib.ptr(ptr), None, B, Cw, _lib.ptr(out), _lib.stream_ptr()))
+        cnt = (ptr[1:] - ptr[:-1]).to(torch.float32).clamp_(min=1).view(-1, 1)
+        ctx.save_for_backward(ptr, cnt)
+        return out / cnt
+
+    @staticmethod
+    def backward(ctx, g):
+        ptr, cnt = ctx.saved_tensors
+        seg = torch.repeat_interleave(torch.arange(ptr.numel() - 1, device=g.device), ptr[1:] - ptr[:-1])
+        return (g / cnt).index_select(0, seg), None
+
+
+class EnergyLayer(nn.Module):
+    """phisnet/nn/modules/energy_layer.py:9-52: per-molecule means of activated scalar atom / pair features -> one energy per molecule."""
+
+    def __init__(self, num_in, num_out, activation, zero_init=False):
+        super().__init__()
+        self.num_in, self.num_out, self.zero_init = num_in, num_out, zero_init
+        self.linear_diagonal, self.linear_offdiagonal = nn.Linear(num_in, num_out), nn.Linear(num_in, num_out)
+        self.linear_out = nn.Linear(2 * num_out, 1)
+        self.activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init = nn.init.zeros_ if self.zero_init else nn.init.orthogonal_
+        for lin in (self.linear_diagonal, self.linear_offdiagonal, self.linear_out):
+            init(lin.weight)
+            nn.init.zeros_(lin.bias)
+
+    def forward(self, fii, fij, sizes, pair_sizes):
+        dev = fii[0].device
+        feats = []
+        for f, lin, sz in ((fii, self.linear_diagonal, sizes), (fij, self.linear_offdiagonal, pair_sizes)):
+            h = self.activation(_linear(f[0].reshape(-1, self.num_in), lin))
+            sz = torch.as_tensor([int(v) for v in sz], dtype=torch.long)
+            ptr = torch.cat([sz.new_zeros(1), sz.cumsum(0)]).to(dev)
+            feats.append(_SegmentMeanFn.apply(h, ptr))
+        full = torch.cat(feats, dim=1)
+        return full @ self.linear_out.weight.t() + self.linear_out.bias                      # [B, 2*num_out] x [2*num_out, 1]: a dot product per molecule
+
+
+def inferred_pair_of_pairs(n: int):
+    """(idx_pi, idx_pj) of one molecule with n atoms over its n(n-1) ordered pairs (i-major, neighbours ascending): pair p = (i, j) receives the
+    rbf-weighted neighbour features of every pair q = (i, k), k not in {i, j}.  INFERRED: the reference reads this table
+    from ``modules/pindex_dict.npy``, which is not part of the reference tree; a model can pass its own table instead."""
+    i = torch.arange(n).repeat_interleave(n - 1)
+    r = torch.arange(n - 1).repeat(n)
+    j = r + (r >= i).long()
+    p = torch.arange(n * (n - 1))
+    pi = p.repeat_interleave(n - 2) if n > 2 else p.new_zeros(0)
+    # for pair p = (i, j): all k != i, j in ascending order -> pair index (i, k)
+    if n > 2:
+        k_all = torch.arange(n).repeat(n * (n - 1), 1)
+        keep = (k_all != i[:, None]) & (k_all != j[:, None])
+        k = k_all[keep].view(-1)
+        ii = i.repeat_interleave(n - 2)
+        pj = ii * (n - 1) + k - (k > ii).long()
+    else:
+        pj = p.new_zeros(0)
+    return pi, pj
+
+
+class NeuralNetwork(nn.Module):
+    """PhiSNet (phisnet/nn/neural_network.py:31-995) on the HIP ops of this package: same constructor keywords, sub-module names and
+    ``forward(atoms_batch) -> dict`` contract for the Hamiltonian / overlap prediction path.  Differences, all explicit:
+      * ``clebsch_gordan``: the CG provider (the reference builds ``ClebschGordan()`` from its data file); default = tensors computed from scratch
+        (nabladft_amd/cg.py, canonical signs -- checkpoints trained with the reference's table need the reference's provider);
+      * ``pindex``: {molecule size: (idx_pi, idx_pj)} (the reference loads ``modules/pindex_dict.npy``, missing from its tree); default = the
+        inferred table ``inferred_pair_of_pairs`` -- UNVERIFIED;
+      * matrices are returned packed (``*_packed``, differentiable) and dense ([1, Norb, Norb], detached copy as in the reference's layout);
+      * forces (``calculate_forces``) and the non-Bernstein radial bases are not built (raise); ``predict_energy`` (EnergyLayer) is."""
+
+    def __init__(self, max_orbitals=None, order=None, num_features=None, num_basis_functions=None, num_modules=None, num_residual_pre_x=None,
+                 num_residual_post_x=None, num_residual_pre_vi=None, num_residual_pre_vj=None, num_residual_post_v=None, num_residual_output=None,
+                 num_residual_pc=None, num_residual_pn=None, num_residual_ii=None, num_residual_ij=None, num_residual_full_ii=None,
+                 num_residual_full_ij=None, num_residual_core_ii=None, num_residual_core_ij=None, num_residual_over_ij=None, basis_functions=None,
+                 cutoff=None, activation=None, load_from=None, Zmax=87, num_energy_features=64, fallback_args=None, clebsch_gordan=None, pindex=None,
+                 electron_config=None):
+        super().__init__()
+        from . import cg as _cg
+        from .hamiltonian import IrrepsAssembler, compute_matrix_irreps
+        from .so3 import ExponentialBernsteinRadialBasisFunctions
+        if load_from is not None:
+            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: construct with hyper-parameters and load_state_dict the checkpoint")
+        if basis_functions != "exp-bernstein":
+            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: basis_functions='exp-bernstein' is built")
+        self.calculate_full_hamiltonian = self.calculate_core_hamiltonian = self.calculate_overlap_matrix = True
+        self.calculate_energy = self.predict_energy = self.calculate_forces = False
+        self.max_orbitals, self.order, self.num_features, self.num_basis_functions = max_orbitals, order, num_features, num_basis_functions
+        self.num_modules, self.cutoff, self.activation, self.Zmax = num_modules, cutoff, activation, Zmax
+        order_max = max(l for orbs in max_orbitals for _, l in orbs)
+        if order < order_max:
+            raise ValueError(f"An orbital with L={order_max} was found, but the neural network was initialized with L={order}")
+        self.clebsch_gordan = clebsch_gordan if clebsch_gordan is not None else (lambda a, b, c: torch.tensor(_cg.canonical(a, b, c), dtype=torch.float32))
+        cgp = self.clebsch_gordan
+        F, K = num_features, num_basis_functions
+        act = {"swish": Swish, "ssp": ShiftedSoftplus}[activation]
+        self.embedding = SphericalEmbedding(order, F, Zmax, electron_config)
+        self.radial_basis_functions = ExponentialBernsteinRadialBasisFunctions(K, cutoff)
+        self.module = nn.ModuleList([ModularBlock(order, F, K, num_residual_pre_x, num_residual_post_x, num_residual_pre_vi, num_residual_pre_vj,
+                                                  num_residual_post_v, num_residual_output, cgp, True, activation) for _ in range(num_modules)])
+        self.angular_fn = SphericalLinear(order, 1, order, F, cgp, mix_orders=False)
+        self.mix_s = PairMixing(order, order, order, K, F, cgp)
+        self.mix_ij = PairMixing(order, order, order, K, F, cgp)
+        self.radial_ii = nn.ModuleList([nn.Linear(K, F, bias=False) for _ in range(order + 1)])
+        self.radial_ij = nn.ModuleList([nn.Linear(K, F, bias=False) for _ in range(order + 1)])
+        mk = lambda n: ResidualStack(n, order, F, cgp, True, activation)
+        self.residual_pc, self.residual_pn, self.residual_ii, self.residual_ij = mk(num_residual_pc), mk(num_residual_pn), mk(num_residual_ii), mk(num_residual_ij)
+        self.residual_full_ii, self.residual_full_ij = mk(num_residual_full_ii), mk(num_residual_full_ij)
+        self.residual_core_ii, self.residual_core_ij = mk(num_residual_core_ii), mk(num_residual_core_ij)
+        self.residual_over_ij = mk(num_residual_over_ij)
+        self.activation_full_ii, self.activation_full_ij, self.activation_core_ii = act(F), act(F), act(F)
+        self.activation_core_ij, self.activation_over_ij = act(F), act(F)
+        self.activation_energy = act(num_energy_features)
+        self.num_energy_features = num_energy_features
+        # index dictionaries for collecting irreps (neural_network.py:368-417)
+        number_L, self.irreps_ii = [0] * (2 * order_max + 1), {}
+        for orbs in max_orbitals:
+            self.irreps_ii, number_L = compute_matrix_irreps(orbs, orbs, self.irreps_ii, number_L)
+        n_ii = max(number_L)
+        out = lambda n: SphericalLinear(order, F, 2 * order_max, n, cgp, zero_init=True)
+        self.output_full_ii, self.output_core_ii, self.output_over_ii = out(n_ii), out(n_ii), out(n_ii)
+        for L in range(self.output_over_ii.order_out + 1):
+            self.output_over_ii.linear[L].weight.requires_grad = False                       # diagonal overlap blocks are constant (:402-403)
+        number_L, self.irreps_ij = [0] * (2 * order_max + 1), {}
+        for i, oi in enumerate(max_orbitals):
+            for j, oj in enumerate(max_orbitals):
+                if i == j:
+                    continue
+                self.irreps_ij, number_L = compute_matrix_irreps(oi, oj, self.irreps_ij, number_L)
+        n_ij = max(number_L) if self.irreps_ij else 1
+        self.output_full_ij, self.output_core_ij, self.output_over_ij = out(n_ij), out(n_ij), out(n_ij)
+        for L in range(order + 1):                                                           # reset_parameters (:460-463)
+            nn.init.orthogonal_(self.radial_ii[L].weight)
+            nn.init.orthogonal_(self.radial_ij[L].weight)
+        self.energy_predictor = EnergyLayer(F, num_energy_features, zero_init=False, activation=self.activation_energy)
+        self._n_out = (n_ii, n_ij)
+        self._order_out = 2 * order_max
+        self._pindex = pindex
+        a2o = {}
+        for orbs in max_orbitals:
+            a2o.setdefault(int(orbs[0][0]), tuple((int(zz), int(l)) for zz, l in orbs))
+        self._assembler = IrrepsAssembler(a2o, self.irreps_ii, self.irreps_ij, cgp)
+
+    # ---- helpers ------------------------------------------------------------------------------------------------------------------------
+    def fill_idx(self, molecule_size, device):
+        """All ordered atom pairs of every molecule (i-major) and the pair-of-pairs index (neural_network.py:515-561)."""
+        from .hamiltonian import full_pair_index
+        sizes = torch.as_tensor(molecule_size).long().cpu()
+        ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+        ei = full_pair_index(ptr)
+        self.idx_i, self.idx_j = ei[1].to(device), ei[0].to(device)
+        pis, pjs, off = [], [], 0
+        for n in sizes.tolist():
+            pi, pj = (self._pindex[n] if self._pindex is not None else inferred_pair_of_pairs(n))
+            pis.append(torch.as_tensor(pi, dtype=torch.long) + off), pjs.append(torch.as_tensor(pj, dtype=torch.long) + off)
+            off += n * (n - 1)
+        self.idx_pi, self.idx_pj = torch.cat(pis).to(device), torch.cat(pjs).to(device)
+        return ptr.to(device)
+
+    def _heads(self, f, res, act, out):
+        g = res(f)
+        g[0] = act(g[0])
+        return out(g)
+
+    def _pack(self, fs, n_out):
+        x = torch.cat([f[0] for f in fs], dim=-2)                                        # [rows, (Lout+1)^2, n_out]
+        pad = max(self._n_out) - n_out
+        return torch.nn.functional.pad(x, (0, pad)) if pad else x
+
+    def forward(self, atoms_batch):
+        R = atoms_batch["positions"]
+        R = R.view(1, -1, 3)
+        _require_gpu(R)
+        Z = atoms_batch["atomic_numbers"].view(1, -1).long()
+        ptr = self.fill_idx(atoms_batch["molecule_size"], R.device)
+        idx_i, idx_j = self.idx_i, self.idx_j
+        N, P = Z.shape[1], idx_i.numel()
+        pidx = PairIndex(idx_i, idx_j, N)
+        # pair-of-pairs index as a second sorted pair structure: rows = pairs, "neighbours" = the pairs listed in idx_pj
+        ppidx = PairIndex(self.idx_pi, self.idx_pj, P) if self.idx_pi.numel() else None
+        rij = R[0].index_select(0, idx_j) - R[0].index_select(0, idx_i)
+        dij = rij.norm(dim=-1, keepdim=True)
+        uij = rij / dij
+        from .so3 import spherical_harmonics
+        rbf = self.radial_basis_functions(dij).view(1, P, 1, self.num_basis_functions)
+        sph = [s.view(1, P, -1, 1) for s in spherical_harmonics(self.order, uij)]
+        xs = self.embedding(Z)
+        gather_i = lambda t: _GatherFn.apply(t, _SwapIndex(pidx))
+        gather_j = lambda t: _GatherFn.apply(t, pidx)
+        results = {}
+        if self.calculate_overlap_matrix:
+            fii_over = self.output_over_ii(xs)
+            a = self.angular_fn(sph)
+            si = [gather_i(x) for x in xs]
+            sj = [gather_j(xs[0])] + [a[L] for L in range(1, self.order + 1)]
+            fij_over = self._heads(self.mix_s(si, sj, rbf), self.residual_over_ij, self.activation_over_ij, self.output_over_ij)
+        fs = [torch.zeros_like(x) for x in xs]
+        for module in self.module:
+            xs, ys = module(xs, rbf, sph, pidx, idx_j)
+            fs = [f + y for f, y in zip(fs, ys)]
+        fpc, fpn = self.residual_pc(fs), self.residual_pn(fs)
+        fpn_j_ii = [_linear(rbf, self.radial_ii[L]) * gather_j(fpn[L]) for L in range(self.order + 1)]
+        fii = self.residual_ii([_SegmentAddFn.apply(fpc[L], fpn_j_ii[L], pidx) for L in range(self.order + 1)])
+        fij = self.mix_ij([gather_i(x) for x in fpc], [gather_j(x) for x in fpc], rbf)
+        if ppidx is not None:
+            fpn_j = [_linear(rbf, self.radial_ij[L]) * gather_j(fpn[L]) for L in range(self.order + 1)]
+            fij = [_SegmentAddFn.apply(fij[L], _GatherFn.apply(fpn_j[L], ppidx), ppidx) for L in range(self.order + 1)]
+        fij = self.residual_ij(fij)
+        asm = self._assembler
+        plan = asm.plan(Z[0], ptr, idx_i, idx_j)
+        n_ii, n_ij = self._n_out
+        if self.calculate_full_hamiltonian:
+            f1 = self._heads(fii, self.residual_full_ii, self.activation_full_ii, self.output_full_ii)
+            f2 = self._heads(fij, self.residual_full_ij, self.activation_full_ij, self.output_full_ij)
+            results["full_hamiltonian_packed"] = asm.assemble(plan, self._pack(f1, n_ii), self._pack(f2, n_ij), symmetrize=True)
+        if self.calculate_core_hamiltonian:
+            f1 = self._heads(fii, self.residual_core_ii, self.activation_core_ii, self.output_core_ii)
+            f2 = self._heads(fij, self.residual_core_ij, self.activation_core_ij, self.output_core_ij)
+            results["core_hamiltonian_packed"] = asm.assemble(plan, self._pack(f1, n_ii), self._pack(f2, n_ij), symmetrize=True)
+        if self.calculate_overlap_matrix:
+            results["overlap_matrix_packed"] = asm.assemble(plan, self._pack(fii_over, n_ii), self._pack(fij_over, n_ij), symmetrize=True, unit_diagonal=True)
+        asm.check(plan)
+        for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
+            if k + "_packed" in results:
+                results[k] = asm.to_dense(plan, results[k + "_packed"].detach()).unsqueeze(0)
+        if self.calculate_forces:
+            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: forces (-dE/dR through the geometry bases) are not built")
+        norb, eye = plan.m_total, None
+        for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):                # a disabled matrix is the identity (:935-966)
+            if k not in results:
+                eye = torch.eye(norb, device=R.device, dtype=R.dtype).unsqueeze(0) if eye is None else eye
+                results[k] = eye
+        if self.predict_energy:
+            sizes = [int(v) for v in torch.as_tensor(atoms_batch["molecule_size"]).tolist()]
+            results["energy"] = self.energy_predictor(fii, fij, sizes, [n * (n - 1) for n in sizes])
+        else:
+            results["energy"] = torch.zeros(1, 1, device=R.device, dtype=R.dtype)
+        results["forces"] = torch.zeros_like(R)
+        results["orbital_energies"] = torch.zeros(1, norb, device=R.device, dtype=R.dtype)
+        results["orbital_coefficients"] = torch.zeros(1, norb, norb, device=R.device, dtype=R.dtype)
+        results["plan"] = plan
+        return results
+
+
+class _SwapIndex:
+    """View of a PairIndex whose gather reads the centre atoms (idx_i) instead of the neighbours."""
+
+    def __init__(self, pidx: PairIndex):
+        self.idx_j, self.N = pidx.idx_i, pidx.N
+        self.order_j = torch.arange(pidx.idx_i.numel(), device=pidx.idx_i.device)        # idx_i is sorted: the pairs of atom n are contiguous
+        self.ptr_j = pidx.ptr_i

@@ -66,7 +66,7 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix", "--network"} & set(sys.argv)):
     main()
 
 
@@ -245,3 +245,69 @@ def matrix_assembly():
 
 if __name__ == "__main__" and "--matrix" in sys.argv:
     matrix_assembly()
+
+
+def network():
+    """The REAL NeuralNetwork end to end (embedding -> modules -> pair features -> irreps -> matrices) on a small batch.  CAVEAT, also in
+    DESIGN.md: the reference reads its pair-of-pairs table from modules/pindex_dict.npy, which its tree does not contain; the load is answered
+    here with the inferred table (nabladft_amd.phisnet.inferred_pair_of_pairs), so this fixture pins everything except that table's content."""
+    import types
+    sys.path.insert(0, os.path.dirname(HERE))
+    from nabladft_amd.phisnet import inferred_pair_of_pairs
+    pkg = types.ModuleType("ref_phisnet_nn4")
+    pkg.__path__ = ["/root/reference/nablaDFT/phisnet/nn"]
+    sys.modules["ref_phisnet_nn4"] = pkg
+    real_load = np.load
+
+    def load(path, *a, **k):
+        if str(path).endswith("pindex_dict.npy"):
+            return np.array({n: tuple(t.numpy() for t in inferred_pair_of_pairs(n)) for n in range(2, 9)}, dtype=object)
+        return real_load(path, *a, **k)
+
+    np.load = load
+    try:
+        nnmod = importlib.import_module("ref_phisnet_nn4.neural_network")
+        shells = {1: (0, 0, 1), 6: (0, 0, 0, 1, 1, 2), 8: (0, 0, 0, 1, 1, 2)}
+        # one entry per list position; elements repeated so that same-element pairs have off-diagonal irreps (neural_network.py:407-417)
+        max_orbitals = tuple(tuple((zz, l) for l in shells[zz]) for zz in (1, 1, 6, 6, 8, 8))
+        torch.manual_seed(5)
+        hp = dict(max_orbitals=max_orbitals, order=2, num_features=32, num_basis_functions=8, num_modules=2, num_residual_pre_x=1, num_residual_post_x=1,
+                  num_residual_pre_vi=1, num_residual_pre_vj=1, num_residual_post_v=1, num_residual_output=1, num_residual_pc=1, num_residual_pn=1,
+                  num_residual_ii=1, num_residual_ij=1, num_residual_full_ii=1, num_residual_full_ij=1, num_residual_core_ii=1, num_residual_core_ij=1,
+                  num_residual_over_ij=1, basis_functions="exp-bernstein", cutoff=8.0, activation="swish")
+        m = nnmod.NeuralNetwork(**hp).float()
+    finally:
+        np.load = real_load
+    rng = np.random.Generator(np.random.PCG64(41))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.abs().max() == 0 or n.endswith("alpha") or n.endswith("beta"):
+                p.add_(torch.tensor(rng.normal(0, 0.2, size=tuple(p.shape)).astype(np.float32)))
+    sizes = [3, 2, 4]
+    zs = np.array([8, 1, 1, 1, 1, 6, 8, 1, 6])
+    pos = np.concatenate([rng.normal(0, 1.1, size=(s, 3)) + 0.0 for s in sizes]).astype(np.float32)
+    batch = dict(positions=torch.tensor(pos).view(1, -1, 3), atomic_numbers=torch.tensor(zs), orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs],
+                 molecule_size=torch.tensor(sizes))
+    m.predict_energy = True
+    out = m(batch)
+    fx = dict(z=zs, positions=pos, sizes=np.array(sizes), electron_config=m.embedding.embedding.electron_config.numpy(),
+              hp=np.array([hp["order"], hp["num_features"], hp["num_basis_functions"], hp["num_modules"]]), cutoff=np.float64(hp["cutoff"]))
+    loss = 0
+    for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
+        w = torch.tensor(rng.normal(size=tuple(out[k].shape)).astype(np.float32))
+        fx[k], fx["w_" + k] = out[k][0].detach().numpy(), w[0].numpy()
+        loss = loss + (out[k] * w).sum()
+    w = torch.tensor(rng.normal(size=tuple(out["energy"].shape)).astype(np.float32))
+    fx["energy"], fx["w_energy"] = out["energy"].detach().numpy(), w.numpy()
+    loss = loss + (out["energy"] * w).sum()
+    loss.backward()
+    for n, p in m.named_parameters():
+        fx["p:" + n] = p.detach().numpy()
+        fx["g:" + n] = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        fx["rg:" + n] = np.bool_(p.requires_grad)
+    np.savez_compressed(os.path.join(OUT, "phisnet_network.npz"), **fx)
+    print("phisnet_network.npz:", len(fx), "arrays; Norb", fx["full_hamiltonian"].shape, "params", sum(p.numel() for p in m.parameters()))
+
+
+if __name__ == "__main__" and "--network" in sys.argv:
+    network()

@@ -42,3 +42,89 @@ def test_modular_block_matches_reference(tag):
         worst = max(worst, (n, e), key=lambda t: t[1])
         assert e < 4 * TOL, (n, e)
     print(f"{tag}: {len(ref_sd)} parameters, worst gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+# ---- the whole network (row a24) ---------------------------------------------------------------------------------------------------------
+def _network_from_fixture(fx):
+    from nabladft_amd.phisnet import NeuralNetwork
+    shells = {1: (0, 0, 1), 6: (0, 0, 0, 1, 1, 2), 8: (0, 0, 0, 1, 1, 2)}
+    max_orbitals = tuple(tuple((zz, l) for l in shells[zz]) for zz in (1, 1, 6, 6, 8, 8))
+    order, F, K, nm = (int(v) for v in fx["hp"])
+    cg = FixtureCG()                                                                    # the reference's table (its signs)
+    m = NeuralNetwork(max_orbitals=max_orbitals, order=order, num_features=F, num_basis_functions=K, num_modules=nm, num_residual_pre_x=1,
+                      num_residual_post_x=1, num_residual_pre_vi=1, num_residual_pre_vj=1, num_residual_post_v=1, num_residual_output=1, num_residual_pc=1,
+                      num_residual_pn=1, num_residual_ii=1, num_residual_ij=1, num_residual_full_ii=1, num_residual_full_ij=1, num_residual_core_ii=1,
+                      num_residual_core_ij=1, num_residual_over_ij=1, basis_functions="exp-bernstein", cutoff=float(fx["cutoff"]), activation="swish",
+                      clebsch_gordan=cg, electron_config=fx["electron_config"])
+    ref_names = sorted(k[2:] for k in fx.files if k.startswith("p:"))
+    assert sorted(n for n, _ in m.named_parameters()) == ref_names                     # the reference's parameter surface, name for name
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            assert tuple(p.shape) == fx["p:" + n].shape, n
+            p.copy_(torch.tensor(fx["p:" + n]))
+            assert bool(fx["rg:" + n]) == p.requires_grad, n
+    return m.cuda(), shells
+
+
+
+def test_neural_network_matches_reference():
+    """End to end against the real NeuralNetwork.forward (oracle/make_golden_phisnet.py --network; the pair-of-pairs table is the inferred one
+    on both sides, see the caveat there): three matrices and every parameter gradient."""
+    fx = np.load(os.path.join(GOLDEN, "phisnet_network.npz"))
+    m, shells = _network_from_fixture(fx)
+    zs = fx["z"]
+    batch = dict(positions=torch.tensor(fx["positions"]).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(zs).cuda(),
+                 orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs], molecule_size=torch.tensor(fx["sizes"]))
+    m.predict_energy = True
+    out = m(batch)
+    plan, asm = out["plan"], m._assembler
+    assert rel_err(out["energy"].detach().cpu().numpy(), fx["energy"]) < TOL
+    loss = (out["energy"] * torch.tensor(fx["w_energy"]).cuda()).sum()
+    for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
+        assert tuple(out[k].shape) == (1,) + fx[k].shape
+        assert rel_err(out[k][0].cpu().numpy(), fx[k]) < TOL, k
+        loss = loss + (out[k + "_packed"] * asm.from_dense(plan, torch.tensor(fx["w_" + k]).cuda())).sum()
+    loss.backward()
+    worst = 0.0
+    for n, p in m.named_parameters():
+        ref = fx["g:" + n]
+        if not p.requires_grad:
+            continue
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        scale = max(float(np.abs(ref).max()), 1e-3)
+        worst = max(worst, float(np.abs(got - ref).max()) / scale)
+        assert float(np.abs(got - ref).max()) / scale < 5e-4, n
+    assert out["energy"].shape == (len(fx["sizes"]), 1) and out["forces"].shape == (1, len(zs), 3)
+
+
+
+def test_neural_network_properties():
+    """Size-independent checks: matrices are symmetric, the overlap has a unit diagonal, molecules do not couple (batch of two == each alone),
+    and a rigid translation leaves everything unchanged."""
+    fx = np.load(os.path.join(GOLDEN, "phisnet_network.npz"))
+    m, shells = _network_from_fixture(fx)
+    zs, sizes, pos = fx["z"], fx["sizes"], fx["positions"]
+
+    def run(sel, shift=0.0):
+        zz, pp = zs[sel], pos[sel] + shift
+        b = dict(positions=torch.tensor(pp, dtype=torch.float32).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(zz).cuda(),
+                 orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zz], molecule_size=torch.tensor([len(zz)]))
+        with torch.no_grad():
+            return m(b)
+    with torch.no_grad():
+        full = m(dict(positions=torch.tensor(pos).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(zs).cuda(),
+                      orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs], molecule_size=torch.tensor(sizes)))
+    H, S = full["full_hamiltonian"][0], full["overlap_matrix"][0]
+    assert torch.equal(H, H.T) and torch.equal(S, S.T)
+    assert torch.equal(torch.diagonal(S), torch.ones_like(torch.diagonal(S)))
+    o = 0
+    a0 = 0
+    for s in sizes:
+        sel = np.arange(a0, a0 + s)
+        alone = run(sel)
+        n = alone["full_hamiltonian"].shape[-1]
+        assert (H[o:o + n, o:o + n] - alone["full_hamiltonian"][0]).abs().max() < 2e-5
+        moved = run(sel, shift=np.float32(3.5))
+        assert (moved["core_hamiltonian"][0] - alone["core_hamiltonian"][0]).abs().max() < 2e-4
+        o, a0 = o + n, a0 + s
+    assert o == H.shape[0]
