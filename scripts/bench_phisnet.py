@@ -1,0 +1,100 @@
+"""PhiSNet training-step timing on one MI355X: nabladft_amd.phisnet.NeuralNetwork at the nablaDFT
+configuration (phisnet/configs/args_nablaDFT_100k_separate.txt: order 4, F = 128, K = 128, 5 modules, cutoff 15, swish; batch of 2 molecules
+as train_batch_size there), forward + MAE loss on the packed full Hamiltonian and overlap + backward.  Synthetic drug-like molecules (H, C, N, O with
+def2-SVP-like shells), random-init weights with the zero-initialised layers randomised.  Prints one JSON line.
+    python scripts/bench_phisnet.py [--molecules 2] [--atoms 42] [--steps 5] [--warmup 2] [--kernels]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SHELLS = {1: (0, 0, 1), 6: (0, 0, 0, 1, 1, 2), 7: (0, 0, 0, 1, 1, 2), 8: (0, 0, 0, 1, 1, 2)}
+HP = dict(order=4, num_features=128, num_basis_functions=128, num_modules=5, num_residual_pre_x=1, num_residual_post_x=1, num_residual_pre_vi=1,
+          num_residual_pre_vj=1, num_residual_post_v=1, num_residual_output=1, num_residual_pc=1, num_residual_pn=1, num_residual_ii=1, num_residual_ij=1,
+          num_residual_full_ii=2, num_residual_full_ij=2, num_residual_core_ii=2, num_residual_core_ij=2, num_residual_over_ij=2,
+          basis_functions="exp-bernstein", cutoff=15.0, activation="swish")
+
+
+def synthetic_batch(molecules, atoms, seed=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    zs, pos, sizes = [], [], []
+    for _ in range(molecules):
+        z = rng.choice([1, 6, 7, 8], size=atoms, p=[0.5, 0.35, 0.07, 0.08])
+        # random points with a minimum separation of ~1 A in a box that keeps the density of an organic molecule
+        side = (atoms * 9.0) ** (1 / 3)
+        p = []
+        while len(p) < atoms:
+            c = rng.uniform(0, side, size=3)
+            if all(np.linalg.norm(c - q) > 0.95 for q in p):
+                p.append(c)
+        zs.append(z), pos.append(np.array(p, dtype=np.float32)), sizes.append(atoms)
+    z = np.concatenate(zs)
+    return dict(z=z, positions=np.concatenate(pos), sizes=np.array(sizes), orbitals=[tuple((int(a), l) for l in SHELLS[int(a)]) for a in z])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--molecules", type=int, default=2)
+    ap.add_argument("--atoms", type=int, default=42)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event table (nq profile hooks)")
+    a = ap.parse_args()
+    import torch
+    from nabladft_amd import _lib
+    from nabladft_amd.phisnet import NeuralNetwork
+    max_orbitals = tuple(tuple((zz, l) for l in SHELLS[zz]) for zz in (1, 1, 6, 6, 7, 7, 8, 8))
+    torch.manual_seed(0)
+    m = NeuralNetwork(max_orbitals=max_orbitals, **HP)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.abs().max() == 0:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    m = m.cuda()
+    b = synthetic_batch(a.molecules, a.atoms)
+    batch = dict(positions=torch.tensor(b["positions"]).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(b["z"]).cuda(), orbitals=b["orbitals"],
+                 molecule_size=torch.tensor(b["sizes"]))
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = m(batch)
+        loss = out["full_hamiltonian_packed"].abs().mean() + out["overlap_matrix_packed"].abs().mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if a.kernels:
+        _lib.profile_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.steps):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.steps
+    n_params = sum(p.numel() for p in params)
+    P = int(sum(s * (s - 1) for s in b["sizes"]))
+    out = {"metric": "PhiSNet molecule-steps/sec (fwd + MAE(H,S) + bwd + clip + AMSGrad)", "value": a.molecules / (ms * 1e-3), "unit": "molecule-steps/s",
+           "ms_per_step": ms, "molecules": a.molecules, "atoms": int(len(b["z"])), "ordered_pairs": P, "orbitals": int(sum(2 * l + 1 for o in b["orbitals"] for _, l in o)),
+           "parameters": n_params, "final_loss": float(loss), "config": {k: v for k, v in HP.items()}, "data": "synthetic", "dtype": "f32"}
+    if a.kernels:
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        out["device_ms_per_step_nq_kernels"] = sum(v[0] for v in prof.values()) / a.steps
+        out["kernel_ms_per_step"] = {k: [round(v[0] / a.steps, 4), int(v[1] // a.steps)] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
