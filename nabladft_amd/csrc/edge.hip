@@ -725,20 +725,12 @@ __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restri
   order[base[key] + hist[(long)key * gridDim.x + blockIdx.x] + local_rank[e]] = e;
 }
 
-template <int CH>
-struct GwrOps { float g[CH], h[CH]; float rr[16], dd[16]; };
-
-template <int CH>
-__device__ __forceinline__ void load_gwr(GwrOps<CH>& o, const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
-                                         int e, int F3, int col) {
-  ldv<CH>(o.g, GPHI + (long)e * F3 + col);
-  ldv<CH>(o.h, GPSI + (long)e * F3 + col);
-  const float4* rw4 = reinterpret_cast<const float4*>(RW + (long)e * RW_STRIDE);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { *reinterpret_cast<float4*>(&o.rr[4 * v]) = rw4[v]; *reinterpret_cast<float4*>(&o.dd[4 * v]) = rw4[4 + v]; }
-}
-
+// Latency: the k0-sorted stream visits the edge rows of GPHI / GPSI in a permuted order, so every edge is a fresh HBM access (~1 us).  A
+// wavefront therefore keeps GWR_DEPTH edges in flight (5 VGPRs each: CH floats of gphi and gpsi per lane plus the edge's 32-float
+// window record spread over the lanes, broadcast with v_readlane when it is consumed); with one edge in flight the kernel ran at
+// edges x latency / waves (1.29 ms per launch at 1.6 M edges), i.e. 3.1 TB/s.
 #define GWR_WAVES 4
+#define GWR_DEPTH 6
 template <int CH>
 __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
                                                                const int* __restrict__ order, int E, int F, int F3, int R, int chunk_len,
@@ -748,47 +740,52 @@ __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __re
   const int r0 = chunk * chunk_len, r1 = min(E, r0 + chunk_len);
   if (r0 >= E) return;   // wave-uniform
   const int col = blockIdx.y * F + lane * CH;   // F3 = row length of GPHI/GPSI (3F for the PaiNN filter, F for SchNet's first filter layer)
-  float acc[16][CH];
+  typedef VOps<CH> VO;
+  typedef typename VO::V V;
+  V acc[16];   // CH-wide accumulators: every tap is two v_pk_fma_f32 at CH = 2
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
-#pragma unroll
-    for (int c = 0; c < CH; ++c) acc[t][c] = 0.f;
+  for (int t = 0; t < 16; ++t) acc[t] = VO::splat(0.f);
   float* out = part + (long)chunk * R * F3 + col;
-  GwrOps<CH> cur, nxt;
-  load_gwr<CH>(cur, GPHI, GPSI, RW, __builtin_amdgcn_readfirstlane(order[r0]), F3, col);
-  nxt = cur;
-  int base = __builtin_amdgcn_readfirstlane(__float_as_int(cur.rr[13]));
+  V g[GWR_DEPTH], h[GWR_DEPTH];
+  float rw[GWR_DEPTH];
+  auto issue = [&](int slot, int r) __attribute__((always_inline)) {
+    const int e = __builtin_amdgcn_readfirstlane(order[r]);
+    g[slot] = VO::load(GPHI + (long)e * F3 + col);
+    h[slot] = VO::load(GPSI + (long)e * F3 + col);
+    rw[slot] = RW[(long)e * RW_STRIDE + (lane & 31)];
+  };
+#pragma unroll
+  for (int s = 0; s < GWR_DEPTH; ++s) issue(s, min(r0 + s, r1 - 1));
+  int base = __builtin_amdgcn_readlane(__float_as_int(rw[0]), 13);
   const int lo = base;
-  for (int r = r0; r < r1; ++r) {
-    if (r + 1 < r1) load_gwr<CH>(nxt, GPHI, GPSI, RW, __builtin_amdgcn_readfirstlane(order[r + 1]), F3, col);
-    const int k0 = __builtin_amdgcn_readfirstlane(__float_as_int(cur.rr[13]));
-    while (base < k0) {   // the window slides up: flush the row that leaves it, shift the accumulators
-      float row[CH];
+  for (int rb = r0; rb < r1; rb += GWR_DEPTH) {
 #pragma unroll
-      for (int c = 0; c < CH; ++c) row[c] = acc[0][c];
-      stv<CH>(out + (long)base * F3, row);
+    for (int s = 0; s < GWR_DEPTH; ++s) {
+      const int r = rb + s;
+      if (r < r1) {   // wave-uniform
+        const int rwi = __float_as_int(rw[s]);
+        const int k0 = __builtin_amdgcn_readlane(rwi, 13);
+        while (base < k0) {   // the window slides up: flush the row that leaves it, shift the accumulators
+          *reinterpret_cast<V*>(out + (long)base * F3) = acc[0];
 #pragma unroll
-      for (int t = 0; t < 15; ++t)
+          for (int t = 0; t < 15; ++t) acc[t] = acc[t + 1];
+          acc[15] = VO::splat(0.f);
+          ++base;
+        }
 #pragma unroll
-        for (int c = 0; c < CH; ++c) acc[t][c] = acc[t + 1][c];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) acc[15][c] = 0.f;
-      ++base;
+        for (int t = 0; t < FWIN; ++t) {
+          const float rr = __int_as_float(__builtin_amdgcn_readlane(rwi, t)), dd = __int_as_float(__builtin_amdgcn_readlane(rwi, 16 + t));
+          acc[t] = VO::fma(g[s], VO::splat(rr), VO::fma(h[s], VO::splat(dd), acc[t]));
+        }
+        if (r + GWR_DEPTH < r1) issue(s, r + GWR_DEPTH);
+      }
     }
-#pragma unroll
-    for (int t = 0; t < FWIN; ++t)
-#pragma unroll
-      for (int c = 0; c < CH; ++c) acc[t][c] = fmaf(cur.g[c], cur.rr[t], fmaf(cur.h[c], cur.dd[t], acc[t][c]));
-    cur = nxt;
   }
   int hi = base;
 #pragma unroll
   for (int t = 0; t < FWIN; ++t) {
     if (base + t < R) {
-      float row[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) row[c] = acc[t][c];
-      stv<CH>(out + (long)(base + t) * F3, row);
+      *reinterpret_cast<V*>(out + (long)(base + t) * F3) = acc[t];
       hi = base + t + 1;
     }
   }
