@@ -117,7 +117,9 @@ struct FilterArgs {
   int mode;           // 0: polynomial envelope inside the projection (painn_pyg); 1: cosine cutoff after the bias, unscaled Gaussians (spk PaiNN);
                       // 2: bare unscaled Gaussians, record slots 14/30 = fcut, fcut' (spk SchNet)
   float cutoff;
+  int* row_ctr;       // fused message kernels: [8 XCDs][slices] zeroed row counters of THIS launch (dynamic row claiming), or null = static striding
 };
+#define NQ_ROWCTR_INTS 32   // counters per launch (8 XCDs x up to 4 channel slices)
 
 struct MsgRevArgs {
   NqGraphView g; int F;

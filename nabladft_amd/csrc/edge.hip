@@ -372,6 +372,33 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
   O::to(qa, ua); O::to(qb, ub); O::to(qc, uc);
 }
 
+// Row scheduling of the fused message kernels.  Static: wavefront w of the XCD's sweep takes rows w, w + stride, ...  Claimed (kinds in
+// NQ_CLAIM_KINDS, bit = kind 0 forward / 1 tangent / 2 force adjoint / 3 dual reverse): a wavefront takes the next NQ_CLAIM_ROWS
+// unprocessed atoms of its XCD's range from a zeroed counter (FilterArgs::row_ctr), so all wavefronts of the XCD stay on one moving
+// front of consecutive atoms; the claim for the following chunk is issued before the current one is processed.  Which wavefront
+// computes a row does not change its result.  Measured (profiles/r01_fused_tuning.txt section 4): only the dual reverse gains (-8 %, one row per
+// claim; larger chunks lose the balance at the tail), the short-row kernels pay for the same-address atomics -> default kinds = 8, rows = 1.
+#ifndef NQ_CLAIM_KINDS
+#define NQ_CLAIM_KINDS 8
+#endif
+#ifndef NQ_CLAIM_ROWS
+#define NQ_CLAIM_ROWS 1
+#endif
+#define FUSED_ROWS(KIND)                                                                        \
+  constexpr bool claim__ = ((NQ_CLAIM_KINDS >> (KIND)) & 1) != 0;                               \
+  constexpr int crows__ = claim__ ? NQ_CLAIM_ROWS : 1;                                          \
+  int* const ctr__ = claim__ ? fa.row_ctr + (int)(blockIdx.x % nxcd) * nslices + slice : nullptr; \
+  int n_static__ = x_lo + wg * nslots + slot;                                                   \
+  auto claim_rows = [&]() __attribute__((always_inline)) -> int {                               \
+    if constexpr (claim__) {                                                                    \
+      int v__ = 0;                                                                              \
+      if (lane == 0) v__ = __hip_atomic_fetch_add(ctr__, crows__, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      return x_lo + __builtin_amdgcn_readfirstlane(v__);                                        \
+    } else { const int v__ = n_static__; n_static__ += n_step; return v__; }                    \
+  };                                                                                            \
+  for (int blk__ = claim_rows(), nxt__ = claim_rows(); blk__ < n_hi; blk__ = nxt__, nxt__ = claim_rows()) \
+    for (int n = blk__; n < min(blk__ + crows__, n_hi); ++n)
+
 // One wavefront per atom; lane l owns channels [l*CH, (l+1)*CH) of each part (F = 64*CH).
 #define FUSED_PROLOGUE                                                                          \
   extern __shared__ __attribute__((aligned(16))) float wrt[];                                  \
@@ -403,8 +430,12 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
      any time an XCD works on ~6 molecules and their rows are fetched into that XCD's 4 MB L2 once. */                              \
   const int per_x = (q.g.N + nxcd - 1) / nxcd;                                                 \
   const int x_lo = (int)(blockIdx.x % nxcd) * per_x, n_hi = min(q.g.N, x_lo + per_x);          \
-  const int n_first = x_lo + wg * nslots + slot;                                               \
-  const int n_step = (int)(gridDim.x / nxcd / nslices) * nslots;
+  const int n_step = (int)(gridDim.x / nxcd / nslices) * nslots;                               \
+  /* Rows are CLAIMED, not strided: every wavefront of an XCD takes the next unprocessed atom of that XCD's range from a counter, so  \
+     the wavefronts stay on one moving front of consecutive atoms (with static striding a wavefront that met short rows ran ahead by   \
+     whole strides of ~400 atoms and the live set outgrew the L2).  The claim for the next row is issued before the current row is     \
+     processed; which wavefront computes a row does not change its result.  */                                                        \
+  /* rows: see FUSED_ROWS */
 
 // ---- forward / tangent -------------------------------------------------------------------------------------
 template <bool TAN, int CH>
@@ -427,7 +458,7 @@ __device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, i
 template <bool TAN, int CH>
 __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  for (int n = n_first; n < n_hi; n += n_step) {
+  FUSED_ROWS(TAN ? 1 : 0) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     float dx[CH], d0[CH], d1[CH], d2[CH];
 #pragma unroll
@@ -530,7 +561,7 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
 template <bool DUAL, int CH>
 __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
-  for (int n = n_first; n < n_hi; n += n_step) {
+  FUSED_ROWS(DUAL ? 3 : 2) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     const long o3 = (long)n * F3 + fb;
     float xa[CH], xb[CH], xc[CH], v0[CH], v1[CH], v2[CH], txa[CH], txb[CH], txc[CH], tv0[CH], tv1[CH], tv2[CH];
@@ -950,7 +981,7 @@ void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, cons
   const double p = env_p;
   fa->WRT = WRT; fa->br = br; fa->mu = mu; fa->RW = RW; fa->R = R; fa->inv_cutoff = (float)(1.0 / cutoff);
   fa->p = (float)p; fa->a = (float)(-(p + 1) * (p + 2) / 2); fa->b = (float)(p * (p + 2)); fa->c = (float)(-p * (p + 1) / 2);
-  fa->coeff = coeff; fa->mode = mode; fa->cutoff = (float)cutoff;
+  fa->coeff = coeff; fa->mode = mode; fa->cutoff = (float)cutoff; fa->row_ctr = nullptr;
 }
 
 int nq_rbf_window(hipStream_t st, const float4* geom, int E, const FilterArgs& fa, float* RW) {

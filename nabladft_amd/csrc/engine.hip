@@ -85,7 +85,7 @@ struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
   size_t RHO2, RW, ORDER, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
-  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, scratch;
+  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, ROWCTR, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
 };
@@ -122,6 +122,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GEDGE = take((F / 64) * E * 4);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
   W->GRHO = take(c->rbf_type ? 2 * E * R : 0); W->BCON = take(c->rbf_type ? E * R : 0);   // learnable bases: adjoints of rho / drho, per-edge contributions
+  W->ROWCTR = take(4 * 64 * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]
   // scratch for split-K partials / column sums / embedding partials: max over all uses
   size_t s = 0;
   auto mx = [&](size_t v) { if (v > s) s = v; };
@@ -295,6 +296,9 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   const NqGraphView g = view_of(graph);
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers;
   const size_t NF = (size_t)N * F;
+  int* const rowctr0 = reinterpret_cast<int*>(ws + W.ROWCTR);   // kinds 0 (forward) and 1 (force adjoint) are zeroed here, 2 / 3 in the backward call
+  NQ_HIP(hipMemsetAsync(rowctr0, 0, 2 * 64 * NQ_ROWCTR_INTS * sizeof(int), st));
+  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * 64 + l) * NQ_ROWCTR_INTS; };
 
   // embedding; zero vec_in0 and the tangent halves of layer-0 inputs (d x0 / d pos = 0)
   NQ_TRY(nq_embed(st, g.z, params + P.emb, N, F, ws + W.X[0]));
@@ -321,6 +325,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
       FilterArgs fa;
       NQ_TRY(nq_transpose(st, params + mp.Wr, 3 * F, R, ws + y.WRT));
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
+      fa.row_ctr = row_ctr(0, l);
       NQ_TRY(nq_msgf_fwd(st, m, fa, false));
     } else {
       NQ_TRY(nq_gemm_nt(st, rho, params + mp.Wr, ws + y.PHI, params + mp.br, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
@@ -369,6 +374,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
+      fa.row_ctr = row_ctr(1, l);
       NQ_TRY(nq_msgf_rev(st, m, fa, false));
     } else {
       NQ_TRY(nq_msg_rev(st, m, false));
@@ -399,6 +405,9 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   const NqGraphView g = view_of(graph);
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers, T = cfg->num_elements;
   const size_t NF = (size_t)N * F;
+  int* const rowctr0 = reinterpret_cast<int*>(ws + W.ROWCTR);
+  NQ_HIP(hipMemsetAsync(rowctr0 + 2 * 64 * NQ_ROWCTR_INTS, 0, 2 * 64 * NQ_ROWCTR_INTS * sizeof(int), st));
+  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * 64 + l) * NQ_ROWCTR_INTS; };
 
   const size_t NH = (size_t)N * H;
   ReadoutArgs r{};
@@ -433,6 +442,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
+      fa.row_ctr = row_ctr(2, l);
       NQ_TRY(nq_msgf_fwd(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_fwd(st, m, true));
@@ -501,6 +511,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
+      fa.row_ctr = row_ctr(3, l);
       NQ_TRY(nq_msgf_rev(st, m, fa, true));
     } else {
       NQ_TRY(nq_msg_rev(st, m, true));

@@ -15,6 +15,11 @@ if [ "$1" = build ]; then
     [ $k = 9 ] && X="-DNQ_DUAL2_THREADS=512 -DNQ_TAN2_THREADS=512"
     [ $k = 10 ] && X="-DNQ_CH_FWD=1 -DNQ_CH_TAN=1 -DNQ_CH_FORCE=1 -DNQ_CH_DUAL=1"   # two 64-channel slices per atom at F=128
     [ $k = 11 ] && X="-DNQ_CH_FWD=1"
+    [ $k = 12 ] && X="-DNQ_CLAIM_KINDS=0"    # static row striding everywhere
+    [ $k = 13 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_ROWS=4"
+    [ $k = 14 ] && X="-DNQ_CLAIM_KINDS=8 -DNQ_CLAIM_ROWS=2"
+    [ $k = 15 ] && X="-DNQ_CLAIM_KINDS=8 -DNQ_CLAIM_ROWS=1"
+    [ $k = 16 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_ROWS=8"
     /opt/rocm/bin/hipcc $FLAGS $X -c nabladft_amd/csrc/edge.hip -o $D/edge_$k.o &
   done
   wait
