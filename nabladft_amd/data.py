@@ -227,3 +227,161 @@ class ArenaLoader:
             # resumed after the consumer has ENQUEUED its kernels for batch k: collate + copy batch k+1 while they run
             if k + 1 < len(plan):
                 staged = self._stage(plan[k + 1], (k + 1) % len(self.staging))
+
+
+# ---- Hamiltonian databases (second half) ----------------------------------------------------------
+class HamiltonianDatabase:
+    """nablaDFT Hamiltonian sqlite file, read (and written) with the standard library -- the accessors of
+    nablaDFT/dataset/hamiltonian_dataset.py:17-283 (which needs ``apsw``), same names and return values:
+      ``len(db)``                       metadata row 0 (:76-78)
+      ``db[i]`` / ``db[[i, j, ...]]``     (Z i32[N], R f32[N,3], E f32[1], F f32[N,3], H, S, C f32[Norb,Norb], moses_id, conformer_id) (:80-106)
+      ``db.get_orbitals(Z)``            angular momenta of the element's shells, i32 (:173-178)
+      ``db.Z``                          elements of the basis-set table, i32 (:277-283)
+      ``add_data / add_orbitals / add_Z``  the writers (:108-171, 266-275): float64 -> float32, int64 -> int32 blobs, little endian.
+    File format: tables ``data(id, Z, R, E, F, H, S, C)``, ``dataset_ids(id, MOSES_ID, CONFORMER_ID)``, ``basisset(Z, orbitals)``,
+    ``nuclear_charges(id, N, Z)``, ``metadata(id, N)`` (:210-257)."""
+
+    def __init__(self, filename: str, readonly: bool = True):
+        import os
+        self.filename = filename
+        new = not os.path.isfile(filename)
+        if new and readonly:
+            raise FileNotFoundError(filename)
+        self._c = sqlite3.connect(("file:" + filename + "?mode=ro") if readonly else filename, uri=readonly, isolation_level=None, check_same_thread=False)
+        self._c.execute("PRAGMA busy_timeout=300000")
+        if new:
+            cur = self._c.cursor()
+            cur.execute("CREATE TABLE IF NOT EXISTS dataset_ids (id INTEGER NOT NULL PRIMARY KEY, MOSES_ID INT, CONFORMER_ID INT)")
+            cur.execute("CREATE TABLE IF NOT EXISTS data (id INTEGER NOT NULL PRIMARY KEY, Z BLOB, R BLOB, E FLOAT, F BLOB, H BLOB, S BLOB, C BLOB)")
+            cur.execute("CREATE TABLE IF NOT EXISTS nuclear_charges (id INTEGER NOT NULL PRIMARY KEY, N INTEGER, Z BLOB)")
+            cur.execute("INSERT OR IGNORE INTO nuclear_charges (id, N, Z) VALUES (?,?,?)", (0, 1, self._blob(np.array([0]))))
+            cur.execute("CREATE TABLE IF NOT EXISTS basisset (Z INTEGER NOT NULL PRIMARY KEY, orbitals BLOB)")
+            cur.execute("CREATE TABLE IF NOT EXISTS metadata (id INTEGER PRIMARY KEY, N INTEGER)")
+            cur.execute("INSERT OR IGNORE INTO metadata (id, N) VALUES (?,?)", (0, 0))
+        self._orbitals = {}
+
+    @staticmethod
+    def _blob(a):
+        if a is None:
+            return None
+        a = np.asarray(a)
+        if a.dtype == np.float64:
+            a = a.astype(np.float32)
+        if a.dtype == np.int64:
+            a = a.astype(np.int32)
+        return memoryview(np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<"), copy=False)))
+
+    @staticmethod
+    def _deblob(buf, dtype, shape):
+        if buf is None:
+            return np.zeros(shape)
+        return np.frombuffer(buf, np.dtype(dtype).newbyteorder("<")).astype(dtype, copy=False).reshape(shape)
+
+    def __len__(self):
+        return int(self._c.execute("SELECT * FROM metadata WHERE id=0").fetchone()[-1])
+
+    def _unpack(self, d):
+        n = len(d[2]) // 12
+        norb = int(round((len(d[5]) // 4) ** 0.5))
+        return (self._deblob(d[1], np.int32, (n,)), self._deblob(d[2], np.float32, (n, 3)), np.array([0.0 if d[3] is None else d[3]], dtype=np.float32),
+                self._deblob(d[4], np.float32, (n, 3)), self._deblob(d[5], np.float32, (norb, norb)), self._deblob(d[6], np.float32, (norb, norb)),
+                self._deblob(d[7], np.float32, (norb, norb)))
+
+    def __getitem__(self, idx):
+        cur = self._c.cursor()
+        if isinstance(idx, (list, tuple, np.ndarray)):       # batched retrieval: rows come back in id order, like the reference's IN (...) query
+            ids = [int(i) for i in idx]
+            q = ",".join(str(i) for i in ids)
+            data = cur.execute("SELECT * FROM data WHERE id IN (" + q + ")").fetchall()
+            names = cur.execute("SELECT * FROM dataset_ids WHERE id IN (" + q + ")").fetchall()
+            return [(*self._unpack(d), nm[1], nm[2]) for d, nm in zip(data, names)]
+        d = cur.execute("SELECT * FROM data WHERE id=" + str(int(idx))).fetchone()
+        if d is None:
+            raise IndexError(idx)
+        nm = cur.execute("SELECT * FROM dataset_ids WHERE id=" + str(int(idx))).fetchone()
+        return (*self._unpack(d), nm[1], nm[2])
+
+    def get_orbitals(self, Z):
+        Z = int(Z)
+        if Z not in self._orbitals:
+            d = self._c.execute("SELECT * FROM basisset WHERE Z=" + str(Z)).fetchone()
+            if d is None:
+                raise KeyError(f"element {Z} has no entry in the basisset table")
+            self._orbitals[Z] = self._deblob(d[1], np.int32, (len(d[1]) // 4,))
+        return self._orbitals[Z]
+
+    @property
+    def Z(self):
+        d = self._c.execute("SELECT * FROM nuclear_charges WHERE id=0").fetchone()
+        return self._deblob(d[2], np.int32, (d[1],))
+
+    # ---- writers ----
+    def add_data(self, Z, R, E, F, H, S, C, moses_id, conformer_id):
+        if any(v is not None and np.any(np.isnan(v)) for v in (Z, R, E, F, H, S, C)):
+            print("encountered NaN, data is not added")
+            return
+        cur = self._c.cursor()
+        cur.execute("BEGIN EXCLUSIVE")
+        try:
+            length = len(self)
+            rid = None if length > 0 else 0
+            cur.execute("INSERT INTO dataset_ids (id, MOSES_ID, CONFORMER_ID) VALUES (?,?,?)", (rid, moses_id, conformer_id))
+            cur.execute("INSERT INTO data (id, Z, R, E, F, H, S, C) VALUES (?,?,?,?,?,?,?,?)",
+                        (rid, self._blob(Z), self._blob(R), None if E is None else float(E), self._blob(F), self._blob(H), self._blob(S), self._blob(C)))
+            cur.execute("INSERT OR REPLACE INTO metadata VALUES (?,?)", (0, length + 1))
+            cur.execute("COMMIT")
+        except Exception:
+            cur.execute("ROLLBACK")
+            raise
+
+    def add_orbitals(self, Z, orbitals):
+        self._c.execute("INSERT OR REPLACE INTO basisset (Z, orbitals) VALUES (?,?)", (int(Z), self._blob(np.asarray(orbitals))))
+        self._orbitals.pop(int(Z), None)
+
+    def add_Z(self, Z):
+        self._c.execute("INSERT OR REPLACE INTO nuclear_charges (id, N, Z) VALUES (?,?,?)", (0, len(Z), self._blob(np.asarray(Z))))
+
+
+class HamiltonianDataset(torch.utils.data.Dataset):
+    """nablaDFT/dataset/hamiltonian_dataset.py:286-405: items are row ids, ``collate_fn`` does one batched query and returns the dict PhiSNet's
+    ``NeuralNetwork.forward`` takes (``molecule_size``, ``atomic_numbers``, ``orbitals``, ``positions``, ``energy``, ``forces``, block-diagonal
+    ``full_hamiltonian`` / ``overlap_matrix`` / ``core_hamiltonian`` / ``mask``), cut at the same three batch limits.  Extra keys for the packed
+    engine path: ``*_packed`` = the molecules' matrices flattened and concatenated (what ``IrrepsAssembler`` / ``BlockAssembler`` produce)."""
+
+    def __init__(self, filepath, max_batch_orbitals=1200, max_batch_atoms=150, max_squares=4802, subset=None, dtype=torch.float32):
+        super().__init__()
+        self.dtype = dtype
+        self._database = HamiltonianDatabase(filepath)
+        self.max_orbitals = tuple(tuple((int(z), int(l)) for l in self._database.get_orbitals(z)) for z in self._database.Z)
+        self.max_batch_orbitals, self.max_batch_atoms, self.max_squares = max_batch_orbitals, max_batch_atoms, max_squares
+        self.subset = np.load(subset) if subset else None
+
+    def __len__(self):
+        return len(self.subset) if self.subset is not None else len(self._database)
+
+    def __getitem__(self, idx):
+        return self.subset[idx] if self.subset is not None else idx
+
+    def collate_fn(self, batch, return_filtered=False):
+        rows = self._database[list(batch)]
+        Z, R, E, F, H, S, C = [], [], [], [], [], [], []
+        orbitals, n_orb, squares = [], 0, 0
+        for Z_, R_, E_, F_, H_, S_, C_, _, _ in rows:
+            local = [tuple((int(z), int(l)) for l in self._database.get_orbitals(z)) for z in Z_]
+            local_n = sum(2 * l + 1 for orbs in local for _, l in orbs)
+            if n_orb + local_n > self.max_batch_orbitals or len(local) + len(orbitals) > self.max_batch_atoms or squares + len(local) ** 2 > self.max_squares:
+                break
+            orbitals += local
+            n_orb += local_n
+            squares += len(local) ** 2
+            Z.append(torch.tensor(Z_, dtype=torch.int64)), R.append(torch.tensor(R_, dtype=self.dtype)), E.append(torch.tensor(E_, dtype=self.dtype))
+            F.append(torch.tensor(F_, dtype=self.dtype)), H.append(torch.tensor(H_, dtype=self.dtype)), S.append(torch.tensor(S_, dtype=self.dtype))
+            C.append(torch.tensor(C_, dtype=self.dtype))
+        out = {"molecule_size": torch.tensor([len(z) for z in Z]), "atomic_numbers": torch.cat(Z), "orbitals": tuple(orbitals), "positions": torch.cat(R),
+               "energy": torch.stack(E), "forces": torch.cat(F), "full_hamiltonian": torch.block_diag(*H), "overlap_matrix": torch.block_diag(*S),
+               "core_hamiltonian": torch.block_diag(*C), "mask": torch.block_diag(*(torch.ones_like(c) for c in C)),
+               "full_hamiltonian_packed": torch.cat([h.reshape(-1) for h in H]), "overlap_matrix_packed": torch.cat([s.reshape(-1) for s in S]),
+               "core_hamiltonian_packed": torch.cat([c.reshape(-1) for c in C])}
+        if return_filtered:
+            out["filtered"] = batch[len(Z):]
+        return out

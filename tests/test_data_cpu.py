@@ -86,3 +86,75 @@ def test_loader_on_cpu_yields_the_plan():
         ref = arena.batch(sel)
         assert torch.equal(bt.pos, ref.pos) and torch.equal(bt.y, ref.y) and torch.equal(bt.ptr, ref.ptr)
     assert not torch.equal(next(iter(ld)).y, got[0].y)                    # next epoch: new permutation
+
+
+# ---- Hamiltonian databases (row f2) ------------------------------------------------------------------------------------------
+def _hamdb():
+    return os.path.join(GOLDEN, "hamiltonian_db_6.db"), np.load(os.path.join(GOLDEN, "hamiltonian_db_6.npz"))
+
+
+def test_hamiltonian_database_reads_like_reference():
+    """Against what the REAL HamiltonianDatabase returned for the same file (oracle/make_golden_hamdb.py): bit-exact."""
+    from nabladft_amd.data import HamiltonianDatabase
+    path, fx = _hamdb()
+    db = HamiltonianDatabase(path)
+    assert len(db) == int(fx["len"]) == 6
+    assert np.array_equal(db.Z, fx["Z_table"]) and db.Z.dtype == np.int32
+    for zz in (1, 6, 7, 8):
+        assert np.array_equal(db.get_orbitals(zz), fx[f"orbitals_{zz}"])
+    for i in range(6):
+        row = db[i]
+        for name, v in zip(("Z", "R", "E", "F", "H", "S", "C", "moses_id", "conformer_id"), row):
+            ref = fx[f"row{i}:{name}"]
+            assert np.array_equal(np.asarray(v), ref), (i, name)
+            if name in "ZRFHSC" and name != "E":
+                assert np.asarray(v).dtype == ref.dtype, (i, name)
+    some = db[[int(v) for v in fx["list_rows"]]]
+    for j, row in enumerate(some):
+        assert np.array_equal(row[4], fx[f"list{j}:H"]) and row[7] == int(fx[f"list{j}:moses_id"])
+    with pytest.raises(KeyError):
+        db.get_orbitals(35)
+    with pytest.raises(FileNotFoundError):
+        HamiltonianDatabase(path + ".missing")
+
+
+def test_hamiltonian_dataset_collate_like_reference():
+    from nabladft_amd.data import HamiltonianDataset
+    path, fx = _hamdb()
+    ds = HamiltonianDataset(path)
+    mo = fx["max_orbitals"]
+    assert ds.max_orbitals == tuple(tuple((int(a), int(b)) for a, b in orbs if a >= 0) for orbs in mo)
+    assert len(ds) == 6 and ds[3] == 3
+    b = ds.collate_fn([0, 1, 3])
+    for k in ("molecule_size", "atomic_numbers", "positions", "energy", "forces", "full_hamiltonian", "overlap_matrix", "core_hamiltonian", "mask"):
+        ref = fx["batch:" + k]
+        assert tuple(b[k].shape) == ref.shape and np.array_equal(b[k].numpy(), ref), k
+        assert str(b[k].dtype).split(".")[-1] == str(ref.dtype), k
+    flat = [t for orbs in b["orbitals"] for t in orbs]
+    assert np.array_equal(np.array(flat), fx["batch:orbitals_flat"]) and [len(o) for o in b["orbitals"]] == list(fx["batch:orbitals_count"])
+    # packed targets = the diagonal blocks, molecule by molecule
+    o, chunks = 0, []
+    for n in (24, 34, 38):
+        chunks.append(b["full_hamiltonian"][o:o + n, o:o + n].reshape(-1))
+        o += n
+    assert o == b["full_hamiltonian"].shape[0] and torch.equal(torch.cat(chunks), b["full_hamiltonian_packed"])
+    tight = HamiltonianDataset(path, max_batch_atoms=8)
+    b2 = tight.collate_fn([1, 3, 0], return_filtered=True)
+    assert np.array_equal(b2["molecule_size"].numpy(), fx["tight:molecule_size"]) and list(b2["filtered"]) == list(fx["tight:filtered"])
+
+
+def test_hamiltonian_database_write_read_roundtrip(tmp_path):
+    from nabladft_amd.data import HamiltonianDatabase
+    p = str(tmp_path / "w.db")
+    db = HamiltonianDatabase(p, readonly=False)
+    db.add_orbitals(1, np.array([0, 0, 1]))
+    db.add_Z(np.array([1]))
+    rng = np.random.default_rng(0)
+    H = rng.normal(size=(10, 10))
+    db.add_data(np.array([1, 1]), rng.normal(size=(2, 3)), -1.25, rng.normal(size=(2, 3)), H, H * 2, H * 3, 5, 9)
+    db.add_data(np.array([1, 1]), np.full((2, 3), np.nan), -1.0, rng.normal(size=(2, 3)), H, H, H, 6, 10)      # NaN rows are refused (:122-125)
+    rd = HamiltonianDatabase(p)
+    assert len(rd) == 1
+    Z, R, E, F, Hh, S, C, mid, cid = rd[0]
+    assert Z.dtype == np.int32 and Hh.dtype == np.float32 and np.array_equal(Hh, H.astype(np.float32)) and np.array_equal(C, (H * 3).astype(np.float32))
+    assert E[0] == np.float32(-1.25) and (mid, cid) == (5, 9) and list(rd.get_orbitals(1)) == [0, 0, 1]

@@ -128,3 +128,34 @@ def test_neural_network_properties():
         assert (moved["core_hamiltonian"][0] - alone["core_hamiltonian"][0]).abs().max() < 2e-4
         o, a0 = o + n, a0 + s
     assert o == H.shape[0]
+
+
+def test_training_from_hamiltonian_database():
+    """Row f2 -> a24: batches collated from the Hamiltonian database drive a few optimiser steps of the network on the packed matrices; the
+    loss goes down and the dense outputs agree with the packed ones."""
+    from nabladft_amd.data import HamiltonianDataset
+    from nabladft_amd.phisnet import NeuralNetwork
+    ds = HamiltonianDataset(os.path.join(GOLDEN, "hamiltonian_db_6.db"))
+    torch.manual_seed(0)
+    m = NeuralNetwork(max_orbitals=ds.max_orbitals * 2, order=2, num_features=32, num_basis_functions=8, num_modules=1, num_residual_pre_x=1,
+                      num_residual_post_x=1, num_residual_pre_vi=1, num_residual_pre_vj=1, num_residual_post_v=1, num_residual_output=1, num_residual_pc=1,
+                      num_residual_pn=1, num_residual_ii=1, num_residual_ij=1, num_residual_full_ii=1, num_residual_full_ij=1, num_residual_core_ii=1,
+                      num_residual_core_ij=1, num_residual_over_ij=1, basis_functions="exp-bernstein", cutoff=8.0, activation="swish").cuda()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-3)
+    b = ds.collate_fn([0, 1, 3])
+    batch = {k: (v.cuda() if torch.is_tensor(v) and k != "molecule_size" else v) for k, v in b.items()}
+    losses = []
+    for _ in range(25):
+        opt.zero_grad(set_to_none=True)
+        out = m(batch)
+        loss = (out["full_hamiltonian_packed"] - batch["full_hamiltonian_packed"]).abs().mean() + \
+               (out["overlap_matrix_packed"] - batch["overlap_matrix_packed"]).abs().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] * 0.97, losses
+    assert tuple(out["full_hamiltonian"].shape) == (1,) + tuple(b["full_hamiltonian"].shape)
+    dense = m._assembler.to_dense(out["plan"], out["full_hamiltonian_packed"].detach())
+    assert torch.equal(dense, out["full_hamiltonian"][0])
+    assert float((out["full_hamiltonian"][0] * (1 - batch["mask"])).abs().max()) == 0.0          # nothing outside the molecules' blocks
