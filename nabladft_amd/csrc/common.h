@@ -119,7 +119,8 @@ struct FilterArgs {
   float cutoff;
   int* row_ctr;       // fused message kernels: [8 XCDs][slices] zeroed row counters of THIS launch (dynamic row claiming), or null = static striding
 };
-#define NQ_ROWCTR_INTS 32   // counters per launch (8 XCDs x up to 4 channel slices)
+#define NQ_ROWCTR_PAD 32                        // one counter per 128-byte line
+#define NQ_ROWCTR_INTS (8 * 4 * 8 * NQ_ROWCTR_PAD)   // ints per launch: 8 XCDs x up to 4 channel slices x up to 8 claim groups, padded
 
 struct MsgRevArgs {
   NqGraphView g; int F;

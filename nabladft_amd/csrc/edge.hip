@@ -379,25 +379,36 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
 // computes a row does not change its result.  Measured (profiles/r01_fused_tuning.txt section 4): only the dual reverse gains (-8 %, one row per
 // claim; larger chunks lose the balance at the tail), the short-row kernels pay for the same-address atomics -> default kinds = 8, rows = 1.
 #ifndef NQ_CLAIM_KINDS
-#define NQ_CLAIM_KINDS 8
+#define NQ_CLAIM_KINDS 15
 #endif
 #ifndef NQ_CLAIM_ROWS
 #define NQ_CLAIM_ROWS 1
 #endif
+#ifndef NQ_CLAIM_GROUPS_DUAL
+#define NQ_CLAIM_GROUPS_DUAL 1
+#endif
+#ifndef NQ_CLAIM_GROUPS
+#define NQ_CLAIM_GROUPS 2   // counters (= sub-ranges, = separate fronts) per XCD: spreads the same-address atomics of the short-row kernels
+#endif
 #define FUSED_ROWS(KIND)                                                                        \
   constexpr bool claim__ = ((NQ_CLAIM_KINDS >> (KIND)) & 1) != 0;                               \
   constexpr int crows__ = claim__ ? NQ_CLAIM_ROWS : 1;                                          \
-  int* const ctr__ = claim__ ? fa.row_ctr + (int)(blockIdx.x % nxcd) * nslices + slice : nullptr; \
+  constexpr int cgrp__ = ((KIND) == 3) ? NQ_CLAIM_GROUPS_DUAL : NQ_CLAIM_GROUPS;                                   \
+  const int grp__ = wg % cgrp__;                                                                \
+  const int sub__ = (n_hi - x_lo + cgrp__ - 1) / cgrp__;                                        \
+  const int s_lo__ = claim__ ? x_lo + grp__ * sub__ : x_lo;                                     \
+  const int s_hi__ = claim__ ? min(n_hi, s_lo__ + sub__) : n_hi;                                \
+  int* const ctr__ = claim__ ? fa.row_ctr + (((int)(blockIdx.x % nxcd) * nslices + slice) * cgrp__ + grp__) * NQ_ROWCTR_PAD : nullptr; \
   int n_static__ = x_lo + wg * nslots + slot;                                                   \
   auto claim_rows = [&]() __attribute__((always_inline)) -> int {                               \
     if constexpr (claim__) {                                                                    \
       int v__ = 0;                                                                              \
       if (lane == 0) v__ = __hip_atomic_fetch_add(ctr__, crows__, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-      return x_lo + __builtin_amdgcn_readfirstlane(v__);                                        \
+      return s_lo__ + __builtin_amdgcn_readfirstlane(v__);                                      \
     } else { const int v__ = n_static__; n_static__ += n_step; return v__; }                    \
   };                                                                                            \
-  for (int blk__ = claim_rows(), nxt__ = claim_rows(); blk__ < n_hi; blk__ = nxt__, nxt__ = claim_rows()) \
-    for (int n = blk__; n < min(blk__ + crows__, n_hi); ++n)
+  for (int blk__ = claim_rows(), nxt__ = claim_rows(); blk__ < s_hi__; blk__ = nxt__, nxt__ = claim_rows()) \
+    for (int n = blk__; n < min(blk__ + crows__, s_hi__); ++n)
 
 // One wavefront per atom; lane l owns channels [l*CH, (l+1)*CH) of each part (F = 64*CH).
 #define FUSED_PROLOGUE                                                                          \

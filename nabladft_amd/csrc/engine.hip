@@ -122,7 +122,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GEDGE = take((F / 64) * E * 4);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
   W->GRHO = take(c->rbf_type ? 2 * E * R : 0); W->BCON = take(c->rbf_type ? E * R : 0);   // learnable bases: adjoints of rho / drho, per-edge contributions
-  W->ROWCTR = take(4 * 64 * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]
+  W->ROWCTR = take(4 * L * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]
   // scratch for split-K partials / column sums / embedding partials: max over all uses
   size_t s = 0;
   auto mx = [&](size_t v) { if (v > s) s = v; };
@@ -297,8 +297,8 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers;
   const size_t NF = (size_t)N * F;
   int* const rowctr0 = reinterpret_cast<int*>(ws + W.ROWCTR);   // kinds 0 (forward) and 1 (force adjoint) are zeroed here, 2 / 3 in the backward call
-  NQ_HIP(hipMemsetAsync(rowctr0, 0, 2 * 64 * NQ_ROWCTR_INTS * sizeof(int), st));
-  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * 64 + l) * NQ_ROWCTR_INTS; };
+  NQ_HIP(hipMemsetAsync(rowctr0, 0, (size_t)2 * L * NQ_ROWCTR_INTS * sizeof(int), st));
+  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * L + l) * NQ_ROWCTR_INTS; };
 
   // embedding; zero vec_in0 and the tangent halves of layer-0 inputs (d x0 / d pos = 0)
   NQ_TRY(nq_embed(st, g.z, params + P.emb, N, F, ws + W.X[0]));
@@ -406,8 +406,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers, T = cfg->num_elements;
   const size_t NF = (size_t)N * F;
   int* const rowctr0 = reinterpret_cast<int*>(ws + W.ROWCTR);
-  NQ_HIP(hipMemsetAsync(rowctr0 + 2 * 64 * NQ_ROWCTR_INTS, 0, 2 * 64 * NQ_ROWCTR_INTS * sizeof(int), st));
-  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * 64 + l) * NQ_ROWCTR_INTS; };
+  NQ_HIP(hipMemsetAsync(rowctr0 + (size_t)2 * L * NQ_ROWCTR_INTS, 0, (size_t)2 * L * NQ_ROWCTR_INTS * sizeof(int), st));
+  auto row_ctr = [&](int kind, int l) { return rowctr0 + ((size_t)kind * L + l) * NQ_ROWCTR_INTS; };
 
   const size_t NH = (size_t)N * H;
   ReadoutArgs r{};

@@ -20,6 +20,12 @@ if [ "$1" = build ]; then
     [ $k = 14 ] && X="-DNQ_CLAIM_KINDS=8 -DNQ_CLAIM_ROWS=2"
     [ $k = 15 ] && X="-DNQ_CLAIM_KINDS=8 -DNQ_CLAIM_ROWS=1"
     [ $k = 16 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_ROWS=8"
+    [ $k = 17 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_GROUPS=8"
+    [ $k = 18 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_GROUPS=4"
+    [ $k = 19 ] && X="-DNQ_CLAIM_KINDS=15 -DNQ_CLAIM_GROUPS=2"
+    [ $k = 20 ] && X="-DNQ_CLAIM_GROUPS_DUAL=2"
+    [ $k = 21 ] && X="-DNQ_CLAIM_GROUPS_DUAL=4 -DNQ_CLAIM_GROUPS=3"
+    [ $k = 22 ] && X="-DNQ_CLAIM_GROUPS=2 -DNQ_CLAIM_ROWS=2"
     /opt/rocm/bin/hipcc $FLAGS $X -c nabladft_amd/csrc/edge.hip -o $D/edge_$k.o &
   done
   wait
