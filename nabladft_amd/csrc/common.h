@@ -189,7 +189,7 @@ void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, cons
 int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, float* RW);
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 size_t nq_k0_sort_scratch_ints(int E, int R);
-int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch);
+int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch, const int* row_of = nullptr, const int* col = nullptr);
 size_t nq_gwr_scratch_floats(int E, int F, int R, int parts = 3);
 int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
                   float* scratch, int parts = 3);

@@ -569,18 +569,28 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
   }
 }
 
+// Dual flavour and the rbf_proj gradient: gphi / gpsi of the two directions of a pair (n -> k and k -> n) multiply the SAME window
+// (d is symmetric), so only their sum is needed.  The row of atom n therefore stores, for its LOWER neighbours k < n (the first
+// lowptr[n+1] - lowptr[n] edges of the ascending row), gphi_nk + gphi_kn at the slot of edge (n -> k), and nothing for k > n: half the
+// stores here and half the reads in k_gwr_sorted (which visits lower slots only).  The reverse direction needs the primal / tangent rows of k
+// (gathered: L2 hits, the adjoint rows of k are being fetched anyway) and the adjoint rows of n (row-resident).
 template <bool DUAL, int CH>
 __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   FUSED_ROWS(DUAL ? 3 : 2) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
+    const int nlow = DUAL ? __builtin_amdgcn_readfirstlane(q.g.lowptr[n + 1]) - __builtin_amdgcn_readfirstlane(q.g.lowptr[n]) : 0;
     const long o3 = (long)n * F3 + fb;
     float xa[CH], xb[CH], xc[CH], v0[CH], v1[CH], v2[CH], txa[CH], txb[CH], txc[CH], tv0[CH], tv1[CH], tv2[CH];
     ldv<CH>(xa, q.XH + o3); ldv<CH>(xb, q.XH + o3 + F); ldv<CH>(xc, q.XH + o3 + 2 * F);
     ldv<CH>(v0, q.V + o3); ldv<CH>(v1, q.V + o3 + F); ldv<CH>(v2, q.V + o3 + 2 * F);
+    float nA0[CH], nA1[CH], nA2[CH], ngma[CH], nT0[CH], nT1[CH], nT2[CH], ngtma[CH];   // adjoint rows of n itself (dual: reverse-direction gphi)
     if (DUAL) {
       ldv<CH>(txa, q.TXH + o3); ldv<CH>(txb, q.TXH + o3 + F); ldv<CH>(txc, q.TXH + o3 + 2 * F);
       ldv<CH>(tv0, q.TV + o3); ldv<CH>(tv1, q.TV + o3 + F); ldv<CH>(tv2, q.TV + o3 + 2 * F);
+      ldv<CH>(nA0, q.GV + o3); ldv<CH>(nA1, q.GV + o3 + F); ldv<CH>(nA2, q.GV + o3 + 2 * F);
+      ldv<CH>(nT0, q.GTV + o3); ldv<CH>(nT1, q.GTV + o3 + F); ldv<CH>(nT2, q.GTV + o3 + 2 * F);
+      ldv<CH>(ngma, q.GX + (long)n * F + fb); ldv<CH>(ngtma, q.GTX + (long)n * F + fb);
     } else {
 #pragma unroll
       for (int c = 0; c < CH; ++c) txa[c] = txb[c] = txc[c] = tv0[c] = tv1[c] = tv2[c] = 0.f;
@@ -594,6 +604,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
     }
     for (int c0 = beg; c0 < end; c0 += 64) {
       const int cnt = min(64, end - c0);
+      const int nlo = DUAL ? max(0, min(cnt, nlow - (c0 - beg))) : 0;   // lower edges of this chunk come first
       RowRegs row;
       load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
       RevOps<DUAL, CH> opA, opB;   // ping-pong operands; scalar window loads are issued after the filter's LDS reads (see k_msgf_fwd)
@@ -601,10 +612,20 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
       WinRegs<true> win;
       load_win<true>(win, RW, ABL_SP(c0));
       float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      auto step = [&](RevOps<DUAL, CH>& cur, RevOps<DUAL, CH>& nxt, int j, auto prefetch) __attribute__((always_inline)) {
+      // LOW (dual only): this edge stores gphi / gpsi of both directions; otherwise the dual flavour stores nothing for the edge
+      auto step = [&](RevOps<DUAL, CH>& cur, RevOps<DUAL, CH>& nxt, int j, auto low_tag) __attribute__((always_inline)) {
+        constexpr bool LOW = decltype(low_tag)::value;
         const int sp = c0 + j;
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded
-        if (decltype(prefetch)::value) load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
+        load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
+        float kxa[CH], kxb[CH], kxc[CH], kv0[CH], kv1[CH], kv2[CH], ktxa[CH], ktxb[CH], ktxc[CH], ktv0[CH], ktv1[CH], ktv2[CH];
+        if (DUAL && LOW) {   // primal / tangent rows of the neighbour: consumed at the end of the step
+          const long k3 = (long)ABL_K(j) * F3 + fb;
+          ldv<CH>(kxa, q.XH + k3); ldv<CH>(kxb, q.XH + k3 + F); ldv<CH>(kxc, q.XH + k3 + 2 * F);
+          ldv<CH>(kv0, q.V + k3); ldv<CH>(kv1, q.V + k3 + F); ldv<CH>(kv2, q.V + k3 + 2 * F);
+          ldv<CH>(ktxa, q.TXH + k3); ldv<CH>(ktxb, q.TXH + k3 + F); ldv<CH>(ktxc, q.TXH + k3 + 2 * F);
+          ldv<CH>(ktv0, q.TV + k3); ldv<CH>(ktv1, q.TV + k3 + F); ldv<CH>(ktv2, q.TV + k3 + 2 * F);
+        }
         float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
 #if NQ_ABLATE == 2
 #pragma unroll
@@ -614,7 +635,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
 #endif
         const float beta = win.rr[14], dbeta = win.dd[14];
         __builtin_amdgcn_sched_barrier(0);
-        if (decltype(prefetch)::value) load_win<true>(win, RW, ABL_SP(c0 + jn));
+        load_win<true>(win, RW, ABL_SP(c0 + jn));
         const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);  // unit vector of the out-edge (n -> k)
         float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
         if (DUAL) { td = bl_f(row.td, j); tr0 = -bl_f(row.t0, j); tr1 = -bl_f(row.t1, j); tr2 = -bl_f(row.t2, j); }
@@ -650,16 +671,21 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
             e0 += A0 * mc; e1 += A1 * mc; e2 += A2 * mc;
           }
         }
-        if (DUAL && NQ_ABLATE != 1) {
+        if (DUAL && LOW && NQ_ABLATE != 1) {
+          // direction k -> n: roles swapped, unit vector and its tangent negated, t_d unchanged
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float rgmb = nA0[c] * kv0[c] + nA1[c] * kv1[c] + nA2[c] * kv2[c] + (nT0[c] * ktv0[c] + nT1[c] * ktv1[c] + nT2[c] * ktv2[c]);
+            const float rgtmb = nT0[c] * kv0[c] + nT1[c] * kv1[c] + nT2[c] * kv2[c];
+            const float rgmc = -(nA0[c] * r0 + nA1[c] * r1 + nA2[c] * r2) - (nT0[c] * tr0 + nT1[c] * tr1 + nT2[c] * tr2);
+            const float rgtmc = -(nT0[c] * r0 + nT1[c] * r1 + nT2[c] * r2);
+            ga[c] += ngma[c] * kxa[c] + ngtma[c] * ktxa[c]; gb[c] += rgmb * kxb[c] + rgtmb * ktxb[c]; gc[c] += rgmc * kxc[c] + rgtmc * ktxc[c];
+            ha[c] += ngtma[c] * kxa[c] * td; hb[c] += rgtmb * kxb[c] * td; hc[c] += rgtmc * kxc[c] * td;
+          }
           float* gp = q.GPHI + (long)sp * F3 + fb;
           float* gs = q.GPSI + (long)sp * F3 + fb;
-#if NQ_ABLATE == 5
-          stv<CH>(gp, ga); stv<CH>(gp + F, gb); stv<CH>(gp + 2 * F, gc);
-          stv<CH>(gs, ha); stv<CH>(gs + F, hb); stv<CH>(gs + 2 * F, hc);
-#else
           stv_stream<CH>(gp, ga); stv_stream<CH>(gp + F, gb); stv_stream<CH>(gp + 2 * F, gc);
           stv_stream<CH>(gs, ha); stv_stream<CH>(gs + F, hb); stv_stream<CH>(gs + 2 * F, hc);
-#endif
         } else if (!DUAL) {
           gd = nq_wave_sum(gd); e0 = nq_wave_sum(e0); e1 = nq_wave_sum(e1); e2 = nq_wave_sum(e2);
           // lane j keeps the four reduced scalars of edge j; one coalesced float4 update per CSR row chunk below
@@ -667,13 +693,30 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
           eacc.x = mine ? gd : eacc.x; eacc.y = mine ? e0 : eacc.y; eacc.z = mine ? e1 : eacc.z; eacc.w = mine ? e2 : eacc.w;
         }
       };
-      const int pairs = cnt & ~1;
+      // edges [0, nlo) with the LOW flavour, [nlo, cnt) without; the ping-pong parity carries over the boundary
+      int j = 0;
 #pragma nounroll
-      for (int j = 0; j < pairs; j += 2) {
+      for (; j + 1 < nlo; j += 2) {
         step(opA, opB, j, std::true_type());
         step(opB, opA, j + 1, std::true_type());
       }
-      if (cnt & 1) step(opA, opB, cnt - 1, std::false_type());
+      if (j < nlo) {   // odd number of lower edges: the next edge's operands sit in opB
+        step(opA, opB, j, std::true_type());
+        ++j;
+#pragma nounroll
+        for (; j + 1 < cnt; j += 2) {
+          step(opB, opA, j, std::false_type());
+          step(opA, opB, j + 1, std::false_type());
+        }
+        if (j < cnt) step(opB, opA, j, std::false_type());
+      } else {
+#pragma nounroll
+        for (; j + 1 < cnt; j += 2) {
+          step(opA, opB, j, std::false_type());
+          step(opB, opA, j + 1, std::false_type());
+        }
+        if (j < cnt) step(opA, opB, j, std::false_type());
+      }
       if (!DUAL && lane < cnt) {
         float4* dstp = q.GEDGE + (long)slice * q.g.E + c0 + lane;   // one accumulator plane per channel slice (summed by k_geom_rev)
         float4 acc = *dstp;
@@ -711,16 +754,22 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
 // =============================================================================================
 #define SORT_CHUNK 256
 // pass A: per 256-edge chunk, histogram over k0 and the stable local rank of every edge inside its bin
+// row_of / col (optional): only LOWER slots (col[e] < row_of[e]) take part -- the PaiNN dual sweep stores one gphi / gpsi row per pair
+__device__ __forceinline__ int k0_key(const float* __restrict__ RW, int e, int E, const int* __restrict__ row_of, const int* __restrict__ col) {
+  if (e >= E) return -1;
+  if (row_of && col[e] >= row_of[e]) return -1;
+  return __float_as_int(RW[(long)e * RW_STRIDE + 13]);
+}
 __global__ __launch_bounds__(SORT_CHUNK) void k_k0_hist(const float* __restrict__ RW, int E, int nbins, int* __restrict__ chunk_hist,
-                                                        int* __restrict__ local_rank) {
+                                                        int* __restrict__ local_rank, const int* __restrict__ row_of, const int* __restrict__ col) {
   __shared__ int keys[SORT_CHUNK];
   __shared__ int hist[256];
   const int e = blockIdx.x * SORT_CHUNK + threadIdx.x;
-  const int key = e < E ? __float_as_int(RW[(long)e * RW_STRIDE + 13]) : -1;
+  const int key = k0_key(RW, e, E, row_of, col);
   keys[threadIdx.x] = key;
   if (threadIdx.x < nbins) hist[threadIdx.x] = 0;
   __syncthreads();
-  if (e < E) {
+  if (key >= 0) {
     int r = 0;
     for (int i = 0; i < (int)threadIdx.x; ++i) r += (keys[i] == key);
     local_rank[e] = r;
@@ -754,7 +803,7 @@ __global__ __launch_bounds__(256) void k_k0_scan(int* __restrict__ hist, int nch
 // pass C: order[bin_base + offset_in_bin(chunk) + local_rank] = edge slot
 __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restrict__ RW, int E, int nbins, const int* __restrict__ hist,
                                                            const int* __restrict__ bin_total, const int* __restrict__ local_rank,
-                                                           int* __restrict__ order) {
+                                                           int* __restrict__ order, const int* __restrict__ row_of, const int* __restrict__ col) {
   __shared__ int base[256];
   if (threadIdx.x == 0) {
     int run = 0;
@@ -762,8 +811,8 @@ __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restri
   }
   __syncthreads();
   const int e = blockIdx.x * SORT_CHUNK + threadIdx.x;
-  if (e >= E) return;
-  const int key = __float_as_int(RW[(long)e * RW_STRIDE + 13]);
+  const int key = k0_key(RW, e, E, row_of, col);
+  if (key < 0) return;
   order[base[key] + hist[(long)key * gridDim.x + blockIdx.x] + local_rank[e]] = e;
 }
 
@@ -1098,17 +1147,17 @@ static int gwr_chunks(int E) {   // ~4096 wavefronts (16 per CU) over 3 column s
   return nq_cdiv(E, chunk_len);
 }
 size_t nq_k0_sort_scratch_ints(int E, int R) { return (size_t)nq_cdiv(E, SORT_CHUNK) * gwr_nbins(R) + (size_t)E + 256; }
-// order[E] <- CSR slots sorted (stably) by window start k0; scratch: nq_k0_sort_scratch_ints() ints
-int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* scratch) {
+// order[] <- CSR slots sorted (stably) by window start k0 (all E slots, or the E/2 lower slots when row_of / col are given); scratch: nq_k0_sort_scratch_ints() ints
+int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* scratch, const int* row_of, const int* col) {
   NQ_PROF(st, "k0_sort");
   const int nbins = gwr_nbins(R), nchunks = nq_cdiv(E, SORT_CHUNK);
   if (nbins > 256) return nq_fail(NQ_ERR_ARG, "k0 sort supports at most 256 bins (num_rbf <= 268)");
   int* chunk_hist = scratch; int* local_rank = scratch + (size_t)nchunks * nbins; int* bin_total = local_rank + E;
-  hipLaunchKernelGGL(k_k0_hist, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank);
+  hipLaunchKernelGGL(k_k0_hist, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank, row_of, col);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_k0_scan, dim3(nq_cdiv(nbins, 4)), dim3(256), 0, st, chunk_hist, nchunks, nbins, bin_total);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, bin_total, local_rank, order);
+  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, bin_total, local_rank, order, row_of, col);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -309,7 +309,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     FilterArgs fa0;
     nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
-    NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch)));
+    NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col));   // lower slots only
   } else {
     NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho, cfg->rbf_type, params + P.basis));
   }
@@ -517,7 +517,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       NQ_TRY(nq_msg_rev(st, m, true));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E, F, R, gp + mp.Wr, scr));
+    if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr));   // one row per pair
     else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
       NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));

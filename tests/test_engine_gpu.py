@@ -201,10 +201,13 @@ def _trace_report(name, model, sw, s2c, tag, lines):
             worst = max(worst, e)
             lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
     else:
-        # k0-sorted edge order: a stable permutation of the CSR slots, keys non-decreasing
-        order = model.workspace_view("order").cpu().view(torch.int32).long()
+        # k0-sorted order of the LOWER CSR slots (col < dst: one gphi / gpsi row per pair): every lower slot once, keys non-decreasing, stable
+        nl = model._last_nl
+        lower = torch.nonzero(nl.t["col"].cpu() < nl.t["dst"].cpu()).view(-1)
+        assert lower.numel() * 2 == nl.E
+        order = model.workspace_view("order").cpu().view(torch.int32).long()[:lower.numel()]
         k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
-        assert torch.equal(torch.sort(order).values, torch.arange(order.numel()))
+        assert torch.equal(torch.sort(order).values, lower)
         assert bool((k0s[order][1:] >= k0s[order][:-1]).all())
         same = k0s[order][1:] == k0s[order][:-1]
         assert bool((order[1:][same] > order[:-1][same]).all()), "sort must be stable"
