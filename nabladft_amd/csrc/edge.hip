@@ -574,6 +574,15 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
 // lowptr[n+1] - lowptr[n] edges of the ascending row), gphi_nk + gphi_kn at the slot of edge (n -> k), and nothing for k > n: half the
 // stores here and half the reads in k_gwr_sorted (which visits lower slots only).  The reverse direction needs the primal / tangent rows of k
 // (gathered: L2 hits, the adjoint rows of k are being fetched anyway) and the adjoint rows of n (row-resident).
+#ifndef NQ_DUAL_NA_RESIDENT
+#define NQ_DUAL_NA_RESIDENT 1   // adjoint rows of n kept in registers for the whole row (1) or re-read from L1 per lower edge (0)
+#endif
+#ifndef NQ_DUAL_MIRROR
+#define NQ_DUAL_MIRROR 1        // odd lower-edge count: mirrored copy of the upper loop (1) or one operand-set copy per row chunk (0)
+#endif
+#ifndef NQ_DUAL_KX_EARLY
+#define NQ_DUAL_KX_EARLY 1      // neighbour primal / tangent rows requested at the start of the step (1) or after the filter evaluation (0)
+#endif
 template <bool DUAL, int CH>
 __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
@@ -588,9 +597,11 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
     if (DUAL) {
       ldv<CH>(txa, q.TXH + o3); ldv<CH>(txb, q.TXH + o3 + F); ldv<CH>(txc, q.TXH + o3 + 2 * F);
       ldv<CH>(tv0, q.TV + o3); ldv<CH>(tv1, q.TV + o3 + F); ldv<CH>(tv2, q.TV + o3 + 2 * F);
+#if NQ_DUAL_NA_RESIDENT
       ldv<CH>(nA0, q.GV + o3); ldv<CH>(nA1, q.GV + o3 + F); ldv<CH>(nA2, q.GV + o3 + 2 * F);
       ldv<CH>(nT0, q.GTV + o3); ldv<CH>(nT1, q.GTV + o3 + F); ldv<CH>(nT2, q.GTV + o3 + 2 * F);
       ldv<CH>(ngma, q.GX + (long)n * F + fb); ldv<CH>(ngtma, q.GTX + (long)n * F + fb);
+#endif
     } else {
 #pragma unroll
       for (int c = 0; c < CH; ++c) txa[c] = txb[c] = txc[c] = tv0[c] = tv1[c] = tv2[c] = 0.f;
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded
         load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
         float kxa[CH], kxb[CH], kxc[CH], kv0[CH], kv1[CH], kv2[CH], ktxa[CH], ktxb[CH], ktxc[CH], ktv0[CH], ktv1[CH], ktv2[CH];
-        if (DUAL && LOW) {   // primal / tangent rows of the neighbour: consumed at the end of the step
+        if (DUAL && LOW && NQ_DUAL_KX_EARLY) {
           const long k3 = (long)ABL_K(j) * F3 + fb;
           ldv<CH>(kxa, q.XH + k3); ldv<CH>(kxb, q.XH + k3 + F); ldv<CH>(kxc, q.XH + k3 + 2 * F);
           ldv<CH>(kv0, q.V + k3); ldv<CH>(kv1, q.V + k3 + F); ldv<CH>(kv2, q.V + k3 + 2 * F);
@@ -636,6 +647,13 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         const float beta = win.rr[14], dbeta = win.dd[14];
         __builtin_amdgcn_sched_barrier(0);
         load_win<true>(win, RW, ABL_SP(c0 + jn));
+        if (DUAL && LOW && !NQ_DUAL_KX_EARLY) {   // primal / tangent rows of the neighbour: issued here, consumed after the main block of the step
+          const long k3 = (long)ABL_K(j) * F3 + fb;
+          ldv<CH>(kxa, q.XH + k3); ldv<CH>(kxb, q.XH + k3 + F); ldv<CH>(kxc, q.XH + k3 + 2 * F);
+          ldv<CH>(kv0, q.V + k3); ldv<CH>(kv1, q.V + k3 + F); ldv<CH>(kv2, q.V + k3 + 2 * F);
+          ldv<CH>(ktxa, q.TXH + k3); ldv<CH>(ktxb, q.TXH + k3 + F); ldv<CH>(ktxc, q.TXH + k3 + 2 * F);
+          ldv<CH>(ktv0, q.TV + k3); ldv<CH>(ktv1, q.TV + k3 + F); ldv<CH>(ktv2, q.TV + k3 + 2 * F);
+        }
         const float r0 = -bl_f(row.gx, j), r1 = -bl_f(row.gy, j), r2 = -bl_f(row.gz, j);  // unit vector of the out-edge (n -> k)
         float td = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
         if (DUAL) { td = bl_f(row.td, j); tr0 = -bl_f(row.t0, j); tr1 = -bl_f(row.t1, j); tr2 = -bl_f(row.t2, j); }
@@ -672,7 +690,14 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
           }
         }
         if (DUAL && LOW && NQ_ABLATE != 1) {
-          // direction k -> n: roles swapped, unit vector and its tangent negated, t_d unchanged
+          // direction k -> n: roles swapped, unit vector and its tangent negated, t_d unchanged.  The adjoint rows of n are the same
+          // addresses for every edge of the row (L1 hits): loaded only now, so that they do not occupy registers during the block above
+#if !NQ_DUAL_NA_RESIDENT
+          __builtin_amdgcn_sched_barrier(0);
+          ldv<CH>(nA0, q.GV + o3); ldv<CH>(nA1, q.GV + o3 + F); ldv<CH>(nA2, q.GV + o3 + 2 * F);
+          ldv<CH>(nT0, q.GTV + o3); ldv<CH>(nT1, q.GTV + o3 + F); ldv<CH>(nT2, q.GTV + o3 + 2 * F);
+          ldv<CH>(ngma, q.GX + (long)n * F + fb); ldv<CH>(ngtma, q.GTX + (long)n * F + fb);
+#endif
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const float rgmb = nA0[c] * kv0[c] + nA1[c] * kv1[c] + nA2[c] * kv2[c] + (nT0[c] * ktv0[c] + nT1[c] * ktv1[c] + nT2[c] * ktv2[c]);
@@ -700,7 +725,8 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         step(opA, opB, j, std::true_type());
         step(opB, opA, j + 1, std::true_type());
       }
-      if (j < nlo) {   // odd number of lower edges: the next edge's operands sit in opB
+#if NQ_DUAL_MIRROR
+      if (j < nlo) {   // odd number of lower edges: the next edge's operands sit in opB -> mirrored copy of the loop
         step(opA, opB, j, std::true_type());
         ++j;
 #pragma nounroll
@@ -717,6 +743,19 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         }
         if (j < cnt) step(opA, opB, j, std::false_type());
       }
+#else
+      if (j < nlo) {   // odd number of lower edges: the next edge's operands land in opB -> move them over (one copy per row chunk)
+        step(opA, opB, j, std::true_type());
+        ++j;
+        opA = opB;
+      }
+#pragma nounroll
+      for (; j + 1 < cnt; j += 2) {
+        step(opA, opB, j, std::false_type());
+        step(opB, opA, j + 1, std::false_type());
+      }
+      if (j < cnt) step(opA, opB, j, std::false_type());
+#endif
       if (!DUAL && lane < cnt) {
         float4* dstp = q.GEDGE + (long)slice * q.g.E + c0 + lane;   // one accumulator plane per channel slice (summed by k_geom_rev)
         float4 acc = *dstp;

@@ -26,6 +26,9 @@ if [ "$1" = build ]; then
     [ $k = 20 ] && X="-DNQ_CLAIM_GROUPS_DUAL=2"
     [ $k = 21 ] && X="-DNQ_CLAIM_GROUPS_DUAL=4 -DNQ_CLAIM_GROUPS=3"
     [ $k = 22 ] && X="-DNQ_CLAIM_GROUPS=2 -DNQ_CLAIM_ROWS=2"
+    [ $k = 23 ] && X="-DNQ_DUAL_NA_RESIDENT=0 -DNQ_DUAL_KX_EARLY=1 -DNQ_DUAL_MIRROR=0"
+    [ $k = 24 ] && X="-DNQ_DUAL_NA_RESIDENT=1 -DNQ_DUAL_KX_EARLY=1 -DNQ_DUAL_MIRROR=1"
+    [ $k = 25 ] && X="-DNQ_DUAL_NA_RESIDENT=0 -DNQ_DUAL_KX_EARLY=1 -DNQ_DUAL_MIRROR=0 -DNQ_DUAL2_THREADS=384"
     /opt/rocm/bin/hipcc $FLAGS $X -c nabladft_amd/csrc/edge.hip -o $D/edge_$k.o &
   done
   wait
