@@ -393,12 +393,13 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
 #define FUSED_ROWS(KIND)                                                                        \
   constexpr bool claim__ = ((NQ_CLAIM_KINDS >> (KIND)) & 1) != 0;                               \
   constexpr int crows__ = claim__ ? NQ_CLAIM_ROWS : 1;                                          \
-  constexpr int cgrp__ = ((KIND) == 3) ? NQ_CLAIM_GROUPS_DUAL : NQ_CLAIM_GROUPS;                                   \
+  constexpr int cgmax__ = ((KIND) == 3) ? NQ_CLAIM_GROUPS_DUAL : NQ_CLAIM_GROUPS;               \
+  const int cgrp__ = max(1, min(cgmax__, (int)(gridDim.x / nxcd / nslices)));   /* every group needs a workgroup of its own on the XCD */ \
   const int grp__ = wg % cgrp__;                                                                \
   const int sub__ = (n_hi - x_lo + cgrp__ - 1) / cgrp__;                                        \
   const int s_lo__ = claim__ ? x_lo + grp__ * sub__ : x_lo;                                     \
   const int s_hi__ = claim__ ? min(n_hi, s_lo__ + sub__) : n_hi;                                \
-  int* const ctr__ = claim__ ? fa.row_ctr + (((int)(blockIdx.x % nxcd) * nslices + slice) * cgrp__ + grp__) * NQ_ROWCTR_PAD : nullptr; \
+  int* const ctr__ = claim__ ? fa.row_ctr + (((int)(blockIdx.x % nxcd) * nslices + slice) * cgmax__ + grp__) * NQ_ROWCTR_PAD : nullptr; \
   int n_static__ = x_lo + wg * nslots + slot;                                                   \
   auto claim_rows = [&]() __attribute__((always_inline)) -> int {                               \
     if constexpr (claim__) {                                                                    \
