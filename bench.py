@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: RCCL needs it before the HSA runtime starts
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -283,7 +284,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
