@@ -17,8 +17,14 @@
 
 #define BM 128
 #define BN 128
-#define BK 32
+// BKT (template parameter of the kernels) = K depth of one staged tile: 32 by default; the input-gradient (NN) launches use 16 -- half the
+// LDS and 64 VGPRs give four workgroups per CU instead of three, measured +10-20 % for that layout (profiles/r01_gemm_variants_microbench.txt)
 #define GEMM_THREADS 256
+#ifdef NQ_GEMM_WAVES8
+#define GEMM_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define GEMM_OCC
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -41,16 +47,16 @@ struct GemmArgs {
 // ---- tile staging, split into fetch (global -> registers) and stash (registers -> LDS) so that the fetch of
 // k-tile t+1 can be issued before the MFMAs of k-tile t (the global latency then hides under the matrix pipe).
 // KC source: element (r, k) at src[r*ld + k]; MC source: element (k, r) at src[k*ld + r].  NT = threads per workgroup.
-template <bool KC, int NT>
-__device__ __forceinline__ void fetch_tile(float4 (&v)[1024 / NT], const float* __restrict__ src, int ld, int r0, int R, int k0, int Kend,
+template <bool KC, int NT, int BKT>
+__device__ __forceinline__ void fetch_tile(float4 (&v)[BM * BKT / 4 / NT], const float* __restrict__ src, int ld, int r0, int R, int k0, int Kend,
                                            bool vec_ok) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < 1024 / NT; ++it) {
+  for (int it = 0; it < BM * BKT / 4 / NT; ++it) {
     const int idx = t + NT * it;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {  // 128 rows x 32 k: consecutive lanes walk k (128-B row segments)
-      const int row = idx >> 3, kq = (idx & 7) * 4;
+    if (KC) {  // 128 rows x BK k: consecutive lanes walk k (128-B row segments at BK = 32)
+      const int row = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
       const int gr = r0 + row, gk = k0 + kq;
       if (gr < R) {
         const float* ptr = src + (long)gr * ld + gk;
@@ -80,14 +86,14 @@ __device__ __forceinline__ void fetch_tile(float4 (&v)[1024 / NT], const float* 
   }
 }
 
-template <bool KC, int NT>
-__device__ __forceinline__ void stash_tile(float* __restrict__ tile, const float4 (&v)[1024 / NT]) {
+template <bool KC, int NT, int BKT>
+__device__ __forceinline__ void stash_tile(float* __restrict__ tile, const float4 (&v)[BM * BKT / 4 / NT]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < 1024 / NT; ++it) {
+  for (int it = 0; it < BM * BKT / 4 / NT; ++it) {
     const int idx = t + NT * it;
     if (KC) {
-      const int row = idx >> 3, kq = (idx & 7) * 4;
+      const int row = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
       tile[(kq + 0) * LDS_KC + row] = v[it].x;
       tile[(kq + 1) * LDS_KC + row] = v[it].y;
       tile[(kq + 2) * LDS_KC + row] = v[it].z;
@@ -101,14 +107,14 @@ __device__ __forceinline__ void stash_tile(float* __restrict__ tile, const float
 
 // NW = wavefronts per 128x128 tile: 4 -> each wave owns 64x64 (2x2 MFMA tiles), 8 -> 64x32 (2x1).
 // PF = register prefetch of the next k-tile (one extra barrier-free overlap of global latency with MFMAs).
-template <bool A_KC, bool B_KC, int EPI, int NW, bool PF>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
+template <bool A_KC, bool B_KC, int EPI, int NW, bool PF, int BKT = 32>
+__global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   constexpr int NT = NW * 64;
   constexpr int TN = NW == 4 ? 2 : 1;
   constexpr int LDA_S = A_KC ? LDS_KC : LDS_MC;
   constexpr int LDB_S = B_KC ? LDS_KC : LDS_MC;
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+  __shared__ __attribute__((aligned(16))) float As[BKT * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BKT * LDB_S];
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   int kbeg = 0, kend = p.K;
@@ -133,32 +139,32 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float bsum = 0.f;
-  float4 ra[1024 / NT], rb[1024 / NT];
+  float4 ra[BM * BKT / 4 / NT], rb[BM * BKT / 4 / NT];
   if (PF) {
-    fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, a_vec);
-    fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, b_vec);
+    fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, a_vec);
+    fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, b_vec);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += BKT) {
     if (!PF) {
-      fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, k0, kend, a_vec);
-      fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
+      fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, k0, kend, a_vec);
+      fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
     }
-    stash_tile<A_KC, NT>(As, ra);
-    stash_tile<B_KC, NT>(Bs, rb);
+    stash_tile<A_KC, NT, BKT>(As, ra);
+    stash_tile<B_KC, NT, BKT>(Bs, rb);
     __syncthreads();
     if (EPI == EPI_PARTIAL && !A_KC) {
       // bias gradient for free: column sums of the A tile (= gy rows) that is already in LDS, primal rows only
       if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM) {
-        const int kmax = min(BK, p.brows - k0);
+        const int kmax = min(BKT, p.brows - k0);
         for (int kk = 0; kk < kmax; ++kk) bsum += As[kk * LDA_S + threadIdx.x];
       }
     }
-    if (PF && k0 + BK < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
-      fetch_tile<A_KC, NT>(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, a_vec);
-      fetch_tile<B_KC, NT>(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, b_vec);
+    if (PF && k0 + BKT < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
+      fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, k0 + BKT, kend, a_vec);
+      fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, k0 + BKT, kend, b_vec);
     }
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < BKT; kk += 2) {
       const float a0 = As[(kk + lk) * LDA_S + wm * 64 + lr];
       const float a1 = As[(kk + lk) * LDA_S + wm * 64 + 32 + lr];
       const float b0 = Bs[(kk + lk) * LDB_S + wcol0 + lr];
@@ -194,6 +200,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         const long off = (long)row * p.ldc + col;
         const float v = acc[i][j][r] + bv;
         if (EPI == EPI_ACC) Cout[off] += v;
+#ifdef NQ_GEMM_NT_STORE
+        else if (EPI == EPI_STORE) __builtin_nontemporal_store(v, &Cout[off]);
+#endif
         else Cout[off] = v;
         if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
       }
@@ -204,17 +213,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 static int g_gemm_variant = 1;  // measured best on MI355X (scripts/gemm_bench.py): 8 wavefronts per tile, no prefetch
 extern "C" void nq_set_gemm_variant(int32_t v) { g_gemm_variant = v; }
 
-template <bool A_KC, bool B_KC, int EPI>
+template <bool A_KC, bool B_KC, int EPI, int BKT = 32>
 static void launch_gemm(hipStream_t st, dim3 grid, const GemmArgs& p) {
   int variant = g_gemm_variant & 3;
   // latency-bound regime (few workgroups, e.g. batch_size 32): nothing else hides the global-load latency of the serial
   // K loop, so the register-prefetch form pays there (it is neutral-to-slightly-negative on full grids)
   if (variant == 1 && (long)grid.x * grid.y * grid.z < 512) variant = 3;
   switch (variant) {
-    case 0: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, false>), grid, dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, false>), grid, dim3(512), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, true>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, true>), grid, dim3(512), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, false, BKT>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, false, BKT>), grid, dim3(512), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, true, BKT>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, true, BKT>), grid, dim3(512), 0, st, p); break;
   }
 }
 
@@ -276,8 +285,8 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
-  if (accumulate) launch_gemm<true, false, EPI_ACC>(st, grid, p);
-  else launch_gemm<true, false, EPI_STORE>(st, grid, p);
+  if (accumulate) launch_gemm<true, false, EPI_ACC, 16>(st, grid, p);
+  else launch_gemm<true, false, EPI_STORE, 16>(st, grid, p);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -308,7 +317,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
   const int ns = tn_splits(rows, Mo, No);
   int kper = (int)((rows + ns - 1) / ns);
-  kper = (kper + BK - 1) / BK * BK;
+  kper = (kper + 31) / 32 * 32;   // whole k-tiles (BKT = 32 for the TN launches)
   float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
   GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
   dim3 grid(nq_cdiv(Mo, BM), nq_cdiv(No, BN), ns);
