@@ -355,6 +355,27 @@ def main():
         host_feed = {"value": args.batch * done / dth, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dth / done,
                      "what": "same step, batches collated from a pinned host arena and copied on a side stream (PCIe-inclusive)"}
 
+    inference = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # serving / geometry-optimisation mode (optimization/calculator.py:124-130 -> model(batch)): energies + forces only, no second-order sweep
+        try:
+            model.eval()
+            with torch.no_grad():
+                for i in range(2):
+                    model(batches[i % len(batches)])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    model(batches[i % len(batches)])
+                torch.cuda.synchronize()
+            dti = time.perf_counter() - t0
+            inference = {"value": args.batch * args.steps / dti, "unit": "conformers/s", "ms_per_call": 1e3 * dti / args.steps,
+                         "what": "model(batch) -> (energy, forces) incl. neighbour list, same batches, eval mode"}
+        except (TypeError, KeyError, AttributeError) as exc:      # the schnetpack-style potentials take dict inputs: not measured here
+            inference = {"value": None, "what": f"not measured for this model interface ({type(exc).__name__})"}
+        finally:
+            model.train()
+
     other, kind2 = None, None
     if rank == 0 and world == 1 and not args.no_roofline:
         # the sibling PaiNN configuration through the same kernels (reported, not `value`)
@@ -388,7 +409,7 @@ def main():
             "cpu_baseline": cpu,
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
-            "host_feed": host_feed,
+            "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},
