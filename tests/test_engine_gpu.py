@@ -534,3 +534,49 @@ def test_every_row_is_processed_at_any_grid_size(n_conf):
     assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
     for k, p in m.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), g_ref[k].numpy()) < 5e-5, k
+
+
+def test_bench_sized_batch_linearity_and_determinism():
+    """At the bench.py workload size (2048 conformers, ~86 k atoms, 1.6 M edges, full config) the oracle is out of reach; size-independent
+    properties instead: (1) the parameter gradient of a LINEAR functional of energies and forces over the whole batch equals the sum of the
+    gradients of eight 256-conformer chunks (molecules do not couple) -- this runs the tangent / dual sweeps and the pair-row weight-gradient
+    path at full size; (2) two runs are bitwise identical; (3) net force per molecule vanishes."""
+    import nabladft_amd as nq
+    dev = _dev()
+    cfg = R.PaiNNConfig()
+    params = R.make_params(cfg, seed=23)
+    model = _model(cfg, params, dev)
+    B, C = 2048, 8
+    pos, z, batch, _, _ = R.gen_conformers(7, B)
+    g = torch.Generator().manual_seed(3)
+    w_e, w_f = torch.randn(B, generator=g), torch.randn(pos.shape[0], 3, generator=g)
+
+    def grads(sel_mol):
+        s = (batch >= sel_mol[0]) & (batch < sel_mol[1])
+        b = nq.Batch(pos[s], z[s], batch[s] - sel_mol[0]).to(dev)
+        for p in model.parameters():
+            p.grad = None
+        e, f = model(b)
+        ((e * w_e[sel_mol[0]:sel_mol[1]].to(dev)).sum() + (f * w_f[s].to(dev)).sum()).backward()
+        return torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone(), e.detach(), f.detach(), b
+
+    g_full, e, f, full = grads((0, B))
+    g_again, e2, f2, _ = grads((0, B))
+    assert torch.equal(g_full, g_again) and torch.equal(e, e2) and torch.equal(f, f2)
+    acc = torch.zeros_like(g_full, dtype=torch.float64)
+    step = B // C
+    for c in range(C):
+        gc, ec, _, _ = grads((c * step, (c + 1) * step))
+        acc += gc.double()
+        assert rel_err(ec.cpu().numpy(), e[c * step:(c + 1) * step].cpu().numpy()) < 2e-6
+    scale = float(g_full.abs().max())
+    assert float((acc - g_full.double()).abs().max()) < 2e-5 * scale
+    # per-tensor check as well (small tensors must not hide behind the largest one)
+    o = 0
+    for k, p in model.named_parameters():
+        n = p.numel()
+        a, b_ = acc[o:o + n], g_full[o:o + n].double()
+        assert float((a - b_).abs().max()) <= 5e-5 * max(float(b_.abs().max()), 1e-3 * scale), k
+        o += n
+    net = torch.zeros(B, 3, device=dev).index_add_(0, full.batch, f)
+    assert float(net.abs().max()) < 5e-4 * float(f.abs().max())
