@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 5
+#define NQ_ABI_VERSION 6
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -230,6 +230,23 @@ int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P
 int nq_feature_act(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t F, int32_t kind, float* y, void* stream);
 int nq_feature_act_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t F, int32_t kind,
                             float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream);
+
+/* The same activation on the scalar component of a packed irreps tensor [rows][ncomp][F] (PhiSNet activates xs[0] only, residual_block.py:58-64);
+ * the other components are copied.  Backward partials of alpha / beta are [rows][F]. */
+int nq_packed_act0(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t ncomp, int32_t F, int32_t kind, float* y, void* stream);
+int nq_packed_act0_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t ncomp, int32_t F, int32_t kind,
+                            float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream);
+
+/* PhiSNet SphericalLinear (phisnet/nn/modules/spherical_linear.py:50-59) on packed irreps tensors x, y: [rows][(order+1)^2][F]: one Linear per order,
+ * y_L = x_L W_L^T (+ bias0 on the scalars), W: HOST array of order+1 device pointers to [Fout][Fin] matrices.  Forward and input gradient are one launch
+ * for all orders; the weight gradient is one split-K contraction per order (scratch: nq_sph_weight_grad_scratch_floats floats; fixed summation order). */
+int nq_sph_linear_forward(const float* x, const float* const* W_host, const float* bias0, float* y, int64_t rows, int32_t order, int32_t Fin, int32_t Fout,
+                          void* stream);
+int nq_sph_linear_input_grad(const float* grad_y, const float* const* W_host, float* grad_x, int64_t rows, int32_t order, int32_t Fin, int32_t Fout,
+                             void* stream);
+size_t nq_sph_weight_grad_scratch_floats(int64_t rows, int32_t order, int32_t Fin, int32_t Fout);
+int nq_sph_linear_weight_grad(const float* grad_y, const float* x, float* const* grad_W_host, float* grad_bias0, int64_t rows, int32_t order, int32_t Fin,
+                              int32_t Fout, float* scratch, void* stream);
 
 /* Pair <-> atom data movement of the interaction blocks (interaction_block.py:135-142).  Rows of C floats.
  * nq_gather_rows: out[p] = x[idx[p]].  nq_segment_sum: out[n] = base[n] (nullable) + sum_{q in [seg_ptr[n], seg_ptr[n+1])} rows[order ? order[q] : q]

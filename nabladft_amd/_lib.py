@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -70,6 +70,12 @@ SYMBOLS = {
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_feature_act": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_feature_act_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "nq_packed_act0": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "nq_packed_act0_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "nq_sph_linear_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "nq_sph_linear_input_grad": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "nq_sph_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32, _I32]),
+    "nq_sph_linear_weight_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "nq_gather_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "nq_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),

@@ -37,7 +37,12 @@ struct GemmArgs {
   long part_stride;      // EPI_PARTIAL: floats between partial slabs
   float* bpart;          // EPI_PARTIAL, optional: per-split column sums of A over rows < brows (bias gradient), [splits][M]
   int brows;
+  // spherical (row-mapped) launches: the operands are packed irreps tensors [rows][ncomp][F]; the logical row q of order L is the pair
+  // (r, m) = (q / w, q % w), w = 2L+1, stored at packed row r * ncomp + L*L + m
+  int rm_rows, rm_ncomp, rm_w, rm_base;   // RM == 2 (weight gradient of one order): w / base given here
+  const float* Bz[5];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
 };
+__device__ __forceinline__ long rm_row(int q, int w, int ncomp, int base) { return (long)(q / w) * ncomp + base + q % w; }
 
 // K-contiguous source (element (r, k) at src[r*ld + k]) -> LDS tile[k][r], stride LDS_KC
 #define LDS_KC (BM + 1)
@@ -47,9 +52,9 @@ struct GemmArgs {
 // ---- tile staging, split into fetch (global -> registers) and stash (registers -> LDS) so that the fetch of
 // k-tile t+1 can be issued before the MFMAs of k-tile t (the global latency then hides under the matrix pipe).
 // KC source: element (r, k) at src[r*ld + k]; MC source: element (k, r) at src[k*ld + r].  NT = threads per workgroup.
-template <bool KC, int NT, int BKT>
+template <bool KC, int NT, int BKT, bool MAP = false>
 __device__ __forceinline__ void fetch_tile(float4 (&v)[BM * BKT / 4 / NT], const float* __restrict__ src, int ld, int r0, int R, int k0, int Kend,
-                                           bool vec_ok) {
+                                           bool vec_ok, int mw = 1, int mn = 1, int mb = 0) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int it = 0; it < BM * BKT / 4 / NT; ++it) {
@@ -59,7 +64,7 @@ __device__ __forceinline__ void fetch_tile(float4 (&v)[BM * BKT / 4 / NT], const
       const int row = idx / (BKT / 4), kq = (idx % (BKT / 4)) * 4;
       const int gr = r0 + row, gk = k0 + kq;
       if (gr < R) {
-        const float* ptr = src + (long)gr * ld + gk;
+        const float* ptr = src + (MAP ? rm_row(gr, mw, mn, mb) : (long)gr) * ld + gk;   // MAP: K-contiguous operand, logical row -> packed row
         if (vec_ok && gk + 3 < Kend) x = *reinterpret_cast<const float4*>(ptr);
         else {
           if (gk + 0 < Kend) x.x = ptr[0];
@@ -72,7 +77,7 @@ __device__ __forceinline__ void fetch_tile(float4 (&v)[BM * BKT / 4 / NT], const
       const int k = idx >> 5, rq = (idx & 31) * 4;
       const int gk = k0 + k, gr = r0 + rq;
       if (gk < Kend) {
-        const float* ptr = src + (long)gk * ld + gr;
+        const float* ptr = src + (MAP ? rm_row(gk, mw, mn, mb) : (long)gk) * ld + gr;   // MAP: the reduction index is the logical row
         if (vec_ok && gr + 3 < R) x = *reinterpret_cast<const float4*>(ptr);
         else {
           if (gr + 0 < R) x.x = ptr[0];
@@ -107,7 +112,7 @@ __device__ __forceinline__ void stash_tile(float* __restrict__ tile, const float
 
 // NW = wavefronts per 128x128 tile: 4 -> each wave owns 64x64 (2x2 MFMA tiles), 8 -> 64x32 (2x1).
 // PF = register prefetch of the next k-tile (one extra barrier-free overlap of global latency with MFMAs).
-template <bool A_KC, bool B_KC, int EPI, int NW, bool PF, int BKT = 32>
+template <bool A_KC, bool B_KC, int EPI, int NW, bool PF, int BKT = 32, int RM = 0>
 __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   constexpr int NT = NW * 64;
   constexpr int TN = NW == 4 ? 2 : 1;
@@ -117,6 +122,11 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float Bs[BKT * LDB_S];
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // row maps (see GemmArgs): RM 1 = all orders in one launch (blockIdx.z = L; A rows and C rows mapped), RM 2 = one order, reduction index mapped
+  const int mw = RM == 1 ? 2 * (int)blockIdx.z + 1 : p.rm_w, mn = p.rm_ncomp, mb = RM == 1 ? (int)(blockIdx.z * blockIdx.z) : p.rm_base;
+  const int Meff = RM == 1 ? p.rm_rows * mw : p.M;
+  const float* const Bsrc = RM == 1 ? p.Bz[blockIdx.z] : p.B;
+  if (RM == 1 && m0 >= Meff) return;   // workgroup-uniform: the grid is sized for the largest order
   int kbeg = 0, kend = p.K;
   if (EPI == EPI_PARTIAL) {
     kbeg = blockIdx.z * p.k_per_split;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   const int lr = lane & 31, lk = lane >> 5;
 
   const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-  const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+  const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bsrc) & 15) == 0);
 
   f32x16 acc[2][TN];
 #pragma unroll
@@ -141,13 +151,13 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   float bsum = 0.f;
   float4 ra[BM * BKT / 4 / NT], rb[BM * BKT / 4 / NT];
   if (PF) {
-    fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, kbeg, kend, a_vec);
-    fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, b_vec);
+    fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, kbeg, kend, a_vec, mw, mn, mb);
+    fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, kbeg, kend, b_vec, mw, mn, mb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
     if (!PF) {
-      fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, k0, kend, a_vec);
-      fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, k0, kend, b_vec);
+      fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, k0, kend, a_vec, mw, mn, mb);
+      fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, k0, kend, b_vec, mw, mn, mb);
     }
     stash_tile<A_KC, NT, BKT>(As, ra);
     stash_tile<B_KC, NT, BKT>(Bs, rb);
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
       }
     }
     if (PF && k0 + BKT < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
-      fetch_tile<A_KC, NT, BKT>(ra, p.A, p.lda, m0, p.M, k0 + BKT, kend, a_vec);
-      fetch_tile<B_KC, NT, BKT>(rb, p.B, p.ldb, n0, p.N, k0 + BKT, kend, b_vec);
+      fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, k0 + BKT, kend, a_vec, mw, mn, mb);
+      fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, k0 + BKT, kend, b_vec, mw, mn, mb);
     }
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 2) {
@@ -192,12 +202,12 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wcol0 + j * 32 + lr;
       if (col >= p.N) continue;
-      const float bv = (EPI != EPI_PARTIAL && p.bias) ? p.bias[col] : 0.f;
+      const float bv = (EPI != EPI_PARTIAL && p.bias && (RM != 1 || blockIdx.z == 0)) ? p.bias[col] : 0.f;   // spherical: bias on the scalars only
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= p.M) continue;
-        const long off = (long)row * p.ldc + col;
+        if (row >= Meff) continue;
+        const long off = (RM == 1 ? rm_row(row, mw, mn, mb) : (long)row) * p.ldc + col;
         const float v = acc[i][j][r] + bv;
         if (EPI == EPI_ACC) Cout[off] += v;
 #ifdef NQ_GEMM_NT_STORE
@@ -354,3 +364,94 @@ int nq_reduce_partials(hipStream_t st, const float* part, int nsplit, long strid
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
+
+// ---- spherical linear layers on packed irreps tensors (PhiSNet SphericalLinear, spherical_linear.py:50-59) -----------------------------------
+// x, y: [rows][(order+1)^2][F]; one weight matrix per order.  Forward and input gradient: ONE launch for all orders (blockIdx.z = L, rows of
+// order L found through the row map) instead of order+1 GEMMs on gathered copies; weight gradient: one split-K launch per order.
+static int sph_check(long rows, int order, int Fin, int Fout) {
+  if (order < 0 || order > 4) return nq_fail(NQ_ERR_ARG, "spherical linear: order must be in 0..4");
+  if (rows < 0 || rows * (2L * order + 1) > 2000000000L || Fin <= 0 || Fout <= 0) return nq_fail(NQ_ERR_ARG, "spherical linear: bad sizes");
+  return NQ_OK;
+}
+
+extern "C" {
+
+int nq_sph_linear_forward(const float* x, const float* const* W_host, const float* bias0, float* y, int64_t rows, int32_t order, int32_t Fin,
+                          int32_t Fout, void* stream) {
+  NQ_TRY(sph_check(rows, order, Fin, Fout));
+  if (!x || !W_host || !y) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "sph_linear_fwd");
+  if (rows == 0) return NQ_OK;
+  const int ncomp = (order + 1) * (order + 1);
+  GemmArgs p{};
+  p.A = x; p.C = y; p.bias = bias0; p.M = (int)rows * (2 * order + 1); p.N = Fout; p.K = Fin; p.lda = Fin; p.ldb = Fin; p.ldc = Fout;
+  p.rm_rows = (int)rows; p.rm_ncomp = ncomp;
+  for (int L = 0; L <= order; ++L) { if (!W_host[L]) return nq_fail(NQ_ERR_ARG, "null weight"); p.Bz[L] = W_host[L]; }
+  p.B = p.Bz[0];
+  dim3 grid(nq_cdiv(p.M, BM), nq_cdiv(Fout, BN), order + 1);
+  hipLaunchKernelGGL((k_gemm<true, true, EPI_STORE, 8, true, 32, 1>), grid, dim3(512), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// gx_L = gy_L W_L   (W_L: [Fout][Fin])
+int nq_sph_linear_input_grad(const float* gy, const float* const* W_host, float* gx, int64_t rows, int32_t order, int32_t Fin, int32_t Fout,
+                             void* stream) {
+  NQ_TRY(sph_check(rows, order, Fin, Fout));
+  if (!gy || !W_host || !gx) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "sph_linear_bwd_x");
+  if (rows == 0) return NQ_OK;
+  const int ncomp = (order + 1) * (order + 1);
+  GemmArgs p{};
+  p.A = gy; p.C = gx; p.M = (int)rows * (2 * order + 1); p.N = Fin; p.K = Fout; p.lda = Fout; p.ldb = Fin; p.ldc = Fin;
+  p.rm_rows = (int)rows; p.rm_ncomp = ncomp;
+  for (int L = 0; L <= order; ++L) { if (!W_host[L]) return nq_fail(NQ_ERR_ARG, "null weight"); p.Bz[L] = W_host[L]; }
+  p.B = p.Bz[0];
+  dim3 grid(nq_cdiv(p.M, BM), nq_cdiv(Fin, BN), order + 1);
+  hipLaunchKernelGGL((k_gemm<true, false, EPI_STORE, 8, true, 16, 1>), grid, dim3(512), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+size_t nq_sph_weight_grad_scratch_floats(int64_t rows, int32_t order, int32_t Fin, int32_t Fout) {
+  return nq_gemm_tn_scratch_floats(rows * (2L * order + 1), Fout, Fin) + nq_colsum_scratch_floats(rows, Fout);
+}
+
+// gW_L[Fout][Fin] = sum over the rows of order L of gy^T x; gbias0[Fout] = column sums of the scalar rows of gy (or null)
+int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_host, float* gbias0, int64_t rows, int32_t order, int32_t Fin,
+                              int32_t Fout, float* scratch, void* stream) {
+  NQ_TRY(sph_check(rows, order, Fin, Fout));
+  if (!gy || !x || !gW_host || !scratch) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "sph_linear_bwd_w");
+  const int ncomp = (order + 1) * (order + 1);
+  for (int L = 0; L <= order; ++L) {
+    float* out = gW_host[L];
+    if (!out) return nq_fail(NQ_ERR_ARG, "null weight gradient");
+    const long K = rows * (2L * L + 1);
+    if (K == 0) { NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Fout * Fin, st)); continue; }
+    const int ns = tn_splits(K, Fout, Fin);
+    int kper = (int)((K + ns - 1) / ns);
+    kper = (kper + 31) / 32 * 32;
+    GemmArgs p{};
+    p.A = gy; p.B = x; p.C = scratch; p.M = Fout; p.N = Fin; p.K = (int)K; p.lda = Fout; p.ldb = Fin; p.ldc = Fin;
+    p.k_per_split = kper; p.part_stride = (long)Fout * Fin;
+    p.rm_rows = (int)rows; p.rm_ncomp = ncomp; p.rm_w = 2 * L + 1; p.rm_base = L * L;
+    dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ns);
+    hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 2>), grid, dim3(512), 0, st, p);
+    NQ_LAUNCH_CHECK();
+    const long cnt = (long)Fout * Fin;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);
+    NQ_LAUNCH_CHECK();
+  }
+  if (gbias0) {
+    if (rows == 0) NQ_HIP(hipMemsetAsync(gbias0, 0, sizeof(float) * Fout, st));
+    else NQ_TRY(nq_colsum(st, gy, rows, Fout, ncomp * Fout, gbias0, scratch));   // scalar rows: packed row r * ncomp
+  }
+  return NQ_OK;
+}
+
+}  // extern "C"
+

@@ -171,6 +171,65 @@ int nq_feature_act_backward(const float* x, const float* alpha, const float* bet
 }
 }  // extern "C"
 
+// The same activation on the scalar component of a PACKED irreps tensor [rows][ncomp][F]; every other component is copied (residual_block.py:58-64
+// activates xs[0] only).  One launch instead of slice + activation + concatenation.
+template <bool BWD>
+__global__ void k_packed_act0(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ beta, long rows, int ncomp, int F, int kind,
+                              float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, float* __restrict__ ga_rows,
+                              float* __restrict__ gb_rows) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * ncomp * F) return;
+  const int f = (int)(idx % F);
+  const long rc = idx / F;
+  if (rc % ncomp != 0) {
+    if (BWD) gx[idx] = gy[idx]; else y[idx] = x[idx];
+    return;
+  }
+  const long r = rc / ncomp;
+  const float xv = x[idx], a = alpha[f], b = beta[f];
+  const float ln2 = 0.69314718055994530942f;
+  float yv, dx, da, db;
+  if (kind == 0) {
+    const float s = act_sig(b * xv);
+    yv = a * xv * s; dx = a * (s + xv * b * s * (1.0f - s)); da = xv * s; db = a * xv * xv * s * (1.0f - s);
+  } else if (b != 0.f) {
+    const float sp = act_softplus(b * xv) - ln2, s = act_sig(b * xv);
+    yv = a * sp / b; dx = a * s; da = sp / b; db = a * (xv * s / b - sp / (b * b));
+  } else {
+    yv = 0.5f * a * xv; dx = 0.5f * a; da = 0.5f * xv; db = a * xv * xv * 0.125f;
+  }
+  if (!BWD) { y[idx] = yv; return; }
+  const float g = gy[idx];
+  gx[idx] = g * dx;
+  ga_rows[r * F + f] = g * da;
+  gb_rows[r * F + f] = g * db;
+}
+
+extern "C" {
+int nq_packed_act0(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t ncomp, int32_t F, int32_t kind, float* y, void* stream) {
+  if (!x || !alpha || !beta || !y || F <= 0 || ncomp <= 0 || rows < 0 || kind < 0 || kind > 1) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "packed_act0");
+  const long n = (long)rows * ncomp * F;
+  if (n > 0) hipLaunchKernelGGL((k_packed_act0<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, alpha, beta, (long)rows, ncomp, F, kind, y,
+                                nullptr, nullptr, nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_packed_act0_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t ncomp, int32_t F, int32_t kind,
+                            float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream) {
+  if (!x || !alpha || !beta || !grad_y || !grad_x || !grad_alpha_rows || !grad_beta_rows || F <= 0 || ncomp <= 0 || rows < 0 || kind < 0 || kind > 1)
+    return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "packed_act0_bwd");
+  const long n = (long)rows * ncomp * F;
+  if (n > 0) hipLaunchKernelGGL((k_packed_act0<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, alpha, beta, (long)rows, ncomp, F, kind, nullptr,
+                                grad_y, grad_x, grad_alpha_rows, grad_beta_rows);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+}  // extern "C"
+
 // ---- pair <-> atom data movement for the interaction blocks (interaction_block.py:135-142: torch.gather over idx_j, index_add over idx_i) -----
 // rows are [C] floats (C = (2l+1) * F); seg_ptr [N+1] delimits the contiguous pair rows of every atom (pairs sorted by centre atom), so the
 // sum is a fixed-order loop per output element: deterministic, no atomics.

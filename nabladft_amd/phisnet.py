@@ -16,7 +16,9 @@ import torch
 from torch import nn
 
 from . import _lib
-from .so3 import PairMixing, SelfMixing, _LinearFn, _require_gpu
+import ctypes as C
+
+from .so3 import PackedList, PairMixing, SelfMixing, _LinearFn, _pack, _require_gpu, _unpack
 
 
 class PairIndex:
@@ -109,6 +111,106 @@ class _ActFn(torch.autograd.Function):
         return gx, ga.view(-1, F).sum(0), gb.view(-1, F).sum(0), None
 
 
+class _PackedAct0Fn(torch.autograd.Function):
+    """Activation of the scalar component of a packed irreps tensor [rows, ncomp, F], copy of the rest (one launch)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta, kind):
+        lib = _lib.load()
+        x2 = x.to(torch.float32).contiguous()
+        rows, ncomp, F = x2.shape
+        a, b = alpha.detach().to(torch.float32).contiguous(), beta.detach().to(torch.float32).contiguous()
+        y = torch.empty_like(x2)
+        _lib.check(lib.nq_packed_act0(_lib.ptr(x2), _lib.ptr(a), _lib.ptr(b), rows, ncomp, F, kind, _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(x2, a, b)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x2, a, b = ctx.saved_tensors
+        rows, ncomp, F = x2.shape
+        g = g.to(torch.float32).contiguous()
+        gx = torch.empty_like(x2)
+        ga, gb = torch.empty(rows, F, device=g.device, dtype=torch.float32), torch.empty(rows, F, device=g.device, dtype=torch.float32)
+        _lib.check(lib.nq_packed_act0_backward(_lib.ptr(x2), _lib.ptr(a), _lib.ptr(b), _lib.ptr(g), rows, ncomp, F, ctx.kind, _lib.ptr(gx), _lib.ptr(ga),
+                                               _lib.ptr(gb), _lib.stream_ptr()))
+        return gx, ga.sum(0), gb.sum(0), None
+
+
+def _act0(xs, act):
+    """``ys = list(xs); ys[0] = act(ys[0])`` of the reference blocks; on a packed list it is one kernel and stays packed."""
+    if isinstance(xs, PackedList) and xs.packed is not None and xs.packed.is_cuda:
+        return _unpack(_PackedAct0Fn.apply(xs.packed, act.alpha, act.beta, act._kind), xs.order, xs.lead, xs.F)
+    ys = list(xs)
+    ys[0] = act(ys[0])
+    return ys
+
+
+def _add_lists(xs, ys):
+    px, py = isinstance(xs, PackedList) and xs.packed is not None, isinstance(ys, PackedList) and ys.packed is not None
+    if px and py and xs.order == ys.order:
+        return _unpack(xs.packed + ys.packed, xs.order, xs.lead, xs.F)
+    if (px or py) and len(xs) == len(ys):            # one side packed: pack the other (one concatenate) instead of order-wise adds
+        p, q = (xs, ys) if px else (ys, xs)
+        return _unpack(p.packed + _pack(q, p.order, p.F)[0], p.order, p.lead, p.F)
+    return [x + y for x, y in zip(xs, ys)]
+
+
+def _gather_list(xs, pidx, order, F):
+    """Neighbour gather of every order: one launch on the packed rows."""
+    x, lead = _pack(xs, order, F)
+    n = x.shape[0]
+    g = _GatherFn.apply(x.view(1, n, x.shape[1], F), pidx)
+    return _unpack(g.view(g.shape[1], x.shape[1], F), order, (*lead[:-1], g.shape[1]), F)
+
+
+def _segment_add_list(base, rows, pidx, order, F):
+    """base + sum over the pair rows of every centre atom, all orders in one launch."""
+    b, lead = _pack(base, order, F)
+    r, _ = _pack(rows, order, F)
+    out = _SegmentAddFn.apply(b.view(1, *b.shape), r.view(1, *r.shape), pidx)
+    return _unpack(out.view(b.shape), order, lead, F)
+
+
+class _SphLinearFn(torch.autograd.Function):
+    """All per-order Linear layers of a SphericalLinear on the packed tensor: one launch forward, one for the input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, bias, *weights):
+        lib = _lib.load()
+        x2 = x.to(torch.float32).contiguous()
+        rows, ncomp, Fin = x2.shape
+        order = len(weights) - 1
+        ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+        Fout = ws[0].shape[0]
+        y = torch.empty(rows, ncomp, Fout, device=x.device, dtype=torch.float32)
+        wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+        _lib.check(lib.nq_sph_linear_forward(_lib.ptr(x2), wp, _lib.ptr(b), _lib.ptr(y), rows, order, Fin, Fout, _lib.stream_ptr()))
+        ctx.save_for_backward(x2, *ws)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x2, *ws = ctx.saved_tensors
+        rows, ncomp, Fin = x2.shape
+        order, Fout = len(ws) - 1, ws[0].shape[0]
+        g = g.to(torch.float32).contiguous()
+        wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        gx = torch.empty_like(x2)
+        _lib.check(lib.nq_sph_linear_input_grad(_lib.ptr(g), wp, _lib.ptr(gx), rows, order, Fin, Fout, _lib.stream_ptr()))
+        gws = [torch.empty_like(w) for w in ws]
+        gwp = (C.c_void_p * len(gws))(*[w.data_ptr() for w in gws])
+        gb = torch.empty(Fout, device=g.device, dtype=torch.float32) if ctx.has_bias else None
+        scr = torch.empty(int(lib.nq_sph_weight_grad_scratch_floats(rows, order, Fin, Fout)) + 64, device=g.device, dtype=torch.float32)
+        _lib.check(lib.nq_sph_linear_weight_grad(_lib.ptr(g), _lib.ptr(x2), gwp, _lib.ptr(gb), rows, order, Fin, Fout, _lib.ptr(scr), _lib.stream_ptr()))
+        return (gx, gb, *gws)
+
+
 class _Activation(nn.Module):
     _kind = 0
 
@@ -170,6 +272,10 @@ class SphericalLinear(nn.Module):
 
     def forward(self, xs):
         ys = self.mixing(xs) if self.mix_orders else xs
+        if self.num_in > 1 and ys[0].is_cuda and len(ys) == self.order_out + 1:
+            x, lead = _pack(ys, self.order_out, self.num_in)
+            y = _SphLinearFn.apply(x, self.linear[0].bias, *[lin.weight for lin in self.linear])
+            return _unpack(y, self.order_out, lead, self.num_out)
         return [_linear(y, lin) for y, lin in zip(ys, self.linear)]
 
 
@@ -185,12 +291,11 @@ class ResidualBlock(nn.Module):
         self.linear2 = SphericalLinear(order, num_features, order, num_features, clebsch_gordan, mix_orders, zero_init=True)
 
     def forward(self, xs):
-        ys = list(xs)
-        ys[0] = self.activation_pre(ys[0])
-        ys = self.linear1(ys)
-        ys[0] = self.activation_post(ys[0])
-        ys = self.linear2(ys)
-        return [x + y for x, y in zip(xs, ys)]
+        if xs[0].is_cuda and not (isinstance(xs, PackedList) and xs.packed is not None):
+            xs = _unpack(*_pack(xs, self.order, self.num_features)[:1], self.order, xs[0].shape[:-2], self.num_features)   # pack once per stack
+        ys = self.linear1(_act0(xs, self.activation_pre))
+        ys = self.linear2(_act0(ys, self.activation_post))
+        return _add_lists(xs, ys)
 
 
 class ResidualStack(nn.Module):
@@ -202,6 +307,8 @@ class ResidualStack(nn.Module):
     def forward(self, xs):
         for block in self.stack:
             xs = block(xs)
+        if isinstance(xs, PackedList) and xs.packed is not None:
+            return _unpack(xs.packed, xs.order, xs.lead, xs.F)      # a fresh list object, as the reference's ``list(xs)``
         return list(xs)
 
 
@@ -234,20 +341,21 @@ class InteractionBlock(nn.Module):
     def forward(self, xs, rbf, sph, idx_i, idx_j):
         _require_gpu(rbf)
         yi = self.residual_pre_vi(xs)
-        yi[0] = self.activation_i(yi[0])
+        yi = _act0(yi, self.activation_i)
         yi = self.linear_i(yi)
         yj = self.residual_pre_vj(xs)
-        yj[0] = self.activation_j(yj[0])
+        yj = _act0(yj, self.activation_j)
         yj = self.linear_j(yj)
         pidx = idx_i if isinstance(idx_i, PairIndex) else PairIndex(idx_i, idx_j, xs[0].shape[1])
-        yj = [_GatherFn.apply(y, pidx) for y in yj]                                   # neighbour gather (interaction_block.py:135-137)
+        yj = _gather_list(yj, pidx, self.order, self.num_features)                    # neighbour gather (interaction_block.py:135-137)
         vs = self.mixing(yj, self.angular_fn1(sph), rbf)
         a = self.angular_fn2(sph)
-        vs = [_SegmentAddFn.apply(yi[L], vs[L] + _linear(rbf, self.radial_fn[L]) * a[L] * yj[0], pidx) for L in range(self.order + 1)]
+        extra = [_linear(rbf, self.radial_fn[L]) * a[L] * yj[0] for L in range(self.order + 1)]
+        vs = _segment_add_list(yi, _add_lists(vs, extra), pidx, self.order, self.num_features)    # index_add over the centre atoms (:139-142)
         vs = self.residual_post_v(vs)
-        vs[0] = self.activation_v(vs[0])
+        vs = _act0(vs, self.activation_v)
         vs = self.linear_v(vs)
-        return [x + v for x, v in zip(xs, vs)]
+        return _add_lists(xs, vs)
 
 
 class ModularBlock(nn.Module):
@@ -494,11 +602,11 @@ class NeuralNetwork(nn.Module):
 
     def _heads(self, f, res, act, out):
         g = res(f)
-        g[0] = act(g[0])
+        g = _act0(g, act)
         return out(g)
 
     def _pack(self, fs, n_out):
-        x = torch.cat([f[0] for f in fs], dim=-2)                                        # [rows, (Lout+1)^2, n_out]
+        x = fs.packed if isinstance(fs, PackedList) and fs.packed is not None else torch.cat([f[0] for f in fs], dim=-2)   # [rows, (Lout+1)^2, n_out]
         pad = max(self._n_out) - n_out
         return torch.nn.functional.pad(x, (0, pad)) if pad else x
 
@@ -520,26 +628,28 @@ class NeuralNetwork(nn.Module):
         rbf = self.radial_basis_functions(dij).view(1, P, 1, self.num_basis_functions)
         sph = [s.view(1, P, -1, 1) for s in spherical_harmonics(self.order, uij)]
         xs = self.embedding(Z)
-        gather_i = lambda t: _GatherFn.apply(t, _SwapIndex(pidx))
-        gather_j = lambda t: _GatherFn.apply(t, pidx)
+        swap = _SwapIndex(pidx)
+        gather_i = lambda ts: _gather_list(ts, swap, self.order, self.num_features)      # all orders of the centre atoms, one launch
+        gather_j = lambda ts: _gather_list(ts, pidx, self.order, self.num_features)
         results = {}
         if self.calculate_overlap_matrix:
             fii_over = self.output_over_ii(xs)
             a = self.angular_fn(sph)
-            si = [gather_i(x) for x in xs]
-            sj = [gather_j(xs[0])] + [a[L] for L in range(1, self.order + 1)]
+            si = gather_i(xs)
+            sj = [_GatherFn.apply(xs[0], pidx)] + [a[L] for L in range(1, self.order + 1)]
             fij_over = self._heads(self.mix_s(si, sj, rbf), self.residual_over_ij, self.activation_over_ij, self.output_over_ij)
         fs = [torch.zeros_like(x) for x in xs]
         for module in self.module:
             xs, ys = module(xs, rbf, sph, pidx, idx_j)
-            fs = [f + y for f, y in zip(fs, ys)]
+            fs = _add_lists(fs, ys)
         fpc, fpn = self.residual_pc(fs), self.residual_pn(fs)
-        fpn_j_ii = [_linear(rbf, self.radial_ii[L]) * gather_j(fpn[L]) for L in range(self.order + 1)]
-        fii = self.residual_ii([_SegmentAddFn.apply(fpc[L], fpn_j_ii[L], pidx) for L in range(self.order + 1)])
-        fij = self.mix_ij([gather_i(x) for x in fpc], [gather_j(x) for x in fpc], rbf)
+        fpn_g = gather_j(fpn)
+        fpn_j_ii = [_linear(rbf, self.radial_ii[L]) * fpn_g[L] for L in range(self.order + 1)]
+        fii = self.residual_ii(_segment_add_list(fpc, fpn_j_ii, pidx, self.order, self.num_features))
+        fij = self.mix_ij(gather_i(fpc), gather_j(fpc), rbf)
         if ppidx is not None:
-            fpn_j = [_linear(rbf, self.radial_ij[L]) * gather_j(fpn[L]) for L in range(self.order + 1)]
-            fij = [_SegmentAddFn.apply(fij[L], _GatherFn.apply(fpn_j[L], ppidx), ppidx) for L in range(self.order + 1)]
+            fpn_j = [_linear(rbf, self.radial_ij[L]) * fpn_g[L] for L in range(self.order + 1)]
+            fij = _segment_add_list(fij, _gather_list(fpn_j, ppidx, self.order, self.num_features), ppidx, self.order, self.num_features)
         fij = self.residual_ij(fij)
         asm = self._assembler
         plan = asm.plan(Z[0], ptr, idx_i, idx_j)

@@ -81,14 +81,30 @@ class _MixFn(torch.autograd.Function):
         return gx1, gx2, gc, gk, None
 
 
+class PackedList(list):
+    """The reference's list-of-orders representation ``[x_0 [..., 1, F], x_1 [..., 3, F], ...]`` whose elements are VIEWS of one packed
+    tensor ``packed [rows, (order+1)^2, F]`` -- what the kernels read and write.  Modules hand it on so that consecutive ops skip the
+    concatenate / split copies; any code that treats it as a plain list still works (replacing an element drops the packed shortcut)."""
+
+    def __init__(self, packed: torch.Tensor, order: int, lead, F: int):
+        super().__init__(packed[:, L * L:(L + 1) * (L + 1), :].reshape(*lead, 2 * L + 1, F) for L in range(order + 1))
+        self.packed, self.order, self.lead, self.F = packed, order, tuple(lead), F
+
+    def __setitem__(self, k, v):
+        self.packed = None
+        super().__setitem__(k, v)
+
+
 def _pack(xs: List[torch.Tensor], order: int, F: int):
+    if isinstance(xs, PackedList) and xs.packed is not None and xs.order == order and xs.F == F:
+        return xs.packed, xs.lead
     lead = xs[0].shape[:-2]
     x = torch.cat([xs[l].reshape(-1, 2 * l + 1, F) for l in range(order + 1)], dim=1).to(torch.float32).contiguous()
     return x, lead
 
 
 def _unpack(y: torch.Tensor, order: int, lead, F: int):
-    return [y[:, L * L:(L + 1) * (L + 1), :].reshape(*lead, 2 * L + 1, F) for L in range(order + 1)]
+    return PackedList(y, order, lead, F)
 
 
 def _path_index(enabled):
