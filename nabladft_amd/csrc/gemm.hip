@@ -40,6 +40,7 @@ struct GemmArgs {
   // spherical (row-mapped) launches: the operands are packed irreps tensors [rows][ncomp][F]; the logical row q of order L is the pair
   // (r, m) = (q / w, q % w), w = 2L+1, stored at packed row r * ncomp + L*L + m
   int rm_rows, rm_ncomp, rm_w, rm_base;   // RM == 2 (weight gradient of one order): w / base given here
+  int rm_s;                               // RM == 3 (weight gradients of all orders): splits per component; blockIdx.z = component * rm_s + split
   const float* Bz[5];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
 };
 __device__ __forceinline__ long rm_row(int q, int w, int ncomp, int base) { return (long)(q / w) * ncomp + base + q % w; }
@@ -123,14 +124,18 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   // row maps (see GemmArgs): RM 1 = all orders in one launch (blockIdx.z = L; A rows and C rows mapped), RM 2 = one order, reduction index mapped
-  const int mw = RM == 1 ? 2 * (int)blockIdx.z + 1 : p.rm_w, mn = p.rm_ncomp, mb = RM == 1 ? (int)(blockIdx.z * blockIdx.z) : p.rm_base;
+  const int zc = RM == 3 ? (int)blockIdx.z / p.rm_s : 0;                                   // RM 3: packed component this split belongs to
+  const int zL = RM == 3 ? (zc >= 16 ? 4 : zc >= 9 ? 3 : zc >= 4 ? 2 : zc >= 1 ? 1 : 0) : (int)blockIdx.z;
+  const int mw = RM == 1 || RM == 3 ? 2 * zL + 1 : p.rm_w, mn = p.rm_ncomp, mb = RM == 1 || RM == 3 ? zL * zL : p.rm_base;
   const int Meff = RM == 1 ? p.rm_rows * mw : p.M;
   const float* const Bsrc = RM == 1 ? p.Bz[blockIdx.z] : p.B;
   if (RM == 1 && m0 >= Meff) return;   // workgroup-uniform: the grid is sized for the largest order
   int kbeg = 0, kend = p.K;
   if (EPI == EPI_PARTIAL) {
-    kbeg = blockIdx.z * p.k_per_split;
-    kend = min(p.K, kbeg + p.k_per_split);
+    const int split = RM == 3 ? (zc - zL * zL) * p.rm_s + (int)blockIdx.z % p.rm_s : (int)blockIdx.z;   // RM 3: order L owns (2L+1) * rm_s splits
+    const int Ktot = RM == 3 ? p.rm_rows * mw : p.K;
+    kbeg = min(Ktot, split * p.k_per_split);
+    kend = min(Ktot, kbeg + p.k_per_split);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
@@ -152,12 +157,12 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   float4 ra[BM * BKT / 4 / NT], rb[BM * BKT / 4 / NT];
   if (PF) {
     fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, kbeg, kend, a_vec, mw, mn, mb);
-    fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, kbeg, kend, b_vec, mw, mn, mb);
+    fetch_tile<B_KC, NT, BKT, RM >= 2>(rb, Bsrc, p.ldb, n0, p.N, kbeg, kend, b_vec, mw, mn, mb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
     if (!PF) {
       fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, k0, kend, a_vec, mw, mn, mb);
-      fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, k0, kend, b_vec, mw, mn, mb);
+      fetch_tile<B_KC, NT, BKT, RM >= 2>(rb, Bsrc, p.ldb, n0, p.N, k0, kend, b_vec, mw, mn, mb);
     }
     stash_tile<A_KC, NT, BKT>(As, ra);
     stash_tile<B_KC, NT, BKT>(Bs, rb);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
     }
     if (PF && k0 + BKT < kend) {  // issue the next tile's global loads; they complete under the MFMAs below
       fetch_tile<A_KC, NT, BKT, RM != 0>(ra, p.A, p.lda, m0, Meff, k0 + BKT, kend, a_vec, mw, mn, mb);
-      fetch_tile<B_KC, NT, BKT, RM == 2>(rb, Bsrc, p.ldb, n0, p.N, k0 + BKT, kend, b_vec, mw, mn, mb);
+      fetch_tile<B_KC, NT, BKT, RM >= 2>(rb, Bsrc, p.ldb, n0, p.N, k0 + BKT, kend, b_vec, mw, mn, mb);
     }
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 2) {
@@ -374,6 +379,28 @@ static int sph_check(long rows, int order, int Fin, int Fout) {
   return NQ_OK;
 }
 
+// weight gradients of all orders in one launch: every packed component gets `s` splits of the logical rows (order L: (2L+1) * s splits)
+static int sph_tn_splits(long rows, int ncomp) {
+  long s = 768 / ncomp;
+  const long by_rows = (rows + 127) / 128;
+  if (s > by_rows) s = by_rows;
+  return (int)(s < 1 ? 1 : s);
+}
+struct SphOut { float* out[5]; };
+// out[L][i] = sum over the (2L+1) * s partial slabs of order L, in slab order (deterministic)
+__global__ void k_reduce_grouped(const float* __restrict__ part, int s, long cnt, SphOut o) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const int L = blockIdx.y;
+  const float* src = part + (long)L * L * s * cnt + i;
+  const int n = (2 * L + 1) * s;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 3 < n; k += 4) { a0 += src[(long)k * cnt]; a1 += src[(long)(k + 1) * cnt]; a2 += src[(long)(k + 2) * cnt]; a3 += src[(long)(k + 3) * cnt]; }
+  for (; k < n; ++k) a0 += src[(long)k * cnt];
+  o.out[L][i] = (a0 + a1) + (a2 + a3);
+}
+
 extern "C" {
 
 int nq_sph_linear_forward(const float* x, const float* const* W_host, const float* bias0, float* y, int64_t rows, int32_t order, int32_t Fin,
@@ -416,7 +443,9 @@ int nq_sph_linear_input_grad(const float* gy, const float* const* W_host, float*
 }
 
 size_t nq_sph_weight_grad_scratch_floats(int64_t rows, int32_t order, int32_t Fin, int32_t Fout) {
-  return nq_gemm_tn_scratch_floats(rows * (2L * order + 1), Fout, Fin) + nq_colsum_scratch_floats(rows, Fout);
+  const size_t ncomp = (size_t)(order + 1) * (order + 1);
+  const size_t part = ncomp * sph_tn_splits(rows, (int)ncomp) * (size_t)Fout * Fin, cs = nq_colsum_scratch_floats(rows, Fout);
+  return part > cs ? part : cs;
 }
 
 // gW_L[Fout][Fin] = sum over the rows of order L of gy^T x; gbias0[Fout] = column sums of the scalar rows of gy (or null)
@@ -427,23 +456,25 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "sph_linear_bwd_w");
   const int ncomp = (order + 1) * (order + 1);
+  GemmArgs p{};
   for (int L = 0; L <= order; ++L) {
-    float* out = gW_host[L];
-    if (!out) return nq_fail(NQ_ERR_ARG, "null weight gradient");
-    const long K = rows * (2L * L + 1);
-    if (K == 0) { NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Fout * Fin, st)); continue; }
-    const int ns = tn_splits(K, Fout, Fin);
-    int kper = (int)((K + ns - 1) / ns);
+    if (!gW_host[L]) return nq_fail(NQ_ERR_ARG, "null weight gradient");
+    if (rows == 0) NQ_HIP(hipMemsetAsync(gW_host[L], 0, sizeof(float) * Fout * Fin, st));
+  }
+  if (rows > 0) {
+    const int sps = sph_tn_splits(rows, ncomp);
+    int kper = (int)((rows + sps - 1) / sps);
     kper = (kper + 31) / 32 * 32;
-    GemmArgs p{};
-    p.A = gy; p.B = x; p.C = scratch; p.M = Fout; p.N = Fin; p.K = (int)K; p.lda = Fout; p.ldb = Fin; p.ldc = Fin;
+    p.A = gy; p.B = x; p.C = scratch; p.M = Fout; p.N = Fin; p.K = (int)rows * (2 * order + 1); p.lda = Fout; p.ldb = Fin; p.ldc = Fin;
     p.k_per_split = kper; p.part_stride = (long)Fout * Fin;
-    p.rm_rows = (int)rows; p.rm_ncomp = ncomp; p.rm_w = 2 * L + 1; p.rm_base = L * L;
-    dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ns);
-    hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 2>), grid, dim3(512), 0, st, p);
+    p.rm_rows = (int)rows; p.rm_ncomp = ncomp; p.rm_s = sps;
+    dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ncomp * sps);
+    hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 3>), grid, dim3(512), 0, st, p);
     NQ_LAUNCH_CHECK();
+    SphOut outs{};
+    for (int L = 0; L <= order; ++L) outs.out[L] = gW_host[L];
     const long cnt = (long)Fout * Fin;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);
+    hipLaunchKernelGGL(k_reduce_grouped, dim3(nq_cdiv(cnt, 64), order + 1), dim3(64), 0, st, scratch, sps, cnt, outs);
     NQ_LAUNCH_CHECK();
   }
   if (gbias0) {

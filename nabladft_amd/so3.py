@@ -81,18 +81,44 @@ class _MixFn(torch.autograd.Function):
         return gx1, gx2, gc, gk, None
 
 
-class PackedList(list):
-    """The reference's list-of-orders representation ``[x_0 [..., 1, F], x_1 [..., 3, F], ...]`` whose elements are VIEWS of one packed
-    tensor ``packed [rows, (order+1)^2, F]`` -- what the kernels read and write.  Modules hand it on so that consecutive ops skip the
-    concatenate / split copies; any code that treats it as a plain list still works (replacing an element drops the packed shortcut)."""
+class PackedList:
+    """The reference's list-of-orders representation ``[x_0 [..., 1, F], x_1 [..., 3, F], ...]`` backed by ONE packed tensor
+    ``packed [rows, (order+1)^2, F]`` -- what the kernels read and write.  Elements are views created on access.  Modules hand the object
+    on so that consecutive ops skip the concatenate / split copies; code that treats it as a list (len, indexing, iteration, ``list(xs)``,
+    item assignment) still works -- replacing an element drops the packed shortcut."""
 
     def __init__(self, packed: torch.Tensor, order: int, lead, F: int):
-        super().__init__(packed[:, L * L:(L + 1) * (L + 1), :].reshape(*lead, 2 * L + 1, F) for L in range(order + 1))
         self.packed, self.order, self.lead, self.F = packed, order, tuple(lead), F
+        self._items = None
+
+    def _view(self, L):
+        return self.packed[:, L * L:(L + 1) * (L + 1), :].reshape(*self.lead, 2 * L + 1, self.F)
+
+    def _all(self):
+        if self._items is None:
+            self._items = [self._view(L) for L in range(self.order + 1)]
+        return self._items
+
+    def __len__(self):
+        return self.order + 1
+
+    def __getitem__(self, k):
+        if self._items is None and isinstance(k, int):
+            return self._view(k if k >= 0 else k + self.order + 1)
+        return self._all()[k]
+
+    def __iter__(self):
+        return iter(self._all())
 
     def __setitem__(self, k, v):
+        self._all()[k] = v
         self.packed = None
-        super().__setitem__(k, v)
+
+    def __add__(self, other):          # list concatenation, as for the reference's plain lists
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
 
 
 def _pack(xs: List[torch.Tensor], order: int, F: int):

@@ -140,3 +140,34 @@ class FusedTrainStep:
     def writeback(self):
         """Make the module's nn.Parameters reflect the trained values (no-op for nabladft_amd.PaiNN)."""
         self._eng.writeback()
+
+
+
+class FlatParameters:
+    """All trainable parameters of a module as views of ONE flat buffer, their gradients as views of one flat gradient buffer.  A model with
+    thousands of small tensors (PhiSNet: 2.4 k) otherwise spends tens of milliseconds per step in per-tensor optimiser bookkeeping; with the
+    flat pair, zero_grad is one memset, clipping one norm, and any torch optimiser (or ``nq_adamw_step``) runs on a single tensor.  The module's
+    parameter objects, names and state_dict are unchanged (``p.data`` / ``p.grad`` are re-pointed)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.nn.Parameter(torch.empty(n, device=dev, dtype=torch.float32))
+        self.flat.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat.data[o:o + k].copy_(p.data.reshape(-1))
+                p.data = self.flat.data[o:o + k].view(p.shape)
+                p.grad = self.flat.grad[o:o + k].view(p.shape)          # autograd accumulates into the view in place
+                o += k
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def clip_grad_norm_(self, max_norm: float):
+        norm = self.flat.grad.norm()
+        self.flat.grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event table (nq profile hooks)")
+    ap.add_argument("--per-tensor-optimizer", action="store_true", help="torch Adam over the 2.4 k parameter tensors instead of the flat buffer")
     a = ap.parse_args()
     import torch
     from nabladft_amd import _lib
@@ -61,14 +62,22 @@ def main():
     batch = dict(positions=torch.tensor(b["positions"]).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(b["z"]).cuda(), orbitals=b["orbitals"],
                  molecule_size=torch.tensor(b["sizes"]))
     params = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=True)
+    from nabladft_amd.trainer import FlatParameters
+    flat = None if a.per_tensor_optimizer else FlatParameters(params)
+    opt = torch.optim.Adam(params if flat is None else [flat.flat], lr=1e-3, amsgrad=True)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if flat is None:
+            opt.zero_grad(set_to_none=True)
+        else:
+            flat.zero_grad()
         out = m(batch)
         loss = out["full_hamiltonian_packed"].abs().mean() + out["overlap_matrix_packed"].abs().mean()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        if flat is None:
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+        else:
+            flat.clip_grad_norm_(1.0)
         opt.step()
         return loss
     for _ in range(a.warmup):
