@@ -41,8 +41,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--molecules", type=int, default=2)
     ap.add_argument("--atoms", type=int, default=42)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event table (nq profile hooks)")
     ap.add_argument("--per-tensor-optimizer", action="store_true", help="torch Adam over the 2.4 k parameter tensors instead of the flat buffer")
     a = ap.parse_args()
