@@ -116,7 +116,8 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
         ach = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = pmc_traffic_bytes(prefix, batch)
         return {"kernel": f"{prefix}, {F // 64}>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+                "traffic": traffic, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,   # measured HBM bytes per second of the launch
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
     if dom.startswith("gemm"):
         flops = gemm_flops(dom, n_atoms, E, launches)
         ach = flops / (avg_ms * 1e-3) / 1e12
