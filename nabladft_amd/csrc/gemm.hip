@@ -234,6 +234,9 @@ static void launch_gemm(hipStream_t st, dim3 grid, const GemmArgs& p) {
   // latency-bound regime (few workgroups, e.g. batch_size 32): nothing else hides the global-load latency of the serial
   // K loop, so the register-prefetch form pays there (it is neutral-to-slightly-negative on full grids)
   if (variant == 1 && (long)grid.x * grid.y * grid.z < 512) variant = 3;
+  // row-major-A layouts (forward, input gradient): the prefetch form also wins on full grids since the input-gradient launches use 16-deep
+  // tiles (+14 % on the U / 2x shapes, +3-5 % forward); the weight-gradient layout (A_KC = false) loses 15 % with it and stays on variant 1
+  if (variant == 1 && A_KC) variant = 3;
   switch (variant) {
     case 0: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 4, false, BKT>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, 8, false, BKT>), grid, dim3(512), 0, st, p); break;
