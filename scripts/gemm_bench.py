@@ -56,7 +56,7 @@ for kind, shapes in (("nt", shapes_nt), ("nn", shapes_nn), ("tn", shapes_tn)):
             got = lambda: out
         flops = 2.0 * M * Nn * K
         line = f"{name:12s} M={M:8d} n={Nn:4d} k={K:4d} "
-        for v in (1, 3, 5, 7):
+        for v in range(4):
             lib.nq_set_gemm_variant(v)
             if kind == "nn":
                 Cc.zero_()
