@@ -224,7 +224,97 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
     }
 }
 
-// process-global kernel variant (tuning / A-B measurements): bit0 = 8 waves per tile, bit1 = register prefetch
+// ---- small problems (few 128x128 tiles: batch sizes of 32-256 conformers, PhiSNet's per-order layers) -----------------------------------------
+// Same contraction on 64x64x32 tiles with 256 threads (2x2 wavefronts, one 32x32 MFMA accumulator each): four times the workgroups, a quarter of
+// the MFMA work per k-tile and workgroup, so the serial K loop is bound by the (prefetched) global-load latency only.  Row-major A (NT / NN).
+#define SM 64
+#define SLDS_KC (SM + 1)
+#define SLDS_MC (SM + 4)
+template <bool KC>
+__device__ __forceinline__ void fetch_small(float4 (&v)[2], const float* __restrict__ src, int ld, int r0, int R, int k0, int Kend, bool vec_ok) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = threadIdx.x + 256 * it;     // 512 float4 = 64 x 32 floats
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row = KC ? idx >> 3 : (idx & 15) * 4, kq = KC ? (idx & 7) * 4 : idx >> 4;   // KC: (row, 4 k's); MC: (k, 4 cols)
+    const int gr = r0 + row, gk = k0 + kq;
+    if (KC) {
+      if (gr < R) {
+        const float* ptr = src + (long)gr * ld + gk;
+        if (vec_ok && gk + 3 < Kend) x = *reinterpret_cast<const float4*>(ptr);
+        else { if (gk < Kend) x.x = ptr[0]; if (gk + 1 < Kend) x.y = ptr[1]; if (gk + 2 < Kend) x.z = ptr[2]; if (gk + 3 < Kend) x.w = ptr[3]; }
+      }
+    } else if (gk < Kend) {
+      const float* ptr = src + (long)gk * ld + gr;
+      if (vec_ok && gr + 3 < R) x = *reinterpret_cast<const float4*>(ptr);
+      else { if (gr < R) x.x = ptr[0]; if (gr + 1 < R) x.y = ptr[1]; if (gr + 2 < R) x.z = ptr[2]; if (gr + 3 < R) x.w = ptr[3]; }
+    }
+    v[it] = x;
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void stash_small(float* __restrict__ tile, const float4 (&v)[2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    if (KC) {
+      const int row = idx >> 3, kq = (idx & 7) * 4;
+      tile[(kq + 0) * SLDS_KC + row] = v[it].x; tile[(kq + 1) * SLDS_KC + row] = v[it].y;
+      tile[(kq + 2) * SLDS_KC + row] = v[it].z; tile[(kq + 3) * SLDS_KC + row] = v[it].w;
+    } else {
+      *reinterpret_cast<float4*>(tile + (idx >> 4) * SLDS_MC + (idx & 15) * 4) = v[it];
+    }
+  }
+}
+template <bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void k_gemm_small(GemmArgs p) {
+  constexpr int LDB_S = B_KC ? SLDS_KC : SLDS_MC;
+  __shared__ __attribute__((aligned(16))) float As[32 * SLDS_KC];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * LDB_S];
+  const int m0 = blockIdx.x * SM, n0 = blockIdx.y * SM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lk = lane >> 5;
+  const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+  const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[2], rb[2];
+  fetch_small<true>(ra, p.A, p.lda, m0, p.M, 0, p.K, a_vec);
+  fetch_small<B_KC>(rb, p.B, p.ldb, n0, p.N, 0, p.K, b_vec);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    stash_small<true>(As, ra);
+    stash_small<B_KC>(Bs, rb);
+    __syncthreads();
+    if (k0 + 32 < p.K) {   // next k-tile's global loads complete under the MFMAs below
+      fetch_small<true>(ra, p.A, p.lda, m0, p.M, k0 + 32, p.K, a_vec);
+      fetch_small<B_KC>(rb, p.B, p.ldb, n0, p.N, k0 + 32, p.K, b_vec);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = As[(kk + lk) * SLDS_KC + wm * 32 + lr];
+      const float b = Bs[(kk + lk) * LDB_S + wn * 32 + lr];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn * 32 + lr;
+  if (col >= p.N) return;
+  const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (row >= p.M) continue;
+    const long off = (long)row * p.ldc + col;
+    const float v = acc[r] + bv;
+    if (EPI == EPI_ACC) p.C[off] += v; else p.C[off] = v;
+    if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
+  }
+}
+// fewer than one 128x128 tile per CU -> the small-tile kernel
+static bool gemm_is_small(int M, int N) { return (long)nq_cdiv(M, BM) * nq_cdiv(N, BN) < 256; }
+
+// process-global kernel variant (tuning / A-B measurements): bit0 = 8 waves per tile, bit1 = register prefetch, bit3 = never use the small-tile kernel
 static int g_gemm_variant = 1;  // measured best on MI355X (scripts/gemm_bench.py): 8 wavefronts per tile, no prefetch
 extern "C" void nq_set_gemm_variant(int32_t v) { g_gemm_variant = v; }
 
@@ -288,6 +378,13 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
+    dim3 gs(nq_cdiv(M, SM), nq_cdiv(N, SM), 1);
+    if (C2_silu) hipLaunchKernelGGL((k_gemm_small<true, EPI_SILU>), gs, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_small<true, EPI_STORE>), gs, dim3(256), 0, st, p);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
   if (C2_silu) launch_gemm<true, true, EPI_SILU>(st, grid, p);
   else launch_gemm<true, true, EPI_STORE>(st, grid, p);
@@ -302,6 +399,13 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm_is_small(M, Kin) && !(g_gemm_variant & 8)) {
+    dim3 gs(nq_cdiv(M, SM), nq_cdiv(Kin, SM), 1);
+    if (accumulate) hipLaunchKernelGGL((k_gemm_small<false, EPI_ACC>), gs, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_small<false, EPI_STORE>), gs, dim3(256), 0, st, p);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
   if (accumulate) launch_gemm<true, false, EPI_ACC, 16>(st, grid, p);
   else launch_gemm<true, false, EPI_STORE, 16>(st, grid, p);

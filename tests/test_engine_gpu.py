@@ -79,7 +79,8 @@ def test_library_is_loaded_native():
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 100), (1000, 128, 128), (257, 64, 128), (129, 384, 20), (4096, 256, 128), (77, 128, 256),
-                                   (500, 1, 64), (501, 2, 64), (333, 64, 64), (1000, 3, 128)])
+                                   (500, 1, 64), (501, 2, 64), (333, 64, 64), (1000, 3, 128),
+                                   (40000, 256, 128), (33100, 128, 100), (16500, 384, 128)])      # >= 256 tiles of 128x128: the large-tile kernels
 def test_gemm_forward_and_grads(M, N, K):
     from nabladft_amd import _lib
     lib, dev = _lib.load(), _dev()
