@@ -392,24 +392,26 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
 #endif
 #define FUSED_ROWS(KIND)                                                                        \
   constexpr bool claim__ = ((NQ_CLAIM_KINDS >> (KIND)) & 1) != 0;                               \
+  const bool dyn__ = claim__ && fa.row_ctr != nullptr;   /* null counter pointer (small batches): static striding */ \
   constexpr int crows__ = claim__ ? NQ_CLAIM_ROWS : 1;                                          \
   constexpr int cgmax__ = ((KIND) == 3) ? NQ_CLAIM_GROUPS_DUAL : NQ_CLAIM_GROUPS;               \
   const int cgrp__ = max(1, min(cgmax__, (int)(gridDim.x / nxcd / nslices)));   /* every group needs a workgroup of its own on the XCD */ \
   const int grp__ = wg % cgrp__;                                                                \
   const int sub__ = (n_hi - x_lo + cgrp__ - 1) / cgrp__;                                        \
-  const int s_lo__ = claim__ ? x_lo + grp__ * sub__ : x_lo;                                     \
-  const int s_hi__ = claim__ ? min(n_hi, s_lo__ + sub__) : n_hi;                                \
-  int* const ctr__ = claim__ ? fa.row_ctr + (((int)(blockIdx.x % nxcd) * nslices + slice) * cgmax__ + grp__) * NQ_ROWCTR_PAD : nullptr; \
+  const int s_lo__ = dyn__ ? x_lo + grp__ * sub__ : x_lo;                                       \
+  const int s_hi__ = dyn__ ? min(n_hi, s_lo__ + sub__) : n_hi;                                  \
+  int* const ctr__ = dyn__ ? fa.row_ctr + (((int)(blockIdx.x % nxcd) * nslices + slice) * cgmax__ + grp__) * NQ_ROWCTR_PAD : nullptr; \
   int n_static__ = x_lo + wg * nslots + slot;                                                   \
   auto claim_rows = [&]() __attribute__((always_inline)) -> int {                               \
-    if constexpr (claim__) {                                                                    \
+    if (dyn__) {                                                                                \
       int v__ = 0;                                                                              \
       if (lane == 0) v__ = __hip_atomic_fetch_add(ctr__, crows__, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
       return s_lo__ + __builtin_amdgcn_readfirstlane(v__);                                      \
-    } else { const int v__ = n_static__; n_static__ += n_step; return v__; }                    \
+    }                                                                                           \
+    const int v__ = n_static__; n_static__ += n_step; return v__;                               \
   };                                                                                            \
   for (int blk__ = claim_rows(), nxt__ = claim_rows(); blk__ < s_hi__; blk__ = nxt__, nxt__ = claim_rows()) \
-    for (int n = blk__; n < min(blk__ + crows__, s_hi__); ++n)
+    for (int n = blk__; n < min(blk__ + (dyn__ ? crows__ : 1), s_hi__); ++n)
 
 // One wavefront per atom; lane l owns channels [l*CH, (l+1)*CH) of each part (F = 64*CH).
 #define FUSED_PROLOGUE                                                                          \
