@@ -353,11 +353,11 @@ __global__ void k_reduce_partials(const float* __restrict__ part, int nsplit, lo
 // workgroup (coalesced 256-B row segments, 4 independent accumulators per thread), lanes combined through LDS;
 // the per-chunk partials are then summed in fixed order by k_reduce_partials -> deterministic.
 #define CS_ROWS 2048
-__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ A, long rows, int cols, int lda, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ A, long rows, int cols, int lda, float* __restrict__ part, int cs_rows) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  const long r0 = (long)blockIdx.y * cs_rows, r1 = min(rows, r0 + cs_rows);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < cols) {
     long r = r0 + rl;
@@ -455,7 +455,10 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   return NQ_OK;
 }
 
-size_t nq_colsum_scratch_floats(long rows, int cols) { return (size_t)nq_cdiv(rows, CS_ROWS) * cols; }
+// rows per workgroup: 2048 for large inputs, shorter chunks (more workgroups, shorter serial loops) for small ones; multiple of 16
+static int cs_rows_for(long rows) { long c = (rows + 127) / 128; c = (c + 15) / 16 * 16; return (int)(c < 64 ? 64 : (c > CS_ROWS ? CS_ROWS : c)); }
+// (the chunk count is not monotonic in `rows` below 128 chunks: callers size one scratch for several row counts, so never report fewer than 128)
+size_t nq_colsum_scratch_floats(long rows, int cols) { const long c = nq_cdiv(rows, cs_rows_for(rows)); return (size_t)(c < 128 ? 128 : c) * cols; }
 
 int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, float* out, float* scratch) {
   NQ_PROF(st, "colsum");
@@ -463,8 +466,8 @@ int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, floa
     NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
     return NQ_OK;
   }
-  const int chunks = nq_cdiv(rows, CS_ROWS);
-  hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(256), 0, st, A, rows, cols, lda, scratch);
+  const int csr = cs_rows_for(rows), chunks = nq_cdiv(rows, csr);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(256), 0, st, A, rows, cols, lda, scratch, csr);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cols, 256)), dim3(256), 0, st, scratch, chunks, (long)cols, (long)cols, out);
   NQ_LAUNCH_CHECK();

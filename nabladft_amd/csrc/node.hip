@@ -379,14 +379,16 @@ int nq_embed(hipStream_t st, const int* z, const float* emb, int N, int F, float
   return NQ_OK;
 }
 #define EMB_CHUNK 512
-size_t nq_embed_grad_scratch_floats(int N, int F, int T) { return (size_t)nq_cdiv(N, EMB_CHUNK) * T * F; }
+// atoms per workgroup: 512 for large batches; small batches get more, shorter chunks (the per-atom LDS update chain is serial)
+static int emb_chunk(int N) { const int c = nq_cdiv(N, 256); return c < 32 ? 32 : (c > EMB_CHUNK ? EMB_CHUNK : c); }
+size_t nq_embed_grad_scratch_floats(int N, int F, int T) { return (size_t)nq_cdiv(N, emb_chunk(N)) * T * F; }
 int nq_embed_grad(hipStream_t st, const int* z, const float* GX, int N, int F, int T, float* out, float* scratch) {
   NQ_PROF(st, "embed_grad");
-  const int chunks = nq_cdiv(N, EMB_CHUNK);
+  const int chunk = emb_chunk(N), chunks = nq_cdiv(N, chunk);
   const size_t lds = (size_t)T * F * sizeof(float);
   if (lds > 160 * 1024) return nq_fail(NQ_ERR_ARG, "embed_grad: num_elements*F too large for LDS (%zu B)", lds);
   { static size_t set__ = 0; if (lds > set__) { NQ_HIP(hipFuncSetAttribute((const void*)k_embed_grad_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set__ = lds; } }
-  hipLaunchKernelGGL(k_embed_grad_partial, dim3(chunks), dim3(F), lds, st, z, GX, N, F, T, EMB_CHUNK, scratch);
+  hipLaunchKernelGGL(k_embed_grad_partial, dim3(chunks), dim3(F), lds, st, z, GX, N, F, T, chunk, scratch);
   NQ_LAUNCH_CHECK();
   return nq_reduce_partials(st, scratch, chunks, (long)T * F, (long)T * F, out);
 }
