@@ -416,9 +416,12 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 // out[Mo, No] = sum_{r<rows} GY[r, Mo] * X[r, No];  scratch must hold nq_gemm_tn_scratch_floats()
 // Split count for the weight-gradient contraction: enough workgroups to fill 256 CUs (~768) given the number
 // of 128x128 output tiles, but at least 512 rows per split so the 64-KB partial slab stays amortised.
+#ifndef NQ_TN_TARGET
+#define NQ_TN_TARGET 768   // workgroups aimed at by the row split (512: U, V1 -5..-7 %, W2, V2 +7..+10 %: no net gain)
+#endif
 static int tn_splits(long rows, int Mo, int No) {
   const long tiles = (long)nq_cdiv(Mo, BM) * nq_cdiv(No, BN);
-  long s = (768 + tiles - 1) / tiles;
+  long s = (NQ_TN_TARGET + tiles - 1) / tiles;
   const long by_rows = (rows + 127) / 128;   // >= 128 rows (4 k-tiles) per split
   if (s > by_rows) s = by_rows;
   if (s < 1) s = 1;
