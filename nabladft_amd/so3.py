@@ -81,6 +81,47 @@ class _MixFn(torch.autograd.Function):
         return gx1, gx2, gc, gk, None
 
 
+class _MixFlatFn(torch.autograd.Function):
+    """SelfMixing whose coefficients live side by side in a flat parameter buffer (trainer.FlatParameters.attach): they are read as one block and
+    their gradient block is added to the flat gradient buffer with ONE kernel in backward (instead of a stack + one accumulation per tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        lib = _lib.load()
+        flat, off, n_mix, n_keep = mod._flat
+        F = mod.num_features
+        block = flat.flat.data[off:off + (n_mix + n_keep) * F].view(n_mix + n_keep, F)
+        coeff = (block[:n_mix] * mod._sign).contiguous() if n_mix else x.new_zeros(1, F)
+        keep = block[n_mix:]
+        rows = x.shape[0]
+        y = torch.empty(rows, (mod.order_out + 1) ** 2, F, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_so3_mix_forward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), rows, F, mod.order_in, mod.order_in, mod.order_out,
+                                          mod._pidx, 0, n_keep, _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(x, coeff, keep)
+        ctx.mod = mod
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, coeff, keep = ctx.saved_tensors
+        mod = ctx.mod
+        flat, off, n_mix, n_keep = mod._flat
+        rows, _, F = x.shape
+        gy = gy.to(torch.float32).contiguous()
+        n_en = coeff.shape[0]
+        gx1, gx2 = torch.empty_like(x), torch.empty_like(x)
+        gc_c = torch.empty(rows, n_en, F, device=x.device, dtype=torch.float32)
+        gk_c = torch.empty(rows, n_keep, F, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, mod.order_in, mod.order_in,
+                                           mod.order_out, mod._pidx, 0, n_keep, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_c), _lib.ptr(gk_c), _lib.stream_ptr()))
+        gblock = flat.flat.grad[off:off + (n_mix + n_keep) * F].view(n_mix + n_keep, F)
+        if n_mix:
+            gblock[:n_mix].addcmul_(gc_c.sum(0), mod._sign)
+        gblock[n_mix:].add_(gk_c.sum(0))
+        return gx1 + gx2, None
+
+
 class PackedList:
     """The reference's list-of-orders representation ``[x_0 [..., 1, F], x_1 [..., 3, F], ...]`` backed by ONE packed tensor
     ``packed [rows, (order+1)^2, F]`` -- what the kernels read and write.  Elements are views created on access.  Modules hand the object
@@ -220,10 +261,23 @@ class SelfMixing(nn.Module):
     def mixcoeff(self, l1, l2, L):
         return getattr(self, "mixcoeff_{}_{}_{}".format(l1, l2, L))
 
+    _flat = None
+
+    def _use_flat_parameters(self, flat):
+        """trainer.FlatParameters.attach: switch to the block form if the coefficient vectors are contiguous in the flat buffer."""
+        ps = [self.mixcoeff(*p) for p in self._paths] + [self.keepcoeff(L) for L in range(self._keep)]
+        blk = flat.block_of(ps)
+        if blk is None or blk[1] != len(ps) * self.num_features:
+            return False
+        self._flat = (flat, blk[0], len(self._paths), self._keep)
+        return True
+
     def forward(self, xs):
         _require_gpu(xs[0])
         F = self.num_features
         x, lead = _pack(xs, self.order_in, F)
+        if self._flat is not None and torch.is_grad_enabled() and x.requires_grad:
+            return _unpack(_MixFlatFn.apply(x, self), self.order_out, lead, F)
         if self._paths:
             coeff = torch.stack([self.mixcoeff(*p) for p in self._paths]) * self._sign                 # [n_paths, F]
         else:

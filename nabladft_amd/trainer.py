@@ -155,6 +155,7 @@ class FlatParameters:
         dev = self.params[0].device
         self.flat = torch.nn.Parameter(torch.empty(n, device=dev, dtype=torch.float32))
         self.flat.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.offset = {}
         o = 0
         with torch.no_grad():
             for p in self.params:
@@ -162,7 +163,30 @@ class FlatParameters:
                 self.flat.data[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.flat.data[o:o + k].view(p.shape)
                 p.grad = self.flat.grad[o:o + k].view(p.shape)          # autograd accumulates into the view in place
+                self.offset[id(p)] = o
                 o += k
+
+    def attach(self, model):
+        """Optional: modules that keep MANY small parameter tensors side by side (``so3.SelfMixing``: one [F] vector per Clebsch-Gordan path)
+        read them as one block of the flat buffer and add their gradient block with one kernel instead of one per tensor (``block_of``).
+        Returns the number of modules switched over."""
+        n = 0
+        for m in model.modules():
+            hook = getattr(m, "_use_flat_parameters", None)
+            if hook is not None and hook(self):
+                n += 1
+        return n
+
+    def block_of(self, params):
+        """(offset, numel) of a run of parameters if they are trainable and contiguous in the flat buffer in this order, else None."""
+        if not params or any(id(p) not in self.offset for p in params):
+            return None
+        o0 = o = self.offset[id(params[0])]
+        for p in params:
+            if self.offset[id(p)] != o:
+                return None
+            o += p.numel()
+        return o0, o - o0
 
     def zero_grad(self):
         self.flat.grad.zero_()

@@ -64,6 +64,8 @@ def main():
     params = [p for p in m.parameters() if p.requires_grad]
     from nabladft_amd.trainer import FlatParameters
     flat = None if a.per_tensor_optimizer else FlatParameters(params)
+    if flat is not None:
+        flat.attach(m)
     opt = torch.optim.Adam(params if flat is None else [flat.flat], lr=1e-3, amsgrad=True)
 
     def step():

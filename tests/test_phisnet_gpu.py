@@ -159,3 +159,33 @@ def test_training_from_hamiltonian_database():
     dense = m._assembler.to_dense(out["plan"], out["full_hamiltonian_packed"].detach())
     assert torch.equal(dense, out["full_hamiltonian"][0])
     assert float((out["full_hamiltonian"][0] * (1 - batch["mask"])).abs().max()) == 0.0          # nothing outside the molecules' blocks
+
+
+def test_neural_network_with_flat_parameters_matches_reference():
+    """Same golden comparison with the parameters in flat buffers and the SelfMixing coefficient blocks attached (trainer.FlatParameters.attach):
+    the gradients land in the flat gradient buffer."""
+    from nabladft_amd.trainer import FlatParameters
+    fx = np.load(os.path.join(GOLDEN, "phisnet_network.npz"))
+    m, shells = _network_from_fixture(fx)
+    flat = FlatParameters(m.parameters())
+    assert flat.attach(m) > 20
+    zs = fx["z"]
+    batch = dict(positions=torch.tensor(fx["positions"]).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(zs).cuda(),
+                 orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs], molecule_size=torch.tensor(fx["sizes"]))
+    m.predict_energy = True
+    for _ in range(2):                                   # twice: zero_grad really clears the flat gradient buffer
+        flat.zero_grad()
+        out = m(batch)
+        plan, asm = out["plan"], m._assembler
+        loss = (out["energy"] * torch.tensor(fx["w_energy"]).cuda()).sum()
+        for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
+            assert rel_err(out[k][0].cpu().numpy(), fx[k]) < TOL, k
+            loss = loss + (out[k + "_packed"] * asm.from_dense(plan, torch.tensor(fx["w_" + k]).cuda())).sum()
+        loss.backward()
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = fx["g:" + n]
+        assert p.grad.data_ptr() >= flat.flat.grad.data_ptr()           # still a view of the flat gradient buffer
+        scale = max(float(np.abs(ref).max()), 1e-3)
+        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale < 5e-4, n
