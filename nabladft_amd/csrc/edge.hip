@@ -1,11 +1,13 @@
 // Edge-level kernels of the PaiNN interaction block (reference: painn.py:475-509 PaiNNMessage,
 // layers.py:14-33,129-185 RadialBasis; math restated in oracle/painn_sweeps.py).
 //
-// All message kernels are node-centric over the symmetric CSR built by graph.hip: one workgroup
-// per atom, one thread per feature channel (blockDim.x == F), looping over the atom's CSR row in
-// ascending neighbour order.  The segment reduction therefore needs no atomics and its summation
-// order equals the reference's sequential scatter_add order.  In the reverse sweeps the same row
-// is read as the atom's OUT-edges (n -> k): phi/psi/d are symmetric, r and t_r change sign.
+// All message kernels are node-centric over the symmetric CSR built by graph.hip: the row of one atom is owned by
+// one workgroup (materialised-filter kernels k_msg_*: one thread per feature channel) or one wavefront (fused-filter
+// kernels k_msgf_*: CH = F/64 channels per lane), which loops over the atom's CSR row in ascending neighbour order.
+// The segment reduction therefore needs no atomics and its summation order equals the reference's sequential
+// scatter_add order.  In the reverse sweeps the same row is read as the atom's OUT-edges (n -> k): phi/psi/d are
+// symmetric, r and t_r change sign.  Which wavefront computes a row (rows are claimed from counters on large batches)
+// never changes the row's result.
 #include "common.h"
 #include <type_traits>
 #include "lanes.h"
@@ -255,7 +257,7 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 #define FUSED_THREADS 1024
 // measured (profiles/r01_fused_tuning.txt): any VGPR spill in these loops costs 1.3-2x, so the two register-hungry flavours trade waves for registers
 #ifndef NQ_DUAL2_THREADS
-#define NQ_DUAL2_THREADS 512    // dual reverse, 2 channels/lane: 251 VGPRs, no spill (768 threads: 31 spilled VGPRs, 8.3 ms vs 5.5-6.4 ms per step)
+#define NQ_DUAL2_THREADS 512    // dual reverse, 2 channels/lane: at the 256-VGPR limit (768 threads: 31 spilled VGPRs, 8.3 ms vs 5.5-6.4 ms per step; 384: +15 %)
 #endif
 #ifndef NQ_TAN2_THREADS
 #define NQ_TAN2_THREADS 768     // tangent, 2 channels/lane: 148 VGPRs (1024 threads: 26 spilled, 7.3 ms vs 3.35 ms per step)
