@@ -56,3 +56,28 @@ def test_mixing_mirrors_have_the_reference_parameter_surface():
         sm([torch.zeros(1, 2, 2 * l + 1, 64) for l in range(5)])
     with pytest.raises(NotImplementedError):
         so3.PairMixing(5, 4, 4, 8, 64, table)
+
+
+def test_packed_list_behaves_like_the_reference_lists():
+    """so3.PackedList: list-of-orders views of one packed tensor (host logic only, CPU tensors)."""
+    import torch
+    from nabladft_amd.so3 import PackedList, _pack, _unpack
+    order, F, rows = 2, 4, 5
+    packed = torch.arange(rows * 9 * F, dtype=torch.float32).view(rows, 9, F)
+    xs = _unpack(packed, order, (1, rows), F)
+    assert isinstance(xs, PackedList) and len(xs) == 3
+    assert [tuple(x.shape) for x in xs] == [(1, rows, 1, F), (1, rows, 3, F), (1, rows, 5, F)]
+    assert torch.equal(xs[1][0, :, 0, :], packed[:, 1, :]) and torch.equal(xs[-1][0], packed[:, 4:9, :])
+    assert xs[0].data_ptr() == packed.data_ptr()                                   # views, not copies
+    p2, lead = _pack(xs, order, F)
+    assert p2 is packed and lead == (1, rows)                                      # the packed tensor is handed on as is
+    ys = list(xs)                                                                  # the reference's ``list(xs)`` idiom: a plain list of the views
+    assert type(ys) is list and len(ys) == 3
+    assert len(xs + xs) == 6 and type(xs + xs) is list                             # list concatenation
+    xs[0] = xs[0] * 2                                                              # replacing an element drops the shortcut, the list stays usable
+    assert xs.packed is None and torch.equal(xs[0], packed[:, :1, :].view(1, rows, 1, F) * 2)
+    p3, _ = _pack(xs, order, F)
+    assert torch.equal(p3[:, 0, :], packed[:, 0, :] * 2) and torch.equal(p3[:, 1:, :], packed[:, 1:, :])
+    # a different order / width is never short-cut
+    zs = _unpack(packed, order, (1, rows), F)
+    assert _pack(zs[:2], 1, F)[0].shape == (rows, 4, F)
