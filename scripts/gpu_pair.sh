@@ -10,7 +10,7 @@ import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('bench', round(d['value']), round(d['ms_per_step'],2), 'dual avg ms', round(r['avg_launch_ms'],4))
 "
-f=$(find gpurun_out/prof_pair -name "*kernel_stats*.csv" | head -1); grep "k_msgf_rev<true" $f | cut -d, -f1-4 | cut -c1-120
+f=$(find gpurun_out/prof_pair -name "*kernel_stats*.csv" | head -1); grep "k_msgf_rev<true" $f | cut -c1-140
 tail -1 gpurun_out/rocprof_pair.log | python -c "
 import json,sys
 try:
