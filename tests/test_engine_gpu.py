@@ -514,7 +514,7 @@ def test_engine_direct_forces_match_reference():
     assert torch.equal(e2, energy.detach()) and torch.equal(f2, forces.detach())
 
 
-@pytest.mark.parametrize("n_conf", [1, 2, 3, 5, 9, 17, 40])
+@pytest.mark.parametrize("n_conf", [1, 2, 3, 5, 9, 17, 40, 300])   # 300: > 4096 atoms -> rows claimed from counters
 def test_every_row_is_processed_at_any_grid_size(n_conf):
     """Row claiming (edge.hip FUSED_ROWS): whatever the number of workgroups per XCD, every atom row is computed exactly once --
     energies, forces and all parameter gradients of small batches against the CPU oracle."""
