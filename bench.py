@@ -305,11 +305,15 @@ def main():
     n_edges = model._last_nl.E
 
     roofline, kernels = None, None
-    if rank == 0 and not args.no_roofline:
-        # second, instrumented pass over the same steps: HIP events around every launch, on the launch stream
-        _lib.profile_enable(True)
+    if not args.no_roofline:
+        # second, instrumented pass over the same steps: HIP events around every launch, on the launch stream.  EVERY rank runs the steps
+        # (a step contains the gradient all-reduce: a rank-0-only pass would deadlock the other ranks); only rank 0 records events.
+        if rank == 0:
+            _lib.profile_enable(True)
         for i in range(args.steps):
             step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         prof = _lib.profile_read()
         _lib.profile_enable(False)
         tot = sum(v[0] for v in prof.values())
