@@ -75,3 +75,28 @@ def test_shard_by_cost_balanced_and_complete():
         load = [sum(sizes[i] ** 2 for i in s) for s in shards]
         assert max(load) <= 1.05 * (sum(load) / world) + 90 * 90
         assert all(s == sorted(s) for s in shards)
+
+
+def test_bench_never_calls_a_training_step_on_one_rank_only():
+    """bench.py: a training step contains the gradient all-reduce, so inside main() every call of step()/step2() must be reached by ALL
+    ranks or be guarded by ``world == 1`` (a rank-0-only instrumented pass once deadlocked every multi-GPU run)."""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "main")
+    parents = {}
+    for node in ast.walk(main):
+        for child in ast.iter_child_nodes(node):
+            parents[child] = node
+    calls = [n for n in ast.walk(main) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in ("step", "step2")]
+    assert len(calls) >= 4
+    for call in calls:
+        conds, node = [], call
+        while node in parents:
+            parent = parents[node]
+            if isinstance(parent, ast.If) and node in parent.body:
+                conds.append(ast.unparse(parent.test))
+            node = parent
+        gated = [c for c in conds if "rank == 0" in c]
+        assert all("world == 1" in c for c in gated), (call.lineno, conds)
