@@ -10,7 +10,7 @@ Public surface mirrors the reference plugin classes for this path:
 from .painn import PaiNN, NeighborList, build_neighbor_list  # noqa: F401
 from .lightning import PaiNNLightning, L2Loss  # noqa: F401
 from .trainer import FusedTrainStep, Batch  # noqa: F401
-from .data import ArenaLoader, ConformerArena, HamiltonianDatabase, HamiltonianDataset, read_energy_database  # noqa: F401
+from .data import ArenaLoader, ConformerArena, HamiltonianBatch, HamiltonianDatabase, HamiltonianDataset, hamiltonian_batch, read_energy_database  # noqa: F401
 
 __all__ = ["PaiNN", "PaiNNLightning", "L2Loss", "FusedTrainStep", "Batch", "build_neighbor_list", "NeighborList", "ArenaLoader", "ConformerArena",
-           "read_energy_database", "HamiltonianDatabase", "HamiltonianDataset"]
+           "read_energy_database", "HamiltonianDatabase", "HamiltonianDataset", "HamiltonianBatch", "hamiltonian_batch"]

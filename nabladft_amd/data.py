@@ -385,3 +385,32 @@ class HamiltonianDataset(torch.utils.data.Dataset):
         if return_filtered:
             out["filtered"] = batch[len(Z):]
         return out
+
+
+class HamiltonianBatch(Batch):
+    """PyG batch of ``PyGHamiltonianNablaDFT`` items (nablaDFT/dataset/pyg_datasets.py:198-222 + Batch.from_data_list): tensors concatenated,
+    ``y`` one energy per molecule, the matrices as LISTS of per-molecule numpy arrays (what PyG's collate does with non-tensor attributes and
+    what ``QHNetLightning.step`` consumes, qhnet/qhnet.py:366-377; ``hamiltonian.BlockAssembler.pack_targets`` packs them for the HIP loss)."""
+
+    def __init__(self, pos, z, batch, y, forces, ptr, hamiltonian, overlap=None, core=None):
+        super().__init__(pos, z, batch, y, forces, ptr)
+        self.hamiltonian, self.overlap, self.core = hamiltonian, overlap, core
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return HamiltonianBatch(mv(self.pos), mv(self.z), mv(self.batch), mv(self.y), mv(self.forces), mv(self.ptr), self.hamiltonian, self.overlap, self.core)
+
+
+def hamiltonian_batch(db: HamiltonianDatabase, indices: Sequence[int], include_overlap: bool = False, include_core: bool = False,
+                      dtype=torch.float32) -> HamiltonianBatch:
+    """Rows ``indices`` of a Hamiltonian database as one batch, in the given order (one batched query; the reference dataset reads row by row)."""
+    idx = [int(i) for i in indices]
+    by_id = dict(zip(sorted(idx), db[sorted(idx)]))
+    rows = [by_id[i] for i in idx]
+    sizes = torch.tensor([len(r[0]) for r in rows], dtype=torch.long)
+    ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+    return HamiltonianBatch(
+        pos=torch.cat([torch.tensor(r[1].copy()).to(dtype) for r in rows]), z=torch.cat([torch.tensor(r[0].copy()).long() for r in rows]),
+        batch=torch.repeat_interleave(torch.arange(len(rows)), sizes), y=torch.cat([torch.from_numpy(r[2].copy()).to(dtype) for r in rows]),
+        forces=torch.cat([torch.from_numpy(r[3].copy()).to(dtype) for r in rows]), ptr=ptr, hamiltonian=[r[4].copy() for r in rows],
+        overlap=[r[5].copy() for r in rows] if include_overlap else None, core=[r[6].copy() for r in rows] if include_core else None)

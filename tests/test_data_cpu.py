@@ -158,3 +158,27 @@ def test_hamiltonian_database_write_read_roundtrip(tmp_path):
     Z, R, E, F, Hh, S, C, mid, cid = rd[0]
     assert Z.dtype == np.int32 and Hh.dtype == np.float32 and np.array_equal(Hh, H.astype(np.float32)) and np.array_equal(C, (H * 3).astype(np.float32))
     assert E[0] == np.float32(-1.25) and (mid, cid) == (5, 9) and list(rd.get_orbitals(1)) == [0, 0, 1]
+
+
+def test_hamiltonian_batch_matches_the_database_rows():
+    """PyG-style batch for the QHNet side (pyg_datasets.py:198-222): concatenated tensors, matrices as per-molecule lists, any row order."""
+    from nabladft_amd.data import HamiltonianDatabase, hamiltonian_batch
+    path, fx = _hamdb()
+    db = HamiltonianDatabase(path)
+    order = [3, 0, 5]
+    b = hamiltonian_batch(db, order, include_overlap=True)
+    sizes = [len(fx[f"row{i}:Z"]) for i in order]
+    assert b.ptr.tolist() == [0] + list(np.cumsum(sizes)) and b.num_nodes == sum(sizes)
+    assert b.z.dtype == torch.long and b.pos.dtype == torch.float32 and b.y.shape == (3,)
+    o = 0
+    for j, i in enumerate(order):
+        n = sizes[j]
+        assert np.array_equal(b.z[o:o + n].numpy(), fx[f"row{i}:Z"]) and np.array_equal(b.pos[o:o + n].numpy(), fx[f"row{i}:R"])
+        assert np.array_equal(b.forces[o:o + n].numpy(), fx[f"row{i}:F"]) and float(b.y[j]) == float(fx[f"row{i}:E"][0])
+        assert np.array_equal(b.hamiltonian[j], fx[f"row{i}:H"]) and np.array_equal(b.overlap[j], fx[f"row{i}:S"])
+        assert (b.batch[o:o + n] == j).all()
+        o += n
+    assert b.core is None
+    # the list is what BlockAssembler.pack_targets flattens: per-molecule row-major blocks
+    flat = np.concatenate([h.reshape(-1) for h in b.hamiltonian])
+    assert flat.size == sum(h.shape[0] ** 2 for h in b.hamiltonian)
