@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 6
+#define NQ_ABI_VERSION 7
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -213,6 +213,53 @@ int nq_so3_mix_forward(const float* x1, const float* x2, const float* coeff, con
 int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, const float* keep, const float* grad_y, int64_t rows, int32_t F,
                         int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int64_t coeff_row_stride,
                         int32_t keep_orders, float* grad_x1, float* grad_x2, float* grad_coeff_rows, float* grad_keep_rows, void* stream);
+
+/* ---- QHNet SO(3) tensor-product layers (nablaDFT/qhnet/layers.py; e3nn 0.5.1 TensorProduct / Linear / Norm semantics restated in
+ *      oracle/e3nn_mini.py, PARITY UNPINNED for the e3nn part).  Irreps features are [rows][(lmax+1)^2][C], component l*l + m + l, channel
+ *      fastest.  Graph arrays (int32, device): row_ptr [N+1] CSR by owner atom = "src" = row 1 of the reference's edge_index (qhnet.py:262),
+ *      col [R] = "dst" = row 0 ascending, own [R] = owner of each slot, rev [R] = slot of the reverse edge (the neighbour relation is
+ *      symmetric).  path_index_host: HOST int8[65] as for nq_so3_mix_* (index of each (l1,l2,L) path among the enabled ones or -1);
+ *      path weights w1 (and optional second factor w2, multiplied in-kernel) are [R][n_enabled][C] and carry e3nn's sign and path
+ *      normalisation (folded in by the caller). ------------------------------------------------------------------------------------- */
+/* s0 [R][(2+lmax) C] = [x_0[dst] | x_0[dst] (conv, layers.py:240-246) or x_0[src] (pair, layers.py:469-475) | <x_l[dst], x_l[src]>/(2l+1)]
+ * = InnerProduct (layers.py:277-294) + the concatenations of ConvLayer.forward / PairNetLayer.forward. */
+int nq_qh_invariants_forward(const float* x, int64_t N, int32_t ncomp, int32_t C, const int32_t* own, const int32_t* col, int64_t R,
+                             int32_t second_from_owner, float* s0, void* stream);
+int nq_qh_invariants_backward(const float* x, const float* grad_s0, int64_t N, int32_t ncomp, int32_t C, const int32_t* row_ptr, const int32_t* col,
+                              const int32_t* rev, int32_t second_from_owner, float* grad_x, void* stream);
+/* ConvLayer message + scatter (layers.py:262-271; replaces e3nn TensorProduct 'uvu' + torch_scatter.scatter):
+ * out[n] = self_x[n] (nullable) + sum_{edges e with dst(e) = n} TP(x[src(e)], sh[e], w1[e] * w2[e]);  x [N][ncomp_in][C] with ncomp_in = 1
+ * (first layer: scalars) or 25;  sh [R][25] real spherical harmonics of pos[dst] - pos[src];  out [N][25][C]. */
+int nq_qh_conv_forward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* self_x, int64_t N, int32_t C,
+                       const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int8_t* path_index_host, float* out, void* stream);
+int nq_qh_conv_backward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* grad_out, int64_t N, int32_t C,
+                        const int32_t* row_ptr, const int32_t* col, const int8_t* path_index_host, int32_t add_self, float* grad_x, float* grad_w1,
+                        float* grad_w2, void* stream);
+/* PairNetLayer tensor product (layers.py:481-485; e3nn 'uuu' with per-pair weights): y[r] = TP(x[idx1[r]], x[idx2[r]], w1[r] * w2[r]);
+ * backward writes per-row operand adjoints [R][25][C] (reduce with nq_qh_pair_reduce) and the weight adjoints. */
+int nq_qh_pairmix_forward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, int64_t R, int32_t C,
+                          const int8_t* path_index_host, float* y, void* stream);
+int nq_qh_pairmix_backward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, const float* grad_y, int64_t R,
+                           int32_t C, const int8_t* path_index_host, float* grad_x1_rows, float* grad_x2_rows, float* grad_w1, float* grad_w2,
+                           void* stream);
+/* out[n][k] = sum_{r in row n} (rows_own[r][k] + rows_nbr[rev[r]][k]), k < width (either operand may be NULL = zeros): fixed order, no atomics. */
+int nq_qh_pair_reduce(const float* rows_own, const float* rows_nbr, const int32_t* row_ptr, const int32_t* rev, int64_t N, int32_t width, float* out,
+                      void* stream);
+/* NormGate pieces (layers.py:141-147; e3nn o3.Norm + ElementwiseTensorProduct): nq_qh_normcat: out [rows][(lmax+1) C] = [x_0 | ||x_1|| | ...]
+ * (grad_f0 == NULL) or the adjoint of x [rows][ncomp][C] given grad_f0;  nq_qh_gate: y = [gates_0 | x_l * gates_l] (grad_y == NULL) or
+ * (grad_x, grad_gates) given grad_y. */
+int nq_qh_normcat(const float* x, const float* grad_f0, int64_t rows, int32_t C, int32_t lmax, float* out, void* stream);
+int nq_qh_gate(const float* x, const float* gates, const float* grad_y, int64_t rows, int32_t C, int32_t lmax, float* y, float* grad_x, float* grad_gates,
+               void* stream);
+/* out = cst * act(x) (grad_y == NULL) or grad_y * cst * act'(x); kind 0 SiLU, 1 shifted softplus (layers.py:21-22). */
+int nq_qh_act(const float* x, const float* grad_y, int32_t kind, float cst, int64_t count, float* out, void* stream);
+/* Expansion.forward (layers.py:598-662): x [R][25][Cb], weights [R][n_weights], bias [R][n_bias] (nullable) -> out [R][S][S];
+ * shells_host: HOST int32[3] = number of s, p, d shells of the padded block (S = s + 3p + 5d); w3j: device [19][5][5][9] real Wigner 3j
+ * tensors w3j(l1, l2, l_in)[i][j][k] in the instruction order of get_expansion_path (layers.py:664-671), zero padded. */
+int nq_qh_expansion_forward(const float* x, const float* weights, const float* bias, int64_t R, int32_t Cb, const int32_t* shells_host, int32_t n_weights,
+                            int32_t n_bias, const float* w3j, float* out, void* stream);
+int nq_qh_expansion_backward(const float* x, const float* weights, const float* grad_out, int64_t R, int32_t Cb, const int32_t* shells_host,
+                             int32_t n_weights, int32_t n_bias, const float* w3j, float* grad_x, float* grad_weights, float* grad_bias, void* stream);
 
 /* ---- geometry bases of the Hamiltonian models --------------------------------------------------------------------------------- */
 /* out [P][(order+1)^2]: real spherical harmonics Y_0..Y_order (order <= 4) of unit vectors [P][3], PhiSNet convention

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -65,6 +65,18 @@ SYMBOLS = {
     "nq_hamiltonian_loss": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P, _P]),
     "nq_so3_mix_forward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P]),
     "nq_so3_mix_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P]),
+    "nq_qh_invariants_forward": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _I32, _P, _P]),
+    "nq_qh_invariants_backward": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
+    "nq_qh_conv_forward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "nq_qh_conv_backward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
+    "nq_qh_pairmix_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "nq_qh_pairmix_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "nq_qh_pair_reduce": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_qh_normcat": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_qh_gate": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "nq_qh_act": (C.c_int, [_P, _P, _I32, _F, _I64, _P, _P]),
+    "nq_qh_expansion_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _P, _P]),
+    "nq_qh_expansion_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "nq_sph_harm": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "nq_bernstein_rbf": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),

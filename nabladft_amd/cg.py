@@ -90,3 +90,45 @@ def path_signs(table, which):
             raise ValueError(f"Clebsch-Gordan tensor ({l1},{l2},{L}) is not +-(unit-norm real 3j tensor in the m=-l..l Condon-Shortley basis)")
         signs.append(1.0 if ov > 0 else -1.0)
     return signs
+
+
+# ---- e3nn's convention (QHNet) ------------------------------------------------------------------------------------------------------------
+def _e3nn_real_to_complex(l):
+    """Change of basis q[complex m, real index] of e3nn 0.5.1 (o3._wigner.change_basis_real_to_complex; third-party, restated from the
+    published behaviour -- SURVEY.md Appendix A): the usual real <-> complex relation times (-i)^l, which makes every real-basis coupling
+    tensor real.  e3nn orders the real components m = -l..l with Y_1 = (x, y, z) of ITS input; QHNet feeds (y, z, x) (qhnet.py:268), so in
+    molecule coordinates the basis is the Condon-Shortley one of ``canonical`` and only a sign per (l1, l2, L) can differ."""
+    n = 2 * l + 1
+    q = np.zeros((n, n), dtype=complex)
+    for m in range(-l, 0):
+        q[l + m, l + abs(m)] = 1 / sqrt(2)
+        q[l + m, l - abs(m)] = -1j / sqrt(2)
+    q[l, l] = 1
+    for m in range(1, l + 1):
+        q[l + m, l + abs(m)] = (-1) ** m / sqrt(2)
+        q[l + m, l - abs(m)] = 1j * (-1) ** m / sqrt(2)
+    return (-1j) ** l * q
+
+
+@lru_cache(maxsize=None)
+def wigner_3j_e3nn(l1, l2, L):
+    """e3nn.o3.wigner_3j(l1, l2, L) restated (unit Frobenius norm): complex Clebsch-Gordan coefficients (Racah) in e3nn's real basis."""
+    C = np.zeros((2 * l1 + 1, 2 * l2 + 1, 2 * L + 1), dtype=complex)
+    for a in range(-l1, l1 + 1):
+        for b in range(-l2, l2 + 1):
+            if abs(a + b) <= L:
+                C[a + l1, b + l2, a + b + L] = _cg_complex(l1, a, l2, b, L, a + b)
+    T = np.einsum("ij,kl,mn,ikn->jlm", _e3nn_real_to_complex(l1), _e3nn_real_to_complex(l2), np.conj(_e3nn_real_to_complex(L).T), C)
+    assert np.abs(T.imag).max() < 1e-12
+    T = np.where(np.abs(T.real) < 1e-14, 0.0, T.real)
+    return T / np.sqrt((T ** 2).sum())
+
+
+@lru_cache(maxsize=None)
+def e3nn_sign(l1, l2, L):
+    """+-1 with wigner_3j_e3nn(l1, l2, L) == sign * canonical(l1, l2, L) (checked)."""
+    t, c = wigner_3j_e3nn(l1, l2, L), canonical(l1, l2, L)
+    ov = float((t * c).sum())
+    if abs(abs(ov) - 1.0) > 1e-9 or np.abs(t - np.sign(ov) * c).max() > 1e-9:
+        raise AssertionError(f"e3nn-convention 3j tensor ({l1},{l2},{L}) is not +-canonical")
+    return 1.0 if ov > 0 else -1.0

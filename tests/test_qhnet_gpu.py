@@ -1,0 +1,174 @@
+"""QHNet on the HIP path vs golden vectors written by the REAL reference classes (qhnet/qhnet.py, qhnet/layers.py, qhnet/loss.py) running on
+oracle/e3nn_mini.py (this repo's restatement of e3nn 0.5.1 -- the one unpinned piece; oracle/make_golden_qhnet_model.py).  SURVEY.md section 8
+rows a13-a20.  Tolerance: the north-star's 1e-5 relative (to the largest element of each tensor) against the reference evaluated in fp64;
+the reference's own fp32 run differs from that truth by 4e-7 (H) to 4e-6 (gradients)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ORBITALS = {1: [0, 0, 1], 6: [0, 0, 0, 1, 1, 2], 7: [0, 0, 0, 1, 1, 2], 8: [0, 0, 0, 1, 1, 2], 9: [0, 0, 0, 1, 1, 2],
+            16: [0, 0, 0, 0, 1, 1, 1, 2], 17: [0, 0, 0, 0, 1, 1, 1, 2], 35: [0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2]}
+TOL = 1e-5
+
+
+class Batch:
+    def __init__(self, pos, z, sizes, dev):
+        self.pos = torch.tensor(pos, dtype=torch.float32, device=dev)
+        self.z = torch.tensor(z, dtype=torch.long, device=dev)
+        self.ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.long, device=dev)
+        self.batch = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev))
+        self.num_nodes = len(z)
+
+
+def load_case(name, dev):
+    from nabladft_amd.qhnet import QHNet
+    from oracle.qhnet_params import make_state
+    g = np.load(os.path.join(GOLD, f"qhnet_{name}.npz"))
+    cfg = {k: (float(v) if k == "max_radius" else int(v)) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    net = QHNet(**cfg, orbitals=ORBITALS)
+    state = make_state([(k, tuple(p.shape)) for k, p in net.named_parameters()], int(g["seed"]))
+    missing = net.load_state_dict(state, strict=False)
+    assert not missing.unexpected_keys and all(not k.endswith(("weight", "bias", "weights", "_alpha")) or "tp" in k or "mul" in k or k.endswith(".bias")
+                                               for k in missing.missing_keys), missing
+    net.to(dev)
+    return g, cfg, net, Batch(g["pos"], g["z"], g["sizes"], dev)
+
+
+def rel(a, ref):
+    ref = torch.as_tensor(ref, dtype=torch.float64)
+    a = torch.as_tensor(a).detach().cpu().double()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-300))
+
+
+def from_e3nn(x, c):
+    """e3nn layout [rows, sum_l c (2l+1)] ([mul, 2l+1] per l) -> [rows, 25, c]."""
+    x = torch.as_tensor(x)
+    out = []
+    for l in range(5):
+        out.append(x[:, c * l * l:c * (l + 1) ** 2].reshape(x.shape[0], c, 2 * l + 1).transpose(1, 2))
+    return torch.cat(out, dim=1)
+
+
+def test_small_forward_layer_by_layer():
+    dev = torch.device("cuda:0")
+    g, cfg, net, batch = load_case("small", dev)
+    c = cfg["hidden_size"]
+    inter = {}
+    hooks = []
+    for i, m in enumerate(net.e3_gnn_layer):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, k=f"conv{i}": inter.__setitem__(k, out.detach())))
+    for i, m in enumerate(net.e3_gnn_node_layer):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, k=f"self{i}": inter.__setitem__(k, out.detach())))
+    for i, m in enumerate(net.e3_gnn_node_pair_layer):
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, k=f"pair{i}": inter.__setitem__(k, out.detach())))
+    hooks.append(net.expand_ii["hamiltonian"].register_forward_hook(lambda mod, inp, out: inter.__setitem__("diag_blocks", out.detach())))
+    hooks.append(net.expand_ij["hamiltonian"].register_forward_hook(lambda mod, inp, out: inter.__setitem__("nondiag_blocks", out.detach())))
+    with torch.no_grad():
+        H = net(batch)
+    # graph: bit-exact indices; geometry bases
+    assert torch.equal(batch.edge_index.cpu(), torch.tensor(g["edge_index"]))
+    assert torch.equal(batch.full_edge_index.cpu(), torch.tensor(g["full_edge_index"]))
+    assert batch.edge_index.shape[1] < batch.full_edge_index.shape[1]           # the cutoff binds in this fixture
+    assert rel(batch.edge_attr, g["edge_attr"]) < 2e-5
+    assert rel(batch.edge_sh, g["edge_sh"]) < 5e-6
+    assert rel(batch.node_attr, g["node_attr"]) == 0.0
+    errs = {}
+    for k, v in inter.items():
+        ref = g["inter64_" + k]
+        errs[k] = rel(v, ref) if k.endswith("blocks") else rel(v, from_e3nn(ref, c))
+    errs["H"] = rel(H, g["H64"])
+    print("qhnet small, rel. error vs the reference in fp64:", {k: f"{v:.1e}" for k, v in errs.items()})
+    print("reference fp32 vs fp64: H", rel(g["H32"], g["H64"]))
+    assert max(errs.values()) < TOL, errs
+    assert float((H - H.T).abs().max()) == 0.0                                  # H + H^T is exactly symmetric
+    # keep_blocks variant (qhnet.py:239-252)
+    with torch.no_grad():
+        blocks = net(batch, keep_blocks=True)
+    d = torch.tensor(g["inter64_diag_blocks"])
+    nd = torch.tensor(g["inter64_nondiag_blocks"])
+    from nabladft_amd.hamiltonian import transpose_index
+    t = transpose_index(batch.ptr.cpu())
+    assert rel(blocks["hamiltonian_diagonal_blocks"], d + d.transpose(-1, -2)) < TOL
+    assert rel(blocks["hamiltonian_non_diagonal_blocks"], nd + nd[t].transpose(-1, -2)) < TOL
+
+
+def _loss_and_grads(net, batch, target_dense):
+    from nabladft_amd.hamiltonian import HamiltonianLoss
+    net.zero_grad()
+    Hp = net(batch, packed=True)
+    plan = net.last_plan
+    tgt = net._asm.from_dense(plan, torch.tensor(target_dense, dtype=torch.float32, device=Hp.device))
+    loss = HamiltonianLoss()(Hp, tgt)
+    loss.backward()
+    return loss, {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in net.named_parameters()}
+
+
+def test_small_loss_and_all_gradients():
+    dev = torch.device("cuda:0")
+    g, cfg, net, batch = load_case("small", dev)
+    loss, grads = _loss_and_grads(net, batch, g["target"])
+    assert abs(float(loss) - float(g["loss64"])) / float(g["loss64"]) < 1e-6
+    unused = set(g["unused_params"].tolist())
+    worst = {}
+    for k, gr in grads.items():
+        if k in unused:
+            assert gr is None or float(gr.abs().max()) == 0.0, k          # Expansion.weights (layers.py:594-595): never read
+            continue
+        worst[k] = rel(gr, g["grad64_" + k])
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print("qhnet small gradients: worst rel. errors", [(k, f"{v:.1e}") for k, v in top], "| reference fp32 vs fp64 worst", float(g["grad32_relerr"].max()))
+    assert top[0][1] < 2e-5, top
+    # dense return value carries the same gradient (the drop-in path: loss on the block_diag matrix with the mask)
+    net.zero_grad()
+    H = net(batch)
+    tgt = torch.tensor(g["target"], dtype=torch.float32, device=dev)
+    mask = (torch.block_diag(*[torch.ones(m, m) for m in np.diff(net.last_plan.mol_orb_ptr.cpu().numpy())])).to(dev)
+    diff = H - tgt
+    mse = torch.mean(diff ** 2)
+    mae = torch.mean(torch.abs(diff))
+    dense_loss = (mse * (mask.numel() / mask.sum())).sqrt() + mae * (mask.numel() / mask.sum())      # qhnet/loss.py:9-16
+    dense_loss.backward()
+    assert abs(float(dense_loss) - float(loss)) / float(loss) < 1e-6
+    k = "e3_gnn_layer.0.conv.fc_node.layer1.weight"
+    assert rel(dict(net.named_parameters())[k].grad, grads[k]) < 1e-5
+
+
+def test_full_configuration():
+    """config/model/qhnet.yaml sizes: hidden 128, bottleneck 32, 5 layers, 32 radial functions, cutoff 12."""
+    dev = torch.device("cuda:0")
+    from oracle.qhnet_params import probe_direction
+    g, cfg, net, batch = load_case("full", dev)
+    assert net.get_number_of_parameters() == 21891529
+    inter = {}
+    net.e3_gnn_layer[4].register_forward_hook(lambda mod, inp, out: inter.__setitem__("conv4", out.detach()))
+    net.e3_gnn_node_layer[1].register_forward_hook(lambda mod, inp, out: inter.__setitem__("self1", out.detach()))
+    net.e3_gnn_node_pair_layer[1].register_forward_hook(lambda mod, inp, out: inter.__setitem__("pair1", out.detach()))
+    net.expand_ii["hamiltonian"].register_forward_hook(lambda mod, inp, out: inter.__setitem__("diag_blocks", out.detach()))
+    net.expand_ij["hamiltonian"].register_forward_hook(lambda mod, inp, out: inter.__setitem__("nondiag_blocks", out.detach()))
+    loss, grads = _loss_and_grads(net, batch, g["target"])
+    with torch.no_grad():
+        H = net(batch)
+    assert torch.equal(batch.edge_index.cpu(), torch.tensor(g["edge_index"])) and torch.equal(batch.full_edge_index.cpu(), torch.tensor(g["full_edge_index"]))
+    errs = {k: (rel(v, g[k]) if k.endswith("blocks") else rel(v, from_e3nn(g[k], 128))) for k, v in inter.items()}
+    errs["H"] = rel(H, g["H64"])
+    print("qhnet full, rel. error vs the reference in fp64:", {k: f"{v:.1e}" for k, v in errs.items()}, "| reference fp32:", rel(g["H32"], g["H64"]))
+    assert max(errs.values()) < TOL, errs
+    assert abs(float(loss) - float(g["loss64"])) / float(g["loss64"]) < 1e-6
+    # gradients: projection of every tensor's gradient on a fixed random direction, relative to |g| |r| / sqrt(n) (the size of a random projection)
+    worst = 0.0
+    for k, n64, p64, p32 in zip(g["grad_names"], g["grad64_norm"], g["grad64_probe"], g["grad32_probe"]):
+        gr = grads[str(k)].double()
+        r = probe_direction(str(k), gr.shape, int(g["seed"]))
+        scale = max(float(n64), 1e-300)
+        e = abs(float((gr * r).sum()) - float(p64)) / scale
+        assert abs(float(gr.norm()) - float(n64)) / scale < 2e-5, (k, float(gr.norm()), float(n64))
+        worst = max(worst, e)
+    print("qhnet full gradient projections: worst", worst)
+    assert worst < 2e-5
+    for k in g["unused_params"]:
+        assert grads[str(k)] is None or float(grads[str(k)].abs().max()) == 0.0
