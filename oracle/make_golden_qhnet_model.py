@@ -82,7 +82,11 @@ def run(ref, cfg, pos, z, sizes, seed, dtype):
     loss.backward()
     grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}
     sd = net.state_dict()
-    extra = dict(state_keys=np.array(list(sd.keys())), state_shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]), edge_index=data.edge_index, full_edge_index=data.full_edge_index, edge_attr=data.edge_attr.detach(), edge_sh=data.edge_sh.detach(),
+
+    def instr(tp):
+        return np.array([[tp.irreps_in1[i.i_in1].ir.l, tp.irreps_in2[i.i_in2].ir.l, tp.irreps_out[i.i_out].ir.l, i.path_weight] for i in tp.instructions])
+    extra = dict(instr_conv0=instr(net.e3_gnn_layer[0].conv.tp_node), instr_conv1=instr(net.e3_gnn_layer[1].conv.tp_node),
+                 instr_pair=instr(net.e3_gnn_node_pair_layer[0].tp_node_pair), instr_self=instr(net.e3_gnn_node_layer[0].tp), state_keys=np.array(list(sd.keys())), state_shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]), edge_index=data.edge_index, full_edge_index=data.full_edge_index, edge_attr=data.edge_attr.detach(), edge_sh=data.edge_sh.detach(),
                  node_attr=data.node_attr.detach())
     return net, names, H.detach(), target, loss.detach(), grads, inter, extra, ptr
 
@@ -101,7 +105,8 @@ def main():
                H32=H32.numpy(), H64=H64.numpy(), target=target.numpy(), loss32=np.float64(loss32), loss64=np.float64(loss64),
                edge_index=extra["edge_index"].numpy(), full_edge_index=extra["full_edge_index"].numpy(), edge_attr=extra["edge_attr"].numpy(),
                edge_sh=extra["edge_sh"].numpy(), node_attr=extra["node_attr"].numpy(), param_names=np.array([n for n, _ in names]),
-               state_keys=extra["state_keys"], state_shapes=extra["state_shapes"])
+               state_keys=extra["state_keys"], state_shapes=extra["state_shapes"], instr_conv0=extra["instr_conv0"], instr_conv1=extra["instr_conv1"],
+               instr_pair=extra["instr_pair"], instr_self=extra["instr_self"])
     for k, v in inter64.items():
         out["inter64_" + k] = v.numpy().astype(np.float32)
     for k, v in g64.items():

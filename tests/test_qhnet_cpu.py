@@ -1,0 +1,178 @@
+"""CPU tests of the QHNet path (no GPU): the oracle restatement (oracle/qhnet_ref.py) against the golden vectors written by the REAL reference
+QHNet classes, internal consistency of the e3nn restatement (oracle/e3nn_mini.py, parity unpinned), and the host logic of nabladft_amd.qhnet
+(state_dict surface, path order and normalisation constants)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ORBITALS = {1: [0, 0, 1], 6: [0, 0, 0, 1, 1, 2], 7: [0, 0, 0, 1, 1, 2], 8: [0, 0, 0, 1, 1, 2], 9: [0, 0, 0, 1, 1, 2],
+            16: [0, 0, 0, 0, 1, 1, 1, 2], 17: [0, 0, 0, 0, 1, 1, 1, 2], 35: [0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2]}
+
+
+def _case(name):
+    g = np.load(os.path.join(GOLD, f"qhnet_{name}.npz"))
+    cfg = {k: (float(v) if k == "max_radius" else int(v)) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    return g, cfg
+
+
+def _from_e3nn(x, c):
+    x = torch.as_tensor(x)
+    return torch.cat([x[:, c * l * l:c * (l + 1) ** 2].reshape(x.shape[0], c, 2 * l + 1).transpose(1, 2) for l in range(5)], dim=1)
+
+
+def _rel(a, ref):
+    a, ref = torch.as_tensor(a).double(), torch.as_tensor(ref).double()
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-300))
+
+
+def _state(g, dtype):
+    from oracle.qhnet_params import make_state
+    names = [(k, tuple(int(d) for d in s.split(",")) if s else ()) for k, s in zip(g["state_keys"], g["state_shapes"])]
+    keep = [(k, s) for k, s in names if "output_mask" not in k and not (np.prod(s) == 0 and len(s) == 1) and not k.startswith("distance_expansion.")
+            or k == "distance_expansion._alpha"]
+    P = make_state(keep, int(g["seed"]))
+    return {k: v.to(dtype).requires_grad_(True) for k, v in P.items()}
+
+
+def test_oracle_restatement_matches_reference_small():
+    """Every layer, the blocks, H, the loss and every gradient of the restatement vs the real reference classes (fp64 both sides)."""
+    from oracle import qhnet_ref as Q
+    g, cfg = _case("small")
+    P = _state(g, torch.float64)
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(g["sizes"])]))
+    keep = {}
+    H = Q.forward(P, cfg, ORBITALS, torch.tensor(g["pos"], dtype=torch.float64), torch.tensor(g["z"]), ptr, keep)
+    gr = keep["graph"]
+    assert torch.equal(torch.stack([gr["dst"], gr["src"]]), torch.tensor(g["edge_index"]))
+    assert torch.equal(torch.stack([gr["full_dst"], gr["full_src"]]), torch.tensor(g["full_edge_index"]))
+    c = cfg["hidden_size"]
+    for k in ("conv0", "conv1", "conv2", "conv3", "self0", "pair0"):
+        assert _rel(keep[k].detach(), _from_e3nn(g["inter64_" + k], c)) < 2e-6, k      # fixtures are stored in float32
+    assert _rel(keep["diag_blocks"].detach(), g["inter64_diag_blocks"]) < 2e-6
+    assert _rel(keep["nondiag_blocks"].detach(), g["inter64_nondiag_blocks"]) < 2e-6
+    assert _rel(H.detach(), g["H64"]) < 1e-12
+    target = torch.tensor(g["target"], dtype=torch.float64)
+    mask = (target != 0).double()                                      # block_diag of ones: the random targets have no exact zeros
+    loss = Q.hamiltonian_loss(H, target, mask)
+    assert abs(float(loss.detach()) - float(g["loss64"])) < 1e-10
+    loss.backward()
+    unused = set(g["unused_params"].tolist())
+    for k, p in P.items():
+        if k in unused:
+            assert p.grad is None
+        else:
+            assert _rel(p.grad, g["grad64_" + k]) < 2e-6, k
+
+
+def test_oracle_restatement_matches_reference_full_config():
+    from oracle import qhnet_ref as Q
+    g, cfg = _case("full")
+    P = _state(g, torch.float64)
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(g["sizes"])]))
+    with torch.no_grad():
+        H = Q.forward(P, cfg, ORBITALS, torch.tensor(g["pos"], dtype=torch.float64), torch.tensor(g["z"]), ptr)
+    assert _rel(H, g["H64"]) < 1e-12
+    assert H.shape == (171, 171) and float((H - H.T).abs().max()) == 0.0
+
+
+def test_e3nn_restatement_is_self_consistent():
+    from oracle import e3nn_mini as e3
+    torch.manual_seed(0)
+    dt = torch.float64
+    # 3j tensors: real, unit norm, identity couplings positive (Norm / ElementwiseTensorProduct rely on it), equal to the in-tree table up to sign
+    cgfix = np.load(os.path.join(GOLD, "phisnet_cg_l4.npz"))
+    for l in range(5):
+        eye = torch.eye(2 * l + 1, dtype=dt) / math.sqrt(2 * l + 1)
+        assert torch.allclose(e3.wigner_3j(l, l, 0, dtype=dt)[:, :, 0], eye) and torch.allclose(e3.wigner_3j(l, 0, l, dtype=dt)[:, 0], eye)
+    for key in cgfix.files:
+        parts = key.split("_")
+        if len(parts) == 4 and parts[0] == "cg":
+            l1, l2, L = (int(x) for x in parts[1:])
+            t = e3.wigner_3j(l1, l2, L, dtype=dt).numpy()
+            ov = float((t * cgfix[key]).sum())
+            assert abs(abs(ov) - 1.0) < 1e-6, key
+            if (l1 + l2 + L) % 2 == 0:
+                assert ov > 0, key           # even couplings: both conventions make sum C Y Y = k Y with k > 0
+    # spherical harmonics of (y, z, x)-permuted vectors == the in-tree PhiSNet closed forms (golden vectors from the real reference code)
+    gb = np.load(os.path.join(GOLD, "geometry_bases.npz"))
+    u = torch.tensor(gb["u"], dtype=dt)
+    Y = e3.spherical_harmonics(e3.Irreps.spherical_harmonics(4), u[:, [1, 2, 0]], True, "component")
+    assert _rel(Y, np.concatenate([gb[f"Y_{l}"] for l in range(5)], axis=-1)) < 1e-6
+    # equivariance of a weighted uvu tensor product and of Linear under a random rotation: D(R) from the harmonics themselves
+    q, _ = np.linalg.qr(np.random.default_rng(1).normal(size=(3, 3)))
+    Rm = torch.tensor(q * np.sign(np.linalg.det(q)), dtype=dt)
+    pts = torch.randn(200, 3, dtype=dt)
+    sh = lambda v: e3.spherical_harmonics(e3.Irreps.spherical_harmonics(4), v[:, [1, 2, 0]], True, "component")
+    A, B = sh(pts), sh(pts @ Rm.T)
+    D = [torch.linalg.lstsq(A[:, l * l:(l + 1) ** 2], B[:, l * l:(l + 1) ** 2]).solution.T for l in range(5)]      # Y(Rx) = D Y(x)
+    irr = e3.Irreps("3x0e+3x1o+3x2e+3x3o+3x4e")
+
+    def rot(x):
+        out = []
+        for (mul, ir), s in zip(irr, irr.slices()):
+            out.append(torch.einsum("ij,zuj->zui", D[ir.l], x[:, s].reshape(-1, mul, ir.dim)).reshape(x.shape[0], -1))
+        return torch.cat(out, -1)
+
+    ins = [(i, j, k, "uvu", True) for i in range(5) for j in range(5) for k in range(5) if abs(i - j) <= k <= i + j and (i + j + k) % 2 == 0]
+    tp = e3.TensorProduct(irr, e3.Irreps.spherical_harmonics(4), irr, ins, shared_weights=False, internal_weights=False)
+    x, v, w = torch.randn(6, irr.dim, dtype=dt), torch.randn(6, 3, dtype=dt), torch.randn(6, tp.weight_numel, dtype=dt)
+    assert _rel(tp(rot(x), sh(v @ Rm.T), w), rot(tp(x, sh(v), w))) < 1e-10
+    lin = e3.Linear(irr, irr, biases=True).double()
+    lin.bias.data.normal_()
+    assert _rel(lin(rot(x)), rot(lin(x))) < 1e-10
+    nrm = e3.Norm(irr)
+    assert _rel(nrm(rot(x)), nrm(x)) < 1e-10
+    assert _rel(nrm(x)[:, 3:6], x[:, 3:12].reshape(6, 3, 3).norm(dim=-1)) < 1e-12
+
+
+def test_irreps_container_semantics():
+    from oracle import e3nn_mini as e3
+    a = e3.Irreps("128x0e + 128x1o + 128x2e")
+    assert a.dim == 128 * 9 and a.num_irreps == 384 and [s.stop for s in a.slices()] == [128, 512, 1152]
+    assert e3.Irrep("1o") in a and e3.Irrep("1e") not in a and a.count("2e") == 128
+    assert list(e3.Irrep("1o") * e3.Irrep("2e")) == [e3.Irrep("1o"), e3.Irrep("2o"), e3.Irrep("3o")]
+    s = e3.Irreps("4x2e + 1x0e + 2x1o").sort()
+    assert str(s.irreps) == "1x0e+2x1o+4x2e" and s.p == (2, 0, 1) and s.inv == (1, 2, 0)
+    assert str(e3.Irreps.spherical_harmonics(2)) == "1x0e+1x1o+1x2e" and a[1:] == e3.Irreps("128x1o+128x2e")
+    assert e3.Irreps("2x0e+3x0e+1x1o").simplify() == e3.Irreps("5x0e+1x1o")
+
+
+def test_host_path_tables_match_reference_instructions():
+    """Path order and |normalisation| of nabladft_amd.qhnet vs the instruction lists the real get_feasible_irrep (layers.py:44-83) produced."""
+    from nabladft_amd import cg
+    from nabladft_amd import qhnet as Qh
+    g, _ = _case("small")
+    for key, paths in (("instr_conv0", Qh.conv_paths(True)), ("instr_conv1", Qh.conv_paths(False)), ("instr_pair", list(cg.ALL_PATHS)),
+                       ("instr_self", list(cg.ALL_PATHS))):
+        tab = g[key]
+        assert [tuple(int(v) for v in row[:3]) for row in tab] == [tuple(p) for p in paths], key
+        pc = Qh.path_constants(paths)
+        assert np.allclose(np.abs(pc), tab[:, 3], rtol=1e-12), key
+        for c, p in zip(pc, paths):
+            assert (c > 0) == (cg.e3nn_sign(*p) > 0)
+    assert len(Qh.conv_paths(False)) == 42 and len(Qh.conv_paths(True)) == 5 and len(cg.ALL_PATHS) == 65
+    # the product's e3nn-convention 3j tensors equal the oracle's
+    from oracle import e3nn_mini as e3
+    for p in cg.ALL_PATHS:
+        assert np.abs(cg.wigner_3j_e3nn(*p) - e3.wigner_3j(*p, dtype=torch.float64).numpy()).max() < 1e-12
+    assert abs(Qh.normalize2mom_constant("ssp") - e3.normalize2mom_constant(lambda t: torch.nn.functional.softplus(t) - math.log(2.0))) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_state_dict_surface_equals_reference(name):
+    """Keys, order and shapes of state_dict() equal those of the reference model (incl. e3nn's buffers as restated)."""
+    from nabladft_amd.qhnet import QHNet
+    g, cfg = _case(name)
+    net = QHNet(**cfg, orbitals=ORBITALS)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert [",".join(str(d) for d in v.shape) for v in sd.values()] == list(g["state_shapes"])
+    assert net.expand_ii["hamiltonian"].num_path_weight == 260 * cfg["bottle_hidden_size"] and net.expand_ii["hamiltonian"].num_bias == 50
+    with pytest.raises(RuntimeError):
+        class B:
+            pos = torch.zeros(3, 3)
+        net(B())           # no CPU path
