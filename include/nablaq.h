@@ -218,33 +218,32 @@ int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, co
  *      oracle/e3nn_mini.py, PARITY UNPINNED for the e3nn part).  Irreps features are [rows][(lmax+1)^2][C], component l*l + m + l, channel
  *      fastest.  Graph arrays (int32, device): row_ptr [N+1] CSR by owner atom = "src" = row 1 of the reference's edge_index (qhnet.py:262),
  *      col [R] = "dst" = row 0 ascending, own [R] = owner of each slot, rev [R] = slot of the reverse edge (the neighbour relation is
- *      symmetric).  path_index_host: HOST int8[65] as for nq_so3_mix_* (index of each (l1,l2,L) path among the enabled ones or -1);
- *      path weights w1 (and optional second factor w2, multiplied in-kernel) are [R][n_enabled][C] and carry e3nn's sign and path
- *      normalisation (folded in by the caller). ------------------------------------------------------------------------------------- */
+ *      symmetric).  Path weights carry e3nn's sign and path normalisation (folded in by the caller). ------------------------------------------------------------------------------------- */
 /* s0 [R][(2+lmax) C] = [x_0[dst] | x_0[dst] (conv, layers.py:240-246) or x_0[src] (pair, layers.py:469-475) | <x_l[dst], x_l[src]>/(2l+1)]
  * = InnerProduct (layers.py:277-294) + the concatenations of ConvLayer.forward / PairNetLayer.forward. */
 int nq_qh_invariants_forward(const float* x, int64_t N, int32_t ncomp, int32_t C, const int32_t* own, const int32_t* col, int64_t R,
                              int32_t second_from_owner, float* s0, void* stream);
 int nq_qh_invariants_backward(const float* x, const float* grad_s0, int64_t N, int32_t ncomp, int32_t C, const int32_t* row_ptr, const int32_t* col,
                               const int32_t* rev, int32_t second_from_owner, float* grad_x, void* stream);
-/* ConvLayer message + scatter (layers.py:262-271; replaces e3nn TensorProduct 'uvu' + torch_scatter.scatter):
- * out[n] = self_x[n] (nullable) + sum_{edges e with dst(e) = n} TP(x[src(e)], sh[e], w1[e] * w2[e]);  x [N][ncomp_in][C] with ncomp_in = 1
- * (first layer: scalars) or 25;  sh [R][25] real spherical harmonics of pos[dst] - pos[src];  out [N][25][C]. */
-int nq_qh_conv_forward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* self_x, int64_t N, int32_t C,
-                       const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int8_t* path_index_host, float* out, void* stream);
-int nq_qh_conv_backward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* grad_out, int64_t N, int32_t C,
-                        const int32_t* row_ptr, const int32_t* col, const int8_t* path_index_host, int32_t add_self, float* grad_x, float* grad_w1,
-                        float* grad_w2, void* stream);
-/* PairNetLayer tensor product (layers.py:481-485; e3nn 'uuu' with per-pair weights): y[r] = TP(x[idx1[r]], x[idx2[r]], w1[r] * w2[r]);
- * backward writes per-row operand adjoints [R][25][C] (reduce with nq_qh_pair_reduce) and the weight adjoints. */
-int nq_qh_pairmix_forward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, int64_t R, int32_t C,
-                          const int8_t* path_index_host, float* y, void* stream);
-int nq_qh_pairmix_backward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, const float* grad_y, int64_t R,
-                           int32_t C, const int8_t* path_index_host, float* grad_x1_rows, float* grad_x2_rows, float* grad_w1, float* grad_w2,
-                           void* stream);
-/* out[n][k] = sum_{r in row n} (rows_own[r][k] + rows_nbr[rev[r]][k]), k < width (either operand may be NULL = zeros): fixed order, no atomics. */
-int nq_qh_pair_reduce(const float* rows_own, const float* rows_nbr, const int32_t* row_ptr, const int32_t* rev, int64_t N, int32_t width, float* out,
-                      void* stream);
+/* Tensor products per row (edge or ordered pair), the arithmetic of e3nn's TensorProduct in QHNet:
+ *   sh != NULL ('uvu', ConvLayer.tp_node, layers.py:262): y[r] = sum_paths w1 w2 CG . x[idx1[r]] . sh[r];  sh [R][25] real spherical harmonics of
+ *       pos[dst] - pos[src];  path_set 1 = the 42 paths with even l1+l2+L (x [N][25][C]), 2 = the 5 paths of the first layer (x [N][1][C]);
+ *   sh == NULL ('uuu', PairNetLayer.tp_node_pair, layers.py:481): second operand x[idx2[r]]; path_set 0 = all 65 paths.
+ * w1, w2 (nullable second factor, multiplied in-kernel): [R][nq_qh_tp_num_paths(path_set)][C] in e3nn instruction order.  y_rows [R][25][C].
+ * Backward: grad_y rows are read at idx_gy[r] (NULL = r); per-row operand adjoints grad_x1_rows [R][ncomp1][C], grad_x2_rows [R][25][C]
+ * (uuu only) are summed over each atom's rows by nq_qh_pair_reduce; grad_w1 / grad_w2 like w1 / w2. */
+int nq_qh_tp_num_paths(int32_t path_set);
+void nq_qh_set_tp_variant(int32_t variant);   /* tuning hook (process-global): 0 per-path weight loads, 1 / 2 chunked prefetch with / without scheduling barriers */
+int nq_qh_tp_forward(const float* x, int32_t ncomp1, const int32_t* idx1, const float* sh, const int32_t* idx2, const float* w1, const float* w2, int64_t R,
+                     int32_t C, int32_t path_set, float* y_rows, void* stream);
+int nq_qh_tp_backward(const float* x, int32_t ncomp1, const int32_t* idx1, const float* sh, const int32_t* idx2, const float* w1, const float* w2,
+                      const float* grad_y, const int32_t* idx_gy, int64_t R, int32_t C, int32_t path_set, float* grad_x1_rows, float* grad_x2_rows,
+                      float* grad_w1, float* grad_w2, void* stream);
+/* out[n][k] = base[n][k] + sum_{r in row n} (rows_own[r][k] + rows_nbr[rev[r]][k]), k < width (each operand may be NULL = zeros): the scatter of
+ * ConvLayer (torch_scatter.scatter, layers.py:268: messages arrive along the reverse slots of the receiver's own row) and the reverse of every
+ * per-row gather; fixed order, no atomics. */
+int nq_qh_pair_reduce(const float* rows_own, const float* rows_nbr, const float* base, const int32_t* row_ptr, const int32_t* rev, int64_t N, int32_t width,
+                      float* out, void* stream);
 /* NormGate pieces (layers.py:141-147; e3nn o3.Norm + ElementwiseTensorProduct): nq_qh_normcat: out [rows][(lmax+1) C] = [x_0 | ||x_1|| | ...]
  * (grad_f0 == NULL) or the adjoint of x [rows][ncomp][C] given grad_f0;  nq_qh_gate: y = [gates_0 | x_l * gates_l] (grad_y == NULL) or
  * (grad_x, grad_gates) given grad_y. */

@@ -67,11 +67,11 @@ SYMBOLS = {
     "nq_so3_mix_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "nq_qh_invariants_forward": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _I32, _P, _P]),
     "nq_qh_invariants_backward": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
-    "nq_qh_conv_forward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
-    "nq_qh_conv_backward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
-    "nq_qh_pairmix_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
-    "nq_qh_pairmix_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
-    "nq_qh_pair_reduce": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_qh_tp_num_paths": (C.c_int, [_I32]),
+    "nq_qh_set_tp_variant": (None, [_I32]),
+    "nq_qh_tp_forward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_qh_tp_backward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nq_qh_pair_reduce": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nq_qh_normcat": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_qh_gate": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
     "nq_qh_act": (C.c_int, [_P, _P, _I32, _F, _I64, _P, _P]),

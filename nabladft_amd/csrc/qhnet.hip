@@ -16,6 +16,9 @@
 
 #define QH_NCOMP 25
 #define QH_NPATHS 65
+#ifndef QH_WCH
+#define QH_WCH 8
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // invariants of an edge / pair (layers.py:236-258 and :466-476): s0 = [x0[dst] | x0[dst or src] | <x_l[dst], x_l[src]> / (2l+1), l = 1..lmax]
@@ -70,126 +73,89 @@ __global__ __launch_bounds__(256) void k_qh_inv_bwd(const float* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// ConvLayer message + aggregation (layers.py:262-271): out[n] = (self) + sum_{edges e: dst(e) = n} TP_uvu(x[src(e)], sh[e], w1[e] * w2[e])
-struct QhConvArgs {
-  const float* x; const float* sh; const float* w1; const float* w2; const float* self_x;
-  float* out;
-  const float* gout; float* gx; float* gw1; float* gw2;
-  const int* row_ptr; const int* col; const int* rev;
-  int N, C, n1, np, add_self;
-  signed char cidx[QH_NPATHS];
-};
-
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_qh_conv(QhConvArgs a) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)a.N * a.C) return;
-  const int n = (int)(idx / a.C), u = (int)(idx % a.C);
-  const long C = a.C;
-  float x1[QH_NCOMP], acc[QH_NCOMP], y[QH_NCOMP], s[QH_NCOMP];
-#pragma unroll
-  for (int k = 0; k < QH_NCOMP; ++k) {
-    acc[k] = 0.f;
-    if (BWD) x1[k] = k < a.n1 ? a.x[((long)n * a.n1 + k) * C + u] : 0.f;     // reverse: own features, gathered output adjoints
-    else x1[k] = 0.f;
-    y[k] = 0.f;
-  }
-  if (a.add_self) {
-#pragma unroll
-    for (int k = 0; k < QH_NCOMP; ++k) acc[k] = BWD ? a.gout[((long)n * QH_NCOMP + k) * C + u] : a.self_x[((long)n * QH_NCOMP + k) * C + u];
-  }
-  for (int r = a.row_ptr[n]; r < a.row_ptr[n + 1]; ++r) {
-    const long j = a.col[r];
-    const long e = BWD ? (long)r : (long)a.rev[r];           // forward: the edge that delivers to n from j is the reverse slot
-    const float* shp = a.sh + e * QH_NCOMP;
-#pragma unroll
-    for (int k = 0; k < QH_NCOMP; ++k) {
-      s[k] = shp[k];
-      if (BWD) y[k] = a.gout[(j * QH_NCOMP + k) * C + u];
-      else x1[k] = k < a.n1 ? a.x[(j * a.n1 + k) * C + u] : 0.f;
-    }
-    const float* w1r = a.w1 + e * a.np * C + u;
-    const float* w2r = a.w2 ? a.w2 + e * a.np * C + u : nullptr;
-    float* g1r = BWD ? a.gw1 + e * a.np * C + u : nullptr;
-    float* g2r = (BWD && a.w2) ? a.gw2 + e * a.np * C + u : nullptr;
-
-#define CG_PATH_BEGIN(pid, l1, l2, L)                                   \
-  if (a.cidx[pid] >= 0) {                                               \
-    const long ci = (long)a.cidx[pid] * C;                              \
-    const float wa = w1r[ci];                                           \
-    const float wb = w2r ? w2r[ci] : 1.f;                               \
-    const float cc = wa * wb;                                           \
-    float t[2 * L + 1];                                                 \
-    _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) t[M] = 0.f;   \
-    constexpr int YO = L * L;
-#define CG_NZ(ia, ib, Mi, v)                                            \
-    {                                                                   \
-      const float q = v * s[ib];                                        \
-      t[Mi] = fmaf(q, x1[ia], t[Mi]);                                   \
-      if (BWD) acc[ia] = fmaf(q * cc, y[YO + Mi], acc[ia]);             \
-    }
-#define CG_PATH_END(pid, l1, l2, L)                                     \
-    if (BWD) {                                                          \
-      float g = 0.f;                                                    \
-      _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) g = fmaf(y[YO + M], t[M], g); \
-      g1r[ci] = g * wb;                                                 \
-      if (g2r) g2r[ci] = g * wa;                                        \
-    } else {                                                            \
-      _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) acc[YO + M] = fmaf(cc, t[M], acc[YO + M]); \
-    }                                                                   \
-  }
-#include "cg_l4.inc"
-#undef CG_PATH_BEGIN
-#undef CG_NZ
-#undef CG_PATH_END
-  }
-  if (BWD) {
-#pragma unroll
-    for (int k = 0; k < QH_NCOMP; ++k)
-      if (k < a.n1) a.gx[((long)n * a.n1 + k) * C + u] = acc[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < QH_NCOMP; ++k) a.out[((long)n * QH_NCOMP + k) * C + u] = acc[k];
-  }
+// Tensor products per ROW (edge or ordered pair), one thread per (row, channel):
+//   UVU (ConvLayer.tp_node, layers.py:262):        y[r] = sum_paths w1 w2 * CG . x[i1[r]] . sh[r]          (sh: one scalar per component and row)
+//   UUU (PairNetLayer.tp_node_pair, layers.py:481): y[r] = sum_paths w1 w2 * CG . x[i1[r]] . x[i2[r]]
+// The set of enabled paths is a template parameter (0: all 65; 1: the 42 with even l1+l2+L; 2: the 5 with l1 = 0 of the first conv layer), so the
+// path loop is branch-free straight-line code and the weight loads of later paths are issued ahead of the FMAs of earlier ones.
+// Reverse: per-row adjoints of the gathered operands (summed over each atom's rows by k_qh_pair_reduce -- parallelism over rows instead of atoms is
+// what fills the chip at the reference's batch size of 2 molecules) and of both weight factors.
+__host__ __device__ constexpr bool qh_path_on(int set, int l1, int l2, int L) { return set == 0 ? true : set == 1 ? ((l1 + l2 + L) % 2 == 0) : (l1 == 0); }
+__host__ __device__ constexpr int qh_path_slot(int set, int pid) {
+  int id = 0, slot = 0;
+  for (int l1 = 0; l1 <= 4; ++l1)
+    for (int l2 = 0; l2 <= 4; ++l2)
+      for (int L = (l1 > l2 ? l1 - l2 : l2 - l1); L <= (l1 + l2 < 4 ? l1 + l2 : 4); ++L) {
+        if (id == pid) return slot;
+        if (qh_path_on(set, l1, l2, L)) ++slot;
+        ++id;
+      }
+  return slot;
 }
+__host__ __device__ constexpr int qh_path_count(int set) { return qh_path_slot(set, QH_NPATHS); }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// PairNetLayer tensor product (layers.py:481-485): y[r] = TP_uuu(x[i1[r]], x[i2[r]], w1[r] * w2[r]) over the 65 paths, rows = ordered pairs
-struct QhPairArgs {
-  const float* x; const int* i1; const int* i2; const float* w1; const float* w2;
+struct QhTpArgs {
+  const float* x; const int* i1; const int* i2; const float* sh; const float* w1; const float* w2;
   float* y;
-  const float* gy; float* gx1; float* gx2; float* gw1; float* gw2;
-  long R; int C, np;
-  signed char cidx[QH_NPATHS];
+  const float* gy; const int* ig; float* gx1; float* gx2; float* gw1; float* gw2;
+  long R; int C, n1, np_rt;
 };
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_qh_pairmix(QhPairArgs a) {
+template <int SET, bool UVU, bool BWD, int VAR>
+__global__ __launch_bounds__(256, (BWD || VAR == 0) ? 1 : (VAR == 1 ? 4 : 3)) void k_qh_tp(QhTpArgs a) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.R * a.C) return;
   const long r = idx / a.C;
   const int u = (int)(idx % a.C);
   const long C = a.C;
+  constexpr int NP = qh_path_count(SET);
+  constexpr int N1 = SET == 2 ? 1 : QH_NCOMP;                                 // components of x1 that can be non-zero
   float x1[QH_NCOMP], x2[QH_NCOMP], y[QH_NCOMP], gx1[QH_NCOMP], gx2[QH_NCOMP];
-  const float* p1 = a.x + (long)a.i1[r] * QH_NCOMP * C + u;
-  const float* p2 = a.x + (long)a.i2[r] * QH_NCOMP * C + u;
+  const float* p1 = a.x + (long)a.i1[r] * a.n1 * C + u;
+  const float* p2 = UVU ? a.sh + r * QH_NCOMP : a.x + (long)a.i2[r] * QH_NCOMP * C + u;
+  const long gr = BWD ? (a.ig ? (long)a.ig[r] : r) : 0;
 #pragma unroll
   for (int k = 0; k < QH_NCOMP; ++k) {
-    x1[k] = p1[k * C];
-    x2[k] = p2[k * C];
-    if (BWD) { y[k] = a.gy[(r * QH_NCOMP + k) * C + u]; gx1[k] = 0.f; gx2[k] = 0.f; }
+    x1[k] = k < N1 ? p1[k * C] : 0.f;
+    x2[k] = UVU ? p2[k] : p2[k * C];
+    if (BWD) { y[k] = a.gy[(gr * QH_NCOMP + k) * C + u]; gx1[k] = 0.f; gx2[k] = 0.f; }
     else y[k] = 0.f;
   }
-  const float* w1r = a.w1 + r * a.np * C + u;
-  const float* w2r = a.w2 ? a.w2 + r * a.np * C + u : nullptr;
-  float* g1r = BWD ? a.gw1 + r * a.np * C + u : nullptr;
-  float* g2r = (BWD && a.w2) ? a.gw2 + r * a.np * C + u : nullptr;
+  const float* w1r = a.w1 + r * NP * C + u;
+  const float* w2r = a.w2 ? a.w2 + r * NP * C + u : nullptr;
+  float* g1r = BWD ? a.gw1 + r * NP * C + u : nullptr;
+  float* g2r = (BWD && a.w2) ? a.gw2 + r * NP * C + u : nullptr;
 
+  // VAR 0: each path loads its own weights; VAR 1 / 2: weights fetched in chunks of QH_WCH paths, double buffered (the loads of chunk k+1 are
+  // issued before the arithmetic of chunk k), with (1) / without (2) scheduling barriers.  The runtime test on np_rt is always true: it keeps one
+  // basic block per path -- as one block the reverse kernel spills 4 kB per lane.
+  constexpr bool CHUNK = VAR != 0, BAR = VAR == 1;
+  float wq1[2][QH_WCH], wq2[2][QH_WCH];
+  if constexpr (CHUNK) {
+#pragma unroll
+    for (int i = 0; i < QH_WCH; ++i) {
+      wq1[0][i] = i < NP ? w1r[(long)i * C] : 0.f;
+      wq2[0][i] = (w2r && i < NP) ? w2r[(long)i * C] : 1.f;
+    }
+  }
 #define CG_PATH_BEGIN(pid, l1, l2, L)                                   \
-  if (a.cidx[pid] >= 0) {                                               \
-    const long ci = (long)a.cidx[pid] * C;                              \
-    const float wa = w1r[ci];                                           \
-    const float wb = w2r ? w2r[ci] : 1.f;                               \
+  if constexpr (qh_path_on(SET, l1, l2, L)) {                           \
+    constexpr int slot = qh_path_slot(SET, pid);                        \
+    if (slot < a.np_rt) {                                               \
+    constexpr long ci = slot;                                           \
+    constexpr int cb = (slot / QH_WCH) % 2, ck = slot % QH_WCH;         \
+    if constexpr (CHUNK && ck == 0) {                                   \
+      _Pragma("unroll") for (int i = 0; i < QH_WCH; ++i) {              \
+        constexpr int nb = 1 - cb;                                      \
+        const int sl = slot + QH_WCH + i;                               \
+        wq1[nb][i] = sl < NP ? w1r[(long)sl * C] : 0.f;                 \
+        wq2[nb][i] = (w2r && sl < NP) ? w2r[(long)sl * C] : 1.f;        \
+      }                                                                 \
+      if constexpr (BAR) __builtin_amdgcn_sched_barrier(0);             \
+    }                                                                   \
+    float wa, wb;                                                       \
+    if constexpr (CHUNK) { wa = wq1[cb][ck]; wb = wq2[cb][ck]; }        \
+    else { wa = w1r[ci * C]; wb = w2r ? w2r[ci * C] : 1.f; }            \
     const float cc = wa * wb;                                           \
     float t[2 * L + 1];                                                 \
     _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) t[M] = 0.f;   \
@@ -197,18 +163,23 @@ __global__ __launch_bounds__(256) void k_qh_pairmix(QhPairArgs a) {
 #define CG_NZ(ia, ib, Mi, v)                                            \
     {                                                                   \
       t[Mi] = fmaf(v, x1[ia] * x2[ib], t[Mi]);                          \
-      if (BWD) { const float w = cc * v * y[YO + Mi]; gx1[ia] = fmaf(w, x2[ib], gx1[ia]); gx2[ib] = fmaf(w, x1[ia], gx2[ib]); } \
+      if (BWD) {                                                        \
+        const float w = cc * v * y[YO + Mi];                            \
+        gx1[ia] = fmaf(w, x2[ib], gx1[ia]);                             \
+        if (!UVU) gx2[ib] = fmaf(w, x1[ia], gx2[ib]);                   \
+      }                                                                 \
     }
 #define CG_PATH_END(pid, l1, l2, L)                                     \
     if (BWD) {                                                          \
       float g = 0.f;                                                    \
       _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) g = fmaf(y[YO + M], t[M], g); \
-      g1r[ci] = g * wb;                                                 \
-      if (g2r) g2r[ci] = g * wa;                                        \
+      g1r[ci * C] = g * wb;                                             \
+      if (g2r) g2r[ci * C] = g * wa;                                    \
     } else {                                                            \
       _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) y[YO + M] = fmaf(cc, t[M], y[YO + M]); \
     }                                                                   \
-  }
+    if constexpr (BAR) __builtin_amdgcn_sched_barrier(0);               \
+  } }
 #include "cg_l4.inc"
 #undef CG_PATH_BEGIN
 #undef CG_NZ
@@ -217,8 +188,8 @@ __global__ __launch_bounds__(256) void k_qh_pairmix(QhPairArgs a) {
   if (BWD) {
 #pragma unroll
     for (int k = 0; k < QH_NCOMP; ++k) {
-      a.gx1[(r * QH_NCOMP + k) * C + u] = gx1[k];
-      a.gx2[(r * QH_NCOMP + k) * C + u] = gx2[k];
+      if (k < N1) a.gx1[(r * N1 + k) * C + u] = gx1[k];
+      if (!UVU) a.gx2[(r * QH_NCOMP + k) * C + u] = gx2[k];
     }
   } else {
 #pragma unroll
@@ -226,13 +197,13 @@ __global__ __launch_bounds__(256) void k_qh_pairmix(QhPairArgs a) {
   }
 }
 
-// out[n] = sum_{r in row n} (a[r] + b[rev[r]]): per-pair adjoints of the two gathered operands back to the atoms (fixed order, no atomics)
-__global__ __launch_bounds__(256) void k_qh_pair_reduce(const float* __restrict__ a, const float* __restrict__ b, const int* __restrict__ row_ptr,
-                                                        const int* __restrict__ rev, int N, int W, float* __restrict__ out) {
+// out[n] = base[n] + sum_{r in row n} (a[r] + b[rev[r]]) (each operand nullable): per-row messages / adjoints of the two gathered operands back to the atoms (fixed order, no atomics)
+__global__ __launch_bounds__(256) void k_qh_pair_reduce(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ base,
+                                                        const int* __restrict__ row_ptr, const int* __restrict__ rev, int N, int W, float* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)N * W) return;
   const int n = (int)(idx / W), k = (int)(idx % W);
-  float s = 0.f;
+  float s = base ? base[idx] : 0.f;
   for (int r = row_ptr[n]; r < row_ptr[n + 1]; ++r) s += (a ? a[(long)r * W + k] : 0.f) + (b ? b[(long)rev[r] * W + k] : 0.f);
   out[idx] = s;
 }
@@ -510,14 +481,6 @@ __global__ __launch_bounds__(256) void k_qh_exp_bwd(QhExpArgs a, int n_ins, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-static int qh_paths(signed char* cidx, const int8_t* path_index_host, int* n_enabled) {
-  if (!path_index_host) return nq_fail(NQ_ERR_ARG, "null path index");
-  int n = 0;
-  for (int p = 0; p < QH_NPATHS; ++p) { cidx[p] = path_index_host[p]; n += path_index_host[p] >= 0; }
-  *n_enabled = n;
-  return NQ_OK;
-}
-
 static int qh_exp_fill(QhExpArgs* a, const float* x, const float* W, const float* bias, int64_t R, int32_t Cb, const int32_t* shells_host, int32_t nw, int32_t nb,
                        const float* w3j, int* n_ins, int* res_total) {
   if (!x || !W || !shells_host || !w3j) return nq_fail(NQ_ERR_ARG, "null argument");
@@ -553,6 +516,32 @@ static int qh_exp_fill(QhExpArgs* a, const float* x, const float* W, const float
   return NQ_OK;
 }
 
+static int qh_tp_variant = 2;   // measured (scripts/bench_qh_tp.py, profiles/r02_qh_tp_variants.txt): chunked weight prefetch without scheduling barriers
+template <int SET, bool UVU, int VAR>
+static void qh_tp_launch_v(const QhTpArgs& a, bool bwd, hipStream_t st) {
+  const unsigned grid = (unsigned)((a.R * a.C + 255) / 256);
+  if (bwd) hipLaunchKernelGGL((k_qh_tp<SET, UVU, true, VAR>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_qh_tp<SET, UVU, false, VAR>), dim3(grid), dim3(256), 0, st, a);
+}
+template <int SET, bool UVU>
+static void qh_tp_launch(const QhTpArgs& a, bool bwd, hipStream_t st) {
+  if (qh_tp_variant == 1) qh_tp_launch_v<SET, UVU, 1>(a, bwd, st);
+  else if (qh_tp_variant == 2) qh_tp_launch_v<SET, UVU, 2>(a, bwd, st);
+  else qh_tp_launch_v<SET, UVU, 0>(a, bwd, st);
+}
+
+static int qh_tp_dispatch(QhTpArgs& a, int path_set, bool bwd, hipStream_t st) {
+  const bool uvu = a.sh != nullptr;
+  if (uvu ? (path_set != 1 && path_set != 2) : path_set != 0) return nq_fail(NQ_ERR_ARG, "path set: 0 (all 65, gathered second operand), 1 (42 even) or 2 (first layer) with spherical harmonics");
+  if (a.n1 != (path_set == 2 ? 1 : QH_NCOMP)) return nq_fail(NQ_ERR_ARG, "first operand must have %d components for this path set", path_set == 2 ? 1 : QH_NCOMP);
+  if (a.R * a.C <= 0) return NQ_OK;
+  a.np_rt = qh_path_count(path_set);
+  if (!uvu) qh_tp_launch<0, false>(a, bwd, st);
+  else if (path_set == 1) qh_tp_launch<1, true>(a, bwd, st);
+  else qh_tp_launch<2, true>(a, bwd, st);
+  return NQ_OK;
+}
+
 extern "C" {
 
 int nq_qh_invariants_forward(const float* x, int64_t N, int32_t ncomp, int32_t C, const int32_t* own, const int32_t* col, int64_t R, int32_t second_from_owner,
@@ -580,70 +569,42 @@ int nq_qh_invariants_backward(const float* x, const float* grad_s0, int64_t N, i
   return NQ_OK;
 }
 
-int nq_qh_conv_forward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* self_x, int64_t N, int32_t C,
-                       const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int8_t* path_index_host, float* out, void* stream) {
-  QhConvArgs a{};
-  if (!x || !sh || !w1 || !row_ptr || !col || !rev || !out) return nq_fail(NQ_ERR_ARG, "null argument");
-  if (ncomp_in != 1 && ncomp_in != 25) return nq_fail(NQ_ERR_ARG, "conv input must be scalars (1 component) or lmax = 4 irreps (25)");
-  NQ_TRY(qh_paths(a.cidx, path_index_host, &a.np));
-  a.x = x; a.sh = sh; a.w1 = w1; a.w2 = w2; a.self_x = self_x; a.out = out; a.row_ptr = row_ptr; a.col = col; a.rev = rev;
-  a.N = (int)N; a.C = C; a.n1 = ncomp_in; a.add_self = self_x != nullptr;
+void nq_qh_set_tp_variant(int32_t v) { qh_tp_variant = v; }
+int nq_qh_tp_num_paths(int32_t path_set) { return path_set == 0 ? qh_path_count(0) : path_set == 1 ? qh_path_count(1) : path_set == 2 ? qh_path_count(2) : -1; }
+
+int nq_qh_tp_forward(const float* x, int32_t ncomp1, const int32_t* idx1, const float* sh, const int32_t* idx2, const float* w1, const float* w2, int64_t R,
+                     int32_t C, int32_t path_set, float* y_rows, void* stream) {
+  QhTpArgs a{};
+  if (!x || !idx1 || (!sh && !idx2) || !w1 || !y_rows) return nq_fail(NQ_ERR_ARG, "null argument");
+  a.x = x; a.i1 = idx1; a.i2 = idx2; a.sh = sh; a.w1 = w1; a.w2 = w2; a.y = y_rows; a.R = R; a.C = C; a.n1 = ncomp1;
   hipStream_t st = (hipStream_t)stream;
-  NQ_PROF(st, "qh_conv_fwd");
-  if (N * C > 0) hipLaunchKernelGGL((k_qh_conv<false>), dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, st, a);
+  NQ_PROF(st, sh ? "qh_tp_uvu_fwd" : "qh_tp_uuu_fwd");
+  NQ_TRY(qh_tp_dispatch(a, path_set, false, st));
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
-int nq_qh_conv_backward(const float* x, int32_t ncomp_in, const float* sh, const float* w1, const float* w2, const float* grad_out, int64_t N, int32_t C,
-                        const int32_t* row_ptr, const int32_t* col, const int8_t* path_index_host, int32_t add_self, float* grad_x, float* grad_w1,
-                        float* grad_w2, void* stream) {
-  QhConvArgs a{};
-  if (!x || !sh || !w1 || !grad_out || !row_ptr || !col || !grad_x || !grad_w1 || (w2 && !grad_w2)) return nq_fail(NQ_ERR_ARG, "null argument");
-  if (ncomp_in != 1 && ncomp_in != 25) return nq_fail(NQ_ERR_ARG, "conv input must be scalars (1 component) or lmax = 4 irreps (25)");
-  if (add_self && ncomp_in != 25) return nq_fail(NQ_ERR_ARG, "self connection needs equal input / output irreps");
-  NQ_TRY(qh_paths(a.cidx, path_index_host, &a.np));
-  a.x = x; a.sh = sh; a.w1 = w1; a.w2 = w2; a.gout = grad_out; a.gx = grad_x; a.gw1 = grad_w1; a.gw2 = grad_w2; a.row_ptr = row_ptr; a.col = col;
-  a.N = (int)N; a.C = C; a.n1 = ncomp_in; a.add_self = add_self;
+int nq_qh_tp_backward(const float* x, int32_t ncomp1, const int32_t* idx1, const float* sh, const int32_t* idx2, const float* w1, const float* w2,
+                      const float* grad_y, const int32_t* idx_gy, int64_t R, int32_t C, int32_t path_set, float* grad_x1_rows, float* grad_x2_rows,
+                      float* grad_w1, float* grad_w2, void* stream) {
+  QhTpArgs a{};
+  if (!x || !idx1 || (!sh && !idx2) || !w1 || !grad_y || !grad_x1_rows || (!sh && !grad_x2_rows) || !grad_w1 || (w2 && !grad_w2))
+    return nq_fail(NQ_ERR_ARG, "null argument");
+  a.x = x; a.i1 = idx1; a.i2 = idx2; a.sh = sh; a.w1 = w1; a.w2 = w2; a.gy = grad_y; a.ig = idx_gy; a.gx1 = grad_x1_rows; a.gx2 = grad_x2_rows;
+  a.gw1 = grad_w1; a.gw2 = grad_w2; a.R = R; a.C = C; a.n1 = ncomp1;
   hipStream_t st = (hipStream_t)stream;
-  NQ_PROF(st, "qh_conv_bwd");
-  if (N * C > 0) hipLaunchKernelGGL((k_qh_conv<true>), dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, st, a);
+  NQ_PROF(st, sh ? "qh_tp_uvu_bwd" : "qh_tp_uuu_bwd");
+  NQ_TRY(qh_tp_dispatch(a, path_set, true, st));
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
-int nq_qh_pairmix_forward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, int64_t R, int32_t C,
-                          const int8_t* path_index_host, float* y, void* stream) {
-  QhPairArgs a{};
-  if (!x || !idx1 || !idx2 || !w1 || !y) return nq_fail(NQ_ERR_ARG, "null argument");
-  NQ_TRY(qh_paths(a.cidx, path_index_host, &a.np));
-  a.x = x; a.i1 = idx1; a.i2 = idx2; a.w1 = w1; a.w2 = w2; a.y = y; a.R = R; a.C = C;
-  hipStream_t st = (hipStream_t)stream;
-  NQ_PROF(st, "qh_pairmix_fwd");
-  if (R * C > 0) hipLaunchKernelGGL((k_qh_pairmix<false>), dim3((unsigned)((R * C + 255) / 256)), dim3(256), 0, st, a);
-  NQ_LAUNCH_CHECK();
-  return NQ_OK;
-}
-
-int nq_qh_pairmix_backward(const float* x, const int32_t* idx1, const int32_t* idx2, const float* w1, const float* w2, const float* grad_y, int64_t R, int32_t C,
-                           const int8_t* path_index_host, float* grad_x1_rows, float* grad_x2_rows, float* grad_w1, float* grad_w2, void* stream) {
-  QhPairArgs a{};
-  if (!x || !idx1 || !idx2 || !w1 || !grad_y || !grad_x1_rows || !grad_x2_rows || !grad_w1 || (w2 && !grad_w2)) return nq_fail(NQ_ERR_ARG, "null argument");
-  NQ_TRY(qh_paths(a.cidx, path_index_host, &a.np));
-  a.x = x; a.i1 = idx1; a.i2 = idx2; a.w1 = w1; a.w2 = w2; a.gy = grad_y; a.gx1 = grad_x1_rows; a.gx2 = grad_x2_rows; a.gw1 = grad_w1; a.gw2 = grad_w2;
-  a.R = R; a.C = C;
-  hipStream_t st = (hipStream_t)stream;
-  NQ_PROF(st, "qh_pairmix_bwd");
-  if (R * C > 0) hipLaunchKernelGGL((k_qh_pairmix<true>), dim3((unsigned)((R * C + 255) / 256)), dim3(256), 0, st, a);
-  NQ_LAUNCH_CHECK();
-  return NQ_OK;
-}
-
-int nq_qh_pair_reduce(const float* rows_own, const float* rows_nbr, const int32_t* row_ptr, const int32_t* rev, int64_t N, int32_t width, float* out, void* stream) {
+int nq_qh_pair_reduce(const float* rows_own, const float* rows_nbr, const float* base, const int32_t* row_ptr, const int32_t* rev, int64_t N, int32_t width, float* out,
+                      void* stream) {
   if ((!rows_own && !rows_nbr) || !row_ptr || !rev || !out) return nq_fail(NQ_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "qh_pair_reduce");
-  if (N * width > 0) hipLaunchKernelGGL(k_qh_pair_reduce, dim3((unsigned)((N * width + 255) / 256)), dim3(256), 0, st, rows_own, rows_nbr, row_ptr, rev, (int)N, width, out);
+  if (N * width > 0) hipLaunchKernelGGL(k_qh_pair_reduce, dim3((unsigned)((N * width + 255) / 256)), dim3(256), 0, st, rows_own, rows_nbr, base, row_ptr, rev, (int)N, width, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

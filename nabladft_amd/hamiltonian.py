@@ -223,6 +223,8 @@ class HamiltonianLoss(nn.Module):
     """rmse + mae over the block-diagonal support (qhnet/loss.py:9-16).  ``pred`` / ``target`` are PACKED tensors (the diagonal blocks);
     for those ``mask.sum() == numel`` so the reference's ``numel / mask.sum()`` rescaling of the dense means is already applied."""
 
+    packed = True          # QHNetLightning hands packed predictions / targets to losses that declare this
+
     def forward(self, pred, target, mask=None):
         if not pred.is_cuda:
             raise RuntimeError("nabladft_amd.hamiltonian.HamiltonianLoss runs on MI355X only")

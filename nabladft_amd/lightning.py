@@ -1,13 +1,18 @@
-"""``PaiNNLightning`` with the constructor and step methods of the reference wrapper
-(/root/reference/nablaDFT/painn_pyg/painn.py:623-776) and ``L2Loss`` (gemnet_oc/loss.py:5-22).
+"""Plugin wrappers of the hot path: the classes ``hydra.utils.instantiate(config.model)`` builds in the reference
 
-pytorch_lightning is used when importable (then ``run.py`` / ``pipelines.py`` drive this class
-unchanged: config/model/painn-oc.yaml only needs its two ``_target_`` lines pointed here, see
-INTEGRATION.md); without it the class degrades to a plain nn.Module with the same methods so the
-step logic stays testable.
+  PaiNNLightning       <-> nablaDFT.painn_pyg.PaiNNLightning   (/root/reference/nablaDFT/painn_pyg/painn.py:623-776)
+  QHNetLightning       <-> nablaDFT.qhnet.QHNetLightning       (/root/reference/nablaDFT/qhnet/qhnet.py:345-536, incl. the EMA hooks :459-482)
+  AtomisticTaskFixed   <-> nablaDFT.ase_model.AtomisticTaskFixed (/root/reference/nablaDFT/ase_model/task.py:9-73, a schnetpack AtomisticTask)
+  ModelOutput          <-> schnetpack.task.ModelOutput (config/model/painn.yaml:30-46)
+  L2Loss               <-> nablaDFT.gemnet_oc.loss.L2Loss      (gemnet_oc/loss.py:5-22)
+
+with the reference constructors and the Lightning hook names, so run.py / pipelines.py drive them unchanged.  The three
+wrappers share one stage machine (``_Task``): a subclass only says how a batch becomes (predictions, targets, loss arguments).
+pytorch_lightning is used when importable; without it the classes are plain nn.Modules with the same methods (the step logic stays testable).
 """
+from contextlib import nullcontext
 from types import SimpleNamespace
-from typing import Dict
+from typing import Any, Dict, List, Optional
 
 import torch
 from torch import nn
@@ -21,79 +26,85 @@ except Exception:  # noqa: BLE001
     _HAVE_PL = False
 
 
-def l2loss_atomwise(pred, target, reduction="mean"):
-    dist = torch.linalg.vector_norm((pred - target), dim=-1)
-    if reduction == "mean":
-        return torch.mean(dist)
-    if reduction == "sum":
-        return torch.sum(dist)
-    return dist
-
-
 class L2Loss(nn.Module):
+    """mean / sum / no reduction of the per-atom Euclidean norm of (pred - target)."""
+
     def __init__(self, reduction="mean"):
         super().__init__()
         self.reduction = reduction
 
     def forward(self, pred, target):
-        return l2loss_atomwise(pred, target, self.reduction)
+        d = torch.linalg.vector_norm(pred - target, dim=-1)
+        return {"mean": torch.mean, "sum": torch.sum}.get(self.reduction, lambda t: t)(d)
 
 
-class PaiNNLightning(_Base):
-    def __init__(self, model_name: str, model: nn.Module, optimizer, lr_scheduler, losses: Dict, metric, loss_coefs) -> None:
-        super().__init__()
-        self.model = model
+def l2loss_atomwise(pred, target, reduction="mean"):
+    return L2Loss(reduction)(pred, target)
+
+
+# what each stage logs: (name, self.log keyword arguments)
+_STAGE_LOGS = {
+    "train": (("train/loss", dict(on_step=True, on_epoch=True, logger=True)),),
+    "val": (("val/loss", dict(prog_bar=True, on_step=True, on_epoch=True, logger=True)),
+            ("val_loss", dict(on_step=False, on_epoch=True, logger=False))),          # the un-slashed name feeds the checkpoint callback
+    "test": (("test/loss", dict(prog_bar=True, on_step=True, on_epoch=True, logger=True)),),
+}
+
+
+class _Task(_Base):
+    """Stage machine shared by the wrappers.  Subclasses implement ``_evaluate(batch) -> (preds, targets, loss_args)``."""
+
+    def _store_hparams(self, ignore, **hp):
         if _HAVE_PL:
-            self.save_hyperparameters(logger=True, ignore=["net"])
+            self.save_hyperparameters(logger=True, ignore=list(ignore))
         else:
-            self.hparams = SimpleNamespace(model_name=model_name, optimizer=optimizer, lr_scheduler=lr_scheduler, losses=losses,
-                                           metric=metric, loss_coefs=loss_coefs)
+            self.hparams = SimpleNamespace(**hp)
 
-    def forward(self, data):
-        energy, forces = self.model(data)
-        return energy, forces
+    # -- loss / metrics ---------------------------------------------------------------------------------------------------------------
+    def _evaluate(self, batch):
+        raise NotImplementedError
+
+    def _calculate_loss(self, y_pred, y_true, *loss_args):
+        return sum(self.hparams.loss_coefs[name] * fn(y_pred[name], y_true[name], *loss_args) for name, fn in self.hparams.losses.items())
+
+    def _calculate_metrics(self, y_pred, y_true, *loss_args):
+        return {} if self.hparams.metric is None else self.hparams.metric(y_pred, y_true)
 
     def step(self, batch, calculate_metrics: bool = False):
-        y = batch.y
-        energy_out, forces_out = self.model(batch)
-        forces = batch.forces
-        preds = {"energy": energy_out, "forces": forces_out}
-        target = {"energy": y, "forces": forces}
-        loss = self._calculate_loss(preds, target)
-        if calculate_metrics:
-            metrics = self._calculate_metrics(preds, target)
-            return loss, metrics
+        preds, targets, loss_args = self._evaluate(batch)
+        loss = self._calculate_loss(preds, targets, *loss_args)
+        return (loss, self._calculate_metrics(preds, targets, *loss_args)) if calculate_metrics else loss
+
+    # -- stages -----------------------------------------------------------------------------------------------------------------------
+    def _stage_context(self, stage):
+        return nullcontext()
+
+    def _run_stage(self, stage, batch):
+        bsz = self._get_batch_size(batch)
+        with self._stage_context(stage):
+            out = self.step(batch, calculate_metrics=stage != "train")
+        loss = out if stage == "train" else out[0]
+        if stage == "train":
+            self._log_current_lr()
+        for name, kw in _STAGE_LOGS[stage]:
+            self._log(name, loss, sync_dist=True, batch_size=bsz, **kw)
         return loss
 
     def training_step(self, batch, batch_idx):
-        bsz = self._get_batch_size(batch)
-        loss = self.step(batch, calculate_metrics=False)
-        self._log("train/loss", loss, on_step=True, on_epoch=True, logger=True, sync_dist=True, batch_size=bsz)
-        return loss
+        return self._run_stage("train", batch)
 
     def validation_step(self, batch, batch_idx):
-        bsz = self._get_batch_size(batch)
-        loss, _ = self.step(batch, calculate_metrics=True)
-        self._log("val/loss", loss, prog_bar=True, on_step=True, on_epoch=True, logger=True, sync_dist=True, batch_size=bsz)
-        self._log("val_loss", loss, on_step=False, on_epoch=True, logger=False, sync_dist=True, batch_size=bsz)
-        return loss
+        return self._run_stage("val", batch)
 
     def test_step(self, batch, batch_idx):
-        bsz = self._get_batch_size(batch)
-        loss, _ = self.step(batch, calculate_metrics=True)
-        self._log("test/loss", loss, prog_bar=True, on_step=True, on_epoch=True, logger=True, sync_dist=True, batch_size=bsz)
-        return loss
-
-    def predict_step(self, data, **kwargs):
-        return self(data)
+        return self._run_stage("test", batch)
 
     def configure_optimizers(self):
         optimizer = self.hparams.optimizer(params=self.parameters())
-        if self.hparams.lr_scheduler is not None:
-            scheduler = self.hparams.lr_scheduler(optimizer=optimizer)
-            return {"optimizer": optimizer,
-                    "lr_scheduler": {"scheduler": scheduler, "interval": "epoch", "monitor": "val_loss", "frequency": 1}}
-        return {"optimizer": optimizer}
+        if self.hparams.lr_scheduler is None:
+            return {"optimizer": optimizer}
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": self.hparams.lr_scheduler(optimizer=optimizer), "interval": "epoch", "monitor": "val_loss", "frequency": 1}}
 
     def on_fit_start(self) -> None:
         self._check_devices()
@@ -102,28 +113,17 @@ class PaiNNLightning(_Base):
         self._check_devices()
 
     def on_validation_epoch_end(self) -> None:
-        self._reduce_metrics(step_type="val")
+        self._reduce_metrics("val")
 
     def on_test_epoch_end(self) -> None:
-        self._reduce_metrics(step_type="test")
+        self._reduce_metrics("test")
 
-    def _calculate_loss(self, y_pred, y_true):
-        total_loss = 0.0
-        for name, loss in self.hparams.losses.items():
-            total_loss += self.hparams.loss_coefs[name] * loss(y_pred[name], y_true[name])
-        return total_loss
-
-    def _calculate_metrics(self, y_pred, y_true):
-        if self.hparams.metric is None:
-            return {}
-        return self.hparams.metric(y_pred, y_true)
-
+    # -- helpers ----------------------------------------------------------------------------------------------------------------------
     def _reduce_metrics(self, step_type: str = "train"):
         if self.hparams.metric is None:
             return
-        metric = self.hparams.metric.compute()
-        for key in metric.keys():
-            self._log(f"{step_type}/{key}", metric[key], logger=True, on_step=False, on_epoch=True, sync_dist=True)
+        for key, value in self.hparams.metric.compute().items():
+            self._log(f"{step_type}/{key}", value, logger=True, on_step=False, on_epoch=True, sync_dist=True)
         self.hparams.metric.reset()
 
     def _check_devices(self):
@@ -131,8 +131,211 @@ class PaiNNLightning(_Base):
             self.hparams.metric = self.hparams.metric.to(next(self.parameters()).device)
 
     def _get_batch_size(self, batch):
-        return batch.batch.max().detach().item() + 1
+        return int(batch.batch.max().detach().item()) + 1
+
+    def _log_current_lr(self):
+        if _HAVE_PL:
+            self.log("LR", self.optimizers().optimizer.param_groups[0]["lr"], logger=True)
 
     def _log(self, *args, **kwargs):
         if _HAVE_PL:
             self.log(*args, **kwargs)
+
+
+class PaiNNLightning(_Task):
+    def __init__(self, model_name: str, model: nn.Module, optimizer, lr_scheduler, losses: Dict, metric, loss_coefs) -> None:
+        super().__init__()
+        self.model = model
+        self._store_hparams(["net"], model_name=model_name, optimizer=optimizer, lr_scheduler=lr_scheduler, losses=losses, metric=metric, loss_coefs=loss_coefs)
+
+    def forward(self, data):
+        energy, forces = self.model(data)
+        return energy, forces
+
+    def _evaluate(self, batch):
+        energy, forces = self.model(batch)
+        return {"energy": energy, "forces": forces}, {"energy": batch.y, "forces": batch.forces}, ()
+
+    def predict_step(self, data, **kwargs):
+        return self(data)
+
+    def _log_current_lr(self):          # the PaiNN wrapper of the reference does not log the learning rate on the step
+        pass
+
+
+class QHNetLightning(_Task):
+    """``net`` is ``nabladft_amd.qhnet.QHNet``.  Losses that declare ``packed = True`` (nabladft_amd.hamiltonian.HamiltonianLoss) get the
+    diagonal blocks packed molecule after molecule -- prediction and target -- and never see the block_diag matrix; any other loss (e.g. the
+    reference's own HamiltonianLoss) is called as in the reference with dense ``(pred, target, mask)``.  ``ema``: a factory
+    ``ema(parameters) -> object with update() / average_parameters() / to()`` (config/model/qhnet.yaml:51-54: torch_ema's class;
+    ``nabladft_amd.ema.ExponentialMovingAverage`` is the in-tree equivalent) or None."""
+
+    def __init__(self, model_name: str, net: nn.Module, optimizer, lr_scheduler, losses: Dict, ema, metric, loss_coefs) -> None:
+        super().__init__()
+        self.net = net
+        self.ema = ema
+        self._store_hparams(["net"], model_name=model_name, optimizer=optimizer, lr_scheduler=lr_scheduler, losses=losses, ema=ema, metric=metric,
+                            loss_coefs=loss_coefs)
+
+    def forward(self, data):
+        return self.net(data)
+
+    def _packed(self):
+        return all(getattr(fn, "packed", False) for fn in self.hparams.losses.values())
+
+    def _evaluate(self, batch):
+        dev = next(self.net.parameters()).device
+        if self._packed():
+            pred = self.net(batch, packed=True)
+            target = self.net._asm.pack_targets(self.net.last_plan, batch.hamiltonian)
+            return {"hamiltonian": pred}, {"hamiltonian": target}, (None,)
+        pred = self.net(batch)
+        blocks = [torch.as_tensor(H) for H in batch.hamiltonian]
+        target = torch.block_diag(*blocks).to(dev)
+        masks = torch.block_diag(*[torch.ones_like(b) for b in blocks]).to(dev)
+        return {"hamiltonian": pred}, {"hamiltonian": target}, (masks,)
+
+    def _calculate_metrics(self, y_pred, y_true, mask=None):
+        if self.hparams.metric is None:
+            return {}
+        metric = self.hparams.metric(y_pred, y_true)
+        if mask is not None:                       # dense matrices: the reference rescales the all-elements mean to the block support
+            metric["hamiltonian"] = metric["hamiltonian"] * (y_pred["hamiltonian"].numel() / mask.sum())
+        return metric
+
+    def _stage_context(self, stage):
+        return self.ema.average_parameters() if stage == "val" and self._ema_live() else nullcontext()
+
+    def predict_step(self, data, **kwargs) -> List[torch.Tensor]:
+        packed = self.net(data, packed=True)
+        plan = self.net.last_plan
+        off, sizes = plan.pack_ptr.tolist(), (plan.mol_orb_ptr[1:] - plan.mol_orb_ptr[:-1]).tolist()
+        return [packed[off[b]:off[b + 1]].view(sizes[b], sizes[b]) for b in range(plan.B)]
+
+    # -- EMA hooks (qhnet.py:459-482, :521-536) -------------------------------------------------------------------------------------------
+    def _ema_live(self):
+        return self.ema is not None and hasattr(self.ema, "average_parameters")
+
+    def _instantiate_ema(self):
+        if self.ema is not None and not self._ema_live():
+            self.ema = self.ema(self.parameters())
+
+    def _check_devices(self):
+        super()._check_devices()
+        self.net.set()
+        if self._ema_live():
+            self.ema.to(next(self.net.parameters()).device)
+
+    def on_before_zero_grad(self, optimizer) -> None:
+        if self._ema_live():
+            self.ema.update()
+
+    def on_fit_start(self) -> None:
+        self._instantiate_ema()
+        self._check_devices()
+
+    def on_test_start(self) -> None:
+        self._instantiate_ema()
+        self._check_devices()
+
+    def on_predict_start(self) -> None:
+        self._instantiate_ema()
+        self._check_devices()
+
+    def on_save_checkpoint(self, checkpoint) -> None:
+        with (self.ema.average_parameters() if self._ema_live() else nullcontext()):
+            checkpoint["state_dict"] = {k: v.detach().clone() for k, v in self.state_dict().items()}
+
+    def _get_hamiltonian_sizes(self, batch):
+        sizes = [0]
+        for b in range(batch.ptr.shape[0] - 1):
+            atoms = batch.z[batch.ptr[b]:batch.ptr[b + 1]]
+            sizes.append(sizes[-1] + sum(int(self.net.orbital_mask[int(a)].shape[0]) for a in atoms))
+        return sizes
+
+
+class ModelOutput(nn.Module):
+    """schnetpack.task.ModelOutput(name, loss_fn, loss_weight, metrics, target_property) -- one supervised output of an AtomisticTask."""
+
+    def __init__(self, name: str, loss_fn: Optional[nn.Module] = None, loss_weight: float = 1.0, metrics: Optional[Dict[str, Any]] = None,
+                 constraints=None, target_property: Optional[str] = None):
+        super().__init__()
+        self.name, self.loss_fn, self.loss_weight = name, loss_fn, loss_weight
+        self.target_property = target_property or name
+        self.metrics = metrics or {}
+        self.constraints = constraints or []
+
+    def calculate_loss(self, pred, target):
+        if self.loss_weight == 0 or self.loss_fn is None:
+            return 0.0
+        return self.loss_weight * self.loss_fn(pred[self.name], target[self.target_property])
+
+
+class AtomisticTaskFixed(_Task):
+    """The schnetpack task of config/model/{schnet,painn}.yaml over ``nabladft_amd.spk.NeuralNetworkPotential``: loss = sum_outputs weight * loss_fn
+    (MSE there), optimiser / scheduler from classes + argument dicts, dict batches keyed by property name.  PARITY UNPINNED like the rest of
+    the schnetpack surface.  Forces come from the analytic adjoint sweep, so ``grad_enabled`` is irrelevant here."""
+
+    def __init__(self, model_name: str, model: nn.Module, outputs: List[ModelOutput], optimizer_cls=torch.optim.Adam, optimizer_args: Optional[Dict[str, Any]] = None,
+                 scheduler_cls=None, scheduler_args: Optional[Dict[str, Any]] = None, scheduler_monitor: Optional[str] = None, warmup_steps: int = 0):
+        super().__init__()
+        self.model = model
+        self.outputs = nn.ModuleList(outputs)
+        self.optimizer_cls, self.optimizer_kwargs = optimizer_cls, optimizer_args or {}
+        self.scheduler_cls, self.scheduler_kwargs, self.schedule_monitor = scheduler_cls, scheduler_args or {}, scheduler_monitor
+        self.warmup_steps, self.grad_enabled = warmup_steps, True
+        self.lr = self.optimizer_kwargs.get("lr")
+        self._store_hparams(["model"], model_name=model_name, warmup_steps=warmup_steps)
+        self.hparams.model_name = model_name
+
+    def forward(self, inputs):
+        return self.model(inputs)
+
+    def _targets(self, batch):
+        return {o.target_property: batch[o.target_property] for o in self.outputs}
+
+    def loss_fn(self, pred, batch):
+        return sum(o.calculate_loss(pred, batch) for o in self.outputs)
+
+    def _evaluate(self, batch):
+        return self(batch), self._targets(batch), ()
+
+    def _calculate_loss(self, y_pred, y_true):
+        return self.loss_fn(y_pred, y_true)
+
+    def _calculate_metrics(self, y_pred, y_true):
+        return {f"{o.name}_{k}": m(y_pred[o.name], y_true[o.target_property]) for o in self.outputs for k, m in o.metrics.items()}
+
+    def _run_stage(self, stage, batch):                       # schnetpack's log names: train_loss / val_loss / test_loss, metrics per output
+        loss, metrics = self.step(batch, calculate_metrics=True)
+        self._log(f"{stage}_loss", loss, on_step=stage == "train", on_epoch=stage != "train", prog_bar=stage != "train")
+        for k, v in metrics.items():
+            self._log(f"{stage}_{k}", v, on_step=stage == "train", on_epoch=stage != "train", prog_bar=False)
+        return loss if stage == "train" else {f"{stage}_loss": loss}
+
+    def predict_step(self, batch, batch_idx=0):
+        return self(batch)
+
+    def configure_optimizers(self):
+        optimizer = self.optimizer_cls(params=self.parameters(), **self.optimizer_kwargs)
+        if self.scheduler_cls is None:
+            return optimizer
+        sched = {"scheduler": self.scheduler_cls(optimizer=optimizer, **self.scheduler_kwargs)}
+        if self.schedule_monitor:
+            sched["monitor"] = self.schedule_monitor
+        return [optimizer], [sched]
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        key = "model.postprocessors.0.mean"       # AddOffsets' scalar statistic must be saved with shape [1] (ase_model/task.py:67-73)
+        mean = checkpoint["state_dict"].get(key, None)
+        if mean is not None:
+            checkpoint["state_dict"][key] = mean.reshape(1)
+
+    def _get_batch_size(self, batch):
+        return int(batch["_idx_m"].max().item()) + 1
+
+    def _reduce_metrics(self, step_type="train"):
+        pass
+
+    def _check_devices(self):
+        pass

@@ -223,30 +223,38 @@ class _InvFn(torch.autograd.Function):
 
 
 class _ConvFn(torch.autograd.Function):
-    """ConvLayer.tp_node + scatter (+ self connection): out [N, 25, C]."""
+    """ConvLayer.tp_node + scatter (+ self connection): out [N, 25, C].  Messages are computed per edge (one thread per edge and channel) and
+    summed per receiving atom along the reverse slots of its CSR row."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, csr, sh, pidx, add_self):
+    def forward(ctx, x, w1, w2, csr, sh, path_set, add_self):
         lib = _lib.load()
         x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
         N, n1, Cc = x.shape
+        msg = torch.empty(csr.R, NCOMP, Cc, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_qh_tp_forward(_lib.ptr(x), n1, _lib.ptr(csr.own), _lib.ptr(sh), None, _lib.ptr(w1), _lib.ptr(w2), csr.R, Cc, path_set, _lib.ptr(msg),
+                                        _lib.stream_ptr()))
         out = torch.empty(N, NCOMP, Cc, device=x.device, dtype=torch.float32)
-        _lib.check(lib.nq_qh_conv_forward(_lib.ptr(x), n1, _lib.ptr(sh), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(x) if add_self else None, N, Cc, _lib.ptr(csr.row_ptr),
-                                          _lib.ptr(csr.col), _lib.ptr(csr.rev), pidx, _lib.ptr(out), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_pair_reduce(None, _lib.ptr(msg), _lib.ptr(x) if add_self else None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), N, NCOMP * Cc,
+                                         _lib.ptr(out), _lib.stream_ptr()))
         ctx.save_for_backward(x, w1, w2)
-        ctx.meta = (csr, sh, pidx, add_self)
+        ctx.meta = (csr, sh, path_set, add_self)
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         x, w1, w2 = ctx.saved_tensors
-        csr, sh, pidx, add_self = ctx.meta
+        csr, sh, path_set, add_self = ctx.meta
         N, n1, Cc = x.shape
         g = _f32(g)
-        gx, gw1, gw2 = torch.empty_like(x), torch.empty_like(w1), torch.empty_like(w2)
-        _lib.check(lib.nq_qh_conv_backward(_lib.ptr(x), n1, _lib.ptr(sh), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(g), N, Cc, _lib.ptr(csr.row_ptr), _lib.ptr(csr.col), pidx,
-                                           int(add_self), _lib.ptr(gx), _lib.ptr(gw1), _lib.ptr(gw2), _lib.stream_ptr()))
+        grow = torch.empty(csr.R, n1, Cc, device=x.device, dtype=torch.float32)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.check(lib.nq_qh_tp_backward(_lib.ptr(x), n1, _lib.ptr(csr.own), _lib.ptr(sh), None, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(g), _lib.ptr(csr.col), csr.R, Cc,
+                                         path_set, _lib.ptr(grow), None, _lib.ptr(gw1), _lib.ptr(gw2), _lib.stream_ptr()))
+        gx = torch.empty_like(x)
+        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(grow), None, _lib.ptr(g) if add_self else None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), N, n1 * Cc, _lib.ptr(gx),
+                                         _lib.stream_ptr()))
         return gx, gw1, gw2, None, None, None, None
 
 
@@ -254,31 +262,32 @@ class _PairMixFn(torch.autograd.Function):
     """PairNetLayer.tp_node_pair: y[r] = TP_uuu(x[src(r)], x[dst(r)], w1[r] * w2[r]) over the full pair list."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, csr, pidx):
+    def forward(ctx, x, w1, w2, csr):
         lib = _lib.load()
         x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
         N, _, Cc = x.shape
         y = torch.empty(csr.R, NCOMP, Cc, device=x.device, dtype=torch.float32)
-        _lib.check(lib.nq_qh_pairmix_forward(_lib.ptr(x), _lib.ptr(csr.own), _lib.ptr(csr.col), _lib.ptr(w1), _lib.ptr(w2), csr.R, Cc, pidx, _lib.ptr(y), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_tp_forward(_lib.ptr(x), NCOMP, _lib.ptr(csr.own), None, _lib.ptr(csr.col), _lib.ptr(w1), _lib.ptr(w2), csr.R, Cc, 0, _lib.ptr(y),
+                                        _lib.stream_ptr()))
         ctx.save_for_backward(x, w1, w2)
-        ctx.meta = (csr, pidx)
+        ctx.csr = csr
         return y
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         x, w1, w2 = ctx.saved_tensors
-        csr, pidx = ctx.meta
+        csr = ctx.csr
         N, _, Cc = x.shape
         g = _f32(g)
         g1 = torch.empty(csr.R, NCOMP, Cc, device=x.device, dtype=torch.float32)
         g2 = torch.empty_like(g1)
         gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
-        _lib.check(lib.nq_qh_pairmix_backward(_lib.ptr(x), _lib.ptr(csr.own), _lib.ptr(csr.col), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(g), csr.R, Cc, pidx, _lib.ptr(g1),
-                                              _lib.ptr(g2), _lib.ptr(gw1), _lib.ptr(gw2), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_tp_backward(_lib.ptr(x), NCOMP, _lib.ptr(csr.own), None, _lib.ptr(csr.col), _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(g), None, csr.R, Cc, 0,
+                                         _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(gw1), _lib.ptr(gw2), _lib.stream_ptr()))
         gx = torch.empty_like(x)
-        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(g1), _lib.ptr(g2), _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), N, NCOMP * Cc, _lib.ptr(gx), _lib.stream_ptr()))
-        return gx, gw1, gw2, None, None
+        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(g1), _lib.ptr(g2), None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), N, NCOMP * Cc, _lib.ptr(gx), _lib.stream_ptr()))
+        return gx, gw1, gw2, None
 
 
 class _PairGatherAddFn(torch.autograd.Function):
@@ -297,8 +306,8 @@ class _PairGatherAddFn(torch.autograd.Function):
         W = g.shape[1]
         ga = torch.empty(csr.N, W, device=g.device, dtype=torch.float32)
         gb = torch.empty_like(ga)
-        _lib.check(lib.nq_qh_pair_reduce(None, _lib.ptr(g), _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), csr.N, W, _lib.ptr(ga), _lib.stream_ptr()))
-        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(g), None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), csr.N, W, _lib.ptr(gb), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_pair_reduce(None, _lib.ptr(g), None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), csr.N, W, _lib.ptr(ga), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(g), None, None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), csr.N, W, _lib.ptr(gb), _lib.stream_ptr()))
         return ga, gb, None
 
 
@@ -510,7 +519,7 @@ class ConvLayer(nn.Module):
             s0 = _InvFn.apply(x, g.conv, False)
         w1 = self.fc_node(g.edge_attr, self._pc)
         w2 = self.layer_l0(s0)
-        out = _ConvFn.apply(x, w1, w2, g.conv, g.edge_sh, self._pidx, not self.first)
+        out = _ConvFn.apply(x, w1, w2, g.conv, g.edge_sh, 2 if self.first else 1, not self.first)
         return self.linear_out(out)
 
 
@@ -577,7 +586,7 @@ class PairNetLayer(nn.Module):
         xn = self.linear_node_pair_n(self.norm_gate_pre(node_attr))
         w1 = self.fc_node_pair(g.full_edge_attr, self._pc)
         w2 = _mlp(self.fc, s0)
-        node_pair = _PairMixFn.apply(xn, w1, w2, g.full, self._pidx)
+        node_pair = _PairMixFn.apply(xn, w1, w2, g.full)
         node_pair = self.linear_node_pair(self.norm_gate(node_pair))
         if self.resnet and node_pair_attr is not None:
             node_pair = node_pair + node_pair_attr
