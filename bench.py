@@ -138,11 +138,45 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
             "avg_launch_ms": avg_ms, "launches_per_step": launches}
 
 
+def bench_qhnet(args, rank, world, local_dev, dev):
+    """--model qhnet: BASELINE.json configs[3] (config/qhnet.yaml) through scripts/bench_qhnet.py; same JSON contract, conformer-steps/s."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_qhnet as BQ
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    mol = args.batch if args.batch != 2048 else 16
+    rec = BQ.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
+    t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        small = BQ.run(2, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != 2 else None
+        cpu = BQ.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
+        out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(H) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
+                          "ordered_pairs": rec["ordered_pairs"], "edges_within_cutoff": rec["edges_within_cutoff"], "parallelism": f"dp{world}"},
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 WORKLOADS = {
     "painn-oc": "PaiNN-OC (nablaDFT/painn_pyg, config/model/painn-oc.yaml: F=128 L=6 R=100 rc=5A K=100) energy+forces train step incl. "
                 "neighbour list, L1+L2 loss, grad all-reduce, clip 5.0, AdamW lr 5e-4",
     "schnet-spk": "SchNet (config/schnet.yaml -> schnetpack SchNet F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                   "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
+    "qhnet": "QHNet (config/qhnet.yaml) Hamiltonian training step -- see scripts/bench_qhnet.py",
     "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
 }
@@ -277,6 +311,8 @@ def main():
 
     if args.gemm_variant is not None:
         _lib.load().nq_set_gemm_variant(args.gemm_variant)
+    if args.model == "qhnet":
+        return bench_qhnet(args, rank, world, local_dev, dev)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
     model, step = build_step(args.model, dev)
     batches = make_batches(1 + rank, 4, args.batch, dev)
@@ -401,6 +437,23 @@ def main():
         dt2 = time.perf_counter() - t0
         other = {"workload": WORKLOADS[kind2], "value": args.batch * args.steps / dt2, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt2 / args.steps}
 
+    hamiltonian = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+        # BASELINE.json configs[3] (QHNet, config/qhnet.yaml) in the same record: a short run at the reference's batch size (2) and at 16
+        try:
+            del step2, model2
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_qhnet as BQ
+        h16 = BQ.run(16, 5, 2, kernels=True, device=dev)
+        h2 = BQ.run(2, 5, 2, kernels=False, device=dev)
+        for h in (h16, h2):
+            h.pop("_dt", None)
+        hamiltonian = {"workload": h16.pop("workload"), "batch16": h16, "batch2_reference_batch_size": {k: h2[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
+                       "cpu_baseline": None if args.no_cpu_baseline else BQ.cpu_baseline(seconds_budget=20.0)}
+
     if rank == 0:
         out = {
             "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
@@ -414,6 +467,7 @@ def main():
             "cpu_baseline": cpu,
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
+            "hamiltonian": hamiltonian,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,

@@ -62,7 +62,9 @@ def gemm_flops_per_step(net, N, E, P):
     return 3.0 * f
 
 
-def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1):
+def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+    """One rank's share of the job: ``molecules`` conformers per step on this GPU; with world > 1 the flat gradient is all-reduced (mean) each step
+    (conformers are independent graphs: data-parallel, no other collective).  Returns the record with THIS rank's wall time in ``_dt``."""
     import torch
     from nabladft_amd import _lib
     from nabladft_amd.ema import ExponentialMovingAverage
@@ -70,7 +72,8 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1):
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
     net = build(dev)
-    batches = [synthetic_batch(molecules, seed * 100 + k, dev) for k in range(4)]
+    from nabladft_amd import dist as nqdist
+    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=5e-4, betas=(0.9, 0.95), amsgrad=True)
     ema = ExponentialMovingAverage([flat.flat], decay=0.9999)
@@ -87,17 +90,22 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1):
         flat.zero_grad()
         loss = loss_fn(net(b, packed=True), t)
         loss.backward()
+        if world > 1:
+            nqdist.allreduce_mean_(flat.flat.grad)
         opt.step()
         ema.update()
         return loss
 
+    sync = sync or torch.cuda.synchronize
+    if world > 1:
+        nqdist.broadcast_(flat.flat.data)
     for i in range(warmup):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(i)
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     b0 = batches[0]
     N, E, P = b0.num_nodes, int(b0.edge_index.shape[1]), int(b0.full_edge_index.shape[1])
@@ -105,7 +113,7 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1):
                        "forward, HamiltonianLoss on the packed blocks, backward, AdamW(amsgrad), EMA; synthetic ~42-atom conformers in bohr",
            "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": N,
            "edges_within_cutoff": E, "ordered_pairs": P, "orbitals": int(net.last_plan.m_total), "parameters": net.get_number_of_parameters(),
-           "final_loss": float(loss), "dtype": "f32", "data": "synthetic", "parity": "pinned to the reference QHNet classes; e3nn arithmetic restated (unpinned)"}
+           "_dt": dt, "final_loss": float(loss), "dtype": "f32", "data": "synthetic", "parity": "pinned to the reference QHNet classes; e3nn arithmetic restated (unpinned)"}
     if kernels:
         _lib.profile_enable(True)
         for i in range(steps):
@@ -123,8 +131,9 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1):
         fl = gemm_flops_per_step(net, N, E, P)
         dom, dom_ms, dom_n = ks[0]
         C = net.hs
-        alg = {"qh_pairmix_fwd": P * (2 * 65 * C + 3 * 25 * C) * 4.0, "qh_pairmix_bwd": P * (4 * 65 * C + 5 * 25 * C) * 4.0,
-               "qh_conv_fwd": E * (2 * 42 * C) * 4.0 + 2 * N * 25 * C * 4.0, "qh_conv_bwd": E * (4 * 42 * C) * 4.0 + 3 * N * 25 * C * 4.0,
+        # per-row algorithmic bytes: both weight factors (+ their adjoints in the reverse kernels), the gathered irreps rows and the row written
+        alg = {"qh_tp_uuu_fwd": P * (2 * 65 * C + 3 * 25 * C) * 4.0, "qh_tp_uuu_bwd": P * (4 * 65 * C + 5 * 25 * C) * 4.0,
+               "qh_tp_uvu_fwd": E * (2 * 42 * C + 2 * 25 * C) * 4.0, "qh_tp_uvu_bwd": E * (4 * 42 * C + 3 * 25 * C) * 4.0,
                "qh_exp_fwd": P * (8320 + 800 + 1024) * 4.0, "qh_exp_bwd": P * (2 * 8320 + 1600 + 1024) * 4.0}
         if dom in alg:
             per_launch = alg[dom]
