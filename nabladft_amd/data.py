@@ -405,8 +405,9 @@ def hamiltonian_batch(db: HamiltonianDatabase, indices: Sequence[int], include_o
                       dtype=torch.float32) -> HamiltonianBatch:
     """Rows ``indices`` of a Hamiltonian database as one batch, in the given order (one batched query; the reference dataset reads row by row)."""
     idx = [int(i) for i in indices]
-    by_id = dict(zip(sorted(idx), db[sorted(idx)]))
-    rows = [by_id[i] for i in idx]
+    uniq = sorted(set(idx))                                  # the batched query returns each row once, in id order
+    by_id = dict(zip(uniq, db[uniq]))
+    rows = [by_id[i] for i in idx]                           # repeated indices repeat the row
     sizes = torch.tensor([len(r[0]) for r in rows], dtype=torch.long)
     ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
     return HamiltonianBatch(

@@ -10,12 +10,17 @@ used for device memory, streams and autograd plumbing only.  There is no CPU pat
 raises if libnablaq.so is missing or the tensors are not on a GPU.
 """
 import ctypes as C
+import weakref
 from typing import Dict, Optional, Union
 
 import torch
 from torch import nn
 
 from . import _lib
+
+
+class _WorkspaceToken:
+    """Lives on the autograd ctx of the forward that owns the cached workspace (PaiNN._take_workspace)."""
 
 
 class NeighborList:
@@ -99,7 +104,7 @@ class _EnergyForces(torch.autograd.Function):
         flat = model._flat
         dev = flat.device
         ws_bytes = lib.nq_painn_workspace_bytes(C.byref(model._cfg), nl.N, nl.E, nl.B)
-        ws = model._take_workspace(ws_bytes, dev)
+        ws = model._take_workspace(ws_bytes, dev, ctx)
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32) if want_forces else None
         _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
@@ -122,7 +127,7 @@ class _EnergyForces(torch.autograd.Function):
                                          _lib.ptr(ctx.ws), ctx.ws_bytes,
                                          _lib.ptr(ge), _lib.ptr(gf), _lib.ptr(grad_flat), _lib.stream_ptr()))
         model._last_grad_flat = grad_flat
-        model._release_workspace(ctx.ws)
+        model._release_workspace(ctx.ws, ctx)
         grads = tuple(grad_flat[o:o + n].view(s) for (o, n, s) in model._param_slices)
         return (None, None, None) + grads
 
@@ -137,7 +142,7 @@ class _EnergyBackbone(torch.autograd.Function):
         flat = model._flat
         dev = flat.device
         ws_bytes = lib.nq_painn_workspace_bytes(C.byref(model._cfg), nl.N, nl.E, nl.B)
-        ws = model._take_workspace(ws_bytes, dev)
+        ws = model._take_workspace(ws_bytes, dev, ctx)
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         _lib.check(lib.nq_painn_forward(C.byref(model._cfg), _lib.ptr(flat), _lib.ptr(model.radial_basis.engine_buffer()), C.byref(nl.c),
                                         _lib.ptr(ws), ws_bytes, _lib.ptr(energy), None, _lib.stream_ptr()))
@@ -159,7 +164,7 @@ class _EnergyBackbone(torch.autograd.Function):
                                                 _lib.ptr(ctx.ws), ctx.ws_bytes, _lib.ptr(cont(g_energy)), _lib.ptr(cont(g_x)), _lib.ptr(cont(g_vec)),
                                                 _lib.ptr(grad_flat), _lib.stream_ptr()))
         model._last_grad_flat = grad_flat
-        model._release_workspace(ctx.ws)
+        model._release_workspace(ctx.ws, ctx)
         n_engine = model._n_engine_params
         grads = tuple((grad_flat[o:o + n].view(s) if o < n_engine else None) for (o, n, s) in model._param_slices)
         return (None, None) + grads
@@ -442,7 +447,7 @@ class PaiNN(nn.Module):
         self._n_engine_params = None
         self._param_slices = None
         self._last_ws = self._last_nl = self._last_grad_flat = None
-        self._ws_cache, self._ws_busy = None, False
+        self._ws_cache, self._ws_owner = None, None
         cfg = _lib.PainnCfg()
         cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = hidden_channels, num_layers, num_rbf, num_elements
         cfg.max_neighbors, cfg.envelope_exponent = max_neighbors, self.radial_basis.exponent
@@ -460,7 +465,7 @@ class PaiNN(nn.Module):
         state = self.__dict__.copy()
         for k in ("_flat", "_param_slices", "_last_ws", "_last_nl", "_last_grad_flat", "_ws_cache", "_n_engine_params"):
             state[k] = None
-        state["_ws_busy"] = False
+        state["_ws_owner"] = None
         return state
 
     # ---- flat parameter buffer (state_dict order) the C ABI consumes -------------------------------
@@ -490,22 +495,36 @@ class PaiNN(nn.Module):
             self._flat, self._param_slices = flat, slices
         return self._flat
 
-    # ---- workspace cache: one grow-only buffer, handed out again once the backward that owns it has run ----
-    def _take_workspace(self, nbytes, dev):
+    # ---- workspace cache: one grow-only buffer.  It is OWNED by the autograd node of the forward that took it (a token stored on that node's
+    # ctx, tracked here by weak reference): the buffer is free again as soon as that backward has run OR the node has died (outputs dropped, a
+    # forward under grad mode that never runs backward -- e.g. the optimisation calculator calling model(batch) -- or an exception in between).
+    def _ws_in_use(self):
+        owner = self._ws_owner
+        return owner is not None and owner() is not None
+
+    def _take_workspace(self, nbytes, dev, ctx=None):
+        def claim():
+            if ctx is not None and torch.is_grad_enabled():
+                ctx.ws_token = _WorkspaceToken()
+                self._ws_owner = weakref.ref(ctx.ws_token)
+            else:
+                self._ws_owner = None
         ws = self._ws_cache
-        if ws is not None and not self._ws_busy and ws.device == dev and ws.numel() >= nbytes:
-            self._ws_busy = torch.is_grad_enabled()
+        if ws is not None and not self._ws_in_use() and ws.device == dev and ws.numel() >= nbytes:
+            claim()
             return ws
-        if not self._ws_busy:
+        if not self._ws_in_use():
             self._ws_cache = None                                      # drop the old buffer before growing
             self._ws_cache = torch.empty((int(nbytes * 1.08) + 4096) // 256 * 256, device=dev, dtype=torch.uint8)
-            self._ws_busy = torch.is_grad_enabled()
+            claim()
             return self._ws_cache
-        return torch.empty(nbytes, device=dev, dtype=torch.uint8)     # a second forward before the pending backward
+        return torch.empty(nbytes, device=dev, dtype=torch.uint8)     # a second forward while the first one's backward is still possible
 
-    def _release_workspace(self, ws):
+    def _release_workspace(self, ws, ctx=None):
         if ws is self._ws_cache:
-            self._ws_busy = False
+            self._ws_owner = None
+            if ctx is not None:
+                ctx.ws_token = None
 
     # ---- reference API -----------------------------------------------------------------------------------
     def generate_graph_values(self, data):

@@ -82,17 +82,18 @@ class _MixFn(torch.autograd.Function):
 
 
 class _MixFlatFn(torch.autograd.Function):
-    """SelfMixing whose coefficients live side by side in a flat parameter buffer (trainer.FlatParameters.attach): they are read as one block and
-    their gradient block is added to the flat gradient buffer with ONE kernel in backward (instead of a stack + one accumulation per tensor)."""
+    """SelfMixing whose coefficients live side by side in a flat parameter buffer (trainer.FlatParameters.attach): they are read as ONE block
+    [n_mix + n_keep, F] -- a leaf tensor aliasing that stretch of the flat buffer, its ``.grad`` aliasing the flat gradient -- and their gradient is
+    returned to autograd as one block (one accumulation instead of a stack + one per tensor; works under torch.autograd.grad / checkpointing)."""
 
     @staticmethod
-    def forward(ctx, x, mod):
+    def forward(ctx, x, block, mod):
         lib = _lib.load()
-        flat, off, n_mix, n_keep = mod._flat
+        n_mix, n_keep = mod._flat[2], mod._flat[3]
         F = mod.num_features
-        block = flat.flat.data[off:off + (n_mix + n_keep) * F].view(n_mix + n_keep, F)
-        coeff = (block[:n_mix] * mod._sign).contiguous() if n_mix else x.new_zeros(1, F)
-        keep = block[n_mix:]
+        blk = block.detach()
+        coeff = (blk[:n_mix] * mod._sign).contiguous() if n_mix else x.new_zeros(1, F)
+        keep = blk[n_mix:]
         rows = x.shape[0]
         y = torch.empty(rows, (mod.order_out + 1) ** 2, F, device=x.device, dtype=torch.float32)
         _lib.check(lib.nq_so3_mix_forward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), rows, F, mod.order_in, mod.order_in, mod.order_out,
@@ -106,7 +107,7 @@ class _MixFlatFn(torch.autograd.Function):
         lib = _lib.load()
         x, coeff, keep = ctx.saved_tensors
         mod = ctx.mod
-        flat, off, n_mix, n_keep = mod._flat
+        n_mix, n_keep = mod._flat[2], mod._flat[3]
         rows, _, F = x.shape
         gy = gy.to(torch.float32).contiguous()
         n_en = coeff.shape[0]
@@ -115,11 +116,8 @@ class _MixFlatFn(torch.autograd.Function):
         gk_c = torch.empty(rows, n_keep, F, device=x.device, dtype=torch.float32)
         _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, mod.order_in, mod.order_in,
                                            mod.order_out, mod._pidx, 0, n_keep, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_c), _lib.ptr(gk_c), _lib.stream_ptr()))
-        gblock = flat.flat.grad[off:off + (n_mix + n_keep) * F].view(n_mix + n_keep, F)
-        if n_mix:
-            gblock[:n_mix].addcmul_(gc_c.sum(0), mod._sign)
-        gblock[n_mix:].add_(gk_c.sum(0))
-        return gx1 + gx2, None
+        parts = ([gc_c.sum(0) * mod._sign] if n_mix else []) + [gk_c.sum(0)]
+        return gx1 + gx2, torch.cat(parts, dim=0), None
 
 
 class PackedList:
@@ -269,7 +267,10 @@ class SelfMixing(nn.Module):
         blk = flat.block_of(ps)
         if blk is None or blk[1] != len(ps) * self.num_features:
             return False
-        self._flat = (flat, blk[0], len(self._paths), self._keep)
+        n = len(ps)
+        block = torch.nn.Parameter(flat.flat.data[blk[0]:blk[0] + blk[1]].view(n, self.num_features))      # a leaf aliasing the flat buffers; NOT registered
+        block.grad = flat.flat.grad[blk[0]:blk[0] + blk[1]].view(n, self.num_features)
+        self._flat = (flat, blk[0], len(self._paths), self._keep, block)
         return True
 
     def forward(self, xs):
@@ -277,7 +278,7 @@ class SelfMixing(nn.Module):
         F = self.num_features
         x, lead = _pack(xs, self.order_in, F)
         if self._flat is not None and torch.is_grad_enabled() and x.requires_grad:
-            return _unpack(_MixFlatFn.apply(x, self), self.order_out, lead, F)
+            return _unpack(_MixFlatFn.apply(x, self._flat[4], self), self.order_out, lead, F)
         if self._paths:
             coeff = torch.stack([self.mixcoeff(*p) for p in self._paths]) * self._sign                 # [n_paths, F]
         else:

@@ -121,9 +121,15 @@ class FusedTrainStep:
         energy = torch.empty(nl.B, device=dev, dtype=torch.float32)
         forces = torch.empty(nl.N, 3, device=dev, dtype=torch.float32)
         gE, gF = torch.empty_like(energy), torch.empty_like(forces)
+        if batch.y is None or batch.forces is None:
+            raise ValueError("FusedTrainStep needs both targets: batch.y [B] and batch.forces [N, 3]")
+        ty = batch.y.to(device=dev, dtype=torch.float32).contiguous().view(-1)          # raw pointers go to the loss kernel: coerce dtype / layout here
+        tf = batch.forces.to(device=dev, dtype=torch.float32).contiguous()
+        if ty.numel() != nl.B or tuple(tf.shape) != (nl.N, 3):
+            raise ValueError(f"targets have shapes {tuple(batch.y.shape)} / {tuple(batch.forces.shape)}, expected [{nl.B}] / [{nl.N}, 3]")
         _lib.check(fwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(energy), _lib.ptr(forces), st))
         loss_fn = lib.nq_loss_mse if self.loss_kind == "mse" else lib.nq_loss_l1_l2
-        _lib.check(loss_fn(_lib.ptr(energy), _lib.ptr(batch.y), nl.B, _lib.ptr(forces), _lib.ptr(batch.forces), nl.N, self.ce, self.cf,
+        _lib.check(loss_fn(_lib.ptr(energy), _lib.ptr(ty), nl.B, _lib.ptr(forces), _lib.ptr(tf), nl.N, self.ce, self.cf,
                            _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
         _lib.check(bwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
                           _lib.ptr(self.grad), st))
@@ -143,6 +149,28 @@ class FusedTrainStep:
 
 
 
+class _FlatParameter(torch.nn.Parameter):
+    """The flat parameter of FlatParameters: its ``.grad`` IS the persistent flat gradient buffer.  ``opt.zero_grad()`` (set_to_none=True by
+    default: ``p.grad = None``) therefore zeroes the buffer instead of detaching it -- the per-parameter ``p.grad`` views that autograd
+    accumulates into keep pointing at the memory the optimiser reads."""
+
+    def __new__(cls, data, grad_buffer):
+        obj = super().__new__(cls, data, requires_grad=True)
+        obj._grad_buffer = grad_buffer
+        return obj
+
+    @property
+    def grad(self):
+        return self._grad_buffer
+
+    @grad.setter
+    def grad(self, value):
+        if value is None:
+            self._grad_buffer.zero_()
+        elif value is not self._grad_buffer:
+            self._grad_buffer.copy_(value)
+
+
 class FlatParameters:
     """All trainable parameters of a module as views of ONE flat buffer, their gradients as views of one flat gradient buffer.  A model with
     thousands of small tensors (PhiSNet: 2.4 k) otherwise spends tens of milliseconds per step in per-tensor optimiser bookkeeping; with the
@@ -153,8 +181,7 @@ class FlatParameters:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.nn.Parameter(torch.empty(n, device=dev, dtype=torch.float32))
-        self.flat.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat = _FlatParameter(torch.empty(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32))
         self.offset = {}
         o = 0
         with torch.no_grad():
@@ -191,7 +218,18 @@ class FlatParameters:
     def zero_grad(self):
         self.flat.grad.zero_()
 
+    def validate(self):
+        """Raises if a parameter's ``.grad`` / ``.data`` no longer aliases the flat buffers (e.g. after ``module.zero_grad(set_to_none=True)`` on
+        the MODULE, ``p.grad = None`` by hand, or ``module.to(...)``): from then on the optimiser would silently see stale gradients."""
+        g0, d0 = self.flat.grad.data_ptr(), self.flat.data.data_ptr()
+        for p in self.params:
+            o = self.offset[id(p)] * 4
+            if p.grad is None or p.grad.data_ptr() != g0 + o or p.data.data_ptr() != d0 + o:
+                raise RuntimeError("FlatParameters: a parameter was detached from the flat buffers (use FlatParameters.zero_grad() or "
+                                   "optimizer.zero_grad() on the flat parameter, not module.zero_grad(set_to_none=True))")
+
     def clip_grad_norm_(self, max_norm: float):
+        self.validate()
         norm = self.flat.grad.norm()
         self.flat.grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
         return norm

@@ -110,3 +110,56 @@ def test_bad_cfg_rejected_by_abi(lib):
     cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.num_elements = 96, 6, 100, 100
     assert lib.nq_painn_num_params(C.byref(cfg)) == 0
     assert lib.nq_painn_workspace_bytes(C.byref(cfg), 10, 10, 1) == 0
+
+
+_CTYPE = {"int32_t": "c_int", "int64_t": "c_long", "double": "c_double", "float": "c_float", "size_t": "c_ulong"}
+
+
+def _header_structs():
+    """{struct name: [(field, C type or 'ptr')]} parsed from include/nablaq.h."""
+    hdr = open(os.path.join(ROOT, "include", "nablaq.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for name, body in re.findall(r"typedef struct (\w+) \{(.*?)\} \1;", hdr, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(const )?(\w+)(\s*\*)?\s*(.*)", decl)
+            typ, is_ptr, names = m.group(2), m.group(3) is not None, m.group(4)
+            for nm in names.split(","):
+                nm = nm.strip()
+                fields.append((nm.lstrip("* "), "ptr" if (is_ptr or nm.startswith("*")) else typ))
+        out[name] = fields
+    return out
+
+
+def _ctypes_fields(cls):
+    out = []
+    for nm, ct in cls._fields_:
+        if ct is C.c_void_p:
+            out.append((nm, "ptr"))
+        else:
+            out.append((nm, {C.c_int32: "int32_t", C.c_int64: "int64_t", C.c_double: "double", C.c_float: "float", C.c_size_t: "size_t"}[ct]))
+    return out
+
+
+def test_struct_layouts_agree_between_header_binding_and_integration_doc():
+    """include/nablaq.h is the source of truth: nabladft_amd/_lib.py and every ctypes.Structure shown in INTEGRATION.md must list the same fields in
+    the same order with the same types (a stale 40-byte nq_painn_cfg in the doc once made copy-pasting bindings read past the struct)."""
+    from nabladft_amd import _lib
+    hs = _header_structs()
+    assert set(hs) == {"nq_painn_cfg", "nq_schnet_cfg", "nq_graph"}
+    for cname, cls in (("nq_painn_cfg", _lib.PainnCfg), ("nq_schnet_cfg", _lib.SchnetCfg), ("nq_graph", _lib.Graph)):
+        assert _ctypes_fields(cls) == hs[cname], cname
+    assert C.sizeof(_lib.PainnCfg) == 48
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snippets = re.findall(r"class (nq_\w+)\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n", doc, flags=re.S)
+    assert {n for n, _ in snippets} >= {"nq_painn_cfg", "nq_graph"}
+    for name, body in snippets:
+        fields = [(f, "ptr" if t == "c_void_p" else {"c_int32": "int32_t", "c_int64": "int64_t", "c_double": "double", "c_float": "float"}[t])
+                  for f, t in re.findall(r'\("(\w+)", ctypes\.(\w+)\)', body)]
+        assert fields == hs[name], f"INTEGRATION.md shows a stale {name}"
+    m = re.search(r"lib\.nq_abi_version\(\) == (\d+)", doc)
+    assert m and int(m.group(1)) == _lib.ABI_VERSION

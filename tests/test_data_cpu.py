@@ -182,3 +182,15 @@ def test_hamiltonian_batch_matches_the_database_rows():
     # the list is what BlockAssembler.pack_targets flattens: per-molecule row-major blocks
     flat = np.concatenate([h.reshape(-1) for h in b.hamiltonian])
     assert flat.size == sum(h.shape[0] ** 2 for h in b.hamiltonian)
+
+
+def test_hamiltonian_batch_with_repeated_and_unordered_indices():
+    """A repeated index repeats the row (the batched query returns every id once, in id order)."""
+    from nabladft_amd.data import HamiltonianDatabase, hamiltonian_batch
+    db = HamiltonianDatabase(os.path.join(GOLDEN, "hamiltonian_db_6.db"))
+    order = [3, 3, 5, 0, 3]
+    b = hamiltonian_batch(db, order)
+    rows = [db[i] for i in order]
+    assert [int(x) for x in (b.ptr[1:] - b.ptr[:-1])] == [len(r[0]) for r in rows]
+    for k, r in enumerate(rows):
+        assert np.array_equal(b.z[b.ptr[k]:b.ptr[k + 1]].numpy(), r[0]) and np.array_equal(b.hamiltonian[k], r[4])

@@ -106,3 +106,51 @@ def test_energy_only_model_trains():
     g_ref = torch.autograd.grad((e_ref * torch.tensor([1.0, -2.0, 0.5, 3.0])).sum(), list(Pg.values()))
     for (k, p), g in zip(m.named_parameters(), g_ref):
         assert rel_err(p.grad.cpu().numpy(), g.numpy()) < 5e-5, k
+
+
+@pytest.mark.gpu
+def test_workspace_is_reused_after_forwards_without_backward():
+    """optimization/calculator.py:124-130 calls model(batch) under grad mode and never runs backward: the cached workspace must be handed out
+    again as soon as that forward's outputs are gone (ownership by the autograd node, not a sticky flag), and an unfinished forward whose
+    outputs are still alive must not be clobbered."""
+    import nabladft_amd as nq
+    dev = torch.device("cuda:0")
+    m = nq.PaiNN(64, 2, 20, 5.0, 100, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
+    pos, z, batch, y, ft = R.gen_conformers(5, 3, size=(6, 14))
+    b = nq.Batch(pos, z, batch, y, ft).to(dev)
+    e, f = m(b)
+    ws0 = m._last_ws.data_ptr()
+    e_keep = e.detach().clone()
+    del e, f                                            # the only references to the autograd node
+    for _ in range(3):
+        e, f = m(b)
+        assert m._last_ws.data_ptr() == ws0             # the one cached buffer, no fresh multi-GB allocation per call
+        del e, f
+    e1, f1 = m(b)                                       # outputs alive -> its backward is still possible
+    assert m._last_ws.data_ptr() == ws0
+    e2, f2 = m(b)
+    assert m._last_ws.data_ptr() != ws0                 # a second workspace instead of overwriting the first one's activations
+    (e1.sum() + f1.sum()).backward()                    # ... which is still intact
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    del e2, f2
+    e3, f3 = m(b)
+    assert m._last_ws.data_ptr() == ws0 and torch.equal(e3.detach(), e_keep)
+    (e3.sum() + f3.sum()).backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
+
+
+@pytest.mark.gpu
+def test_fused_step_coerces_and_checks_targets():
+    import nabladft_amd as nq
+    dev = torch.device("cuda:0")
+    m = nq.PaiNN(64, 2, 20, 5.0, 100, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
+    pos, z, batch, y, ft = R.gen_conformers(6, 3, size=(6, 14))
+    step = nq.FusedTrainStep(m, max_grad_norm=0.0)
+    ref = float(step(nq.Batch(pos, z, batch, y, ft).to(dev), update=False))
+    b64 = nq.Batch(pos, z, batch, y.double(), ft.double().t().contiguous().t()).to(dev)     # float64, non-contiguous forces
+    assert abs(float(step(b64, update=False)) - ref) < 1e-6 * abs(ref)
+    with pytest.raises(ValueError):
+        step(nq.Batch(pos, z, batch, y, None).to(dev), update=False)
+    with pytest.raises(ValueError):
+        step(nq.Batch(pos, z, batch, y[:-1], ft).to(dev), update=False)

@@ -33,3 +33,25 @@ def test_flat_parameters_match_per_tensor_adam():
     assert set(b.state_dict()) == set(a.state_dict())
     # parameters are views of the flat buffer
     assert b[0].weight.data_ptr() == fb.flat.data_ptr()
+
+
+def test_flat_parameters_survive_optimizer_zero_grad():
+    """``optimizer.zero_grad()`` defaults to set_to_none=True; on the flat parameter that must zero the gradient buffer, not detach it
+    (otherwise autograd keeps accumulating into the old views while the optimiser sees grad=None and silently skips every update)."""
+    import pytest
+    net = _net(1)
+    fp = FlatParameters(net.parameters())
+    opt = torch.optim.AdamW([fp.flat], lr=0.1)
+    x = torch.randn(7, 6)
+    before = fp.flat.detach().clone()
+    for _ in range(2):
+        opt.zero_grad()                                # set_to_none=True
+        assert float(fp.flat.grad.abs().max()) == 0.0
+        net(x).sum().backward()
+        assert float(fp.flat.grad.abs().max()) > 0.0
+        fp.validate()
+        opt.step()
+    assert float((fp.flat.detach() - before).abs().max()) > 1e-3
+    net.zero_grad(set_to_none=True)                    # detaches the per-parameter views: must be reported, not silently accepted
+    with pytest.raises(RuntimeError):
+        fp.clip_grad_norm_(1.0)
