@@ -504,7 +504,7 @@ class PaiNN(nn.Module):
 
     def _take_workspace(self, nbytes, dev, ctx=None):
         def claim():
-            if ctx is not None and torch.is_grad_enabled():
+            if ctx is not None and any(ctx.needs_input_grad):     # (grad mode itself is always off inside Function.forward)
                 ctx.ws_token = _WorkspaceToken()
                 self._ws_owner = weakref.ref(ctx.ws_token)
             else:
