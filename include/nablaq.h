@@ -109,6 +109,16 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
  * Must follow nq_painn_forward (with forces) on the same workspace and graph. */
 int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                       size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream);
+/* nq_painn_backward with completion events: layer_events_host[i] (HOST array of L hipEvent_t, entries may be NULL) is recorded on `stream` as soon as
+ * every gradient slice of layer L-1-i is final (the reverse sweep runs from the last layer to the first; the read-out head's slices are final with
+ * event 0, the embedding's when the call's work is complete), so that a data-parallel caller can all-reduce finished slices on a side stream while the
+ * earlier layers are still being differentiated (reference: torch DDP's bucketed all-reduce under Lightning's DDPStrategy, utils/pipelines.py:65-68).
+ * nq_painn_layer_param_ranges: ranges_host int64[4 (L+1)] = per layer {message offset, count, update offset, count} in floats of the flat buffer,
+ * then {head offset, count, embedding offset, count}. */
+int nq_painn_backward_events(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                             size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* const* layer_events_host,
+                             void* stream);
+int nq_painn_layer_param_ranges(const nq_painn_cfg* cfg, int64_t* ranges_host);
 /* First-order reverse for the direct-force model (direct_forces=True, painn.py:130-133; the PaiNNOutput head itself, painn.py:551-620, is
  * evaluated by the caller on the final node state "x_in"/"vec_in" at layer L of the workspace): given dL/dE[B] and the adjoints of the
  * final x [N][F] and vec [N][3][F] (any may be NULL) writes dL/dparams.  Must follow nq_painn_forward (forces == NULL) on the same workspace. */

@@ -45,6 +45,8 @@ SYMBOLS = {
     "nq_painn_workspace_bytes": (_SZ, [C.POINTER(PainnCfg), _I32, _I32, _I32]),
     "nq_painn_forward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P]),
     "nq_painn_backward": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P]),
+    "nq_painn_backward_events": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P, _P]),
+    "nq_painn_layer_param_ranges": (C.c_int, [C.POINTER(PainnCfg), _P]),
     "nq_painn_backward_seeded": (C.c_int, [C.POINTER(PainnCfg), _P, _P, C.POINTER(Graph), _P, _SZ, _P, _P, _P, _P, _P]),
     "nq_scaled_silu": (C.c_int, [_P, _P, _P, _I64, _P]),
     "nq_geb_cat": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),

@@ -396,7 +396,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 // (from the PaiNNOutput head, evaluated by the caller) are added to the seeds.
 static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                                size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream,
-                               bool seeded, const float* seed_x, const float* seed_vec) {
+                               bool seeded, const float* seed_x, const float* seed_vec, void* const* layer_events = nullptr) {
   WsLayout W; ParamLayout P;
   NQ_TRY(check_common(cfg, graph, workspace, workspace_bytes, &W, &P));
   if (!params || !grad_params || !rbf_offsets) return nq_fail(NQ_ERR_ARG, "null argument");
@@ -531,6 +531,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
     NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
+    // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final here: the caller's side stream may start reducing it
+    if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], st));
   }
   NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));
   if (cfg->rbf_type) {   // dL/d(frequencies) [R] or dL/d(pregamma) [1]
@@ -545,6 +547,27 @@ int nq_painn_backward(const nq_painn_cfg* cfg, const float* params, const float*
                       size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream) {
   return painn_backward_impl(cfg, params, rbf_offsets, graph, workspace, workspace_bytes, grad_energy, grad_forces, grad_params, stream, false, nullptr,
                              nullptr);
+}
+int nq_painn_backward_events(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
+                             size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* const* layer_events_host,
+                             void* stream) {
+  return painn_backward_impl(cfg, params, rbf_offsets, graph, workspace, workspace_bytes, grad_energy, grad_forces, grad_params, stream, false, nullptr,
+                             nullptr, layer_events_host);
+}
+int nq_painn_layer_param_ranges(const nq_painn_cfg* cfg, int64_t* ranges_host) {
+  ParamLayout P;
+  if (!cfg || !ranges_host) return nq_fail(NQ_ERR_ARG, "null argument");
+  NQ_TRY(make_param_layout(cfg, &P));
+  const int L = cfg->num_layers;
+  for (int l = 0; l < L; ++l) {
+    const size_t m0 = P.msg[l].W1, m1 = l + 1 < L ? P.msg[l + 1].W1 : P.upd[0].U;
+    const size_t u0 = P.upd[l].U, u1 = l + 1 < L ? P.upd[l + 1].U : P.O1;
+    ranges_host[4 * l + 0] = (int64_t)m0; ranges_host[4 * l + 1] = (int64_t)(m1 - m0);
+    ranges_host[4 * l + 2] = (int64_t)u0; ranges_host[4 * l + 3] = (int64_t)(u1 - u0);
+  }
+  ranges_host[4 * L + 0] = (int64_t)P.O1; ranges_host[4 * L + 1] = (int64_t)(P.total - P.O1);       // read-out head: final with layer L-1
+  ranges_host[4 * L + 2] = 0; ranges_host[4 * L + 3] = (int64_t)P.msg[0].W1;                          // embedding (+ basis parameters): final at the end
+  return NQ_OK;
 }
 int nq_painn_backward_seeded(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                              size_t workspace_bytes, const float* grad_energy, const float* grad_x, const float* grad_vec, float* grad_params,

@@ -5,6 +5,8 @@ all-reduce of the flat gradient -> clip + AdamW kernel.  Semantically this is on
 ``torch.optim.AdamW.step`` (config/model/painn-oc.yaml:23-27)."""
 import ctypes as C
 
+from types import SimpleNamespace
+
 import torch
 
 from . import _lib, dist as nqdist
@@ -100,6 +102,7 @@ class FusedTrainStep:
         self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.t = 0
         self.energy = self.forces = None
+        self._ov = None   # lazily built state of the overlapped gradient all-reduce
         self._ws = None   # persistent, grow-only workspace (forward+backward finish inside one call, so reuse is safe)
 
     def __call__(self, batch, update=True):
@@ -131,9 +134,12 @@ class FusedTrainStep:
         loss_fn = lib.nq_loss_mse if self.loss_kind == "mse" else lib.nq_loss_l1_l2
         _lib.check(loss_fn(_lib.ptr(energy), _lib.ptr(ty), nl.B, _lib.ptr(forces), _lib.ptr(tf), nl.N, self.ce, self.cf,
                            _lib.ptr(self.loss), _lib.ptr(gE), _lib.ptr(gF), st))
-        _lib.check(bwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
-                          _lib.ptr(self.grad), st))
-        nqdist.allreduce_mean_(self.grad, self.group)
+        if self._overlap_ready(lib, bwd_fn):
+            self._backward_overlapped(lib, cfg, flat, eng, nl, ws, ws_bytes, gE, gF, st)
+        else:
+            _lib.check(bwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
+                              _lib.ptr(self.grad), st))
+            nqdist.allreduce_mean_(self.grad, self.group)
         if update:
             self.t += 1
             _lib.check(lib.nq_adamw_step(_lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.m), _lib.ptr(self.v), flat.numel(),
@@ -146,6 +152,51 @@ class FusedTrainStep:
     def writeback(self):
         """Make the module's nn.Parameters reflect the trained values (no-op for nabladft_amd.PaiNN)."""
         self._eng.writeback()
+
+    # ---- gradient all-reduce overlapped with the reverse sweep (data parallel, world > 1) -------------------------------------------------------
+    overlap = True      # set False to fall back to one all-reduce of the whole flat gradient after the backward
+
+    def _overlap_ready(self, lib, bwd_fn):
+        if not self.overlap or nqdist.world_size(self.group) <= 1 or bwd_fn is not lib.nq_painn_backward:
+            return False
+        if self._ov is None:
+            L = int(self._eng.cfg.num_layers)
+            ranges = (C.c_int64 * (4 * (L + 1)))()
+            _lib.check(lib.nq_painn_layer_param_ranges(C.byref(self._eng.cfg), ranges))
+            events = [torch.cuda.Event() for _ in range(L)]
+            for e in events:
+                e.record()                                     # creates the underlying hipEvent_t
+            self._ov = SimpleNamespace(L=L, ranges=list(ranges), events=events, handles=(C.c_void_p * L)(*[e.cuda_event for e in events]),
+                                       side=torch.cuda.Stream(), done=torch.cuda.Event())
+        return True
+
+    def _backward_overlapped(self, lib, cfg, flat, eng, nl, ws, ws_bytes, gE, gF, st):
+        """The reverse sweep differentiates layer L-1 first; as soon as a layer's gradient slices are final (an event recorded by the engine) a side
+        stream all-reduces them while the main stream goes on with the earlier layers.  The flat buffer is ordered [embedding | message layers |
+        update layers | head], so a layer is two slices; the head goes with the last layer, the embedding after the sweep."""
+        ov, g, w = self._ov, self.grad, nqdist.world_size(self.group)
+        main = torch.cuda.current_stream()
+        _lib.check(lib.nq_painn_backward_events(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
+                                                _lib.ptr(g), ov.handles, st))
+        ov.done.record(main)
+        r = ov.ranges
+
+        def reduce(off, cnt):
+            if cnt > 0:
+                torch.distributed.all_reduce(g[off:off + cnt], op=torch.distributed.ReduceOp.SUM, group=self.group)
+
+        with torch.cuda.stream(ov.side):
+            for i in range(ov.L):
+                l = ov.L - 1 - i
+                ov.side.wait_event(ov.events[i])
+                if i == 0:
+                    reduce(r[4 * ov.L], r[4 * ov.L + 1])
+                reduce(r[4 * l], r[4 * l + 1])
+                reduce(r[4 * l + 2], r[4 * l + 3])
+            ov.side.wait_event(ov.done)
+            reduce(r[4 * ov.L + 2], r[4 * ov.L + 3])
+        main.wait_stream(ov.side)
+        g.mul_(1.0 / w)
 
 
 

@@ -1,0 +1,92 @@
+"""GPU, world_size 2 (two processes sharing the one GPU of the test box, gloo backend): FusedTrainStep on the HIP path with the gradient
+all-reduce overlapped with the reverse sweep (per-layer completion events from nq_painn_backward_events, side stream) vs. the plain path
+(one all-reduce after the backward) vs. two single-process runs.  Data-parallel semantics of the reference: Lightning DDPStrategy
+(utils/pipelines.py:65-68) = mean of the per-rank gradients of a shared model.  No scaling number comes out of this: RCCL/xGMI are not involved."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import painn_ref as R
+
+pytestmark = pytest.mark.gpu
+CFG = dict(hidden_channels=64, num_layers=3, num_rbf=20, cutoff=5.0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(dev):
+    import nabladft_amd as nq
+    cfg = R.PaiNNConfig(**CFG)
+    m = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, 100, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False,
+                 False, True, cfg.num_elements)
+    m.load_state_dict(R.make_params(cfg, seed=41), strict=False)
+    return m.to(dev)
+
+
+def _shard(rank):
+    import nabladft_amd as nq
+    pos, z, batch, y, ft = R.gen_conformers(70 + rank, 4, size=(8, 20))
+    return nq.Batch(pos, z, batch, y, ft)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import nabladft_amd as nq
+    from nabladft_amd import dist as nqdist
+    nqdist.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    out = {}
+    for mode in ("overlap", "plain"):
+        step = nq.FusedTrainStep(_model(dev), lr=1e-3, max_grad_norm=5.0)
+        step.overlap = mode == "overlap"
+        b = _shard(rank).to(dev)
+        losses = [float(step(b)) for _ in range(2)]
+        torch.cuda.synchronize()
+        out[mode] = dict(grad=step.grad.cpu(), flat=step._eng.flat().detach().cpu(), losses=losses, used_overlap=step._ov is not None)
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_step_two_ranks_overlapped_allreduce(tmp_path):
+    import nabladft_amd as nq
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["overlap"]["used_overlap"] and not r0["plain"]["used_overlap"]
+    for mode in ("overlap", "plain"):                      # both ranks end with identical gradients and parameters
+        assert torch.equal(r0[mode]["grad"], r1[mode]["grad"]) and torch.equal(r0[mode]["flat"], r1[mode]["flat"])
+    # overlapped == plain, bit for bit (same per-slice sums, same scaling)
+    assert torch.equal(r0["overlap"]["grad"], r0["plain"]["grad"]) and torch.equal(r0["overlap"]["flat"], r0["plain"]["flat"])
+    # ... and equal to the mean of two single-process gradients taken at the same parameters (second step: after one identical update)
+    dev = torch.device("cuda:0")
+    gs = []
+    for rank in range(2):
+        step = nq.FusedTrainStep(_model(dev), lr=1e-3, max_grad_norm=5.0)
+        step(_shard(rank).to(dev), update=False)
+        gs.append(step.grad.clone())
+    first = (gs[0] + gs[1]) / 2
+    chk = nq.FusedTrainStep(_model(dev), lr=1e-3, max_grad_norm=5.0)          # replay: step 1 with the averaged gradient, then gradient of step 2
+    chk(_shard(0).to(dev), update=False)
+    chk.grad.copy_(first)
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    chk.t = 1
+    _lib.check(lib.nq_adamw_step(_lib.ptr(chk._eng.flat()), _lib.ptr(chk.grad), _lib.ptr(chk.m), _lib.ptr(chk.v), chk.grad.numel(), 5.0, 1e-3, 0.9, 0.999, 1e-8,
+                                 0.0, 1, _lib.ptr(chk.scratch), _lib.stream_ptr()))
+    g2 = []
+    for rank in range(2):
+        chk(_shard(rank).to(dev), update=False)
+        g2.append(chk.grad.clone())
+    expect = ((g2[0] + g2[1]) / 2).cpu()
+    got = r0["overlap"]["grad"]
+    assert float((got - expect).abs().max()) <= 2e-6 * float(expect.abs().max())
