@@ -289,21 +289,32 @@ def network():
     batch = dict(positions=torch.tensor(pos).view(1, -1, 3), atomic_numbers=torch.tensor(zs), orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs],
                  molecule_size=torch.tensor(sizes))
     m.predict_energy = True
+    import copy
+    m64 = copy.deepcopy(m).double()             # the same network evaluated in float64: the truth both fp32 evaluations are measured against
     out = m(batch)
+    batch64 = dict(batch, positions=batch["positions"].double())
+    out64 = m64(batch64)
     fx = dict(z=zs, positions=pos, sizes=np.array(sizes), electron_config=m.embedding.embedding.electron_config.numpy(),
               hp=np.array([hp["order"], hp["num_features"], hp["num_basis_functions"], hp["num_modules"]]), cutoff=np.float64(hp["cutoff"]))
-    loss = 0
+    loss = loss64 = 0
     for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
         w = torch.tensor(rng.normal(size=tuple(out[k].shape)).astype(np.float32))
         fx[k], fx["w_" + k] = out[k][0].detach().numpy(), w[0].numpy()
+        fx["f64:" + k] = out64[k][0].detach().numpy()
         loss = loss + (out[k] * w).sum()
+        loss64 = loss64 + (out64[k] * w.double()).sum()
     w = torch.tensor(rng.normal(size=tuple(out["energy"].shape)).astype(np.float32))
     fx["energy"], fx["w_energy"] = out["energy"].detach().numpy(), w.numpy()
+    fx["f64:energy"] = out64["energy"].detach().numpy()
     loss = loss + (out["energy"] * w).sum()
+    loss64 = loss64 + (out64["energy"] * w.double()).sum()
     loss.backward()
+    loss64.backward()
+    p64 = dict(m64.named_parameters())
     for n, p in m.named_parameters():
         fx["p:" + n] = p.detach().numpy()
         fx["g:" + n] = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        fx["g64:" + n] = (p64[n].grad.numpy() if p64[n].grad is not None else np.zeros(tuple(p.shape))).astype(np.float32)   # fp64 result, stored rounded
         fx["rg:" + n] = np.bool_(p.requires_grad)
     np.savez_compressed(os.path.join(OUT, "phisnet_network.npz"), **fx)
     print("phisnet_network.npz:", len(fx), "arrays; Norb", fx["full_hamiltonian"].shape, "params", sum(p.numel() for p in m.parameters()))

@@ -1,5 +1,5 @@
 """GPU: PhiSNet block mirrors (nabladft_amd/phisnet.py: residual stacks, SphericalLinear, InteractionBlock, ModularBlock) against golden
-vectors from the REAL reference ModularBlock (oracle/make_golden_phisnet.py --blocks).  Tolerance 5e-5 relative (fp32, deep composition)."""
+vectors from the REAL reference ModularBlock (oracle/make_golden_phisnet.py --blocks).  Tolerance 1e-5 relative on outputs."""
 import os
 
 import numpy as np
@@ -10,7 +10,7 @@ from tests.helpers import GOLDEN, rel_err
 from tests.so3_helpers import FixtureCG
 
 pytestmark = pytest.mark.gpu
-TOL = 5e-5
+TOL = 1e-5      # the north-star tolerance (outputs); gradients are measured against a float64 evaluation of the reference, see below
 
 
 @pytest.mark.parametrize("tag", ["mb2", "mb1ssp"])
@@ -78,22 +78,36 @@ def test_neural_network_matches_reference():
     m.predict_energy = True
     out = m(batch)
     plan, asm = out["plan"], m._assembler
-    assert rel_err(out["energy"].detach().cpu().numpy(), fx["energy"]) < TOL
+    # Truth = the reference network evaluated in float64 (fixture keys f64:*, g64:*).  The reference's own float32 run is one noisy evaluation of
+    # it (its PairMixing sums 5-D broadcast products in whatever order ATen picks); the HIP path is another.  North-star tolerance: 1e-5 relative
+    # -- asserted against the float64 truth; where the reference's float32 itself is further away than that, the bar is its distance.
+    def rel64(a, ref64):
+        return float(np.abs(np.asarray(a, dtype=np.float64) - ref64).max() / max(float(np.abs(ref64).max()), 1e-300))
+    report = {}
+    e_hip, e_ref = rel64(out["energy"].detach().cpu().numpy(), fx["f64:energy"]), rel64(fx["energy"], fx["f64:energy"])
+    report["energy"] = (e_hip, e_ref)
+    assert e_hip < max(1e-5, 1.5 * e_ref), report
     loss = (out["energy"] * torch.tensor(fx["w_energy"]).cuda()).sum()
     for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
         assert tuple(out[k].shape) == (1,) + fx[k].shape
+        e_hip, e_ref = rel64(out[k][0].cpu().numpy(), fx["f64:" + k]), rel64(fx[k], fx["f64:" + k])
+        report[k] = (e_hip, e_ref)
+        assert e_hip < max(1e-5, 1.5 * e_ref), report
         assert rel_err(out[k][0].cpu().numpy(), fx[k]) < TOL, k
         loss = loss + (out[k + "_packed"] * asm.from_dense(plan, torch.tensor(fx["w_" + k]).cuda())).sum()
     loss.backward()
-    worst = 0.0
+    worst = worst_ref = 0.0
     for n, p in m.named_parameters():
-        ref = fx["g:" + n]
+        ref, ref64 = fx["g:" + n], fx["g64:" + n].astype(np.float64)
         if not p.requires_grad:
             continue
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
-        scale = max(float(np.abs(ref).max()), 1e-3)
-        worst = max(worst, float(np.abs(got - ref).max()) / scale)
-        assert float(np.abs(got - ref).max()) / scale < 5e-4, n
+        scale = max(float(np.abs(ref64).max()), 1e-3)
+        e_hip, e_ref = float(np.abs(got - ref64).max()) / scale, float(np.abs(ref - ref64).max()) / scale
+        worst, worst_ref = max(worst, e_hip), max(worst_ref, e_ref)
+        assert e_hip < max(2e-5, 2.0 * e_ref), (n, e_hip, e_ref)
+    report["gradients (worst tensor)"] = (worst, worst_ref)
+    print("PhiSNet network vs float64 truth, (HIP fp32, reference fp32):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
     assert out["energy"].shape == (len(fx["sizes"]), 1) and out["forces"].shape == (1, len(zs), 3)
 
 
@@ -185,7 +199,8 @@ def test_neural_network_with_flat_parameters_matches_reference():
     for n, p in m.named_parameters():
         if not p.requires_grad:
             continue
-        ref = fx["g:" + n]
+        ref, ref64 = fx["g:" + n], fx["g64:" + n].astype(np.float64)          # reference in float32 and in float64 (the truth)
         assert p.grad.data_ptr() >= flat.flat.grad.data_ptr()           # still a view of the flat gradient buffer
-        scale = max(float(np.abs(ref).max()), 1e-3)
-        assert float(np.abs(p.grad.cpu().numpy() - ref).max()) / scale < 5e-4, n
+        scale = max(float(np.abs(ref64).max()), 1e-3)
+        e_hip, e_ref = float(np.abs(p.grad.cpu().numpy() - ref64).max()) / scale, float(np.abs(ref - ref64).max()) / scale
+        assert e_hip < max(2e-5, 2.0 * e_ref), (n, e_hip, e_ref)
