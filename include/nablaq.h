@@ -224,6 +224,14 @@ int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, co
                         int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int64_t coeff_row_stride,
                         int32_t keep_orders, float* grad_x1, float* grad_x2, float* grad_coeff_rows, float* grad_keep_rows, void* stream);
 
+/* The same reverse pass for coefficients SHARED by all rows (SelfMixing; QHNet's SelfNetLayer): dL/dcoeff is reduced over rows inside the kernel;
+ * grad_coeff_partials [nq_so3_mix_partial_blocks(rows, F)][n_enabled][F] are per-workgroup partial sums (sum them in order for the result).
+ * F must divide 256. */
+int64_t nq_so3_mix_partial_blocks(int64_t rows, int32_t F);
+int nq_so3_mix_backward_shared(const float* x1, const float* x2, const float* coeff, const float* keep, const float* grad_y, int64_t rows, int32_t F,
+                               int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int32_t keep_orders, float* grad_x1,
+                               float* grad_x2, float* grad_coeff_partials, float* grad_keep_rows, void* stream);
+
 /* ---- QHNet SO(3) tensor-product layers (nablaDFT/qhnet/layers.py; e3nn 0.5.1 TensorProduct / Linear / Norm semantics restated in
  *      oracle/e3nn_mini.py, PARITY UNPINNED for the e3nn part).  Irreps features are [rows][(lmax+1)^2][C], component l*l + m + l, channel
  *      fastest.  Graph arrays (int32, device): row_ptr [N+1] CSR by owner atom = "src" = row 1 of the reference's edge_index (qhnet.py:262),

@@ -79,6 +79,8 @@ SYMBOLS = {
     "nq_qh_act": (C.c_int, [_P, _P, _I32, _F, _I64, _P, _P]),
     "nq_qh_expansion_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _P, _P]),
     "nq_qh_expansion_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nq_so3_mix_partial_blocks": (C.c_int64, [_I64, _I32]),
+    "nq_so3_mix_backward_shared": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "nq_sph_harm": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "nq_bernstein_rbf": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),

@@ -25,13 +25,28 @@ struct So3Args {
   long c_row_stride;                                                      // n_enabled * F, or 0 for row-broadcast coefficients
   long gc_row_stride;                                                     // n_enabled * F: the coefficient gradient is always written per row
   int keep_orders;                                                        // number of orders with a keep coefficient
+  float* gc_part; int rows_per_block;                                     // RED kernels: per-workgroup partial sums of dL/dc, [blocks][n_enabled][F]
+  int n_enabled;
   signed char cidx[SO3_NPATHS];                                           // path id -> index among the enabled paths, -1 = disabled
 };
 
-template <bool BWD>
+// RED (reverse pass with coefficients shared by all rows, SelfMixing): a workgroup walks rows_per_block rows, every thread adds its dL/dc
+// contributions into ITS OWN slot of an LDS slab [256 / F][n_enabled][F] (no conflicts, fixed order), and the workgroup writes one partial
+// [n_enabled][F] at the end -- instead of a [rows][n_enabled][F] array for the host to sum (PhiSNet calls this ~100 times per step).
+template <bool BWD, bool RED = false>
 __global__ __launch_bounds__(256) void k_so3_mix(So3Args a) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.rows * a.F) return;
+  extern __shared__ float so3_slab[];
+  const int rpp = RED ? 256 / a.F : 1;                       // rows per pass of the workgroup
+  const int sub = RED ? (int)threadIdx.x / a.F : 0;
+  float* const sg = RED ? so3_slab + (long)sub * a.n_enabled * a.F + (threadIdx.x % a.F) : nullptr;
+  if (RED) {
+    for (int i = threadIdx.x; i < rpp * a.n_enabled * a.F; i += blockDim.x) so3_slab[i] = 0.f;
+    __syncthreads();
+  }
+  const int passes = RED ? a.rows_per_block / rpp : 1;
+  for (int pass = 0; pass < passes; ++pass) {
+  const long idx = RED ? ((long)blockIdx.x * a.rows_per_block + (long)pass * rpp) * a.F + threadIdx.x : (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.rows * a.F) { if (RED) break; else return; }
   const long r = idx / a.F;
   const int f = (int)(idx % a.F);
   float x1[SO3_NCOMP], x2[SO3_NCOMP], y[SO3_NCOMP], gx1[SO3_NCOMP], gx2[SO3_NCOMP];
@@ -43,7 +58,7 @@ __global__ __launch_bounds__(256) void k_so3_mix(So3Args a) {
     else y[k] = 0.f;
   }
   const float* crow = a.c + r * a.c_row_stride + f;
-  float* gcrow = BWD ? a.gc + r * a.gc_row_stride + f : nullptr;            // per row even for row-broadcast coefficients: the host sums over rows
+  float* gcrow = (BWD && !RED) ? a.gc + r * a.gc_row_stride + f : nullptr;   // per-row coefficient gradients (PairMixing: every row has its own)
 
 #define CG_PATH_BEGIN(pid, l1, l2, L)                       \
   if (a.cidx[pid] >= 0) {                                   \
@@ -61,7 +76,7 @@ __global__ __launch_bounds__(256) void k_so3_mix(So3Args a) {
     if (BWD) {                                                                                 \
       float g = 0.f;                                                                           \
       _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) g = fmaf(y[YO + M], t[M], g);      \
-      gcrow[(long)ci * a.F] = g;                                                               \
+      if (RED) sg[(long)ci * a.F] += g; else gcrow[(long)ci * a.F] = g;                        \
     } else {                                                                                   \
       _Pragma("unroll") for (int M = 0; M < 2 * L + 1; ++M) y[YO + M] = fmaf(cc, t[M], y[YO + M]); \
     }                                                                                          \
@@ -94,6 +109,16 @@ __global__ __launch_bounds__(256) void k_so3_mix(So3Args a) {
 #pragma unroll
     for (int k = 0; k < SO3_NCOMP; ++k)
       if (k < a.ny) a.y[(r * a.ny + k) * a.F + f] = y[k];
+  }
+  }   // passes
+  if (RED) {
+    __syncthreads();
+    float* out = a.gc_part + (long)blockIdx.x * a.n_enabled * a.F;
+    for (int i = threadIdx.x; i < a.n_enabled * a.F; i += blockDim.x) {
+      float s = 0.f;
+      for (int q = 0; q < rpp; ++q) s += so3_slab[(long)q * a.n_enabled * a.F + i];
+      out[i] = s;
+    }
   }
 }
 
@@ -153,6 +178,49 @@ int nq_so3_mix_backward(const float* x1, const float* x2, const float* coeff, co
     for (int p = 0; p < SO3_NPATHS; ++p) n_enabled += path_index_host[p] >= 0;
     a.gc_row_stride = (long)n_enabled * F;
     hipLaunchKernelGGL((k_so3_mix<true>), dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, a);
+    NQ_LAUNCH_CHECK();
+    if (keep && grad_keep_rows && keep_orders > 0) {
+      hipLaunchKernelGGL(k_so3_keep_grad, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, x1, grad_y, (long)rows, F, a.n1, a.ny, keep_orders,
+                         grad_keep_rows);
+      NQ_LAUNCH_CHECK();
+    }
+  }
+  return NQ_OK;
+}
+
+/* rows a workgroup of the reduced reverse kernel walks: ~1024 workgroups for large inputs, never fewer rows than one pass */
+static int so3_rows_per_block(int64_t rows, int32_t F) {
+  const int rpp = 256 / F;
+  long k = (rows + 1023) / 1024;
+  k = (k + rpp - 1) / rpp * rpp;
+  if (k < rpp) k = rpp;
+  if (k > 128) k = 128 / rpp * rpp;
+  return (int)k;
+}
+int64_t nq_so3_mix_partial_blocks(int64_t rows, int32_t F) {
+  if (F <= 0 || 256 % F != 0 || rows <= 0) return 0;
+  const int k = so3_rows_per_block(rows, F);
+  return (rows + k - 1) / k;
+}
+int nq_so3_mix_backward_shared(const float* x1, const float* x2, const float* coeff, const float* keep, const float* grad_y, int64_t rows, int32_t F,
+                               int32_t order1, int32_t order2, int32_t order_out, const int8_t* path_index_host, int32_t keep_orders, float* grad_x1,
+                               float* grad_x2, float* grad_coeff_partials, float* grad_keep_rows, void* stream) {
+  So3Args a{};
+  NQ_TRY(so3_fill(&a, x1, x2, coeff, keep, rows, F, order1, order2, order_out, path_index_host, 0, keep_orders));
+  if (!grad_y || !grad_x1 || !grad_x2 || !grad_coeff_partials) return nq_fail(NQ_ERR_ARG, "null argument");
+  if (256 % F != 0) return nq_fail(NQ_ERR_ARG, "reduced coefficient gradient: F must divide 256");
+  a.gy = grad_y; a.gx1 = grad_x1; a.gx2 = grad_x2; a.gc_part = grad_coeff_partials;
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "so3_mix_bwd_shared");
+  if (rows > 0) {
+    int n_enabled = 0;
+    for (int p = 0; p < SO3_NPATHS; ++p) n_enabled += path_index_host[p] >= 0;
+    a.n_enabled = n_enabled;
+    a.rows_per_block = so3_rows_per_block(rows, F);
+    const long blocks = (rows + a.rows_per_block - 1) / a.rows_per_block;
+    const size_t lds = sizeof(float) * (size_t)(256 / F) * n_enabled * F;
+    if (lds > 64 * 1024) NQ_HIP(hipFuncSetAttribute((const void*)k_so3_mix<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_so3_mix<true, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     NQ_LAUNCH_CHECK();
     if (keep && grad_keep_rows && keep_orders > 0) {
       hipLaunchKernelGGL(k_so3_keep_grad, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, x1, grad_y, (long)rows, F, a.n1, a.ny, keep_orders,

@@ -71,12 +71,20 @@ class _MixFn(torch.autograd.Function):
         gy = gy.to(torch.float32).contiguous()
         n_en = coeff.shape[-2]
         gx1, gx2 = torch.empty_like(x1), torch.empty_like(x2)
-        gc_rows = torch.empty(rows, n_en, F, device=x1.device, dtype=torch.float32)
         gk_rows = torch.empty(rows, keep_orders, F, device=x1.device, dtype=torch.float32) if keep is not None else None
-        stride = n_en * F if per_row else 0
-        _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, o1, o2, oy, pidx, stride,
-                                           keep_orders, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_rows), _lib.ptr(gk_rows), _lib.stream_ptr()))
-        gc = gc_rows if per_row else gc_rows.sum(0)
+        if not per_row and 256 % F == 0 and rows > 0:
+            # shared coefficients: dL/dc is reduced over the rows inside the kernel (per-workgroup partials, summed here in block order)
+            nblk = int(lib.nq_so3_mix_partial_blocks(rows, F))
+            part = torch.empty(nblk, n_en, F, device=x1.device, dtype=torch.float32)
+            _lib.check(lib.nq_so3_mix_backward_shared(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, o1, o2, oy, pidx, keep_orders,
+                                                      _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(part), _lib.ptr(gk_rows), _lib.stream_ptr()))
+            gc = part.sum(0) if nblk > 1 else part[0]
+        else:
+            gc_rows = torch.empty(rows, n_en, F, device=x1.device, dtype=torch.float32)
+            stride = n_en * F if per_row else 0
+            _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, o1, o2, oy, pidx, stride,
+                                               keep_orders, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_rows), _lib.ptr(gk_rows), _lib.stream_ptr()))
+            gc = gc_rows if per_row else gc_rows.sum(0)
         gk = None if keep is None else gk_rows.sum(0)
         return gx1, gx2, gc, gk, None
 
@@ -112,10 +120,17 @@ class _MixFlatFn(torch.autograd.Function):
         gy = gy.to(torch.float32).contiguous()
         n_en = coeff.shape[0]
         gx1, gx2 = torch.empty_like(x), torch.empty_like(x)
-        gc_c = torch.empty(rows, n_en, F, device=x.device, dtype=torch.float32)
         gk_c = torch.empty(rows, n_keep, F, device=x.device, dtype=torch.float32)
-        _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, mod.order_in, mod.order_in,
-                                           mod.order_out, mod._pidx, 0, n_keep, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_c), _lib.ptr(gk_c), _lib.stream_ptr()))
+        if 256 % F == 0 and rows > 0:
+            nblk = int(lib.nq_so3_mix_partial_blocks(rows, F))
+            part = torch.empty(nblk, n_en, F, device=x.device, dtype=torch.float32)
+            _lib.check(lib.nq_so3_mix_backward_shared(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, mod.order_in, mod.order_in,
+                                                      mod.order_out, mod._pidx, n_keep, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(part), _lib.ptr(gk_c), _lib.stream_ptr()))
+            gc_c = part
+        else:
+            gc_c = torch.empty(rows, n_en, F, device=x.device, dtype=torch.float32)
+            _lib.check(lib.nq_so3_mix_backward(_lib.ptr(x), _lib.ptr(x), _lib.ptr(coeff), _lib.ptr(keep), _lib.ptr(gy), rows, F, mod.order_in, mod.order_in,
+                                               mod.order_out, mod._pidx, 0, n_keep, _lib.ptr(gx1), _lib.ptr(gx2), _lib.ptr(gc_c), _lib.ptr(gk_c), _lib.stream_ptr()))
         parts = ([gc_c.sum(0) * mod._sign] if n_mix else []) + [gk_c.sum(0)]
         return gx1 + gx2, torch.cat(parts, dim=0), None
 
