@@ -289,6 +289,14 @@ int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cu
 int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
                                 const float* v, float* galpha_rows, void* stream);
 
+/* The other radial bases of PhiSNet (neural_network.py:210-221), all times cutoff_function(r): kind 1 gaussian (t0 = centres, width), 2 exp-gaussian
+ * (t0 = centres, width, alpha), 3 overlap-bernstein (t0 = logc, t1 = n, t2 = v, alpha), 4 bernstein (t0 = logc, t1 = n, t2 = v).  out [P][K];
+ * nq_radial_basis_grad_alpha (kinds 2, 3): per-row dL/dalpha given grad_out [P][K]. */
+int nq_radial_basis(int32_t kind, const float* r, int64_t P, int32_t K, float alpha, float cutoff, float width, const float* t0, const float* t1, const float* t2,
+                    float* out, void* stream);
+int nq_radial_basis_grad_alpha(int32_t kind, const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, float width, const float* t0,
+                               const float* t1, const float* t2, float* galpha_rows, void* stream);
+
 /* Learnable feature-wise activations of PhiSNet on [rows][F]: kind 0 = Swish (swish.py:23-24), kind 1 = ShiftedSoftplus
  * (shifted_softplus.py:26-32).  Backward writes grad_x and per-element partials of dL/dalpha, dL/dbeta ([rows][F], sum over rows). */
 int nq_feature_act(const float* x, const float* alpha, const float* beta, int64_t rows, int32_t F, int32_t kind, float* y, void* stream);

@@ -285,3 +285,68 @@ int nq_segment_sum(const float* rows, const int64_t* order, const int64_t* seg_p
   return NQ_OK;
 }
 }  // extern "C"
+
+// ---- the other radial bases PhiSNet's NeuralNetwork can be built with (neural_network.py:210-221) -----------------------------------------------
+//   kind 1  gaussian              fc * exp(-width (r - center_k)^2)                          gaussian_radial_basis_functions.py:10-33
+//   kind 2  exp-gaussian          fc * exp(-width (e^{-alpha r} - center_k)^2)               exponential_gaussian_radial_basis_functions.py:10-32
+//   kind 3  overlap-bernstein     x = log1p(alpha r) - alpha r; fc * exp(logc + n x + v log(1 - e^x))   overlap_bernstein_radial_basis_functions.py:10-41
+//   kind 4  bernstein             x = log(r / cutoff);          fc * exp(logc + n x + v log(1 - e^x))   bernstein_radial_basis_functions.py:10-37
+// t0 = center_k (1, 2) or logc_k (3, 4); t1 = n_k, t2 = v_k (3, 4).  GRAD: per-row dL/dalpha (kinds 2, 3; the others have no learnable parameter).
+template <bool GRAD>
+__global__ void k_radial_basis(int kind, const float* __restrict__ r, long P, int K, float alpha, float cutoff, float width, const float* __restrict__ t0,
+                               const float* __restrict__ t1, const float* __restrict__ t2, float* __restrict__ out, const float* __restrict__ gout,
+                               float* __restrict__ galpha_rows) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * (GRAD ? 1 : K)) return;
+  const long p = GRAD ? idx : idx / K;
+  const float rr = r[p];
+  const bool in = rr < cutoff;
+  const float fc = in ? expf(-(rr * rr) / ((cutoff - rr) * (cutoff + rr))) : 0.f;
+  float acc = 0.f;
+  for (int k = GRAD ? 0 : (int)(idx % K); k < (GRAD ? K : (int)(idx % K) + 1); ++k) {
+    float val = 0.f, dval = 0.f;                       // value and d(value)/d(alpha)
+    if (in) {
+      if (kind == 1) {
+        const float d = rr - t0[k];
+        val = fc * expf(-width * d * d);
+      } else if (kind == 2) {
+        const float e = expf(-alpha * rr), d = e - t0[k];
+        val = fc * expf(-width * d * d);
+        dval = val * (-2.0f * width * d) * (-rr * e);
+      } else {
+        float x, dx = 0.f;
+        if (kind == 3) { const float ar = alpha * rr; x = log1pf(ar) - ar; dx = -rr * ar / (1.0f + ar); }
+        else x = logf(rr / cutoff);
+        const float om = -expm1f(x);                   // 1 - e^x
+        val = fc * expf(t0[k] + t1[k] * x + t2[k] * logf(om));
+        dval = val * (t1[k] - t2[k] * (1.0f - om) / om) * dx;
+      }
+    }
+    if (GRAD) acc = fmaf(gout[p * K + k], dval, acc);
+    else out[idx] = val;
+  }
+  if (GRAD) galpha_rows[p] = acc;
+}
+
+extern "C" {
+int nq_radial_basis(int32_t kind, const float* r, int64_t P, int32_t K, float alpha, float cutoff, float width, const float* t0, const float* t1, const float* t2,
+                    float* out, void* stream) {
+  if (!r || !t0 || !out || kind < 1 || kind > 4 || (kind >= 3 && (!t1 || !t2))) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "radial_basis");
+  if (P > 0) hipLaunchKernelGGL((k_radial_basis<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, kind, r, (long)P, K, alpha, cutoff, width, t0, t1, t2, out,
+                                nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_radial_basis_grad_alpha(int32_t kind, const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, float width, const float* t0,
+                               const float* t1, const float* t2, float* galpha_rows, void* stream) {
+  if (!r || !t0 || !grad_out || !galpha_rows || (kind != 2 && kind != 3) || (kind == 3 && (!t1 || !t2))) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "radial_basis_grad");
+  if (P > 0) hipLaunchKernelGGL((k_radial_basis<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, kind, r, (long)P, K, alpha, cutoff, width, t0, t1, t2, nullptr,
+                                grad_out, galpha_rows);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+}

@@ -521,11 +521,11 @@ class NeuralNetwork(nn.Module):
         super().__init__()
         from . import cg as _cg
         from .hamiltonian import IrrepsAssembler, compute_matrix_irreps
-        from .so3 import ExponentialBernsteinRadialBasisFunctions
+        from .so3 import RADIAL_BASES
         if load_from is not None:
             raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: construct with hyper-parameters and load_state_dict the checkpoint")
-        if basis_functions != "exp-bernstein":
-            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: basis_functions='exp-bernstein' is built")
+        if basis_functions not in ("exp-gaussian", "exp-bernstein", "gaussian", "bernstein"):         # the four choices of neural_network.py:210-221
+            raise ValueError(f"basis function type: {basis_functions} is not supported")
         self.calculate_full_hamiltonian = self.calculate_core_hamiltonian = self.calculate_overlap_matrix = True
         self.calculate_energy = self.predict_energy = self.calculate_forces = False
         self.max_orbitals, self.order, self.num_features, self.num_basis_functions = max_orbitals, order, num_features, num_basis_functions
@@ -538,7 +538,7 @@ class NeuralNetwork(nn.Module):
         F, K = num_features, num_basis_functions
         act = {"swish": Swish, "ssp": ShiftedSoftplus}[activation]
         self.embedding = SphericalEmbedding(order, F, Zmax, electron_config)
-        self.radial_basis_functions = ExponentialBernsteinRadialBasisFunctions(K, cutoff)
+        self.radial_basis_functions = RADIAL_BASES[basis_functions](K, cutoff)
         self.module = nn.ModuleList([ModularBlock(order, F, K, num_residual_pre_x, num_residual_post_x, num_residual_pre_vi, num_residual_pre_vj,
                                                   num_residual_post_v, num_residual_output, cgp, True, activation) for _ in range(num_modules)])
         self.angular_fn = SphericalLinear(order, 1, order, F, cgp, mix_orders=False)

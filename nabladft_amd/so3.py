@@ -374,3 +374,144 @@ class ExponentialBernsteinRadialBasisFunctions(nn.Module):
     def forward(self, r):
         _require_gpu(r)
         return _BernsteinFn.apply(r, self._alpha, self)
+
+
+# ---- the other radial bases of PhiSNet ------------------------------------------------------------------------------
+class _RadialFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, raw_alpha, mod):
+        lib = _lib.load()
+        r2 = r.detach().to(torch.float32).reshape(-1).contiguous()
+        alpha = float(torch.nn.functional.softplus(raw_alpha.detach().double())) if mod._kind in (2, 3) else 0.0
+        K = mod.num_basis_functions
+        t = [b.to(device=r.device, dtype=torch.float32).contiguous() for b in mod._tables()]
+        t += [None] * (3 - len(t))
+        out = torch.empty(r2.shape[0], K, device=r.device, dtype=torch.float32)
+        _lib.check(lib.nq_radial_basis(mod._kind, _lib.ptr(r2), r2.shape[0], K, alpha, float(mod.cutoff), float(mod._width()), _lib.ptr(t[0]), _lib.ptr(t[1]),
+                                       _lib.ptr(t[2]), _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(r2, raw_alpha, *[x for x in t if x is not None])
+        ctx.meta = (mod._kind, alpha, float(mod.cutoff), float(mod._width()), K)
+        return out.view(*r.shape[:-1], K) if r.shape[-1] == 1 else out.view(*r.shape, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        kind, alpha, cutoff, width, K = ctx.meta
+        r2, raw_alpha, *t = ctx.saved_tensors
+        if kind not in (2, 3):
+            return None, torch.zeros_like(raw_alpha), None            # "_alpha" of the Gaussian basis "doesn't do anything"
+        lib = _lib.load()
+        t += [None] * (3 - len(t))
+        g2 = g.to(torch.float32).reshape(-1, K).contiguous()
+        rows = torch.empty(r2.shape[0], device=r2.device, dtype=torch.float32)
+        _lib.check(lib.nq_radial_basis_grad_alpha(kind, _lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, alpha, cutoff, width, _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]),
+                                                  _lib.ptr(rows), _lib.stream_ptr()))
+        g_raw = rows.double().sum() * torch.sigmoid(raw_alpha.detach().double())
+        return None, g_raw.to(raw_alpha.dtype).reshape(raw_alpha.shape), None
+
+
+def _bernstein_tables(K):
+    logfactorial = np.zeros(K)
+    for i in range(2, K):
+        logfactorial[i] = logfactorial[i - 1] + np.log(i)
+    v = np.arange(0, K)
+    n = (K - 1) - v
+    return logfactorial[-1] - logfactorial[v] - logfactorial[n], n, v
+
+
+class _RadialBase(nn.Module):
+    """Same constructors, buffers and parameter as the reference classes of these names (phisnet/nn/modules/*_radial_basis_functions.py; float64 buffers
+    there until ``model.to(dtype)``).  forward(r [..., 1]) -> [..., K]; gradient w.r.t. ``_alpha`` only."""
+    _kind = 0
+
+    def _softplus_inverse_init(self, ini_alpha):
+        x = torch.tensor(float(ini_alpha), dtype=torch.float64)
+        nn.init.constant_(self._alpha, float(x + torch.log(-torch.expm1(-x))))
+
+    def _width(self):
+        return getattr(self, "width", torch.tensor(0.0))
+
+    def forward(self, r):
+        _require_gpu(r)
+        alpha = self._alpha if hasattr(self, "_alpha") else r.new_zeros(())
+        return _RadialFn.apply(r, alpha, self)
+
+
+class GaussianRadialBasisFunctions(_RadialBase):
+    _kind = 1
+
+    def __init__(self, num_basis_functions, cutoff, dtype=torch.float32):
+        super().__init__()
+        self.num_basis_functions = num_basis_functions
+        self.register_buffer("cutoff", torch.tensor(cutoff, dtype=dtype))
+        self.register_buffer("center", torch.linspace(0, cutoff, num_basis_functions, dtype=torch.float64).to(dtype))
+        self.register_buffer("width", torch.tensor(num_basis_functions / cutoff, dtype=dtype))
+        self.register_parameter("_alpha", nn.Parameter(torch.tensor(1.0, dtype=dtype)))
+
+    def reset_parameters(self):
+        pass
+
+    def _tables(self):
+        return [self.center]
+
+
+class ExponentialGaussianRadialBasisFunctions(_RadialBase):
+    _kind = 2
+
+    def __init__(self, num_basis_functions, cutoff, ini_alpha=0.5, dtype=torch.float32):
+        super().__init__()
+        self.num_basis_functions, self.ini_alpha = num_basis_functions, ini_alpha
+        self.register_buffer("cutoff", torch.tensor(cutoff, dtype=dtype))
+        self.register_buffer("center", torch.linspace(1, 0, num_basis_functions, dtype=torch.float64).to(dtype))
+        self.register_buffer("width", torch.tensor(1.0 * num_basis_functions, dtype=dtype))
+        self.register_parameter("_alpha", nn.Parameter(torch.tensor(1.0, dtype=dtype)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._softplus_inverse_init(self.ini_alpha)
+
+    def _tables(self):
+        return [self.center]
+
+
+class OverlapBernsteinRadialBasisFunctions(_RadialBase):
+    _kind = 3
+
+    def __init__(self, num_basis_functions, cutoff, ini_alpha=0.5, dtype=torch.float32):
+        super().__init__()
+        self.num_basis_functions, self.ini_alpha = num_basis_functions, ini_alpha
+        logc, n, v = _bernstein_tables(num_basis_functions)
+        self.register_buffer("cutoff", torch.tensor(cutoff, dtype=dtype))
+        self.register_buffer("logc", torch.tensor(logc, dtype=dtype))
+        self.register_buffer("n", torch.tensor(n, dtype=dtype))
+        self.register_buffer("v", torch.tensor(v, dtype=dtype))
+        self.register_parameter("_alpha", nn.Parameter(torch.tensor(1.0, dtype=dtype)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self._softplus_inverse_init(self.ini_alpha)
+
+    def _tables(self):
+        return [self.logc, self.n, self.v]
+
+
+class BernsteinRadialBasisFunctions(_RadialBase):
+    _kind = 4
+
+    def __init__(self, num_basis_functions, cutoff, dtype=torch.float32):
+        super().__init__()
+        self.num_basis_functions = num_basis_functions
+        logc, n, v = _bernstein_tables(num_basis_functions)
+        self.register_buffer("cutoff", torch.tensor(cutoff, dtype=dtype))
+        self.register_buffer("logc", torch.tensor(logc, dtype=dtype))
+        self.register_buffer("n", torch.tensor(n, dtype=dtype))
+        self.register_buffer("v", torch.tensor(v, dtype=dtype))
+
+    def reset_parameters(self):
+        pass
+
+    def _tables(self):
+        return [self.logc, self.n, self.v]
+
+
+RADIAL_BASES = {"exp-bernstein": ExponentialBernsteinRadialBasisFunctions, "exp-gaussian": ExponentialGaussianRadialBasisFunctions,
+                "gaussian": GaussianRadialBasisFunctions, "bernstein": BernsteinRadialBasisFunctions, "overlap-bernstein": OverlapBernsteinRadialBasisFunctions}

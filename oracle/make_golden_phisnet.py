@@ -110,6 +110,25 @@ def geometry_bases():
         fx[f"{tag}:r"], fx[f"{tag}:rbf"], fx[f"{tag}:w"] = r.numpy(), out.detach().numpy(), w.numpy()
         fx[f"{tag}:g_alpha"], fx[f"{tag}:_alpha"] = m._alpha.grad.numpy(), m._alpha.detach().numpy()
         fx[f"{tag}:logc"] = m.logc.numpy()
+    # the other radial bases NeuralNetwork can be built with (neural_network.py:210-221) + the overlap variant, from the real reference modules
+    others = {"gaussian": ("gaussian_radial_basis_functions", "GaussianRadialBasisFunctions", (16, 6.0)),
+              "exp-gaussian": ("exponential_gaussian_radial_basis_functions", "ExponentialGaussianRadialBasisFunctions", (16, 6.0, 0.7)),
+              "overlap-bernstein": ("overlap_bernstein_radial_basis_functions", "OverlapBernsteinRadialBasisFunctions", (12, 7.0, 0.9)),
+              "bernstein": ("bernstein_radial_basis_functions", "BernsteinRadialBasisFunctions", (12, 5.0))}
+    for tag, (modname, clsname, args) in others.items():
+        cls = getattr(importlib.import_module("ref_phisnet_nn.modules." + modname), clsname)
+        m = cls(*args).float()
+        cutoff = args[1]
+        r = torch.tensor(np.concatenate([rng.uniform(0.3, cutoff * 0.999, size=29), [cutoff * 0.9999, cutoff, cutoff * 1.2]]).astype(np.float32)).view(-1, 1)
+        out = m(r)
+        w = torch.tensor(rng.normal(size=tuple(out.shape)).astype(np.float32))
+        if out.requires_grad:
+            (out * w).sum().backward()
+        fx[f"rb:{tag}:args"] = np.array(args, dtype=np.float64)
+        fx[f"rb:{tag}:r"], fx[f"rb:{tag}:rbf"], fx[f"rb:{tag}:w"] = r.numpy(), out.detach().numpy(), w.numpy()
+        has_alpha = hasattr(m, "_alpha")
+        fx[f"rb:{tag}:g_alpha"] = np.float64(m._alpha.grad.item() if has_alpha and m._alpha.grad is not None else 0.0)
+        fx[f"rb:{tag}:state_keys"] = np.array(list(m.state_dict().keys()))
     np.savez_compressed(os.path.join(OUT, "geometry_bases.npz"), **fx)
     print("geometry_bases.npz:", len(fx), "arrays")
 
