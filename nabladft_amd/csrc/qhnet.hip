@@ -307,6 +307,19 @@ struct QhExpArgs {
   float scale;
 };
 
+// coalesced float4 copy of n floats (n % 4 == 0 and 16-byte aligned source assumed by the caller) into LDS, four independent loads in flight per thread
+__device__ __forceinline__ void qh_stage4(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  const int n4 = n >> 2, T = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + 3 * T < n4; i += 4 * T) {
+    const float4 a = s4[i], b = s4[i + T], c = s4[i + 2 * T], d = s4[i + 3 * T];
+    d4[i] = a; d4[i + T] = b; d4[i + 2 * T] = c; d4[i + 3 * T] = d;
+  }
+  for (; i < n4; i += T) d4[i] = s4[i];
+}
+
 template <int L1, int L2>
 __device__ __forceinline__ void qh_exp_fwd_body(const QhExpArgs& a, const float* sW, const float* sX, const float* sB, int u, int v, float* orow) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1;
@@ -354,9 +367,8 @@ __global__ __launch_bounds__(256) void k_qh_exp_fwd(QhExpArgs a) {
   float* sX = sW + ((a.nw + 3) & ~3);
   float* sB = sX + QH_NCOMP * a.Cb;
   const long r = blockIdx.x;
-  const float* Wr = a.W + r * a.nw;
-  for (int i = threadIdx.x; i < a.nw; i += blockDim.x) sW[i] = Wr[i];
-  for (int i = threadIdx.x; i < QH_NCOMP * a.Cb; i += blockDim.x) sX[i] = a.x[r * QH_NCOMP * a.Cb + i];
+  qh_stage4(sW, a.W + r * a.nw, a.nw);                                   // nw = Cb * (sum of shell products): a multiple of 4 (checked by the launcher)
+  qh_stage4(sX, a.x + r * QH_NCOMP * a.Cb, QH_NCOMP * a.Cb);
   for (int i = threadIdx.x; i < a.nb; i += blockDim.x) sB[i] = a.bias ? a.bias[r * a.nb + i] : 0.f;
   __syncthreads();
   float* orow = a.out + r * (long)a.S * a.S;
@@ -420,9 +432,8 @@ __global__ __launch_bounds__(256) void k_qh_exp_bwd(QhExpArgs a, int n_ins, int 
   float* sG = sX + QH_NCOMP * a.Cb;
   float* sR = sG + a.S * a.S;
   const long r = blockIdx.x;
-  const float* Wr = a.W + r * a.nw;
-  for (int i = threadIdx.x; i < a.nw; i += blockDim.x) sW[i] = Wr[i];
-  for (int i = threadIdx.x; i < QH_NCOMP * a.Cb; i += blockDim.x) sX[i] = a.x[r * QH_NCOMP * a.Cb + i];
+  qh_stage4(sW, a.W + r * a.nw, a.nw);
+  qh_stage4(sX, a.x + r * QH_NCOMP * a.Cb, QH_NCOMP * a.Cb);
   for (int i = threadIdx.x; i < a.S * a.S; i += blockDim.x) sG[i] = a.gout[r * (long)a.S * a.S + i];
   __syncthreads();
   float* gbrow = a.gbias ? a.gbias + r * a.nb : nullptr;
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(256) void k_qh_exp_bwd(QhExpArgs a, int n_ins, int 
 static int qh_exp_fill(QhExpArgs* a, const float* x, const float* W, const float* bias, int64_t R, int32_t Cb, const int32_t* shells_host, int32_t nw, int32_t nb,
                        const float* w3j, int* n_ins, int* res_total) {
   if (!x || !W || !shells_host || !w3j) return nq_fail(NQ_ERR_ARG, "null argument");
-  if (Cb <= 0 || Cb > 64 || R < 0) return nq_fail(NQ_ERR_ARG, "expansion: bad sizes (bottleneck channels <= 64)");
+  if (Cb <= 0 || Cb > 64 || Cb % 4 != 0 || R < 0) return nq_fail(NQ_ERR_ARG, "expansion: bottleneck channels must be a multiple of 4, <= 64");
   a->x = x; a->W = W; a->bias = bias; a->R = R; a->Cb = Cb; a->nw = nw; a->nb = nb; a->w3j = w3j; a->scale = 1.0f / (float)Cb;
   int ro = 0;
   for (int l = 0; l < 3; ++l) {
@@ -649,7 +660,7 @@ int nq_qh_expansion_forward(const float* x, const float* weights, const float* b
   const size_t lds = sizeof(float) * (((size_t)n_weights + 3) / 4 * 4 + QH_NCOMP * Cb + n_bias + 4);
   if (lds > 160 * 1024) return nq_fail(NQ_ERR_ARG, "expansion: weight row does not fit the LDS");
   if (lds > 64 * 1024) NQ_HIP(hipFuncSetAttribute((const void*)k_qh_exp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (R > 0) hipLaunchKernelGGL(k_qh_exp_fwd, dim3((unsigned)R), dim3(192), lds, st, a);
+  if (R > 0) hipLaunchKernelGGL(k_qh_exp_fwd, dim3((unsigned)R), dim3(256), lds, st, a);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
