@@ -85,7 +85,7 @@ struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
   size_t RHO2, RW, ORDER, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
-  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, ROWCTR, scratch;
+  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GBR, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, ROWCTR, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
 };
@@ -118,6 +118,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GX = take(2 * N * F); W->GVa = take(2 * N * 3 * F); W->GVb = take(2 * N * 3 * F);
   W->GY = take(2 * N * 3 * F); W->GQ = take(2 * N * F); W->GCAT = take(2 * N * 2 * F); W->GU = take(2 * N * 6 * F);
   W->GXH = take(2 * N * 3 * F); W->GH = take(2 * N * F);
+  W->GBR = take(N * 3 * F);   // per-atom sums of gphi (rbf_proj bias gradient): its own buffer so that the side stream may still be reading GY
   W->GPHI2 = take(2 * E * 3 * F);
   W->GEDGE = take((F / 64) * E * 4);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
@@ -394,6 +395,47 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 // seeded = true: first-order reverse for the direct-force model (painn.py:130-133): no tangent sweep; the tangent halves of every
 // stacked buffer are zeroed so that the dual-reverse kernels reduce to the plain reverse, and the adjoints of the final node state
 // (from the PaiNNOutput head, evaluated by the caller) are added to the seeds.
+// ---- side stream for the weight gradients ---------------------------------------------------------------------------------------------------
+// Nothing downstream of the reverse sweep waits for dL/dW (split-K TN GEMMs, the k0-sorted rbf_proj gradient, bias column sums): only the
+// optimiser does.  They are issued on a second HIP stream and run under the critical path (input-gradient GEMMs, node kernels, message sweeps),
+// which leaves matrix-core and bandwidth gaps: the dual message kernel waits on gathers for half of its cycles.  Ordering is by events: a side
+// launch waits for its producer on the main stream; the main stream waits before it overwrites a buffer the side stream may still read.
+// One process drives one GPU from one thread (SURVEY.md 8b threading): the stream and the event pool are process-global.
+struct SideStream {
+  hipStream_t main = nullptr, side = nullptr;
+  bool on = false;
+  std::vector<hipEvent_t>* pool = nullptr;
+  size_t used = 0;
+  hipEvent_t last_read[8] = {};
+  hipEvent_t next() {
+    if (used == pool->size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; pool->push_back(e); }
+    return (*pool)[used++];
+  }
+  hipStream_t fork() {                       // the side stream sees everything issued on main so far
+    if (!on) return main;
+    hipEvent_t e = next();
+    (void)hipEventRecord(e, main); (void)hipStreamWaitEvent(side, e, 0);
+    return side;
+  }
+  void read_by_side(int buf) { if (on) { hipEvent_t e = next(); (void)hipEventRecord(e, side); last_read[buf] = e; } }
+  void before_main_writes(int buf) { if (on && last_read[buf]) { (void)hipStreamWaitEvent(main, last_read[buf], 0); last_read[buf] = nullptr; } }
+  void join() { if (on) { hipEvent_t e = next(); (void)hipEventRecord(e, side); (void)hipStreamWaitEvent(main, e, 0); } }
+};
+enum { SB_GY = 0, SB_GQ, SB_GU, SB_GXH, SB_GH, SB_GPHI, SB_GBR };
+static hipStream_t g_side_stream = nullptr;
+static std::vector<hipEvent_t> g_side_events;
+static SideStream side_stream_for(hipStream_t main) {
+  SideStream s;
+  s.main = main; s.pool = &g_side_events;
+  // Measured (profiles/r02_side_stream_ab.txt, 2048 conformers / step): 60.5 ms with the side stream vs 60.1 ms without -- every kernel of the sweep
+  // already fills the chip, concurrency only adds scheduling noise.  Kept as an opt-in (NQ_SIDE_STREAM=1) for small batches / other shapes.
+  const char* on = getenv("NQ_SIDE_STREAM");
+  if (!(on && on[0] == '1')) return s;
+  if (!g_side_stream && hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) { g_side_stream = nullptr; return s; }
+  s.side = g_side_stream; s.on = true;
+  return s;
+}
+
 static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                                size_t workspace_bytes, const float* grad_energy, const float* grad_forces, float* grad_params, void* stream,
                                bool seeded, const float* seed_x, const float* seed_vec, void* const* layer_events = nullptr) {
@@ -478,9 +520,11 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   if (seeded) NQ_HIP(hipMemsetAsync(ws + W.gte, 0, (size_t)N * sizeof(float), st));   // no Edot term
   r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
   NQ_TRY(nq_readout_rev(st, r, true));
-  NQ_TRY(nq_colsum(st, ws + W.TMPW, N, H, H, gp + P.w2, scr));
-  NQ_TRY(nq_colsum(st, ws + W.ge, N, 1, 1, gp + P.o2, scr));
-  NQ_TRY(nq_gemm_tn(st, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1", gp + P.o1, N));
+  SideStream ss = side_stream_for(st);
+  hipStream_t sd = ss.fork();          // sd == st when the side stream is off
+  NQ_TRY(nq_colsum(sd, ws + W.TMPW, N, H, H, gp + P.w2, scr));
+  NQ_TRY(nq_colsum(sd, ws + W.ge, N, 1, 1, gp + P.o2, scr));
+  NQ_TRY(nq_gemm_tn(sd, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1", gp + P.o1, N));
   NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
@@ -497,21 +541,31 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     u.GX = ws + W.GX; u.GTX = ws + W.GX + NF; u.GV = gv_cur; u.GTV = gv_cur + 3 * NF;
     u.GY = ws + W.GY; u.GTY = ws + W.GY + 3 * NF; u.GCAT = ws + W.GCAT; u.GTCAT = ws + W.GCAT + 2 * NF;
     u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
+    ss.before_main_writes(SB_GY);
     NQ_TRY(nq_upd_rev(st, u, 1, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
+    sd = ss.fork();
+    NQ_TRY(nq_gemm_tn(sd, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
+    ss.read_by_side(SB_GY);
+    ss.before_main_writes(SB_GQ);
     NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2"));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
+    sd = ss.fork();
+    NQ_TRY(nq_gemm_tn(sd, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
+    ss.read_by_side(SB_GQ);
     NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
+    ss.before_main_writes(SB_GU);
     NQ_TRY(nq_upd_rev(st, u, 2, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
+    sd = ss.fork();
+    NQ_TRY(nq_gemm_tn(sd, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
+    ss.read_by_side(SB_GU);
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
     m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
-    m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GY;  // GY is free again at this point of the layer
+    m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GBR;
+    ss.before_main_writes(SB_GXH); ss.before_main_writes(SB_GPHI); ss.before_main_writes(SB_GBR);
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
@@ -521,19 +575,26 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       NQ_TRY(nq_msg_rev(st, m, true));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    if (W.fused) NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr));   // one row per pair
-    else NQ_TRY(nq_gemm_tn(st, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
+    sd = ss.fork();
+    if (W.fused) NQ_TRY(nq_gwr_sorted(sd, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr));   // one row per pair
+    else NQ_TRY(nq_gemm_tn(sd, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
       NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));
-    NQ_TRY(nq_colsum(st, ws + W.GY, N, 3 * F, 3 * F, gp + mp.br, scr));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
+    NQ_TRY(nq_colsum(sd, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
+    NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
+    ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); ss.read_by_side(SB_GXH);
+    ss.before_main_writes(SB_GH);
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
-    NQ_TRY(nq_gemm_tn(st, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
+    sd = ss.fork();
+    NQ_TRY(nq_gemm_tn(sd, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
+    ss.read_by_side(SB_GH);
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
-    // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final here: the caller's side stream may start reducing it
-    if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], st));
+    // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final once the weight-gradient stream gets here: the caller's
+    // collective stream may start reducing it
+    if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], ss.on ? ss.side : st));
   }
+  ss.join();
   NQ_TRY(nq_embed_grad(st, g.z, ws + W.GX, N, F, T, gp + P.emb, scr));
   if (cfg->rbf_type) {   // dL/d(frequencies) [R] or dL/d(pregamma) [1]
     NQ_TRY(nq_rbf_param_grad(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, rbf_offsets, cfg->rbf_type, params + P.basis, ws + W.GRHO, ws + W.BCON));
