@@ -62,6 +62,26 @@ def gemm_flops_per_step(net, N, E, P):
     return 3.0 * f
 
 
+def pmc_traffic_bytes(kernel_prefix, molecules):
+    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r02_pmc_traffic_qhnet.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), only if it was taken at this batch size."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_qhnet.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("batch") != molecules:
+        return None
+    for name, v in rec.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return 1024.0 * (2.0 * v.get("fetch_kb_per_launch", 0.0) + v.get("write_kb_per_launch", 0.0))
+    return None
+
+
+_KERNEL_OF = {"qh_tp_uuu_fwd": "k_qh_tp<0, false, false", "qh_tp_uuu_bwd": "k_qh_tp<0, false, true", "qh_tp_uvu_fwd": "k_qh_tp<1, true, false",
+              "qh_tp_uvu_bwd": "k_qh_tp<1, true, true", "qh_exp_fwd": "k_qh_exp_fwd", "qh_exp_bwd": "k_qh_exp_bwd"}
+
+
 def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
     """One rank's share of the job: ``molecules`` conformers per step on this GPU; with world > 1 the flat gradient is all-reduced (mean) each step
     (conformers are independent graphs: data-parallel, no other collective).  Returns the record with THIS rank's wall time in ``_dt``."""
@@ -139,7 +159,9 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
             per_launch = alg[dom]
             avg_ms = dom_ms / max(dom_n, 1)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            traffic = pmc_traffic_bytes(_KERNEL_OF.get(dom, dom), molecules)
+            out["roofline"] = {"kernel": _KERNEL_OF.get(dom, dom) + ">", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches_per_step": dom_n}
         else:
             ach = fl / (max(gemm_ms, 1e-9) * 1e-3) / 1e12

@@ -8,7 +8,9 @@ import json
 import sys
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-out = {"batch": batch, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) around `python bench.py --batch %d`" % batch,
+cmd = sys.argv[2] if len(sys.argv) > 2 else "python bench.py --batch %d" % batch
+dest = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/pmc_traffic.json"
+out = {"batch": batch, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) around `%s`" % cmd,
        "units": "KB per launch (raw counter values)", "kernels": {}}
 for tag, key in (("fetch", "fetch_kb_per_launch"), ("write", "write_kb_per_launch")):
     fs = glob.glob(f"gpurun_out/pmc_{tag}/*counter_collection*.csv")
@@ -27,6 +29,6 @@ for tag, key in (("fetch", "fetch_kb_per_launch"), ("write", "write_kb_per_launc
 top = sorted(out["kernels"].items(), key=lambda kv: -(kv[1].get("fetch_kb_per_launch", 0) * kv[1].get("launches_fetch", 0)
                                                       + kv[1].get("write_kb_per_launch", 0) * kv[1].get("launches_write", 0)))[:25]
 out["kernels"] = dict(top)
-json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(dest, "w"), indent=1)
 for k, v in top[:12]:
     print(f"{k[:70]:70s} fetch {v.get('fetch_kb_per_launch', 0) / 1e6:8.3f} GB(raw)  write {v.get('write_kb_per_launch', 0) / 1e6:8.3f} GB per launch")
