@@ -289,6 +289,13 @@ int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cu
 int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
                                 const float* v, float* galpha_rows, void* stream);
 
+/* The same two calls with alpha = softplus(_alpha) read from a DEVICE scalar: no host read of the learnable parameter, so a whole training step can be
+ * captured into a HIP graph (trainer.GraphedStep). */
+int nq_bernstein_rbf_dev(const float* r, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc, const float* n, const float* v, float* out,
+                         void* stream);
+int nq_bernstein_rbf_grad_alpha_dev(const float* r, const float* grad_out, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc,
+                                    const float* n, const float* v, float* galpha_rows, void* stream);
+
 /* The other radial bases of PhiSNet (neural_network.py:210-221), all times cutoff_function(r): kind 1 gaussian (t0 = centres, width), 2 exp-gaussian
  * (t0 = centres, width, alpha), 3 overlap-bernstein (t0 = logc, t1 = n, t2 = v, alpha), 4 bernstein (t0 = logc, t1 = n, t2 = v).  out [P][K];
  * nq_radial_basis_grad_alpha (kinds 2, 3): per-row dL/dalpha given grad_out [P][K]. */

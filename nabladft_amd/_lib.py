@@ -84,6 +84,8 @@ SYMBOLS = {
     "nq_sph_harm": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "nq_bernstein_rbf": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
+    "nq_bernstein_rbf_dev": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P, _P, _P, _P]),
+    "nq_bernstein_rbf_grad_alpha_dev": (C.c_int, [_P, _P, _I64, _I32, _P, _F, _P, _P, _P, _P, _P]),
     "nq_radial_basis": (C.c_int, [_I32, _P, _I64, _I32, _F, _F, _F, _P, _P, _P, _P, _P]),
     "nq_radial_basis_grad_alpha": (C.c_int, [_I32, _P, _P, _I64, _I32, _F, _F, _F, _P, _P, _P, _P, _P]),
     "nq_feature_act": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),

@@ -41,11 +41,12 @@ __global__ void k_sph_harm(const float* __restrict__ u, long P, int L, float* __
 
 // rbf[p][k] and (optionally) the integrand of d/d alpha:  drbf/dalpha = rbf * (-r) * (n_k - v_k e^x / (1 - e^x))
 template <bool GRAD>
-__global__ void k_bernstein_rbf(const float* __restrict__ r, long P, int K, float alpha, float cutoff, const float* __restrict__ logc,
+__global__ void k_bernstein_rbf(const float* __restrict__ r, long P, int K, float alpha_host, float cutoff, const float* __restrict__ logc,
                                 const float* __restrict__ nk, const float* __restrict__ vk, float* __restrict__ out,
-                                const float* __restrict__ gout, float* __restrict__ galpha_rows) {
+                                const float* __restrict__ gout, float* __restrict__ galpha_rows, const float* __restrict__ alpha_dev) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * (GRAD ? 1 : K)) return;
+  const float alpha = alpha_dev ? *alpha_dev : alpha_host;     // device scalar: no host read of the learnable parameter (stream capture)
   if (!GRAD) {
     const long p = idx / K; const int k = (int)(idx % K);
     const float rr = r[p];
@@ -92,7 +93,29 @@ int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cu
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf");
   if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
-                                out, nullptr, nullptr);
+                                out, nullptr, nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* the same with alpha = softplus(_alpha) read from a device scalar (no host synchronisation: usable inside a captured HIP graph) */
+int nq_bernstein_rbf_dev(const float* r, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc, const float* n, const float* v, float* out,
+                         void* stream) {
+  if (!r || !alpha_dev || !logc || !n || !v || !out || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bernstein_rbf");
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
+                                out, nullptr, nullptr, alpha_dev);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_bernstein_rbf_grad_alpha_dev(const float* r, const float* grad_out, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc,
+                                    const float* n, const float* v, float* galpha_rows, void* stream) {
+  if (!r || !grad_out || !alpha_dev || !logc || !n || !v || !galpha_rows || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bernstein_rbf_grad");
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
+                                nullptr, grad_out, galpha_rows, alpha_dev);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -104,7 +127,7 @@ int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf_grad");
   if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
-                                nullptr, grad_out, galpha_rows);
+                                nullptr, grad_out, galpha_rows, nullptr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

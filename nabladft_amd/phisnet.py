@@ -610,9 +610,13 @@ class NeuralNetwork(nn.Module):
         pad = max(self._n_out) - n_out
         return torch.nn.functional.pad(x, (0, pad)) if pad else x
 
-    def forward(self, atoms_batch):
-        R = atoms_batch["positions"]
-        R = R.view(1, -1, 3)
+    def prepare(self, atoms_batch):
+        """Everything of a batch that depends only on its composition (molecule sizes, atomic numbers): pair lists, the pair-of-pairs index, the sorted
+        index structures of the gather / segment-sum kernels and the matrix-assembly tables.  Building it reads sizes on the host; pass the result back as
+        ``atoms_batch["prepared"]`` and ``forward`` issues no host synchronisation at all (a training step on a repeating composition can then be captured
+        into a HIP graph, trainer.GraphedStep)."""
+        from types import SimpleNamespace
+        R = atoms_batch["positions"].view(1, -1, 3)
         _require_gpu(R)
         Z = atoms_batch["atomic_numbers"].view(1, -1).long()
         ptr = self.fill_idx(atoms_batch["molecule_size"], R.device)
@@ -621,6 +625,21 @@ class NeuralNetwork(nn.Module):
         pidx = PairIndex(idx_i, idx_j, N)
         # pair-of-pairs index as a second sorted pair structure: rows = pairs, "neighbours" = the pairs listed in idx_pj
         ppidx = PairIndex(self.idx_pi, self.idx_pj, P) if self.idx_pi.numel() else None
+        sizes = [int(v) for v in torch.as_tensor(atoms_batch["molecule_size"]).tolist()]
+        return SimpleNamespace(ptr=ptr, idx_i=idx_i, idx_j=idx_j, idx_pi=self.idx_pi, idx_pj=self.idx_pj, pidx=pidx, ppidx=ppidx, swap=_SwapIndex(pidx),
+                               plan=self._assembler.plan(Z[0], ptr, idx_i, idx_j), sizes=sizes, checked=False)
+
+    def forward(self, atoms_batch):
+        R = atoms_batch["positions"]
+        R = R.view(1, -1, 3)
+        _require_gpu(R)
+        Z = atoms_batch["atomic_numbers"].view(1, -1).long()
+        prep = atoms_batch.get("prepared") if isinstance(atoms_batch, dict) else None
+        if prep is None:
+            prep = self.prepare(atoms_batch)
+        self.idx_i, self.idx_j, self.idx_pi, self.idx_pj = prep.idx_i, prep.idx_j, prep.idx_pi, prep.idx_pj
+        ptr, idx_i, idx_j, pidx, ppidx = prep.ptr, prep.idx_i, prep.idx_j, prep.pidx, prep.ppidx
+        N, P = Z.shape[1], idx_i.numel()
         rij = R[0].index_select(0, idx_j) - R[0].index_select(0, idx_i)
         dij = rij.norm(dim=-1, keepdim=True)
         uij = rij / dij
@@ -628,7 +647,7 @@ class NeuralNetwork(nn.Module):
         rbf = self.radial_basis_functions(dij).view(1, P, 1, self.num_basis_functions)
         sph = [s.view(1, P, -1, 1) for s in spherical_harmonics(self.order, uij)]
         xs = self.embedding(Z)
-        swap = _SwapIndex(pidx)
+        swap = prep.swap
         gather_i = lambda ts: _gather_list(ts, swap, self.order, self.num_features)      # all orders of the centre atoms, one launch
         gather_j = lambda ts: _gather_list(ts, pidx, self.order, self.num_features)
         results = {}
@@ -652,7 +671,7 @@ class NeuralNetwork(nn.Module):
             fij = _segment_add_list(fij, _gather_list(fpn_j, ppidx, self.order, self.num_features), ppidx, self.order, self.num_features)
         fij = self.residual_ij(fij)
         asm = self._assembler
-        plan = asm.plan(Z[0], ptr, idx_i, idx_j)
+        plan = prep.plan
         n_ii, n_ij = self._n_out
         if self.calculate_full_hamiltonian:
             f1 = self._heads(fii, self.residual_full_ii, self.activation_full_ii, self.output_full_ii)
@@ -664,7 +683,9 @@ class NeuralNetwork(nn.Module):
             results["core_hamiltonian_packed"] = asm.assemble(plan, self._pack(f1, n_ii), self._pack(f2, n_ij), symmetrize=True)
         if self.calculate_overlap_matrix:
             results["overlap_matrix_packed"] = asm.assemble(plan, self._pack(fii_over, n_ii), self._pack(fij_over, n_ij), symmetrize=True, unit_diagonal=True)
-        asm.check(plan)
+        if not prep.checked:                      # error flag of the assembly kernels: read once per prepared composition (a host synchronisation)
+            asm.check(plan)
+            prep.checked = True
         for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
             if k + "_packed" in results:
                 results[k] = asm.to_dense(plan, results[k + "_packed"].detach()).unsqueeze(0)
@@ -676,7 +697,7 @@ class NeuralNetwork(nn.Module):
                 eye = torch.eye(norb, device=R.device, dtype=R.dtype).unsqueeze(0) if eye is None else eye
                 results[k] = eye
         if self.predict_energy:
-            sizes = [int(v) for v in torch.as_tensor(atoms_batch["molecule_size"]).tolist()]
+            sizes = prep.sizes
             results["energy"] = self.energy_predictor(fii, fij, sizes, [n * (n - 1) for n in sizes])
         else:
             results["energy"] = torch.zeros(1, 1, device=R.device, dtype=R.dtype)

@@ -319,29 +319,31 @@ def spherical_harmonics(L: int, u: torch.Tensor) -> List[torch.Tensor]:
 
 
 class _BernsteinFn(torch.autograd.Function):
+    """alpha = softplus(_alpha) stays on the device (a 1-element tensor handed to the kernels): no host read of the parameter per call."""
+
     @staticmethod
     def forward(ctx, r, raw_alpha, mod):
         lib = _lib.load()
         r2 = r.detach().to(torch.float32).reshape(-1).contiguous()
-        alpha = float(torch.nn.functional.softplus(raw_alpha.detach().double()))
+        alpha = torch.nn.functional.softplus(raw_alpha.detach().double()).to(torch.float32).reshape(1).contiguous()
         K = mod.num_basis_functions
         out = torch.empty(r2.shape[0], K, device=r.device, dtype=torch.float32)
-        logc, n, v = (t.to(device=r.device, dtype=torch.float32).contiguous() for t in (mod.logc, mod.n, mod.v))
-        _lib.check(lib.nq_bernstein_rbf(_lib.ptr(r2), r2.shape[0], K, alpha, float(mod.cutoff), _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v), _lib.ptr(out),
-                                        _lib.stream_ptr()))
-        ctx.save_for_backward(r2, raw_alpha, logc, n, v)
-        ctx.meta = (alpha, float(mod.cutoff), K, r.shape)
+        logc, n, v = mod._tables32(r.device)
+        _lib.check(lib.nq_bernstein_rbf_dev(_lib.ptr(r2), r2.shape[0], K, _lib.ptr(alpha), mod._cutoff_f, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v), _lib.ptr(out),
+                                            _lib.stream_ptr()))
+        ctx.save_for_backward(r2, raw_alpha, alpha, logc, n, v)
+        ctx.meta = (mod._cutoff_f, K, r.shape)
         return out.view(*r.shape[:-1], K) if r.shape[-1] == 1 else out.view(*r.shape, K)
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        r2, raw_alpha, logc, n, v = ctx.saved_tensors
-        alpha, cutoff, K, _ = ctx.meta
+        r2, raw_alpha, alpha, logc, n, v = ctx.saved_tensors
+        cutoff, K, _ = ctx.meta
         g2 = g.to(torch.float32).reshape(-1, K).contiguous()
         rows = torch.empty(r2.shape[0], device=r2.device, dtype=torch.float32)
-        _lib.check(lib.nq_bernstein_rbf_grad_alpha(_lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, alpha, cutoff, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v),
-                                                   _lib.ptr(rows), _lib.stream_ptr()))
+        _lib.check(lib.nq_bernstein_rbf_grad_alpha_dev(_lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, _lib.ptr(alpha), cutoff, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v),
+                                                       _lib.ptr(rows), _lib.stream_ptr()))
         g_raw = rows.double().sum() * torch.sigmoid(raw_alpha.detach().double())       # d softplus
         return None, g_raw.to(raw_alpha.dtype).reshape(raw_alpha.shape), None
 
@@ -371,8 +373,18 @@ class ExponentialBernsteinRadialBasisFunctions(nn.Module):
         x = torch.tensor(float(self.ini_alpha), dtype=torch.float64)
         nn.init.constant_(self._alpha, float(x + torch.log(-torch.expm1(-x))))          # softplus_inverse (phisnet/nn/functional.py)
 
+    def _tables32(self, device):
+        """float32 device copies of the buffers the kernels read, rebuilt only when the module's buffers change (dtype / device moves)."""
+        key = (self.logc.data_ptr(), str(device))
+        if getattr(self, "_t32_key", None) != key:
+            self._t32 = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in (self.logc, self.n, self.v))
+            self._cutoff_f = float(self.cutoff)
+            self._t32_key = key
+        return self._t32
+
     def forward(self, r):
         _require_gpu(r)
+        self._tables32(r.device)
         return _BernsteinFn.apply(r, self._alpha, self)
 
 

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event table (nq profile hooks)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph (trainer.GraphedStep) and replay it")
     ap.add_argument("--per-tensor-optimizer", action="store_true", help="torch Adam over the 2.4 k parameter tensors instead of the flat buffer")
     a = ap.parse_args()
     import torch
@@ -66,7 +67,9 @@ def main():
     flat = None if a.per_tensor_optimizer else FlatParameters(params)
     if flat is not None:
         flat.attach(m)
-    opt = torch.optim.Adam(params if flat is None else [flat.flat], lr=1e-3, amsgrad=True)
+    opt = torch.optim.Adam(params if flat is None else [flat.flat], lr=1e-3, amsgrad=True, capturable=a.graph)
+    if a.graph:
+        batch["prepared"] = m.prepare(batch)
 
     def step():
         if flat is None:
@@ -82,6 +85,9 @@ def main():
             flat.clip_grad_norm_(1.0)
         opt.step()
         return loss
+    if a.graph:
+        from nabladft_amd.trainer import GraphedStep
+        step = GraphedStep(step, warmup=max(a.warmup, 3))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -96,7 +102,12 @@ def main():
     ms = e0.elapsed_time(e1) / a.steps
     n_params = sum(p.numel() for p in params)
     P = int(sum(s * (s - 1) for s in b["sizes"]))
-    out = {"metric": "PhiSNet molecule-steps/sec (fwd + MAE(H,S) + bwd + clip + AMSGrad)", "value": a.molecules / (ms * 1e-3), "unit": "molecule-steps/s",
+    wall0 = __import__("time").perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (__import__("time").perf_counter() - wall0) / a.steps
+    out = {"graph_replay": bool(a.graph), "wall_ms_per_step": wall_ms, "metric": "PhiSNet molecule-steps/sec (fwd + MAE(H,S) + bwd + clip + AMSGrad)", "value": a.molecules / (ms * 1e-3), "unit": "molecule-steps/s",
            "ms_per_step": ms, "molecules": a.molecules, "atoms": int(len(b["z"])), "ordered_pairs": P, "orbitals": int(sum(2 * l + 1 for o in b["orbitals"] for _, l in o)),
            "parameters": n_params, "final_loss": float(loss), "config": {k: v for k, v in HP.items()}, "data": "synthetic", "dtype": "f32"}
     if a.kernels:
