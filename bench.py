@@ -423,6 +423,20 @@ def main():
         kind2 = "painn-spk" if args.model == "painn-oc" else "painn-oc"
         if args.model == "schnet-spk":
             kind2 = None
+    small = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.batch > 32:
+        # the reference's default per-GPU batch (config/painn-oc.yaml:11: 32 conformers), same model and step, next to the throughput batch
+        sb = make_batches(77, 4, 32, dev)
+        for i in range(5):
+            step(sb[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(40):
+            step(sb[i % 4])
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        small = {"conformers_per_step": 32, "value": 32 * 40 / dts, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dts / 40,
+                 "what": "same training step at the reference's default batch size (latency-bound: ~330 small kernels back to back)"}
     if rank == 0 and world == 1 and not args.no_roofline and kind2 is not None:
         del step, model
         torch.cuda.empty_cache()
@@ -435,7 +449,23 @@ def main():
             step2(batches[i % len(batches)])
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t0
-        other = {"workload": WORKLOADS[kind2], "value": args.batch * args.steps / dt2, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt2 / args.steps}
+        other = {"workload": WORKLOADS[kind2], "value": args.batch * args.steps / dt2, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                 "parity": "pinned (reference golden vectors)" if kind2 == "painn-oc" else "unpinned (schnetpack is not in the reference tree; restatement oracle/spk_painn_ref.py)"}
+        # its own roofline record (same instrumented pass as the headline workload) and accuracy against its CPU restatement
+        _lib.profile_enable(True)
+        for i in range(args.steps):
+            step2(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        prof2 = _lib.profile_read()
+        _lib.profile_enable(False)
+        k2 = sorted(((k, v[0] / args.steps, v[1] // args.steps) for k, v in prof2.items()), key=lambda x: -x[1])
+        if k2:
+            d2, ms2, n2 = k2[0]
+            other["roofline"] = roofline_record(d2, ms2 / max(n2, 1), n2, n_atoms, model2._last_nl.E if hasattr(model2, "_last_nl") else n_edges, args.batch)
+            other["kernel_ms_per_step"] = {k: round(ms, 4) for k, ms, _ in k2[:6]}
+        if not args.no_cpu_baseline and kind2 != "painn-oc":
+            cpu2, par2 = cpu_baseline_spk(kind2, seconds_budget=8.0)
+            other["cpu_baseline"], other["mae_vs_cpu_reference"] = cpu2, par2
 
     hamiltonian = None
     if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
@@ -468,6 +498,7 @@ def main():
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
             "hamiltonian": hamiltonian,
+            "reference_batch_size_32": small,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,

@@ -13,6 +13,7 @@ Public surface mirrors the reference plugin classes for this path:
 from .painn import PaiNN, NeighborList, build_neighbor_list  # noqa: F401
 from .lightning import AtomisticTaskFixed, L2Loss, ModelOutput, PaiNNLightning, QHNetLightning  # noqa: F401
 from .qhnet import QHNet  # noqa: F401
+from . import ema  # noqa: F401
 from .trainer import FusedTrainStep, Batch  # noqa: F401
 from .data import ArenaLoader, ConformerArena, HamiltonianBatch, HamiltonianDatabase, HamiltonianDataset, hamiltonian_batch, read_energy_database  # noqa: F401
 

@@ -11,6 +11,12 @@ def _locate(path: str):
     return getattr(importlib.import_module(mod), name)
 
 
+def locate(path: str):
+    """``{_target_: nabladft_amd.config.locate, path: torch.optim.AdamW}`` -> the class object itself (what hydra's ``_target_: hydra.utils.get_class`` does for the
+    ``optimizer_cls`` / ``scheduler_cls`` arguments of the schnetpack task, config/model/painn.yaml:48-56)."""
+    return _locate(path)
+
+
 def instantiate(cfg: Any, **overrides):
     if isinstance(cfg, (list, tuple)):
         return type(cfg)(instantiate(c) for c in cfg)

@@ -154,3 +154,81 @@ def test_fused_step_coerces_and_checks_targets():
         step(nq.Batch(pos, z, batch, y, None).to(dev), update=False)
     with pytest.raises(ValueError):
         step(nq.Batch(pos, z, batch, y[:-1], ft).to(dev), update=False)
+
+
+QHNET_YAML = """
+_target_: nabladft_amd.QHNetLightning
+model_name: "QHNet"
+net:
+  _target_: nabladft_amd.QHNet
+  _convert_: partial
+  sh_lmax: 4
+  hidden_size: 128
+  bottle_hidden_size: 32
+  num_gnn_layers: 5
+  max_radius: 12
+  num_nodes: 83
+  radius_embed_dim: 32
+  orbitals:
+    1: [0, 0, 1]
+    6: [0, 0, 0, 1, 1, 2]
+    7: [0, 0, 0, 1, 1, 2]
+    8: [0, 0, 0, 1, 1, 2]
+    9: [0, 0, 0, 1, 1, 2]
+    16: [0, 0, 0, 0, 1, 1, 1, 2]
+    17: [0, 0, 0, 0, 1, 1, 1, 2]
+    35: [0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2]
+optimizer: {_target_: torch.optim.AdamW, _partial_: true, amsgrad: true, betas: [0.9, 0.95], lr: 5.0e-4}
+lr_scheduler: {_target_: torch.optim.lr_scheduler.ReduceLROnPlateau, _partial_: true, factor: 0.8, patience: 10, min_lr: 1.0e-6}
+losses:
+  hamiltonian: {_target_: nabladft_amd.hamiltonian.HamiltonianLoss}
+loss_coefs: {hamiltonian: 1.0}
+metric: null
+ema: {_target_: nabladft_amd.ema.ExponentialMovingAverage, _partial_: true, decay: 0.9999}
+"""
+
+SPK_TASK_YAML = """
+_target_: nabladft_amd.AtomisticTaskFixed
+model_name: "PaiNN"
+model:
+  _target_: nabladft_amd.spk.NeuralNetworkPotential
+  representation:
+    _target_: nabladft_amd.spk.PaiNN
+    n_interactions: 2
+    n_atom_basis: 64
+    radial_basis: {_target_: nabladft_amd.spk.GaussianRBF, n_rbf: 20, cutoff: 5.0}
+    cutoff_fn: {_target_: nabladft_amd.spk.CosineCutoff, cutoff: 5.0}
+  input_modules: [{_target_: nabladft_amd.spk.PairwiseDistances}]
+  output_modules:
+    - {_target_: nabladft_amd.spk.Atomwise, n_in: 64, output_key: "energy"}
+    - {_target_: nabladft_amd.spk.Forces}
+  postprocessors: [{_target_: nabladft_amd.spk.AddOffsets, property: "energy", add_mean: True}]
+outputs:
+  - {_target_: nabladft_amd.ModelOutput, name: "energy", loss_fn: {_target_: torch.nn.MSELoss}, loss_weight: 1.0}
+  - {_target_: nabladft_amd.ModelOutput, name: "forces", loss_fn: {_target_: torch.nn.MSELoss}, loss_weight: 1.0}
+optimizer_cls: {_target_: nabladft_amd.config.locate, path: torch.optim.AdamW}
+optimizer_args: {lr: 1.0e-4}
+scheduler_cls: {_target_: nabladft_amd.config.locate, path: torch.optim.lr_scheduler.ReduceLROnPlateau}
+scheduler_args: {mode: "min", factor: 0.8, patience: 10}
+scheduler_monitor: val_loss
+"""
+
+
+def test_qhnet_and_spk_task_configs_instantiate():
+    """config/model/qhnet.yaml and config/model/painn.yaml (schnetpack task) with the `_target_` lines pointed at this package."""
+    import nabladft_amd as nq
+    from nabladft_amd.config import instantiate
+    task = instantiate(yaml.safe_load(QHNET_YAML))
+    assert isinstance(task, nq.QHNetLightning) and isinstance(task.net, nq.QHNet)
+    assert task.net.get_number_of_parameters() == 21891529 and all(k.startswith("net.") for k in task.state_dict())
+    opt = task.configure_optimizers()
+    assert opt["optimizer"].defaults["amsgrad"] and opt["lr_scheduler"]["monitor"] == "val_loss"
+    task._instantiate_ema()
+    assert isinstance(task.ema, nq.ema.ExponentialMovingAverage) and task.ema.decay == 0.9999
+    spk_task = instantiate(yaml.safe_load(SPK_TASK_YAML))
+    assert isinstance(spk_task, nq.AtomisticTaskFixed) and len(spk_task.outputs) == 2 and spk_task.hparams.model_name == "PaiNN"
+    optimizers, schedulers = spk_task.configure_optimizers()
+    assert isinstance(optimizers[0], torch.optim.AdamW) and schedulers[0]["monitor"] == "val_loss"
+    ck = {"state_dict": {"model.postprocessors.0.mean": torch.tensor(3.0)}}
+    spk_task.on_save_checkpoint(ck)
+    assert tuple(ck["state_dict"]["model.postprocessors.0.mean"].shape) == (1,)
