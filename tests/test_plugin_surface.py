@@ -206,10 +206,10 @@ model:
 outputs:
   - {_target_: nabladft_amd.ModelOutput, name: "energy", loss_fn: {_target_: torch.nn.MSELoss}, loss_weight: 1.0}
   - {_target_: nabladft_amd.ModelOutput, name: "forces", loss_fn: {_target_: torch.nn.MSELoss}, loss_weight: 1.0}
-optimizer_cls: {_target_: nabladft_amd.config.locate, path: torch.optim.AdamW}
+optimizer_cls: {_partial_: True, _target_: torch.optim.AdamW}
 optimizer_args: {lr: 1.0e-4}
-scheduler_cls: {_target_: nabladft_amd.config.locate, path: torch.optim.lr_scheduler.ReduceLROnPlateau}
-scheduler_args: {mode: "min", factor: 0.8, patience: 10}
+scheduler_cls: {_partial_: True, _target_: torch.optim.lr_scheduler.ReduceLROnPlateau}
+scheduler_args: {factor: 0.8, patience: 10, min_lr: 1.0e-6}
 scheduler_monitor: val_loss
 """
 
