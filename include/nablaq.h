@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 7
+#define NQ_ABI_VERSION 8
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -332,6 +332,94 @@ int nq_sph_linear_weight_grad(const float* grad_y, const float* x, float* const*
  * -- fixed summation order, no atomics (the reference's index_add on a GPU is not reproducible). */
 int nq_gather_rows(const float* x, const int64_t* idx, int64_t P, int32_t C, float* out, void* stream);
 int nq_segment_sum(const float* rows, const int64_t* order, const int64_t* seg_ptr, const float* base, int64_t N, int32_t C, float* out, void* stream);
+
+/* ---- GemNet-OC (reference nablaDFT/gemnet_oc/) ------------------------------------------------------------------ */
+/* One edge set stored as a CSR by target atom (sources ascending): ptr [atoms+1], src / dst [n], geom [n][4] = {unit vector source -> target, distance}. */
+typedef struct nq_gn_set {
+  int32_t n, reserved;
+  const int32_t* ptr;
+  const int32_t* src;
+  const int32_t* dst;
+  const float* geom;
+} nq_gn_set;
+/* All graphs of gemnet_oc.py:892-958 (get_graphs_and_indices) derived from the a2a graph (nq_graph_count / nq_graph_fill with cutoff_aint, CSR arrays
+ * row_ptr / col / rev / dst; geom [E][4] is REWRITTEN with the reference's CPU arithmetic: d = torch.norm(pos[j] - pos[i]), unit vector = difference / d):
+ * sub-graph selection by cutoff and the K nearest per target (utils.py:408-500, enforce_max_strictly), the symmetrised main
+ * graph (gemnet_oc.py:694-775: source < target kept, flips added) with the counter-edge slot m_rev (= id_swap), the a2ee2a and qint graphs; triplet and
+ * quadruplet lists (interaction_indices.py) are not materialised.  The caller owns every array: [N] counters, [N+1] prefix arrays, [E] flags / mpos / apos /
+ * a_of_rev, and -- sized from the four totals nq_gn_graph_count returns -- the per-graph arrays. */
+typedef struct nq_gn_graphs {
+  int32_t N, E, k_main, k_aea, k_qint, reserved;
+  double cutoff_main, cutoff_aea, cutoff_qint;
+  const int32_t* row_ptr;
+  const int32_t* col;
+  const int32_t* rev;
+  const int32_t* dst;
+  const float* pos;
+  float* geom;
+  uint8_t* flags;
+  int32_t *degm, *lowm, *cnt_a, *cnt_q, *tin_atom;
+  int32_t *ptr_m, *lowptr_m, *ptr_a, *ptr_q, *tin_aptr;
+  int32_t *m_src, *m_dst, *m_rev, *m_slot;
+  float* m_geom;
+  int32_t *a_src, *a_dst;
+  float* a_geom;
+  int32_t* a_of_rev;
+  int32_t *q_src, *q_dst;
+  float* q_geom;
+  int32_t* tin_ptr;
+  int32_t *mpos, *apos;
+  int32_t *tin_main, *q_of_rev, *qpos;
+} nq_gn_graphs;
+/* totals_host[4] = {main edges, a2ee2a edges, qint edges, rows of the (qint edge, main in-edge of its source) table}; synchronises `stream`.
+ * max_degree: largest a2a in-degree (<= 512). */
+int nq_gn_graph_count(const void* graphs /* nq_gn_graphs* */, int32_t max_degree, int32_t* totals_host, void* stream);
+int nq_gn_graph_fill(const void* graphs /* nq_gn_graphs* */, void* stream);
+/* RadialBasis (layers/radial_basis.py:196-220): out[n][R] = scale * envelope_p(d/cutoff) * exp(coeff (d/cutoff - offset_k)^2); d = geom[.][3]. */
+int nq_gn_radial_basis(const float* geom, int64_t n, int32_t num_radial, const float* offset, double cutoff, double exponent, float scale, float* out,
+                       void* stream);
+/* EfficientInteractionBilinear's first contraction (layers/efficient.py:213-229) for the triplet families (interaction_indices.py:13-118):
+ * S[o][s][c] = sum over in-edges p of target(o) in `in_set` with source(p) != source(o) of Y_s0(clamp(v_o . v_p)) * scale * x[p][c];  backward: d x. */
+int nq_gn_triplet_forward(const void* out_set, const void* in_set, const float* x, int32_t C, int32_t NS, float scale, float* S, void* stream);
+int nq_gn_triplet_backward(const void* out_set, const void* in_set, const float* dS, int32_t C, int32_t NS, float scale, float* dx, void* stream);
+/* Quadruplets (interaction_indices.py:121-282, angles gemnet_oc.py:597-655, "legendre_outer" basis spherical_basis.py:104-110): x rows are indexed
+ * tin_ptr[q] + j (j-th main in-edge of source(q)); S[o][l * NS + l'][c].  backward scratch: f32[main edges * KQ * NS * C], KQ >= largest qint in-degree. */
+int nq_gn_quad_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, const float* x, int32_t C, int32_t NS, float scale, float* S,
+                       void* stream);
+int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int64_t T, const float* dS, int32_t C, int32_t NS, int32_t KQ,
+                        float scale, float* scratch, float* dx, void* stream);
+/* BasisEmbedding without inner index (layers/efficient.py:136-141): cir[(q, j)][i] = sum_s rad_w1[q][i * NS + s] Y_s0(v_q . v_p) * scale. */
+int nq_gn_cir_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int64_t T, const float* rad_w1, int32_t I, int32_t NS, float scale,
+                      float* cir, void* stream);
+int nq_gn_cir_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, const float* dcir, int32_t I, int32_t NS, float scale,
+                       float* d_rad_w1, void* stream);
+/* rad_W1 @ sph_m (layers/efficient.py:231-244): out[o][i][c] = sum_s R[o][i * NSS + s] S[o][s][c]; backward writes dR and / or dS (nullable). */
+int nq_gn_rowmm_forward(const float* R, const float* S, int64_t n, int32_t I, int32_t NSS, int32_t C, float* out, void* stream);
+int nq_gn_rowmm_backward(const float* R, const float* S, const float* dout, int64_t n, int32_t I, int32_t NSS, int32_t C, float* dR, float* dS, void* stream);
+/* PairInteraction (layers/interaction_block.py:721-733): out[a][r][c] = sum_{p in row(a)} rad_w[p][r] x[source(p)][c]; the a2a graph is symmetric (rev). */
+int nq_gn_pair_forward(const void* a2a_set, const float* rad_w, const float* x, int32_t N, int32_t Rr, int32_t C, float* out, void* stream);
+int nq_gn_pair_backward(const void* a2a_set, const int32_t* rev, const float* rad_w, const float* x, const float* dout, int32_t N, int32_t Rr, int32_t C,
+                        float* d_rad_w, float* dx, void* stream);
+/* Adjoint of the row gather x_tin[row] = x[tin_main[row]] of the quadruplet path (interaction_block.py:579: x_db[idx["triplet_in"]["in"]]):
+ * out[p] = sum over the qint edges q whose source is target(p) of g[tin_ptr[q] + position of p in its row]; a2a_row_ptr / q_of_rev from nq_gn_graphs. */
+int nq_gn_tin_scatter(const void* main_set, const int32_t* a2a_row_ptr, const int32_t* q_of_rev, const int32_t* tin_ptr, const float* g, int32_t C,
+                      float* out, void* stream);
+/* EdgeEmbedding input (layers/embedding_block.py:85-90): cat[e] = [h[source] | h[target] | m[e]]; backward_h: dh from the first two blocks of dcat. */
+int nq_gn_cat_forward(const void* main_set, const float* h, const float* m, int32_t A, int32_t Em, float* cat, void* stream);
+int nq_gn_cat_backward_h(const void* main_set, const int32_t* rev, const float* dcat, int32_t N, int32_t A, int32_t Em, float* dh, void* stream);
+/* AtomUpdateBlock / OutputBlock head (layers/atom_update_block.py:88-93): out[a][c] = sum_{p in row(a)} m[p][c] r[p][c]. */
+int nq_gn_mulsum_forward(const void* main_set, const float* m, const float* r, int32_t N, int32_t C, float* out, void* stream);
+int nq_gn_mulsum_backward(const void* main_set, const float* m, const float* r, const float* dout, int32_t C, float* dm, float* dr, void* stream);
+/* Direct forces (gemnet_oc.py:1216-1243): per-edge scalar, averaged with the counter-edge if coupled, times the edge vector, summed per target atom. */
+int nq_gn_forces_forward(const void* main_set, const int32_t* rev, const float* f_edge, int32_t N, int32_t coupled, float* forces, void* stream);
+int nq_gn_forces_backward(const void* main_set, const int32_t* rev, const float* d_forces, int32_t coupled, float* d_f_edge, void* stream);
+/* out[p] = x[idx[p]] (* y[p] if y); out[n] = sum_{q in [ptr[n], ptr[n+1])} rows[r] (* y[r] if y), r = order ? order[q] : q, entries r < 0 skipped;
+ * out = a * b;  out = alpha a + beta b (b nullable);  dW[t] = sum_{n: z[n] == t + 1} g[n] (Embedding(z - 1), layers/embedding_block.py:39-53). */
+int nq_gn_gather(const float* x, const int32_t* idx, const float* y, int64_t P, int32_t C, float* out, void* stream);
+int nq_gn_segment_sum(const float* rows, const float* y, const int32_t* order, const int32_t* ptr, int64_t N, int32_t C, float* out, void* stream);
+int nq_gn_mul(const float* a, const float* b, int64_t n, float* out, void* stream);
+int nq_gn_lincomb(const float* a, const float* b, float alpha, float beta, int64_t n, float* out, void* stream);
+int nq_gn_embed_grad(const int32_t* z, const float* g, int32_t N, int32_t num_elements, int32_t C, float* dW, void* stream);
 
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -31,6 +31,18 @@ class Graph(C.Structure):
     _fields_ = [("N", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("reserved", C.c_int32),
                 ("mol_ptr", C.c_void_p), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("dst", C.c_void_p),
                 ("rev", C.c_void_p), ("geom", C.c_void_p), ("z", C.c_void_p), ("atom_mol", C.c_void_p), ("lowptr", C.c_void_p)]
+
+
+class GnSet(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("ptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("geom", C.c_void_p)]
+
+
+class GnGraphs(C.Structure):
+    _fields_ = ([("N", C.c_int32), ("E", C.c_int32), ("k_main", C.c_int32), ("k_aea", C.c_int32), ("k_qint", C.c_int32), ("reserved", C.c_int32),
+                 ("cutoff_main", C.c_double), ("cutoff_aea", C.c_double), ("cutoff_qint", C.c_double)]
+                + [(k, C.c_void_p) for k in ("row_ptr", "col", "rev", "dst", "pos", "geom", "flags", "degm", "lowm", "cnt_a", "cnt_q", "tin_atom", "ptr_m", "lowptr_m", "ptr_a",
+                                             "ptr_q", "tin_aptr", "m_src", "m_dst", "m_rev", "m_slot", "m_geom", "a_src", "a_dst", "a_geom", "a_of_rev",
+                                             "q_src", "q_dst", "q_geom", "tin_ptr", "mpos", "apos", "tin_main", "q_of_rev", "qpos")])
 
 
 _P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
@@ -98,6 +110,31 @@ SYMBOLS = {
     "nq_sph_linear_weight_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "nq_gather_rows": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "nq_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_gn_graph_count": (C.c_int, [_P, _I32, C.POINTER(C.c_int32), _P]),
+    "nq_gn_graph_fill": (C.c_int, [_P, _P]),
+    "nq_gn_radial_basis": (C.c_int, [_P, _I64, _I32, _P, _D, _D, _F, _P, _P]),
+    "nq_gn_triplet_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_triplet_backward": (C.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_quad_forward": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_quad_backward": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "nq_gn_tin_scatter": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
+    "nq_gn_cir_forward": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_cir_backward": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_rowmm_forward": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "nq_gn_rowmm_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "nq_gn_pair_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "nq_gn_pair_backward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "nq_gn_cat_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "nq_gn_cat_backward_h": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "nq_gn_mulsum_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "nq_gn_mulsum_backward": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P]),
+    "nq_gn_forces_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "nq_gn_forces_backward": (C.c_int, [_P, _P, _P, _I32, _P, _P]),
+    "nq_gn_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_gn_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_gn_mul": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "nq_gn_lincomb": (C.c_int, [_P, _P, _F, _F, _I64, _P, _P]),
+    "nq_gn_embed_grad": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

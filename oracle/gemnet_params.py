@@ -18,7 +18,7 @@ def make_tensor(name, shape, seed, fit_scales=False):
     if name.endswith("scale_factor"):
         if not fit_scales:
             return torch.tensor(0.0)
-        return torch.tensor(0.75 + 0.5 * float(torch.rand((), generator=g)), dtype=torch.float32)
+        return torch.tensor(0.75 + 0.5 * float(torch.rand((), generator=g, dtype=torch.float32)), dtype=torch.float32)
     r = torch.randn(shape, generator=g, dtype=torch.float32)
     if name.endswith("embeddings.weight"):
         return r

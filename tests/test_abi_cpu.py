@@ -150,8 +150,9 @@ def test_struct_layouts_agree_between_header_binding_and_integration_doc():
     the same order with the same types (a stale 40-byte nq_painn_cfg in the doc once made copy-pasting bindings read past the struct)."""
     from nabladft_amd import _lib
     hs = _header_structs()
-    assert set(hs) == {"nq_painn_cfg", "nq_schnet_cfg", "nq_graph"}
-    for cname, cls in (("nq_painn_cfg", _lib.PainnCfg), ("nq_schnet_cfg", _lib.SchnetCfg), ("nq_graph", _lib.Graph)):
+    assert set(hs) == {"nq_painn_cfg", "nq_schnet_cfg", "nq_graph", "nq_gn_set", "nq_gn_graphs"}
+    for cname, cls in (("nq_painn_cfg", _lib.PainnCfg), ("nq_schnet_cfg", _lib.SchnetCfg), ("nq_graph", _lib.Graph), ("nq_gn_set", _lib.GnSet),
+                       ("nq_gn_graphs", _lib.GnGraphs)):
         assert _ctypes_fields(cls) == hs[cname], cname
     assert C.sizeof(_lib.PainnCfg) == 48
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
