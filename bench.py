@@ -138,6 +138,38 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
             "avg_launch_ms": avg_ms, "launches_per_step": launches}
 
 
+def bench_gemnet(args, rank, world, local_dev, dev):
+    """--model gemnet: BASELINE.json configs[2] (config/model/gemnet-oc.yaml) through scripts/bench_gemnet.py; same JSON contract, conformer-steps/s, fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_gemnet as BG
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    mol = args.batch if args.batch != 2048 else 16
+    rec = BG.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
+    t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        cpu = BG.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
+        out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
+                          "edges": rec["edges"], "parallelism": f"dp{world}"},
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "parity": rec.get("parity")}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_qhnet(args, rank, world, local_dev, dev):
     """--model qhnet: BASELINE.json configs[3] (config/qhnet.yaml) through scripts/bench_qhnet.py; same JSON contract, conformer-steps/s."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -177,6 +209,7 @@ WORKLOADS = {
     "schnet-spk": "SchNet (config/schnet.yaml -> schnetpack SchNet F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                   "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
     "qhnet": "QHNet (config/qhnet.yaml) Hamiltonian training step -- see scripts/bench_qhnet.py",
+    "gemnet": "GemNet-OC (config/model/gemnet-oc.yaml) energy + direct forces training step -- see scripts/bench_gemnet.py",
     "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
 }
@@ -313,6 +346,8 @@ def main():
         _lib.load().nq_set_gemm_variant(args.gemm_variant)
     if args.model == "qhnet":
         return bench_qhnet(args, rank, world, local_dev, dev)
+    if args.model == "gemnet":
+        return bench_gemnet(args, rank, world, local_dev, dev)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
     model, step = build_step(args.model, dev)
     batches = make_batches(1 + rank, 4, args.batch, dev)
@@ -484,6 +519,15 @@ def main():
         hamiltonian = {"workload": h16.pop("workload"), "batch16": h16, "batch2_reference_batch_size": {k: h2[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
                        "cpu_baseline": None if args.no_cpu_baseline else BQ.cpu_baseline(seconds_budget=20.0)}
 
+    gemnet = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+        # BASELINE.json configs[2] (GemNet-OC, config/model/gemnet-oc.yaml, fp32) in the same record
+        torch.cuda.empty_cache()
+        import bench_gemnet as BG
+        g16 = BG.run(16, 5, 2, kernels=True, device=dev)
+        g16.pop("_dt", None)
+        gemnet = {"workload": g16.pop("workload"), "batch16": g16, "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
+
     if rank == 0:
         out = {
             "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
@@ -498,6 +542,7 @@ def main():
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
             "hamiltonian": hamiltonian,
+            "gemnet_oc": gemnet,
             "reference_batch_size_32": small,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)

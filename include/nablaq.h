@@ -419,6 +419,8 @@ int nq_gn_gather(const float* x, const int32_t* idx, const float* y, int64_t P, 
 int nq_gn_segment_sum(const float* rows, const float* y, const int32_t* order, const int32_t* ptr, int64_t N, int32_t C, float* out, void* stream);
 int nq_gn_mul(const float* a, const float* b, int64_t n, float* out, void* stream);
 int nq_gn_lincomb(const float* a, const float* b, float alpha, float beta, int64_t n, float* out, void* stream);
+/* out = scale * g * d/dz [silu(z) / 0.6] (adjoint of ScaledSiLU with a folded constant). */
+int nq_gn_ssilu_backward(const float* z, const float* g, float scale, int64_t n, float* out, void* stream);
 int nq_gn_embed_grad(const int32_t* z, const float* g, int32_t N, int32_t num_elements, int32_t C, float* dW, void* stream);
 
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
@@ -449,6 +451,9 @@ void nq_set_gemm_variant(int32_t variant);
 /* C[M,N] = A[M,K] W[N,K]^T (+bias[N]); if C_silu != NULL also writes silu(C). */
 int nq_linear_forward(const float* A, const float* W, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K,
                       void* stream);
+/* C[M,N] = A W^T and C_act = alpha * resid (nullable) + beta * silu(C): Dense + ScaledSiLU (+ residual) of gemnet_oc/layers/base_layers.py:11-97 in one pass. */
+int nq_linear_forward_act(const float* A, const float* W, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
+                          int32_t K, void* stream);
 /* C[M,K] (+)= G[M,N] W[N,K] */
 int nq_linear_input_grad(const float* G, const float* W, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
 /* gW[N,K] = G[rows,N]^T X[rows,K]; scratch: f32[nq_weight_grad_scratch_floats(rows,N,K)] */

@@ -134,6 +134,8 @@ SYMBOLS = {
     "nq_gn_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "nq_gn_mul": (C.c_int, [_P, _P, _I64, _P, _P]),
     "nq_gn_lincomb": (C.c_int, [_P, _P, _F, _F, _I64, _P, _P]),
+    "nq_gn_ssilu_backward": (C.c_int, [_P, _P, _F, _I64, _P, _P]),
+    "nq_linear_forward_act": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _I32, _I32, _I32, _P]),
     "nq_gn_embed_grad": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),

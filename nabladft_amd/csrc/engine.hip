@@ -659,6 +659,11 @@ int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 int nq_linear_forward(const float* A, const float* Wt, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K, void* stream) {
   return nq_gemm_nt((hipStream_t)stream, A, Wt, C, bias, C_silu, M, N, K, K, K, N);
 }
+int nq_linear_forward_act(const float* A, const float* Wt, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N, int32_t K,
+                          void* stream) {
+  if (!A || !Wt || !C || !C_act) return nq_fail(NQ_ERR_ARG, "null argument");
+  return nq_gemm_nt_act((hipStream_t)stream, A, Wt, C, C_act, resid, alpha, beta, M, N, K);
+}
 int nq_linear_input_grad(const float* G, const float* Wt, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
   return nq_gemm_nn((hipStream_t)stream, G, Wt, C, M, N, K, N, K, K, accumulate);
 }

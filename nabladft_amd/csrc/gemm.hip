@@ -28,7 +28,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3 };
+enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4 };   // 4: C = v, C2 = ea * resid + eb * silu(v)
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias; float* C2;
@@ -42,6 +42,7 @@ struct GemmArgs {
   int rm_rows, rm_ncomp, rm_w, rm_base;   // RM == 2 (weight gradient of one order): w / base given here
   int rm_s;                               // RM == 3 (weight gradients of all orders): splits per component; blockIdx.z = component * rm_s + split
   const float* Bz[5];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
+  const float* resid; float ea, eb;       // EPI_SILU_RES (resid nullable, same leading dimension as C)
 };
 __device__ __forceinline__ long rm_row(int q, int w, int ncomp, int base) { return (long)(q / w) * ncomp + base + q % w; }
 
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
 #endif
         else Cout[off] = v;
         if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
+        if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu(v) : p.eb * nq_silu(v);
       }
     }
 }
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(256) void k_gemm_small(GemmArgs p) {
     const float v = acc[r] + bv;
     if (EPI == EPI_ACC) p.C[off] += v; else p.C[off] = v;
     if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
+    if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu(v) : p.eb * nq_silu(v);
   }
 }
 // fewer than one 128x128 tile per CU -> the small-tile kernel
@@ -388,6 +391,25 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
   if (C2_silu) launch_gemm<true, true, EPI_SILU>(st, grid, p);
   else launch_gemm<true, true, EPI_STORE>(st, grid, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// C[M, N] = A W^T and C2 = ea * resid + eb * silu(C)  (Dense + ScaledSiLU + residual of the GemNet-OC blocks in one pass)
+int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
+                   const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{A, W, C, nullptr, C2, M, N, K, K, K, N, 0, 0, nullptr, 0};
+  p.resid = resid; p.ea = ea; p.eb = eb;
+  if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
+    dim3 gs(nq_cdiv(M, SM), nq_cdiv(N, SM), 1);
+    hipLaunchKernelGGL((k_gemm_small<true, EPI_SILU_RES>), gs, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(nq_cdiv(M, BM), nq_cdiv(N, BN), 1);
+    launch_gemm<true, true, EPI_SILU_RES>(st, grid, p);
+  }
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -249,33 +249,47 @@ __global__ void k_gn_cir_bwd(GnSet M, GnSet Q, const int* __restrict__ tin_ptr, 
 }
 
 // ---- per-row product out[o][i][c] = sum_s R[o][i * NSS + s] S[o][s][c] (rad_W1 @ sph_m, efficient.py:231-244) and its two adjoints --------------------
-__global__ void k_gn_rowmm_fwd(const float* __restrict__ R, const float* __restrict__ S, long n, int I, int NSS, int C, float* __restrict__ out) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * I * C) return;
-  const int ch = (int)(t % C); const long r = t / C; const int i = (int)(r % I); const long o = r / I;
-  const float* w = R + (o * I + i) * NSS;
-  const float* s = S + o * NSS * C + ch;
-  float acc = 0.f;
-  for (int k = 0; k < NSS; ++k) acc += w[k] * s[(long)k * C];
-  out[t] = acc;
+// One workgroup per row: R[o] (I x NSS), S[o] (NSS x C) (and dout[o], I x C) are staged in LDS once (S with a padded row stride so that the dR contraction,
+// whose lanes differ in s, is conflict free); every global element is read exactly once.
+__global__ __launch_bounds__(256) void k_gn_rowmm_fwd(const float* __restrict__ R, const float* __restrict__ S, long n, int I, int NSS, int C,
+                                                        float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* sR = lds; float* sS = lds + I * NSS;
+  const long o = blockIdx.x;
+  for (int t = threadIdx.x; t < I * NSS; t += 256) sR[t] = R[o * I * NSS + t];
+  for (int t = threadIdx.x; t < NSS * C; t += 256) sS[t] = S[o * NSS * C + t];
+  __syncthreads();
+  for (int t = threadIdx.x; t < I * C; t += 256) {
+    const int i = t / C, ch = t - i * C;
+    float acc = 0.f;
+    for (int k = 0; k < NSS; ++k) acc += sR[i * NSS + k] * sS[k * C + ch];
+    out[o * I * C + t] = acc;
+  }
 }
-__global__ void k_gn_rowmm_bwd_s(const float* __restrict__ R, const float* __restrict__ dout, long n, int I, int NSS, int C, float* __restrict__ dS) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * NSS * C) return;
-  const int ch = (int)(t % C); const long r = t / C; const int k = (int)(r % NSS); const long o = r / NSS;
-  float acc = 0.f;
-  for (int i = 0; i < I; ++i) acc += R[(o * I + i) * NSS + k] * dout[(o * I + i) * C + ch];
-  dS[t] = acc;
-}
-__global__ void k_gn_rowmm_bwd_r(const float* __restrict__ S, const float* __restrict__ dout, long n, int I, int NSS, int C, float* __restrict__ dR) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * I * NSS) return;
-  const int k = (int)(t % NSS); const long r = t / NSS; const int i = (int)(r % I); const long o = r / I;
-  const float* s = S + (o * NSS + k) * C;
-  const float* g = dout + (o * I + i) * C;
-  float acc = 0.f;
-  for (int ch = 0; ch < C; ++ch) acc += s[ch] * g[ch];
-  dR[t] = acc;
+__global__ __launch_bounds__(256) void k_gn_rowmm_bwd(const float* __restrict__ R, const float* __restrict__ S, const float* __restrict__ dout, long n, int I,
+                                                        int NSS, int C, float* __restrict__ dR, float* __restrict__ dS) {
+  extern __shared__ float lds[];
+  const int CP = C + 1;
+  float* sR = lds; float* sS = sR + I * NSS; float* sG = sS + NSS * CP;
+  const long o = blockIdx.x;
+  for (int t = threadIdx.x; t < I * NSS; t += 256) sR[t] = R[o * I * NSS + t];
+  for (int t = threadIdx.x; t < NSS * C; t += 256) { const int k = t / C; sS[k * CP + (t - k * C)] = S[o * NSS * C + t]; }
+  for (int t = threadIdx.x; t < I * C; t += 256) sG[t] = dout[o * I * C + t];
+  __syncthreads();
+  if (dS)
+    for (int t = threadIdx.x; t < NSS * C; t += 256) {
+      const int k = t / C, ch = t - k * C;
+      float acc = 0.f;
+      for (int i = 0; i < I; ++i) acc += sR[i * NSS + k] * sG[i * C + ch];
+      dS[o * NSS * C + t] = acc;
+    }
+  if (dR)
+    for (int t = threadIdx.x; t < I * NSS; t += 256) {
+      const int i = t / NSS, k = t - i * NSS;
+      float acc = 0.f;
+      for (int ch = 0; ch < C; ++ch) acc += sG[i * C + ch] * sS[k * CP + ch];
+      dR[o * I * NSS + t] = acc;
+    }
 }
 
 // ---- atom-atom pairs: out[a][r][c] = sum_{p in row(a)} RW[p][r] X[source(p)][c] (interaction_block.py:721-733) ---------------------------------------
@@ -416,6 +430,10 @@ __global__ void k_gn_lincomb(const float* __restrict__ a, const float* __restric
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) out[t] = b ? alpha * a[t] + beta * b[t] : alpha * a[t];
 }
+__global__ void k_gn_ssilu_bwd(const float* __restrict__ z, const float* __restrict__ g, float scale, long n, float* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = scale * g[t] * nq_dsilu(z[t]);
+}
 // dW[t][c] = sum_{n : z[n] == t + 1} g[n][c]  (adjoint of Embedding(z - 1), embedding_block.py:39-53), fixed order
 __global__ void k_gn_embed_grad(const int* __restrict__ z, const float* __restrict__ g, int N, int T, int C, float* __restrict__ dW) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,16 +551,20 @@ int nq_gn_rowmm_forward(const float* R, const float* S, int64_t n, int32_t I, in
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "gn_rowmm_fwd");
   if (n <= 0) return NQ_OK;
-  hipLaunchKernelGGL(k_gn_rowmm_fwd, GN_GRID(n * I * C), R, S, (long)n, I, NSS, C, out);
+  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)NSS * C);
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowmm: I=%d NSS=%d C=%d does not fit the LDS tile", I, NSS, C);
+  hipLaunchKernelGGL(k_gn_rowmm_fwd, dim3((unsigned)n), dim3(256), lds, st, R, S, (long)n, I, NSS, C, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 int nq_gn_rowmm_backward(const float* R, const float* S, const float* dout, int64_t n, int32_t I, int32_t NSS, int32_t C, float* dR, float* dS, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "gn_rowmm_bwd");
-  if (n <= 0) return NQ_OK;
-  if (dS) { hipLaunchKernelGGL(k_gn_rowmm_bwd_s, GN_GRID(n * NSS * C), R, dout, (long)n, I, NSS, C, dS); NQ_LAUNCH_CHECK(); }
-  if (dR) { hipLaunchKernelGGL(k_gn_rowmm_bwd_r, GN_GRID(n * I * NSS), S, dout, (long)n, I, NSS, C, dR); NQ_LAUNCH_CHECK(); }
+  if (n <= 0 || (!dR && !dS)) return NQ_OK;
+  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)NSS * (C + 1) + (size_t)I * C);
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowmm: I=%d NSS=%d C=%d does not fit the LDS tile", I, NSS, C);
+  hipLaunchKernelGGL(k_gn_rowmm_bwd, dim3((unsigned)n), dim3(256), lds, st, R, S, dout, (long)n, I, NSS, C, dR, dS);
+  NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
@@ -648,6 +670,14 @@ int nq_gn_lincomb(const float* a, const float* b, float alpha, float beta, int64
   NQ_PROF(st, "gn_lincomb");
   if (n <= 0) return NQ_OK;
   hipLaunchKernelGGL(k_gn_lincomb, GN_GRID(n), a, b, alpha, beta, (long)n, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_gn_ssilu_backward(const float* z, const float* g, float scale, int64_t n, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "gn_ssilu_bwd");
+  if (n <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_gn_ssilu_bwd, GN_GRID(n), z, g, scale / 0.6f, (long)n, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -140,54 +140,113 @@ def build_graphs(pos, batch, z, cutoff, cutoff_qint, cutoff_aeaint, cutoff_aint,
 # ============================================================================================================================================
 # autograd wrappers of the C entry points (no CPU path)
 # ============================================================================================================================================
+GEMM_FLOPS = [None]      # bench hook: set GEMM_FLOPS[0] = 0.0 to accumulate 2*M*N*K of every dense product of the forward pass (backward = 2x that)
+
+
 def _new(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+_SSILU = 1.0 / 0.6       # ScaledSiLU (layers/base_layers.py:61-71)
+
+
+def _gemm_act(x, W, resid, alpha, beta):
+    """(pre, out): pre = x W^T, out = alpha * resid + beta * silu(pre) in the GEMM epilogue (one pass over the output tile)."""
+    M, K = x.shape
+    N = W.shape[0]
+    pre, out = _new(M, N, like=x), _new(M, N, like=x)
+    if M > 0:
+        _lib.check(_lib.load().nq_linear_forward_act(_lib.ptr(x), _lib.ptr(W), _lib.ptr(pre), _lib.ptr(out), None if resid is None else _lib.ptr(resid),
+                                                     float(alpha), float(beta), M, N, K, _st()))
+    if GEMM_FLOPS[0] is not None:
+        GEMM_FLOPS[0] += 2.0 * M * N * K
+    return pre, out
+
+
+def _ssilu_bwd(pre, g, scale):
+    out = torch.empty_like(g)
+    _lib.check(_lib.load().nq_gn_ssilu_backward(_lib.ptr(pre), _lib.ptr(g), float(scale), g.numel(), _lib.ptr(out), _st()))
+    return out
+
+
+def _dgrad(g, W, out=None, accumulate=False):
+    M, N = g.shape
+    K = W.shape[1]
+    if out is None:
+        out = _new(M, K, like=g)
+    if M > 0:
+        _lib.check(_lib.load().nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(out), M, N, K, int(accumulate), _st()))
+    return out
+
+
+def _wgrad(g, x):
+    lib = _lib.load()
+    M, N = g.shape
+    K = x.shape[1]
+    gW = _new(N, K, like=g)
+    scr = _new(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, like=g)
+    _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _st()))
+    return gW
+
+
 class _DenseFn(torch.autograd.Function):
-    """Dense without bias (layers/base_layers.py:11-58): y = act(x W^T), act = ScaledSiLU (silu / 0.6) or identity."""
+    """Dense without bias (layers/base_layers.py:11-58): y = act(x W^T), act = ScaledSiLU (silu / 0.6, fused into the GEMM epilogue) or identity."""
 
     @staticmethod
     def forward(ctx, x, W, act):
-        lib = _lib.load()
         x, W = _f32(x), _f32(W)
+        ctx.act = act
+        if act:
+            pre, y = _gemm_act(x, W, None, 0.0, _SSILU)
+            ctx.save_for_backward(x, W, pre)
+            return y
         M, K = x.shape
         N = W.shape[0]
         pre = _new(M, N, like=x)
         if M > 0:
-            _lib.check(lib.nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(pre), None, M, N, K, _st()))
-        ctx.act = act
-        if act:
-            y = torch.empty_like(pre)
-            _lib.check(lib.nq_scaled_silu(_lib.ptr(pre), None, _lib.ptr(y), pre.numel(), _st()))
-            ctx.save_for_backward(x, W, pre)
-            return y
+            _lib.check(_lib.load().nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(pre), None, M, N, K, _st()))
+        if GEMM_FLOPS[0] is not None:
+            GEMM_FLOPS[0] += 2.0 * M * N * K
         ctx.save_for_backward(x, W)
         return pre
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         g = _f32(g)
         if ctx.act:
             x, W, pre = ctx.saved_tensors
-            gp = torch.empty_like(g)
-            _lib.check(lib.nq_scaled_silu(_lib.ptr(pre), _lib.ptr(g), _lib.ptr(gp), g.numel(), _st()))
-            g = gp
+            g = _ssilu_bwd(pre, g, 1.0)
         else:
             x, W = ctx.saved_tensors
-        M, K = x.shape
-        N = W.shape[0]
-        gx = gW = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            if M > 0:
-                _lib.check(lib.nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(gx), M, N, K, 0, _st()))
-        if ctx.needs_input_grad[1]:
-            gW = torch.empty_like(W)
-            scr = _new(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, like=x)
-            _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _st()))
+        gx = _dgrad(g, W) if ctx.needs_input_grad[0] else None
+        gW = _wgrad(g, x) if ctx.needs_input_grad[1] else None
         return gx, gW, None
+
+
+class _ResidualFn(torch.autograd.Function):
+    """ResidualLayer (layers/base_layers.py:74-97) with two activated Dense layers: out = (x + ssilu(ssilu(x W1^T) W2^T)) / sqrt(2) -- two GEMM launches
+    forward (activation and residual in the epilogues), two elementwise + four GEMM launches backward."""
+
+    @staticmethod
+    def forward(ctx, x, W1, W2):
+        x, W1, W2 = _f32(x), _f32(W1), _f32(W2)
+        pre1, a1 = _gemm_act(x, W1, None, 0.0, _SSILU)
+        pre2, out = _gemm_act(a1, W2, x, _INV_SQRT2, _INV_SQRT2 * _SSILU)
+        ctx.save_for_backward(x, W1, W2, pre1, a1, pre2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W1, W2, pre1, a1, pre2 = ctx.saved_tensors
+        g = _f32(g)
+        gp2 = _ssilu_bwd(pre2, g, _INV_SQRT2)
+        gW2 = _wgrad(gp2, a1) if ctx.needs_input_grad[2] else None
+        gp1 = _ssilu_bwd(pre1, _dgrad(gp2, W2), 1.0)
+        gW1 = _wgrad(gp1, x) if ctx.needs_input_grad[1] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _dgrad(gp1, W1, out=_lin_raw(g, None, _INV_SQRT2, 0.0), accumulate=True)
+        return gx, gW1, gW2
 
 
 def _mul_raw(a, b):
@@ -521,6 +580,8 @@ class ResidualLayer(torch.nn.Module):
         self.dense_mlp = torch.nn.Sequential(*[Dense(units, units, activation=activation) for _ in range(nLayers)])
 
     def forward(self, x):
+        if len(self.dense_mlp) == 2 and self.dense_mlp[0]._act and self.dense_mlp[1]._act:
+            return _ResidualFn.apply(x, self.dense_mlp[0].linear.weight, self.dense_mlp[1].linear.weight)
         return lin(x, self.dense_mlp(x), _INV_SQRT2, _INV_SQRT2)
 
 

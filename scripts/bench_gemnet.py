@@ -1,0 +1,170 @@
+"""GemNet-OC (BASELINE.json configs[2]: config/model/gemnet-oc.yaml -- 4 blocks, atom 256 / edge 512, 128 radial / 7 spherical functions, 12 A cutoffs,
+neighbour caps 30 / 20 / 8, quadruplet + atom-edge + edge-atom + atom-atom interactions, direct coupled forces; AdamW(amsgrad, betas 0.9/0.95, lr 1e-3),
+loss = L1(E) + 100 * L2(F)) training-step timing on one MI355X in fp32: graphs -> forward -> loss -> backward -> AdamW, on synthetic drug-like
+conformers already resident in HBM.  ``run()`` is what ``bench.py --model gemnet`` calls.
+
+    python scripts/bench_gemnet.py [--molecules 16] [--steps 10] [--warmup 3] [--kernels] [--cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+COMMON = dict(num_targets=1, num_before_skip=2, num_after_skip=2, num_concat=1, num_atom=3, num_output_afteratom=3, num_global_out_layers=2,
+              regress_forces=True, direct_forces=True, use_pbc=False, scale_backprop_forces=False, enforce_max_neighbors_strictly=True,
+              rbf={"name": "gaussian"}, rbf_spherical=None, envelope={"name": "polynomial", "exponent": 5}, cbf={"name": "spherical_harmonics"},
+              sbf={"name": "legendre_outer"}, extensive=True, forces_coupled=True, output_init="HeOrthogonal", activation="silu", scale_file=None,
+              quad_interaction=True, atom_edge_interaction=True, edge_atom_interaction=True, atom_interaction=True, scale_basis=True)
+CFG = dict(COMMON, num_spherical=7, num_radial=128, num_blocks=4, emb_size_atom=256, emb_size_edge=512, emb_size_trip_in=64, emb_size_trip_out=64,
+           emb_size_quad_in=32, emb_size_quad_out=32, emb_size_aint_in=64, emb_size_aint_out=64, emb_size_rbf=16, emb_size_cbf=16, emb_size_sbf=32,
+           num_atom_emb_layers=0, cutoff=12.0, cutoff_qint=12.0, cutoff_aeaint=12.0, cutoff_aint=12.0, max_neighbors=30, max_neighbors_qint=8,
+           max_neighbors_aeaint=20, max_neighbors_aint=1000)            # config/model/gemnet-oc.yaml:5-60
+MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+class Batch:
+    pass
+
+
+def synthetic_batch(molecules, seed, device):
+    import torch
+    from nabladft_amd.synth import gen_conformers
+    pos, z, batch, y, f = gen_conformers(seed, molecules)
+    b = Batch()
+    b.pos, b.z, b.batch, b.y, b.forces = pos.to(device), z.to(device), batch.to(device), y.to(device), f.to(device)
+    cnt = torch.bincount(batch, minlength=molecules)
+    b.ptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)]).to(device)
+    return b
+
+
+def build(device, seed=23):
+    import torch
+    from nabladft_amd.gemnet_oc import GemNetOC
+    torch.manual_seed(seed)
+    return GemNetOC(**CFG).to(device)
+
+
+def loss_fn(E, F, b):
+    import torch
+    return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()          # config/model/gemnet-oc.yaml:78-85
+
+
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+    import torch
+    from nabladft_amd import _lib, gemnet_oc
+    from nabladft_amd import dist as nqdist
+    from nabladft_amd.trainer import FlatParameters
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    net = build(dev)
+    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    flat = FlatParameters(net.parameters())
+    opt = torch.optim.AdamW([flat.flat], lr=1e-3, betas=(0.9, 0.95), amsgrad=True, weight_decay=0)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        flat.zero_grad()
+        E, F = net(b)
+        loss = loss_fn(E, F, b)
+        loss.backward()
+        if world > 1:
+            nqdist.allreduce_mean_(flat.flat.grad)
+        opt.step()
+        return loss
+
+    sync = sync or torch.cuda.synchronize
+    if world > 1:
+        nqdist.broadcast_(flat.flat.data)
+    for i in range(warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    G = net.get_graphs_and_indices(batches[0])
+    out = {"workload": "GemNet-OC (config/model/gemnet-oc.yaml: 4 blocks, atom 256 / edge 512, 128 rbf, 7 spherical, 12 A cutoffs, caps 30/20/8, all four extra "
+                       "interactions, direct coupled forces) train step: graphs, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N,
+           "edges": {"a2a": G.Ea2a, "main": G.Em, "a2ee2a": G.Ea, "qint": G.Eq, "qint_x_main_rows": G.Tin}, "parameters": net.num_params, "_dt": dt,
+           "final_loss": float(loss.detach()), "dtype": "f32", "data": "synthetic",
+           "parity": "pinned to the reference GemNetOC classes run on CPU (tests/golden/gemnet_*.npz); torch_scatter / torch_sparse / torch_cluster restated"}
+    if kernels:
+        gemnet_oc.GEMM_FLOPS[0] = 0.0
+        step(0)
+        fwd_flops = gemnet_oc.GEMM_FLOPS[0]
+        gemnet_oc.GEMM_FLOPS[0] = None
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        tot = sum(v[0] for v in prof.values()) / steps
+        ks = sorted(((k, v[0] / steps, v[1] // steps) for k, v in prof.items()), key=lambda x: -x[1])
+        out["device_ms_per_step_nq_kernels"] = tot
+        out["kernel_ms_per_step"] = {k: [round(ms, 4), int(n)] for k, ms, n in ks[:24]}
+        gemm_ms = sum(ms for k, ms, _ in ks if k.startswith("gemm"))
+        fl = 3.0 * fwd_flops                                                # forward + input gradient + weight gradient of every Dense (batch 0's sizes)
+        ach = fl / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_gemm (Dense layers, fp32 MFMA)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "gemm_ms_per_step": gemm_ms, "flops_per_step": fl}
+    return out
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """oracle/gemnet_ref.py (torch CPU, fp32; pinned to the reference classes' golden vectors) forward + loss + backward on ONE synthetic conformer."""
+    import torch
+    from nabladft_amd.gemnet_oc import GemNetOC
+    from nabladft_amd.synth import gen_conformers
+    from oracle import gemnet_ref as R
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pos, z, batch, y, f = gen_conformers(101, 1)
+    torch.manual_seed(23)
+    net = GemNetOC(**CFG)
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, _ in net.named_parameters():
+        if not k.endswith("scale_factor"):
+            P[k].requires_grad_(True)
+    for i in range(CFG["num_blocks"] + 1):                              # state_dict aliases of the shared modules must be the same tensors
+        for k in list(P):
+            if k.startswith(f"out_blocks.{i}.seq_energy_pre."):
+                P[k] = P[k.replace(".seq_energy_pre.", ".layers.")]
+    del net
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        E, F = R.forward(P, CFG, pos, z, [pos.shape[0]])
+        R.loss(E, F, y, f).backward()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 3:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"1 synthetic conformer ({pos.shape[0]} atoms), GemNet-OC yaml configuration, forward + loss + backward of oracle/gemnet_ref.py (index lists "
+                      f"built by Python loops, as part of the step), mean of {n} steps, torch {torch.__version__} CPU fp32, no optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--molecules", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kernels", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    out = run(a.molecules, a.steps, a.warmup, a.kernels)
+    if a.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
