@@ -384,10 +384,12 @@ int nq_gn_triplet_forward(const void* out_set, const void* in_set, const float* 
 int nq_gn_triplet_backward(const void* out_set, const void* in_set, const float* dS, int32_t C, int32_t NS, float scale, float* dx, void* stream);
 /* Quadruplets (interaction_indices.py:121-282, angles gemnet_oc.py:597-655, "legendre_outer" basis spherical_basis.py:104-110): x rows are indexed
  * tin_ptr[q] + j (j-th main in-edge of source(q)); S[o][l * NS + l'][c].  backward scratch: f32[main edges * KQ * NS * C], KQ >= largest qint in-degree. */
-int nq_gn_quad_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, const float* x, int32_t C, int32_t NS, float scale, float* S,
-                       void* stream);
-int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int64_t T, const float* dS, int32_t C, int32_t NS, int32_t KQ,
-                        float scale, float* scratch, float* dx, void* stream);
+int nq_gn_quad_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int32_t n_atoms, const float* x, int32_t C, int32_t NS, float scale,
+                       float* S, void* stream);
+int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int32_t n_atoms, int64_t T, const float* dS, int32_t C, int32_t NS,
+                        int32_t KQ, float scale, float* scratch, float* dx, void* stream);
+/* Tuning hook (process-global): 1 = one workgroup per centre atom with LDS-shared bases (default), 0 = one thread per (edge, channel). */
+void nq_gn_set_quad_variant(int32_t variant);
 /* BasisEmbedding without inner index (layers/efficient.py:136-141): cir[(q, j)][i] = sum_s rad_w1[q][i * NS + s] Y_s0(v_q . v_p) * scale. */
 int nq_gn_cir_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int64_t T, const float* rad_w1, int32_t I, int32_t NS, float scale,
                       float* cir, void* stream);
@@ -454,8 +456,21 @@ int nq_linear_forward(const float* A, const float* W, const float* bias, float* 
 /* C[M,N] = A W^T and C_act = alpha * resid (nullable) + beta * silu(C): Dense + ScaledSiLU (+ residual) of gemnet_oc/layers/base_layers.py:11-97 in one pass. */
 int nq_linear_forward_act(const float* A, const float* W, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
                           int32_t K, void* stream);
+/* bf16 MFMA variants (fp32 operands in HBM rounded to bf16 on the way into LDS, fp32 accumulation; BASELINE.json configs[2] names bf16 for GemNet-OC):
+ * nq_bf16_pack: W [N][K] fp32 -> Wb [N][K], WbT [K][N] (bf16, round to nearest even).  nq_linear_forward_bf16: as nq_linear_forward_act with W = Wb (C_act
+ * nullable -> plain store); K % 32 == 0.  nq_linear_input_grad_bf16: C[M,K] (+)= G[M,N] W[N,K] with W given as WbT; N % 32 == 0. */
+int nq_bf16_pack(const float* W, int32_t N, int32_t K, void* Wb, void* WbT, void* stream);
+int nq_linear_forward_bf16(const float* A, const void* Wb, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
+                           int32_t K, void* stream);
+int nq_linear_input_grad_bf16(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
 /* C[M,K] (+)= G[M,N] W[N,K] */
 int nq_linear_input_grad(const float* G, const float* W, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* Input gradient with a fused epilogue on C[M,K] = G W: mode 1: C = beta * (G W) * silu'(aux) (adjoint of the activation below), mode 2: C = alpha * aux + G W
+ * (skip connection of the adjoint); aux [M,K].  _bf16_epi: the same on the bf16 MFMA kernel (W given as WbT, N % 32 == 0). */
+int nq_linear_input_grad_epi(const float* G, const float* W, float* C, int32_t M, int32_t N, int32_t K, const float* aux, float alpha, float beta, int32_t mode,
+                             void* stream);
+int nq_linear_input_grad_bf16_epi(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, const float* aux, float alpha, float beta,
+                                  int32_t mode, void* stream);
 /* gW[N,K] = G[rows,N]^T X[rows,K]; scratch: f32[nq_weight_grad_scratch_floats(rows,N,K)] */
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);

@@ -115,8 +115,9 @@ SYMBOLS = {
     "nq_gn_radial_basis": (C.c_int, [_P, _I64, _I32, _P, _D, _D, _F, _P, _P]),
     "nq_gn_triplet_forward": (C.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P]),
     "nq_gn_triplet_backward": (C.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P]),
-    "nq_gn_quad_forward": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P]),
-    "nq_gn_quad_backward": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "nq_gn_quad_forward": (C.c_int, [_P, _P, _P, _I32, _P, _I32, _I32, _F, _P, _P]),
+    "nq_gn_quad_backward": (C.c_int, [_P, _P, _P, _I32, _I64, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "nq_gn_set_quad_variant": (None, [_I32]),
     "nq_gn_tin_scatter": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
     "nq_gn_cir_forward": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _F, _P, _P]),
     "nq_gn_cir_backward": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P, _P]),
@@ -136,6 +137,11 @@ SYMBOLS = {
     "nq_gn_lincomb": (C.c_int, [_P, _P, _F, _F, _I64, _P, _P]),
     "nq_gn_ssilu_backward": (C.c_int, [_P, _P, _F, _I64, _P, _P]),
     "nq_linear_forward_act": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _I32, _I32, _I32, _P]),
+    "nq_bf16_pack": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
+    "nq_linear_forward_bf16": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _I32, _I32, _I32, _P]),
+    "nq_linear_input_grad_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "nq_linear_input_grad_epi": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _F, _F, _I32, _P]),
+    "nq_linear_input_grad_bf16_epi": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _F, _F, _I32, _P]),
     "nq_gn_embed_grad": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),

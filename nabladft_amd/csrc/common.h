@@ -61,6 +61,14 @@ __device__ __forceinline__ float nq_d2silu(float z) {
   return ds * (2.0f + z * (1.0f - 2.0f * s));
 }
 
+// Hardware-rate forms for GEMM epilogues (v_exp_f32 + v_rcp_f32, ~1 ulp each: 2e-7 relative, inside every parity budget of the paths that use them)
+__device__ __forceinline__ float nq_sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float nq_silu_fast(float z) { return z * nq_sigmoid_fast(z); }
+__device__ __forceinline__ float nq_dsilu_fast(float z) {
+  const float s = nq_sigmoid_fast(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+
 // Sum over the 64 lanes of the wavefront, result broadcast to every lane.  DPP only (no LDS round trips):
 // an inclusive scan inside each 16-lane row (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals
 // upwards, so lane 63 holds the full sum; v_readlane broadcasts it as a scalar.  Fixed order -> deterministic.
@@ -167,6 +175,7 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
                         int* row_ptr, int* lowptr, int* E_host, hipStream_t st);
 int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st);
 
+int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode);
 int nq_gemm_nt_act(hipStream_t, const float* A, const float* W, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
                    const char* tag = nullptr);
 int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K, int lda,

@@ -667,6 +667,11 @@ int nq_linear_forward_act(const float* A, const float* Wt, float* C, float* C_ac
 int nq_linear_input_grad(const float* G, const float* Wt, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
   return nq_gemm_nn((hipStream_t)stream, G, Wt, C, M, N, K, N, K, K, accumulate);
 }
+int nq_linear_input_grad_epi(const float* G, const float* Wt, float* C, int32_t M, int32_t N, int32_t K, const float* aux, float alpha, float beta, int32_t mode,
+                             void* stream) {
+  if (!G || !Wt || !C || !aux || (mode != 1 && mode != 2)) return nq_fail(NQ_ERR_ARG, "bad argument");
+  return nq_gemm_nn_epi((hipStream_t)stream, G, Wt, C, M, N, K, aux, alpha, beta, mode);
+}
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K) { return nq_gemm_tn_scratch_floats(rows, N, K); }
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream) {
   return nq_gemm_tn((hipStream_t)stream, G, X, gW, rows, N, K, N, K, scratch);

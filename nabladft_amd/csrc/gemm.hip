@@ -28,7 +28,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4 };   // 4: C = v, C2 = ea * resid + eb * silu(v)
+enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4, EPI_DSILU = 5, EPI_RES = 6 };   // 4: C = v, C2 = ea * resid + eb * silu(v)
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias; float* C2;
@@ -216,12 +216,14 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
         const long off = (RM == 1 ? rm_row(row, mw, mn, mb) : (long)row) * p.ldc + col;
         const float v = acc[i][j][r] + bv;
         if (EPI == EPI_ACC) Cout[off] += v;
+        else if (EPI == EPI_DSILU) Cout[off] = p.eb * v * nq_dsilu_fast(p.resid[off]);       // 5: C = eb * v * silu'(aux)   (adjoint of the activation of the layer below)
+        else if (EPI == EPI_RES) Cout[off] = p.ea * p.resid[off] + v;                 // 6: C = ea * aux + v          (skip connection of the adjoint)
 #ifdef NQ_GEMM_NT_STORE
         else if (EPI == EPI_STORE) __builtin_nontemporal_store(v, &Cout[off]);
 #endif
         else Cout[off] = v;
         if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
-        if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu(v) : p.eb * nq_silu(v);
+        if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);
       }
     }
 }
@@ -309,9 +311,12 @@ __global__ __launch_bounds__(256) void k_gemm_small(GemmArgs p) {
     if (row >= p.M) continue;
     const long off = (long)row * p.ldc + col;
     const float v = acc[r] + bv;
-    if (EPI == EPI_ACC) p.C[off] += v; else p.C[off] = v;
+    if (EPI == EPI_ACC) p.C[off] += v;
+    else if (EPI == EPI_DSILU) p.C[off] = p.eb * v * nq_dsilu_fast(p.resid[off]);
+    else if (EPI == EPI_RES) p.C[off] = p.ea * p.resid[off] + v;
+    else p.C[off] = v;
     if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
-    if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu(v) : p.eb * nq_silu(v);
+    if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);
   }
 }
 // fewer than one 128x128 tile per CU -> the small-tile kernel
@@ -431,6 +436,26 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
   if (accumulate) launch_gemm<true, false, EPI_ACC, 16>(st, grid, p);
   else launch_gemm<true, false, EPI_STORE, 16>(st, grid, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// C[M, Kin] = epilogue(G[M, Nout] * W[Nout, Kin]): mode 1: eb * v * silu'(aux), mode 2: ea * aux + v   (aux [M, Kin])
+int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:[n=%d,k=%d]", Kin, Nout); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
+  p.resid = aux; p.ea = ea; p.eb = eb;
+  if (gemm_is_small(M, Kin) && !(g_gemm_variant & 8)) {
+    dim3 gs(nq_cdiv(M, SM), nq_cdiv(Kin, SM), 1);
+    if (mode == 1) hipLaunchKernelGGL((k_gemm_small<false, EPI_DSILU>), gs, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_small<false, EPI_RES>), gs, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1);
+    if (mode == 1) launch_gemm<true, false, EPI_DSILU, 16>(st, grid, p);
+    else launch_gemm<true, false, EPI_RES, 16>(st, grid, p);
+  }
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -1,0 +1,173 @@
+// bf16 MFMA GEMM for the GemNet-OC Dense layers (BASELINE.json configs[2]: "bf16 with fp32 scatter-accumulate").
+//   C[M, N] = A[M, K] (fp32 in HBM, rounded to bf16 while it is staged into LDS) x B[N, K]^T (bf16, packed once per optimizer step), fp32 accumulation
+// on v_mfma_f32_32x32x16_bf16 (16x the issue rate of the exact-f32 MFMA the rest of the engine uses).  One kernel serves the forward product (B = W) and the
+// input gradient (B = W^T, packed next to W); the weight gradient stays on the fp32 split-K kernel (its contraction runs over the rows of both operands).
+// 128x128x32 tiles, 4 wavefronts (2x2, each 64x64 = 2x2 MFMA tiles), register prefetch of the next k-tile under the MFMAs, two LDS buffers, one barrier
+// per k-tile.  LDS rows are K-contiguous with a 16-byte pad (80-byte stride): every lane fetches its 8 consecutive k of one row with a single ds_read_b128.
+// Epilogues as in gemm.hip: store / accumulate / ScaledSiLU + residual (gemnet_oc/layers/base_layers.py:11-97).
+#include "common.h"
+
+typedef __bf16 hb8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hb4 __attribute__((ext_vector_type(4)));
+typedef float hf16 __attribute__((ext_vector_type(16)));
+
+#define HB_BM 128
+#define HB_BN 128
+#define HB_BK 32
+#define HB_LD (HB_BK + 8)
+
+struct HbArgs {
+  const float* A; const __bf16* B; float* C; float* C2; const float* resid;
+  float ea, eb;
+  int M, N, K, lda, ldb, ldc;
+};
+enum { HB_STORE = 0, HB_ACC = 1, HB_SILU_RES = 2, HB_DSILU = 3, HB_RES = 4 };
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_bf16_nt(HbArgs p) {
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][HB_BM * HB_LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[2][HB_BN * HB_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * HB_BM, n0 = blockIdx.y * HB_BN;
+  hf16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 ra[4];
+  uint4 rb[2];
+  const int ar = t >> 3, ak = (t & 7) * 4;      // A: 8 threads x float4 per row of 32 k
+  const int br = t >> 2, bk = (t & 3) * 8;      // B: 4 threads x 8 bf16 per row
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + ar + 32 * i;
+      ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + k0 + ak) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = n0 + br + 64 * i;
+      rb[i] = row < p.N ? *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + k0 + bk) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hb4 v;
+      v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+      *reinterpret_cast<hb4*>(&sA[buf][(ar + 32 * i) * HB_LD + ak]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(&sB[buf][(br + 64 * i) * HB_LD + bk]) = rb[i];
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int k0 = 0; k0 < p.K; k0 += HB_BK) {
+    const bool more = k0 + HB_BK < p.K;
+    if (more) fetch(k0 + HB_BK);
+#pragma unroll
+    for (int kk = 0; kk < HB_BK; kk += 16) {
+      hb8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const hb8*>(&sA[buf][(wm * 64 + i * 32 + lr) * HB_LD + kk + 8 * lk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const hb8*>(&sB[buf][(wn * 64 + j * 32 + lr) * HB_LD + kk + 8 * lk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lr;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= p.M) continue;
+        const long off = (long)row * p.ldc + col;
+        const float v = acc[i][j][r];
+        if (EPI == HB_ACC) p.C[off] += v;
+        else if (EPI == HB_DSILU) p.C[off] = p.eb * v * nq_dsilu_fast(p.resid[off]);
+        else if (EPI == HB_RES) p.C[off] = p.ea * p.resid[off] + v;
+        else p.C[off] = v;
+        if (EPI == HB_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);
+      }
+    }
+}
+
+// W [N][K] fp32 -> Wb [N][K] and WbT [K][N] in bf16 (round to nearest even)
+__global__ void k_bf16_pack(const float* __restrict__ W, int N, int K, __bf16* __restrict__ Wb, __bf16* __restrict__ WbT) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    const float v = (n < N && k < K) ? W[(long)n * K + k] : 0.f;
+    tile[r][tx] = v;
+    if (n < N && k < K) Wb[(long)n * K + k] = (__bf16)v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    if (n < N && k < K) WbT[(long)k * N + n] = (__bf16)tile[tx][r];
+  }
+}
+
+static int hb_launch(hipStream_t st, const float* A, const void* B, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
+                     int accumulate, const char* kind, int mode = 0) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_bf16_%s:[n=%d,k=%d]", kind, N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (M <= 0) return NQ_OK;
+  if (K % HB_BK != 0 || N <= 0) return nq_fail(NQ_ERR_ARG, "bf16 gemm: K = %d must be a multiple of %d", K, HB_BK);
+  HbArgs p{A, (const __bf16*)B, C, C2, resid, ea, eb, M, N, K, K, K, N};
+  dim3 grid(nq_cdiv(M, HB_BM), nq_cdiv(N, HB_BN), 1);
+  if (mode == 1) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_DSILU>), grid, dim3(256), 0, st, p);
+  else if (mode == 2) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_RES>), grid, dim3(256), 0, st, p);
+  else if (C2) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_SILU_RES>), grid, dim3(256), 0, st, p);
+  else if (accumulate) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_ACC>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_bf16_nt<HB_STORE>), grid, dim3(256), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+extern "C" {
+
+int nq_bf16_pack(const float* W, int32_t N, int32_t K, void* Wb, void* WbT, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bf16_pack");
+  if (!W || !Wb || !WbT || N <= 0 || K <= 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(k_bf16_pack, dim3(nq_cdiv(K, 32), nq_cdiv(N, 32)), dim3(256), 0, st, W, N, K, (__bf16*)Wb, (__bf16*)WbT);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+int nq_linear_forward_bf16(const float* A, const void* Wb, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
+                           int32_t K, void* stream) {
+  if (!A || !Wb || !C) return nq_fail(NQ_ERR_ARG, "null argument");
+  return hb_launch((hipStream_t)stream, A, Wb, C, C_act, resid, alpha, beta, M, N, K, 0, "nt");
+}
+
+int nq_linear_input_grad_bf16(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
+  if (!G || !WbT || !C) return nq_fail(NQ_ERR_ARG, "null argument");
+  return hb_launch((hipStream_t)stream, G, WbT, C, nullptr, nullptr, 0.f, 0.f, M, K, N, accumulate, "nn");
+}
+
+int nq_linear_input_grad_bf16_epi(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, const float* aux, float alpha, float beta,
+                                  int32_t mode, void* stream) {
+  if (!G || !WbT || !C || !aux || (mode != 1 && mode != 2)) return nq_fail(NQ_ERR_ARG, "bad argument");
+  return hb_launch((hipStream_t)stream, G, WbT, C, nullptr, aux, alpha, beta, M, K, N, 0, "nn", mode);
+}
+
+}  // extern "C"

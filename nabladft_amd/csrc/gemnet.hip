@@ -100,7 +100,7 @@ __device__ __forceinline__ float gn_cos_dihedral(float4 crossA, float4 vdb, floa
   const float x = gn_dot(crossA, crossD);
   const float4 cc = gn_cross(crossA, crossD);
   const float y = fmaxf(sqrtf(gn_dot(cc, cc)), 1e-9f);
-  return cosf(atan2f(y, x));
+  return x * rsqrtf(x * x + y * y);                 // = cos(atan2(y, x)) (gemnet_oc.py:650 + spherical_basis.py:107: torch.cos of the atan2 angle)
 }
 __global__ void k_gn_quad_fwd(GnSet M, GnSet Q, const int* __restrict__ tin_ptr, const float* __restrict__ X, int C, int NS, float scale,
                               float* __restrict__ S) {
@@ -142,6 +142,131 @@ __global__ void k_gn_quad_fwd(GnSet M, GnSet Q, const int* __restrict__ tin_ptr,
   for (int l = 0; l < NS; ++l)
     for (int k = 0; k < NS; ++k) S[((long)o * NS * NS + l * NS + k) * C + ch] = acc[l][k];
 }
+// Per-atom form of the two kernels above/below (the ones launched): one workgroup per centre atom a.  All out edges of a share the qint row of a and the main
+// rows of its sources, so the feature rows (q, .) are staged once in LDS, the 7-vector Y_l'(dihedral) of every (o, q, p) is evaluated ONCE by one thread
+// (the per-(edge, channel) kernels evaluate it in every channel lane: ~100 instructions per inner iteration) and the inner loop becomes 8 LDS reads + 7 FMAs.
+#define GQ_PC 64      // main in-edges per staged chunk
+#define GQ_OC 8       // out edges per pass
+__global__ __launch_bounds__(256) void k_gn_quad_fwd_atom(GnSet M, GnSet Q, const int* __restrict__ tin_ptr, const float* __restrict__ X, int C, int NS, float scale,
+                                                            float* __restrict__ S) {
+  __shared__ float sX[GQ_PC * 64];
+  __shared__ float sY[GQ_OC * GQ_PC * GN_MAXNS];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int ob = M.ptr[a], on = M.ptr[a + 1] - ob, qb = Q.ptr[a], qe = Q.ptr[a + 1];
+  const int OC = min(GQ_OC, 256 / C);
+  const int ol = tid / C, ch = tid - ol * C;
+  const bool active = ol < OC;
+  for (int o0 = 0; o0 < on; o0 += OC) {
+    const int o = ob + o0 + ol;
+    const bool ovalid = active && (o0 + ol) < on;
+    const int c = ovalid ? M.src[o] : -1;
+    const float4 vca = ovalid ? M.geom[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[GN_MAXNS][GN_MAXNS];
+#pragma unroll
+    for (int l = 0; l < GN_MAXNS; ++l)
+#pragma unroll
+      for (int k = 0; k < GN_MAXNS; ++k) acc[l][k] = 0.f;
+    for (int q = qb; q < qe; ++q) {
+      const int b = Q.src[q];
+      const float4 vba = Q.geom[q];
+      const int pb = M.ptr[b], pn = M.ptr[b + 1] - pb;
+      const long base = tin_ptr[q];
+      float tl[GN_MAXNS];
+#pragma unroll
+      for (int k = 0; k < GN_MAXNS; ++k) tl[k] = 0.f;
+      for (int p0 = 0; p0 < pn; p0 += GQ_PC) {
+        const int np = min(GQ_PC, pn - p0);
+        for (int e = tid; e < np * C; e += 256) sX[e] = X[(base + p0) * C + e];
+        for (int e = tid; e < OC * np; e += 256) {
+          const int oi = e / np, pj = e - oi * np;
+          float Yk[GN_MAXNS];
+#pragma unroll
+          for (int k = 0; k < GN_MAXNS; ++k) Yk[k] = 0.f;
+          if (o0 + oi < on) {
+            const int oo = ob + o0 + oi, cc = M.src[oo], p = pb + p0 + pj, d = M.src[p];
+            if (cc != b && d != a && d != cc) gn_zonal(gn_cos_dihedral(gn_cross(M.geom[oo], vba), M.geom[p], vba), NS, 1.f, Yk);
+          }
+#pragma unroll
+          for (int k = 0; k < GN_MAXNS; ++k) sY[(oi * GQ_PC + pj) * GN_MAXNS + k] = Yk[k];
+        }
+        __syncthreads();
+        if (ovalid) {
+          for (int pj = 0; pj < np; ++pj) {
+            const float x = sX[pj * C + ch];
+            const float* y = &sY[(ol * GQ_PC + pj) * GN_MAXNS];
+#pragma unroll
+            for (int k = 0; k < GN_MAXNS; ++k) tl[k] += y[k] * x;
+          }
+        }
+        __syncthreads();
+      }
+      if (ovalid && b != c) {
+        float Yl[GN_MAXNS];
+        gn_zonal(gn_clamp1(gn_dot(vca, vba)), NS, scale, Yl);
+#pragma unroll
+        for (int l = 0; l < GN_MAXNS; ++l)
+#pragma unroll
+          for (int k = 0; k < GN_MAXNS; ++k) acc[l][k] += Yl[l] * tl[k];
+      }
+    }
+    if (ovalid)
+      for (int l = 0; l < NS; ++l)
+        for (int k = 0; k < NS; ++k) S[((long)o * NS * NS + l * NS + k) * C + ch] = acc[l][k];
+  }
+}
+// dX[(q, j)][c] for all qint in-edges q of atom a: U rows of a's out edges staged in chunks of GQ_UC, Y_l'(dihedral) evaluated once per (p, o)
+#define GQ_UC 16
+__global__ __launch_bounds__(256) void k_gn_quad_bwd_x_atom(GnSet M, GnSet Q, const int* __restrict__ tin_ptr, const float* __restrict__ U, int C, int NS, int KQ,
+                                                              float* __restrict__ dX) {
+  __shared__ float sU[GQ_UC * GN_MAXNS * 64];
+  __shared__ float sY[GQ_OC * GQ_UC * GN_MAXNS];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const int ob = M.ptr[a], on = M.ptr[a + 1] - ob, qb = Q.ptr[a], qe = Q.ptr[a + 1];
+  const int PC = min(GQ_OC, 256 / C);
+  const int pl = tid / C, ch = tid - pl * C;
+  const bool active = pl < PC;
+  for (int q = qb; q < qe; ++q) {
+    const int b = Q.src[q], jq = q - qb;
+    const float4 vba = Q.geom[q];
+    const int pb = M.ptr[b], pn = M.ptr[b + 1] - pb;
+    const long base = tin_ptr[q];
+    for (int p0 = 0; p0 < pn; p0 += PC) {
+      const bool pvalid = active && (p0 + pl) < pn;
+      float acc = 0.f;
+      for (int o0 = 0; o0 < on; o0 += GQ_UC) {
+        const int no = min(GQ_UC, on - o0);
+        for (int e = tid; e < no * NS * C; e += 256) {
+          const int oi = e / (NS * C), r = e - oi * NS * C;
+          sU[oi * GN_MAXNS * C + r] = U[((long)(ob + o0 + oi) * KQ + jq) * NS * C + r];
+        }
+        for (int e = tid; e < PC * no; e += 256) {
+          const int pi = e / no, oi = e - pi * no;
+          float Yk[GN_MAXNS];
+#pragma unroll
+          for (int k = 0; k < GN_MAXNS; ++k) Yk[k] = 0.f;
+          if (p0 + pi < pn) {
+            const int p = pb + p0 + pi, d = M.src[p], oo = ob + o0 + oi, cc = M.src[oo];
+            if (d != a && cc != b && cc != d) gn_zonal(gn_cos_dihedral(gn_cross(M.geom[oo], vba), M.geom[p], vba), NS, 1.f, Yk);
+          }
+#pragma unroll
+          for (int k = 0; k < GN_MAXNS; ++k) sY[(pi * GQ_UC + oi) * GN_MAXNS + k] = Yk[k];
+        }
+        __syncthreads();
+        if (pvalid) {
+          for (int oi = 0; oi < no; ++oi) {
+            const float* y = &sY[(pl * GQ_UC + oi) * GN_MAXNS];
+            const float* u = &sU[oi * GN_MAXNS * C + ch];
+#pragma unroll
+            for (int k = 0; k < GN_MAXNS; ++k) if (k < NS) acc += y[k] * u[k * C];
+          }
+        }
+        __syncthreads();
+      }
+      if (pvalid) dX[(base + p0 + pl) * C + ch] = acc;
+    }
+  }
+}
+
 // adjoint, step 1: U[o][jq][l'][c] = sum_l Y_l(cos cab(o, q)) dS[o][l][l'][c]  for the jq-th qint in-edge q of target(o) (KQ = maximum qint in-degree)
 __global__ void k_gn_quad_bwd_u(GnSet M, GnSet Q, const float* __restrict__ dS, int C, int NS, int KQ, float scale, float* __restrict__ U) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -487,20 +612,27 @@ int nq_gn_triplet_backward(const void* out_set, const void* in_set, const float*
   return NQ_OK;
 }
 
-int nq_gn_quad_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, const float* x, int32_t C, int32_t NS, float scale, float* S,
-                       void* stream) {
+static int g_gn_quad_variant = 1;
+extern "C" void nq_gn_set_quad_variant(int32_t v) { g_gn_quad_variant = v; }
+
+int nq_gn_quad_forward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int32_t n_atoms, const float* x, int32_t C, int32_t NS, float scale,
+                       float* S, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "gn_quad_fwd");
   GN_CHECK_NS(NS);
   const GnSet M = gn_view((const nq_gn_set_c*)main_set), Q = gn_view((const nq_gn_set_c*)qint_set);
   if (M.n <= 0) return NQ_OK;
-  hipLaunchKernelGGL(k_gn_quad_fwd, GN_GRID((long)M.n * C), M, Q, tin_ptr, x, C, NS, scale, S);
+  if (C <= 64 && g_gn_quad_variant == 1) {
+    hipLaunchKernelGGL(k_gn_quad_fwd_atom, dim3(n_atoms), dim3(256), 0, st, M, Q, tin_ptr, x, C, NS, scale, S);
+  } else {
+    hipLaunchKernelGGL(k_gn_quad_fwd, GN_GRID((long)M.n * C), M, Q, tin_ptr, x, C, NS, scale, S);
+  }
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 /* scratch: f32[main edges * KQ * NS * C] */
-int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int64_t T, const float* dS, int32_t C, int32_t NS, int32_t KQ,
-                        float scale, float* scratch, float* dx, void* stream) {
+int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_t* tin_ptr, int32_t n_atoms, int64_t T, const float* dS, int32_t C, int32_t NS,
+                        int32_t KQ, float scale, float* scratch, float* dx, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "gn_quad_bwd");
   GN_CHECK_NS(NS);
@@ -508,7 +640,8 @@ int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_
   if (M.n <= 0 || T <= 0 || KQ <= 0) return NQ_OK;
   hipLaunchKernelGGL(k_gn_quad_bwd_u, GN_GRID((long)M.n * KQ * C), M, Q, dS, C, NS, KQ, scale, scratch);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gn_quad_bwd_x, GN_GRID(T * C), M, Q, tin_ptr, scratch, C, NS, KQ, dx);
+  if (C <= 64 && g_gn_quad_variant == 1) hipLaunchKernelGGL(k_gn_quad_bwd_x_atom, dim3(n_atoms), dim3(256), 0, st, M, Q, tin_ptr, scratch, C, NS, KQ, dx);
+  else hipLaunchKernelGGL(k_gn_quad_bwd_x, GN_GRID(T * C), M, Q, tin_ptr, scratch, C, NS, KQ, dx);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -148,6 +148,36 @@ def _new(*shape, like):
 
 
 _SSILU = 1.0 / 0.6       # ScaledSiLU (layers/base_layers.py:61-71)
+_PRECISION = ["f32"]
+_PACKED = {}
+
+
+def set_gemm_precision(mode: str) -> None:
+    """"f32" (default: exact-f32 MFMA, the parity-tested path) or "bf16": the forward and input-gradient products of the Dense layers run on bf16 MFMA with
+    fp32 accumulation (operands rounded to bf16, weights packed once per parameter version); weight gradients, all sums over edges / triplets /
+    quadruplets and the optimizer stay fp32 -- the mode BASELINE.json names for config/model/gemnet-oc.yaml."""
+    if mode not in ("f32", "bf16"):
+        raise ValueError(mode)
+    _PRECISION[0] = mode
+    _PACKED.clear()
+
+
+def _packed(W):
+    """(Wb [N, K], WbT [K, N]) bf16 copies of a weight, refreshed when the parameter (or the flat buffer it lives in) was modified in place."""
+    key = (W.data_ptr(), tuple(W.shape))
+    ent = _PACKED.get(key)
+    if ent is None or ent[0] != W._version:
+        N, K = W.shape
+        Wb = torch.empty(N, K, device=W.device, dtype=torch.bfloat16)
+        WbT = torch.empty(K, N, device=W.device, dtype=torch.bfloat16)
+        _lib.check(_lib.load().nq_bf16_pack(_lib.ptr(W), N, K, _lib.ptr(Wb), _lib.ptr(WbT), _st()))
+        ent = (W._version, Wb, WbT)
+        _PACKED[key] = ent
+    return ent[1], ent[2]
+
+
+def _use_bf16(M, contract):
+    return _PRECISION[0] == "bf16" and contract % 32 == 0 and M >= 256
 
 
 def _gemm_act(x, W, resid, alpha, beta):
@@ -155,7 +185,10 @@ def _gemm_act(x, W, resid, alpha, beta):
     M, K = x.shape
     N = W.shape[0]
     pre, out = _new(M, N, like=x), _new(M, N, like=x)
-    if M > 0:
+    if M > 0 and _use_bf16(M, K):
+        _lib.check(_lib.load().nq_linear_forward_bf16(_lib.ptr(x), _lib.ptr(_packed(W)[0]), _lib.ptr(pre), _lib.ptr(out), None if resid is None else _lib.ptr(resid),
+                                                      float(alpha), float(beta), M, N, K, _st()))
+    elif M > 0:
         _lib.check(_lib.load().nq_linear_forward_act(_lib.ptr(x), _lib.ptr(W), _lib.ptr(pre), _lib.ptr(out), None if resid is None else _lib.ptr(resid),
                                                      float(alpha), float(beta), M, N, K, _st()))
     if GEMM_FLOPS[0] is not None:
@@ -174,8 +207,25 @@ def _dgrad(g, W, out=None, accumulate=False):
     K = W.shape[1]
     if out is None:
         out = _new(M, K, like=g)
-    if M > 0:
+    if M > 0 and _use_bf16(M, N):
+        _lib.check(_lib.load().nq_linear_input_grad_bf16(_lib.ptr(g), _lib.ptr(_packed(W)[1]), _lib.ptr(out), M, N, K, int(accumulate), _st()))
+    elif M > 0:
         _lib.check(_lib.load().nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(out), M, N, K, int(accumulate), _st()))
+    return out
+
+
+def _dgrad_epi(g, W, aux, alpha, beta, mode):
+    """mode 1: beta * (g W) * silu'(aux); mode 2: alpha * aux + g W -- in the GEMM epilogue."""
+    M, N = g.shape
+    K = W.shape[1]
+    if M > 0 and _use_bf16(M, N):
+        # measured: on the short bf16 kernel the 64 scattered aux loads per lane of the fused epilogue cost more (73 us vs 37 us per 20 k x 512 x 512 product)
+        # than the separate streaming pass they replace -- keep the passes separate there
+        raw = _dgrad(g, W)
+        return _ssilu_bwd(aux, raw, beta / _SSILU) if mode == 1 else _lin_raw(aux, raw, alpha, 1.0)
+    out = _new(M, K, like=g)
+    if M > 0:
+        _lib.check(_lib.load().nq_linear_input_grad_epi(_lib.ptr(g), _lib.ptr(W), _lib.ptr(out), M, N, K, _lib.ptr(aux), float(alpha), float(beta), mode, _st()))
     return out
 
 
@@ -203,7 +253,9 @@ class _DenseFn(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         pre = _new(M, N, like=x)
-        if M > 0:
+        if M > 0 and _use_bf16(M, K):
+            _lib.check(_lib.load().nq_linear_forward_bf16(_lib.ptr(x), _lib.ptr(_packed(W)[0]), _lib.ptr(pre), None, None, 0.0, 0.0, M, N, K, _st()))
+        elif M > 0:
             _lib.check(_lib.load().nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(pre), None, M, N, K, _st()))
         if GEMM_FLOPS[0] is not None:
             GEMM_FLOPS[0] += 2.0 * M * N * K
@@ -241,11 +293,9 @@ class _ResidualFn(torch.autograd.Function):
         g = _f32(g)
         gp2 = _ssilu_bwd(pre2, g, _INV_SQRT2)
         gW2 = _wgrad(gp2, a1) if ctx.needs_input_grad[2] else None
-        gp1 = _ssilu_bwd(pre1, _dgrad(gp2, W2), 1.0)
+        gp1 = _dgrad_epi(gp2, W2, pre1, 0.0, _SSILU, 1)                      # (gp2 W2) * d ssilu(pre1)
         gW1 = _wgrad(gp1, x) if ctx.needs_input_grad[1] else None
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = _dgrad(gp1, W1, out=_lin_raw(g, None, _INV_SQRT2, 0.0), accumulate=True)
+        gx = _dgrad_epi(gp1, W1, g, _INV_SQRT2, 0.0, 2) if ctx.needs_input_grad[0] else None      # g / sqrt(2) + gp1 W1
         return gx, gW1, gW2
 
 
@@ -371,7 +421,8 @@ class _QuadFn(torch.autograd.Function):
         x = _f32(x)
         Cc = x.shape[1]
         S = _new(G.Em, NS * NS * Cc, like=x)
-        _lib.check(_lib.load().nq_gn_quad_forward(C.byref(G.main), C.byref(G.qint), _lib.ptr(G.t["tin_ptr"]), _lib.ptr(x), Cc, NS, scale, _lib.ptr(S), _st()))
+        _lib.check(_lib.load().nq_gn_quad_forward(C.byref(G.main), C.byref(G.qint), _lib.ptr(G.t["tin_ptr"]), G.N, _lib.ptr(x), Cc, NS, scale, _lib.ptr(S),
+                                                  _st()))
         ctx.meta = (G, NS, scale, Cc)
         return S
 
@@ -381,7 +432,7 @@ class _QuadFn(torch.autograd.Function):
         g = _f32(g)
         dx = _new(max(G.Tin, 1), Cc, like=g)[:G.Tin]
         scr = _new(G.Em * G.KQ * NS * Cc + 64, like=g)
-        _lib.check(_lib.load().nq_gn_quad_backward(C.byref(G.main), C.byref(G.qint), _lib.ptr(G.t["tin_ptr"]), G.Tin, _lib.ptr(g), Cc, NS, G.KQ, scale,
+        _lib.check(_lib.load().nq_gn_quad_backward(C.byref(G.main), C.byref(G.qint), _lib.ptr(G.t["tin_ptr"]), G.N, G.Tin, _lib.ptr(g), Cc, NS, G.KQ, scale,
                                                    _lib.ptr(scr), _lib.ptr(dx), _st()))
         return dx, None, None, None
 

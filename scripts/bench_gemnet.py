@@ -54,9 +54,10 @@ def loss_fn(E, F, b):
     return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()          # config/model/gemnet-oc.yaml:78-85
 
 
-def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32"):
     import torch
     from nabladft_amd import _lib, gemnet_oc
+    gemnet_oc.set_gemm_precision(precision)
     from nabladft_amd import dist as nqdist
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
@@ -92,7 +93,7 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
                        "interactions, direct coupled forces) train step: graphs, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
            "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N,
            "edges": {"a2a": G.Ea2a, "main": G.Em, "a2ee2a": G.Ea, "qint": G.Eq, "qint_x_main_rows": G.Tin}, "parameters": net.num_params, "_dt": dt,
-           "final_loss": float(loss.detach()), "dtype": "f32", "data": "synthetic",
+           "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
            "parity": "pinned to the reference GemNetOC classes run on CPU (tests/golden/gemnet_*.npz); torch_scatter / torch_sparse / torch_cluster restated"}
     if kernels:
         gemnet_oc.GEMM_FLOPS[0] = 0.0
@@ -111,10 +112,12 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         out["device_ms_per_step_nq_kernels"] = tot
         out["kernel_ms_per_step"] = {k: [round(ms, 4), int(n)] for k, ms, n in ks[:24]}
         gemm_ms = sum(ms for k, ms, _ in ks if k.startswith("gemm"))
+        out["gemm_bf16_ms_per_step"] = sum(ms for k, ms, _ in ks if k.startswith("gemm_bf16"))
         fl = 3.0 * fwd_flops                                                # forward + input gradient + weight gradient of every Dense (batch 0's sizes)
         ach = fl / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_gemm (Dense layers, fp32 MFMA)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "gemm_ms_per_step": gemm_ms, "flops_per_step": fl}
+    gemnet_oc.set_gemm_precision("f32")
     return out
 
 
@@ -159,8 +162,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
     a = ap.parse_args()
-    out = run(a.molecules, a.steps, a.warmup, a.kernels)
+    out = run(a.molecules, a.steps, a.warmup, a.kernels, precision=a.precision)
     if a.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -264,3 +264,50 @@ def test_equivariance_and_batch_independence(small):
         # bitwise reproducible
         E3, F3 = net(data)
         assert torch.equal(E3, E0) and torch.equal(F3, F0)
+
+
+def test_bf16_gemm_matches_bf16_rounded_operands_and_model_stays_close(small, full):
+    """bf16 mode (BASELINE.json configs[2]): the MFMA kernel equals an fp32 product of bf16-rounded operands to accumulation round-off (so the only
+    deviation from the fp32 path is the documented operand rounding), asymmetric operands catch layout swaps; the model's outputs move by O(1e-2)."""
+    import ctypes as C
+    from nabladft_amd import _lib, gemnet_oc
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for M, N, K in [(300, 200, 64), (1000, 512, 512), (257, 48, 32), (4096, 1568, 128)]:
+        x, W = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+        Wb, WbT = torch.empty(N, K, device=dev, dtype=torch.bfloat16), torch.empty(K, N, device=dev, dtype=torch.bfloat16)
+        _lib.check(lib.nq_bf16_pack(_lib.ptr(W), N, K, _lib.ptr(Wb), _lib.ptr(WbT), _lib.stream_ptr()))
+        assert torch.equal(Wb, W.to(torch.bfloat16)) and torch.equal(WbT, W.t().contiguous().to(torch.bfloat16))
+        xr, Wr = x.to(torch.bfloat16).double(), W.to(torch.bfloat16).double()
+        ref = xr @ Wr.T
+        y = torch.empty(M, N, device=dev)
+        _lib.check(lib.nq_linear_forward_bf16(_lib.ptr(x), _lib.ptr(Wb), _lib.ptr(y), None, None, 0.0, 0.0, M, N, K, _lib.stream_ptr()))
+        assert (y.double() - ref).abs().max() < 2e-6 * ref.abs().max() * (K ** 0.5), (M, N, K)
+        res, act = torch.randn(M, N, generator=g).to(dev), torch.empty(M, N, device=dev)
+        _lib.check(lib.nq_linear_forward_bf16(_lib.ptr(x), _lib.ptr(Wb), _lib.ptr(y), _lib.ptr(act), _lib.ptr(res), 0.5, 0.25, M, N, K, _lib.stream_ptr()))
+        assert (act.double() - (0.5 * res.double() + 0.25 * torch.nn.functional.silu(ref))).abs().max() < 1e-5 * ref.abs().max()
+        if N % 32 == 0:
+            gy = torch.randn(M, N, generator=g).to(dev)
+            gx = torch.full((M, K), 1.0, device=dev)
+            _lib.check(lib.nq_linear_input_grad_bf16(_lib.ptr(gy), _lib.ptr(WbT), _lib.ptr(gx), M, N, K, 1, _lib.stream_ptr()))
+            refg = gy.to(torch.bfloat16).double() @ Wr + 1.0
+            assert (gx.double() - refg).abs().max() < 2e-6 * refg.abs().max() * (N ** 0.5), (M, N, K)
+    d = full
+    net = build(FULL, d, dev, False)
+    data = Data(d, dev)
+    E0, F0 = net(data)
+    _loss(E0, F0, data).backward()
+    g0 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    gemnet_oc.set_gemm_precision("bf16")
+    try:
+        E1, F1 = net(data)
+        _loss(E1, F1, data).backward()
+    finally:
+        gemnet_oc.set_gemm_precision("f32")
+    assert (E1 - E0).abs().max() < 3e-2 * max(1.0, float(E0.abs().max())) and (F1 - F0).abs().max() < 3e-2 * float(F0.abs().max())
+    num = sum(float(((p.grad - g0[k]) ** 2).sum()) for k, p in net.named_parameters() if p.grad is not None)
+    den = sum(float((v ** 2).sum()) for v in g0.values())
+    assert (num / den) ** 0.5 < 5e-2                                   # whole-gradient relative deviation of the bf16 step
+    assert float((E1 - E0).abs().max()) > 0.0                           # the mode really took another path
