@@ -155,6 +155,12 @@ def bench_gemnet(args, rank, world, local_dev, dev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    bf = None
+    if world == 1 and not args.no_roofline:
+        bf = BG.run(mol, args.steps, args.warmup, kernels=False, device=dev, precision="bf16")
+        bf = {"what": "same step with the Dense products (forward, input and weight gradients) on bf16 MFMA, fp32 accumulation, fp32 sums over edges / triplets / "
+                      "quadruplets, fp32 master weights and optimizer -- the mode BASELINE.json names for this configuration; not parity-grade (operands rounded to bf16)",
+              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"]}
     if rank == 0:
         cpu = BG.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
@@ -163,7 +169,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
-               "parity": rec.get("parity")}
+               "parity": rec.get("parity"), "bf16_mode": bf}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -525,8 +531,11 @@ def main():
         torch.cuda.empty_cache()
         import bench_gemnet as BG
         g16 = BG.run(16, 5, 2, kernels=True, device=dev)
+        g16b = BG.run(16, 5, 2, kernels=False, device=dev, precision="bf16")
         g16.pop("_dt", None)
-        gemnet = {"workload": g16.pop("workload"), "batch16": g16, "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
+        gemnet = {"workload": g16.pop("workload"), "batch16": g16,
+                  "batch16_bf16_gemms": {k: g16b[k] for k in ("value", "unit", "ms_per_step", "dtype", "final_loss")},
+                  "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
     if rank == 0:
         out = {

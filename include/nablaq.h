@@ -463,6 +463,9 @@ int nq_bf16_pack(const float* W, int32_t N, int32_t K, void* Wb, void* WbT, void
 int nq_linear_forward_bf16(const float* A, const void* Wb, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
                            int32_t K, void* stream);
 int nq_linear_input_grad_bf16(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* gW[N][K] = G[rows][N]^T X[rows][K] on the bf16 MFMA (operands transposed into bf16 copies inside `scratch`, split over the rows, fixed-order reduction). */
+size_t nq_weight_grad_bf16_scratch_bytes(int64_t rows, int32_t N, int32_t K);
+int nq_linear_weight_grad_bf16(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, void* scratch, void* stream);
 /* C[M,K] (+)= G[M,N] W[N,K] */
 int nq_linear_input_grad(const float* G, const float* W, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
 /* Input gradient with a fused epilogue on C[M,K] = G W: mode 1: C = beta * (G W) * silu'(aux) (adjoint of the activation below), mode 2: C = alpha * aux + G W

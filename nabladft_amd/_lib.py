@@ -142,6 +142,8 @@ SYMBOLS = {
     "nq_linear_input_grad_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "nq_linear_input_grad_epi": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _F, _F, _I32, _P]),
     "nq_linear_input_grad_bf16_epi": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _F, _F, _I32, _P]),
+    "nq_weight_grad_bf16_scratch_bytes": (_SZ, [_I64, _I32, _I32]),
+    "nq_linear_weight_grad_bf16": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_gn_embed_grad": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),

@@ -20,10 +20,12 @@ struct HbArgs {
   const float* A; const __bf16* B; float* C; float* C2; const float* resid;
   float ea, eb;
   int M, N, K, lda, ldb, ldc;
+  const __bf16* Ab;          // A_BF16: A already packed in bf16 (weight gradient: transposed activations)
+  int k_split; long part_stride;   // split over the contraction: blockIdx.z covers [z * k_split, (z + 1) * k_split), output slab z
 };
 enum { HB_STORE = 0, HB_ACC = 1, HB_SILU_RES = 2, HB_DSILU = 3, HB_RES = 4 };
 
-template <int EPI>
+template <int EPI, bool A_BF16 = false>
 __global__ __launch_bounds__(256) void k_gemm_bf16_nt(HbArgs p) {
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][HB_BM * HB_LD];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2][HB_BN * HB_LD];
@@ -37,14 +39,23 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(HbArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 ra[4];
-  uint4 rb[2];
+  uint4 rb[2], rab[2];
+  const int kbeg = A_BF16 ? blockIdx.z * p.k_split : 0, kend = A_BF16 ? min(p.K, kbeg + p.k_split) : p.K;
   const int ar = t >> 3, ak = (t & 7) * 4;      // A: 8 threads x float4 per row of 32 k
   const int br = t >> 2, bk = (t & 3) * 8;      // B: 4 threads x 8 bf16 per row
   auto fetch = [&](int k0) {
+    if (A_BF16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = m0 + ar + 32 * i;
-      ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + k0 + ak) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < 2; ++i) {
+        const int row = m0 + br + 64 * i;
+        rab[i] = row < p.M ? *reinterpret_cast<const uint4*>(p.Ab + (long)row * p.lda + k0 + bk) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + ar + 32 * i;
+        ra[i] = row < p.M ? *reinterpret_cast<const float4*>(p.A + (long)row * p.lda + k0 + ak) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -53,22 +64,27 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(HbArgs p) {
     }
   };
   auto stash = [&](int buf) {
+    if (A_BF16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      hb4 v;
-      v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
-      *reinterpret_cast<hb4*>(&sA[buf][(ar + 32 * i) * HB_LD + ak]) = v;
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(&sA[buf][(br + 64 * i) * HB_LD + bk]) = rab[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hb4 v;
+        v[0] = (__bf16)ra[i].x; v[1] = (__bf16)ra[i].y; v[2] = (__bf16)ra[i].z; v[3] = (__bf16)ra[i].w;
+        *reinterpret_cast<hb4*>(&sA[buf][(ar + 32 * i) * HB_LD + ak]) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(&sB[buf][(br + 64 * i) * HB_LD + bk]) = rb[i];
   };
-  fetch(0);
+  fetch(kbeg);
   stash(0);
   __syncthreads();
   int buf = 0;
   const int lr = lane & 31, lk = lane >> 5;
-  for (int k0 = 0; k0 < p.K; k0 += HB_BK) {
-    const bool more = k0 + HB_BK < p.K;
+  for (int k0 = kbeg; k0 < kend; k0 += HB_BK) {
+    const bool more = k0 + HB_BK < kend;
     if (more) fetch(k0 + HB_BK);
 #pragma unroll
     for (int kk = 0; kk < HB_BK; kk += 16) {
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_nt(HbArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= p.M) continue;
-        const long off = (long)row * p.ldc + col;
+        const long off = (long)row * p.ldc + col + (A_BF16 ? (long)blockIdx.z * p.part_stride : 0L);
         const float v = acc[i][j][r];
         if (EPI == HB_ACC) p.C[off] += v;
         else if (EPI == HB_DSILU) p.C[off] = p.eb * v * nq_dsilu_fast(p.resid[off]);
@@ -125,13 +141,46 @@ __global__ void k_bf16_pack(const float* __restrict__ W, int N, int K, __bf16* _
   }
 }
 
+// x [M][C] fp32 -> xT [C][Mp] bf16, zero for m >= M (Mp = M rounded up to the k-tile); 32x32 tiles through LDS
+__global__ void k_transpose_bf16(const float* __restrict__ x, long M, int C, long Mp, __bf16* __restrict__ xT) {
+  __shared__ float tile[32][33];
+  const long m0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const long m = m0 + r; const int c = c0 + tx;
+    tile[r][tx] = (m < M && c < C) ? x[m * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r; const long m = m0 + tx;
+    if (c < C && m < Mp) xT[(long)c * Mp + m] = (__bf16)tile[tx][r];
+  }
+}
+__global__ void k_hb_reduce(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += part[(long)k * stride + i];      // fixed order
+  out[i] = s;
+}
+
+static void hb_wgrad_plan(long rows, int N, int K, long* Mp, int* nsplit, int* ksplit) {
+  *Mp = (rows + HB_BK - 1) / HB_BK * HB_BK;
+  const long tiles = (long)nq_cdiv(N, HB_BM) * nq_cdiv(K, HB_BN);
+  long s = 768 / tiles; if (s < 1) s = 1;
+  const long maxs = (*Mp + 255) / 256; if (s > maxs) s = maxs;
+  long ks = (*Mp + s - 1) / s; ks = (ks + HB_BK - 1) / HB_BK * HB_BK;
+  *ksplit = (int)ks;
+  *nsplit = (int)((*Mp + ks - 1) / ks);
+}
+
 static int hb_launch(hipStream_t st, const float* A, const void* B, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
                      int accumulate, const char* kind, int mode = 0) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_bf16_%s:[n=%d,k=%d]", kind, N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   if (K % HB_BK != 0 || N <= 0) return nq_fail(NQ_ERR_ARG, "bf16 gemm: K = %d must be a multiple of %d", K, HB_BK);
-  HbArgs p{A, (const __bf16*)B, C, C2, resid, ea, eb, M, N, K, K, K, N};
+  HbArgs p{A, (const __bf16*)B, C, C2, resid, ea, eb, M, N, K, K, K, N, nullptr, 0, 0};
   dim3 grid(nq_cdiv(M, HB_BM), nq_cdiv(N, HB_BN), 1);
   if (mode == 1) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_DSILU>), grid, dim3(256), 0, st, p);
   else if (mode == 2) hipLaunchKernelGGL((k_gemm_bf16_nt<HB_RES>), grid, dim3(256), 0, st, p);
@@ -168,6 +217,38 @@ int nq_linear_input_grad_bf16_epi(const float* G, const void* WbT, float* C, int
                                   int32_t mode, void* stream) {
   if (!G || !WbT || !C || !aux || (mode != 1 && mode != 2)) return nq_fail(NQ_ERR_ARG, "bad argument");
   return hb_launch((hipStream_t)stream, G, WbT, C, nullptr, aux, alpha, beta, M, K, N, 0, "nn", mode);
+}
+
+/* Weight gradient gW[N][K] = G[rows][N]^T X[rows][K] on the bf16 MFMA: both operands are transposed into bf16 [features][rows] copies (the contraction
+ * must be the contiguous index of both MFMA operands), multiplied by the NT kernel split over the rows, partial slabs reduced in a fixed order. */
+size_t nq_weight_grad_bf16_scratch_bytes(int64_t rows, int32_t N, int32_t K) {
+  long Mp; int ns, ks;
+  hb_wgrad_plan(rows, N, K, &Mp, &ns, &ks);
+  return (size_t)(N + K) * Mp * 2 + (size_t)ns * N * K * 4 + 512;
+}
+int nq_linear_weight_grad_bf16(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, void* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_bf16_tn:[%dx%d]", N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  if (!G || !X || !gW || !scratch || rows <= 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  long Mp; int ns, ks;
+  hb_wgrad_plan(rows, N, K, &Mp, &ns, &ks);
+  __bf16* GT = (__bf16*)scratch;
+  __bf16* XT = GT + (size_t)N * Mp;
+  float* part = (float*)(((uintptr_t)(XT + (size_t)K * Mp) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)(Mp / 32), nq_cdiv(N, 32)), dim3(256), 0, st, G, (long)rows, N, Mp, GT);
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)(Mp / 32), nq_cdiv(K, 32)), dim3(256), 0, st, X, (long)rows, K, Mp, XT);
+  NQ_LAUNCH_CHECK();
+  HbArgs p{nullptr, XT, ns > 1 ? part : gW, nullptr, nullptr, 0.f, 0.f, N, K, (int)Mp, (int)Mp, (int)Mp, K, GT, ks, (long)N * K};
+  dim3 grid(nq_cdiv(N, HB_BM), nq_cdiv(K, HB_BN), ns);
+  hipLaunchKernelGGL((k_gemm_bf16_nt<HB_STORE, true>), grid, dim3(256), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  if (ns > 1) {
+    const long cnt = (long)N * K;
+    hipLaunchKernelGGL(k_hb_reduce, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, part, ns, cnt, cnt, gW);
+    NQ_LAUNCH_CHECK();
+  }
+  return NQ_OK;
 }
 
 }  // extern "C"

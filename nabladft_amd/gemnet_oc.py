@@ -234,6 +234,10 @@ def _wgrad(g, x):
     M, N = g.shape
     K = x.shape[1]
     gW = _new(N, K, like=g)
+    if _PRECISION[0] == "bf16" and M >= 2048:
+        scr = torch.empty(int(lib.nq_weight_grad_bf16_scratch_bytes(M, N, K)), device=g.device, dtype=torch.uint8)
+        _lib.check(lib.nq_linear_weight_grad_bf16(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _st()))
+        return gW
     scr = _new(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, like=g)
     _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _st()))
     return gW

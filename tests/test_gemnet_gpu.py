@@ -293,6 +293,16 @@ def test_bf16_gemm_matches_bf16_rounded_operands_and_model_stays_close(small, fu
             _lib.check(lib.nq_linear_input_grad_bf16(_lib.ptr(gy), _lib.ptr(WbT), _lib.ptr(gx), M, N, K, 1, _lib.stream_ptr()))
             refg = gy.to(torch.bfloat16).double() @ Wr + 1.0
             assert (gx.double() - refg).abs().max() < 2e-6 * refg.abs().max() * (N ** 0.5), (M, N, K)
+    for M, N, K in [(5000, 512, 512), (2049, 48, 200), (20468, 512, 64), (3000, 1, 512)]:           # weight gradient: transposed bf16 operands, split over the rows
+        gy, x = torch.randn(M, N, generator=g).to(dev), torch.randn(M, K, generator=g).to(dev)
+        gW = torch.empty(N, K, device=dev)
+        scr = torch.empty(int(lib.nq_weight_grad_bf16_scratch_bytes(M, N, K)), device=dev, dtype=torch.uint8)
+        _lib.check(lib.nq_linear_weight_grad_bf16(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
+        ref = gy.to(torch.bfloat16).double().T @ x.to(torch.bfloat16).double()
+        assert (gW.double() - ref).abs().max() < 2e-6 * ref.abs().max() * (M ** 0.5), (M, N, K)
+        gW2 = torch.empty(N, K, device=dev)
+        _lib.check(lib.nq_linear_weight_grad_bf16(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(gW2), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
+        assert torch.equal(gW, gW2)                                                                   # fixed-order reduction
     d = full
     net = build(FULL, d, dev, False)
     data = Data(d, dev)
