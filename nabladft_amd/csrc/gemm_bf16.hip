@@ -141,19 +141,25 @@ __global__ void k_bf16_pack(const float* __restrict__ W, int N, int K, __bf16* _
   }
 }
 
-// x [M][C] fp32 -> xT [C][Mp] bf16, zero for m >= M (Mp = M rounded up to the k-tile); 32x32 tiles through LDS
-__global__ void k_transpose_bf16(const float* __restrict__ x, long M, int C, long Mp, __bf16* __restrict__ xT) {
-  __shared__ float tile[32][33];
-  const long m0 = (long)blockIdx.x * 32;
+// x [M][C] fp32 -> xT [C][Mp] bf16, zero for m >= M (Mp = M rounded up to the k-tile).  64 (rows) x 32 (columns) tiles through LDS: reads are 128-byte row
+// segments, writes are 128-byte segments of 64 consecutive m
+__global__ __launch_bounds__(256) void k_transpose_bf16(const float* __restrict__ x, long M, int C, long Mp, __bf16* __restrict__ xT) {
+  __shared__ float tile[64][33];
+  const long m0 = (long)blockIdx.x * 64;
   const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
+  for (int r = ty; r < 64; r += 8) {
     const long m = m0 + r; const int c = c0 + tx;
     tile[r][tx] = (m < M && c < C) ? x[m * C + c] : 0.f;
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int c = c0 + r; const long m = m0 + tx;
-    if (c < C && m < Mp) xT[(long)c * Mp + m] = (__bf16)tile[tx][r];
+  const int mx = (threadIdx.x & 31) * 2, cy = threadIdx.x >> 5;   // each thread writes two consecutive m (4 bytes)
+  for (int r = cy; r < 32; r += 8) {
+    const int c = c0 + r; const long m = m0 + mx;
+    if (c < C && m + 1 < Mp + 1 && m < Mp) {
+      typedef __bf16 hb2 __attribute__((ext_vector_type(2)));
+      hb2 v; v[0] = (__bf16)tile[mx][r]; v[1] = (__bf16)tile[mx + 1][r];
+      *reinterpret_cast<hb2*>(&xT[(long)c * Mp + m]) = v;
+    }
   }
 }
 __global__ void k_hb_reduce(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
@@ -167,7 +173,7 @@ __global__ void k_hb_reduce(const float* __restrict__ part, int nsplit, long str
 static void hb_wgrad_plan(long rows, int N, int K, long* Mp, int* nsplit, int* ksplit) {
   *Mp = (rows + HB_BK - 1) / HB_BK * HB_BK;
   const long tiles = (long)nq_cdiv(N, HB_BM) * nq_cdiv(K, HB_BN);
-  long s = 768 / tiles; if (s < 1) s = 1;
+  long s = 256 / tiles; if (s < 1) s = 1;       // one workgroup per CU: every extra split is one more fp32 slab written and re-read by the reduction
   const long maxs = (*Mp + 255) / 256; if (s > maxs) s = maxs;
   long ks = (*Mp + s - 1) / s; ks = (ks + HB_BK - 1) / HB_BK * HB_BK;
   *ksplit = (int)ks;
@@ -236,8 +242,8 @@ int nq_linear_weight_grad_bf16(const float* G, const float* X, float* gW, int64_
   __bf16* GT = (__bf16*)scratch;
   __bf16* XT = GT + (size_t)N * Mp;
   float* part = (float*)(((uintptr_t)(XT + (size_t)K * Mp) + 255) & ~(uintptr_t)255);
-  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)(Mp / 32), nq_cdiv(N, 32)), dim3(256), 0, st, G, (long)rows, N, Mp, GT);
-  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)(Mp / 32), nq_cdiv(K, 32)), dim3(256), 0, st, X, (long)rows, K, Mp, XT);
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((Mp + 63) / 64), nq_cdiv(N, 32)), dim3(256), 0, st, G, (long)rows, N, Mp, GT);
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((Mp + 63) / 64), nq_cdiv(K, 32)), dim3(256), 0, st, X, (long)rows, K, Mp, XT);
   NQ_LAUNCH_CHECK();
   HbArgs p{nullptr, XT, ns > 1 ? part : gW, nullptr, nullptr, 0.f, 0.f, N, K, (int)Mp, (int)Mp, (int)Mp, K, GT, ks, (long)N * K};
   dim3 grid(nq_cdiv(N, HB_BM), nq_cdiv(K, HB_BN), ns);

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void k_gn_quad_fwd_atom(GnSet M, GnSet Q, cons
                                                             float* __restrict__ S) {
   __shared__ float sX[GQ_PC * 64];
   __shared__ float sY[GQ_OC * GQ_PC * GN_MAXNS];
+  __shared__ float4 sPg[GQ_PC], sOg[GQ_OC];
+  __shared__ int sPs[GQ_PC], sOs[GQ_OC];
   const int a = blockIdx.x, tid = threadIdx.x;
   const int ob = M.ptr[a], on = M.ptr[a + 1] - ob, qb = Q.ptr[a], qe = Q.ptr[a + 1];
   const int OC = min(GQ_OC, 256 / C);
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256) void k_gn_quad_fwd_atom(GnSet M, GnSet Q, cons
     const bool ovalid = active && (o0 + ol) < on;
     const int c = ovalid ? M.src[o] : -1;
     const float4 vca = ovalid ? M.geom[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tid < OC && o0 + tid < on) { sOg[tid] = M.geom[ob + o0 + tid]; sOs[tid] = M.src[ob + o0 + tid]; }
     float acc[GN_MAXNS][GN_MAXNS];
 #pragma unroll
     for (int l = 0; l < GN_MAXNS; ++l)
@@ -177,14 +181,16 @@ __global__ __launch_bounds__(256) void k_gn_quad_fwd_atom(GnSet M, GnSet Q, cons
       for (int p0 = 0; p0 < pn; p0 += GQ_PC) {
         const int np = min(GQ_PC, pn - p0);
         for (int e = tid; e < np * C; e += 256) sX[e] = X[(base + p0) * C + e];
+        if (tid < np) { sPg[tid] = M.geom[pb + p0 + tid]; sPs[tid] = M.src[pb + p0 + tid]; }
+        __syncthreads();
         for (int e = tid; e < OC * np; e += 256) {
           const int oi = e / np, pj = e - oi * np;
           float Yk[GN_MAXNS];
 #pragma unroll
           for (int k = 0; k < GN_MAXNS; ++k) Yk[k] = 0.f;
           if (o0 + oi < on) {
-            const int oo = ob + o0 + oi, cc = M.src[oo], p = pb + p0 + pj, d = M.src[p];
-            if (cc != b && d != a && d != cc) gn_zonal(gn_cos_dihedral(gn_cross(M.geom[oo], vba), M.geom[p], vba), NS, 1.f, Yk);
+            const int cc = sOs[oi], d = sPs[pj];
+            if (cc != b && d != a && d != cc) gn_zonal(gn_cos_dihedral(gn_cross(sOg[oi], vba), sPg[pj], vba), NS, 1.f, Yk);
           }
 #pragma unroll
           for (int k = 0; k < GN_MAXNS; ++k) sY[(oi * GQ_PC + pj) * GN_MAXNS + k] = Yk[k];
@@ -214,15 +220,24 @@ __global__ __launch_bounds__(256) void k_gn_quad_fwd_atom(GnSet M, GnSet Q, cons
         for (int k = 0; k < NS; ++k) S[((long)o * NS * NS + l * NS + k) * C + ch] = acc[l][k];
   }
 }
-// dX[(q, j)][c] for all qint in-edges q of atom a: U rows of a's out edges staged in chunks of GQ_UC, Y_l'(dihedral) evaluated once per (p, o)
+// dX[(q, j)][c] for all qint in-edges q of atom a.  Per (q, block of 32 main in-edges p of source(q), chunk of 16 out edges o): edge geometry, the U rows of
+// the chunk and the whole 32 x 16 table of Y_l'(dihedral(o, q, p)) are staged in LDS (the table is computed from LDS-resident geometry: no dependent global
+// loads in the loop), then every thread accumulates its rows of the block.  Dynamic LDS: (16 * 8 * C + 32 * 16 * 8 + 48 * 5) floats (C = 32: 33 kB).
 #define GQ_UC 16
+#define GQ_PB 32
 __global__ __launch_bounds__(256) void k_gn_quad_bwd_x_atom(GnSet M, GnSet Q, const int* __restrict__ tin_ptr, const float* __restrict__ U, int C, int NS, int KQ,
                                                               float* __restrict__ dX) {
-  __shared__ float sU[GQ_UC * GN_MAXNS * 64];
-  __shared__ float sY[GQ_OC * GQ_UC * GN_MAXNS];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  float* sU = dyn_lds;                                   // [GQ_UC][8][C]
+  float* sY = sU + GQ_UC * GN_MAXNS * C;                 // [GQ_PB][GQ_UC][8]
+  float4* sPg = reinterpret_cast<float4*>(sY + GQ_PB * GQ_UC * GN_MAXNS);   // [GQ_PB] geometry of the p edges
+  float4* sOg = sPg + GQ_PB;                             // [GQ_UC] geometry of the o edges
+  int* sPs = reinterpret_cast<int*>(sOg + GQ_UC);        // [GQ_PB] sources d
+  int* sOs = sPs + GQ_PB;                                // [GQ_UC] sources c
   const int a = blockIdx.x, tid = threadIdx.x;
   const int ob = M.ptr[a], on = M.ptr[a + 1] - ob, qb = Q.ptr[a], qe = Q.ptr[a + 1];
-  const int PC = min(GQ_OC, 256 / C);
+  const int PC = min(8, 256 / C);
+  const int NPASS = GQ_PB / PC;                          // <= 8
   const int pl = tid / C, ch = tid - pl * C;
   const bool active = pl < PC;
   for (int q = qb; q < qe; ++q) {
@@ -230,39 +245,56 @@ __global__ __launch_bounds__(256) void k_gn_quad_bwd_x_atom(GnSet M, GnSet Q, co
     const float4 vba = Q.geom[q];
     const int pb = M.ptr[b], pn = M.ptr[b + 1] - pb;
     const long base = tin_ptr[q];
-    for (int p0 = 0; p0 < pn; p0 += PC) {
-      const bool pvalid = active && (p0 + pl) < pn;
-      float acc = 0.f;
+    for (int pblk = 0; pblk < pn; pblk += GQ_PB) {
+      const int npb = min(GQ_PB, pn - pblk);
+      float acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      if (tid < npb) { sPg[tid] = M.geom[pb + pblk + tid]; sPs[tid] = M.src[pb + pblk + tid]; }
       for (int o0 = 0; o0 < on; o0 += GQ_UC) {
         const int no = min(GQ_UC, on - o0);
+        if (tid >= 64 && tid < 64 + no) { sOg[tid - 64] = M.geom[ob + o0 + tid - 64]; sOs[tid - 64] = M.src[ob + o0 + tid - 64]; }
         for (int e = tid; e < no * NS * C; e += 256) {
           const int oi = e / (NS * C), r = e - oi * NS * C;
           sU[oi * GN_MAXNS * C + r] = U[((long)(ob + o0 + oi) * KQ + jq) * NS * C + r];
         }
-        for (int e = tid; e < PC * no; e += 256) {
+        __syncthreads();
+        for (int e = tid; e < npb * no; e += 256) {
           const int pi = e / no, oi = e - pi * no;
           float Yk[GN_MAXNS];
 #pragma unroll
           for (int k = 0; k < GN_MAXNS; ++k) Yk[k] = 0.f;
-          if (p0 + pi < pn) {
-            const int p = pb + p0 + pi, d = M.src[p], oo = ob + o0 + oi, cc = M.src[oo];
-            if (d != a && cc != b && cc != d) gn_zonal(gn_cos_dihedral(gn_cross(M.geom[oo], vba), M.geom[p], vba), NS, 1.f, Yk);
-          }
+          const int d = sPs[pi], cc = sOs[oi];
+          if (d != a && cc != b && cc != d) gn_zonal(gn_cos_dihedral(gn_cross(sOg[oi], vba), sPg[pi], vba), NS, 1.f, Yk);
 #pragma unroll
           for (int k = 0; k < GN_MAXNS; ++k) sY[(pi * GQ_UC + oi) * GN_MAXNS + k] = Yk[k];
         }
         __syncthreads();
-        if (pvalid) {
-          for (int oi = 0; oi < no; ++oi) {
-            const float* y = &sY[(pl * GQ_UC + oi) * GN_MAXNS];
-            const float* u = &sU[oi * GN_MAXNS * C + ch];
+        if (active) {
 #pragma unroll
-            for (int k = 0; k < GN_MAXNS; ++k) if (k < NS) acc += y[k] * u[k * C];
+          for (int ps = 0; ps < 8; ++ps) {
+            const int pi = ps * PC + pl;
+            if (ps < NPASS && pi < npb) {
+              float s0 = 0.f;
+              for (int oi = 0; oi < no; ++oi) {
+                const float* y = &sY[(pi * GQ_UC + oi) * GN_MAXNS];
+                const float* u = &sU[oi * GN_MAXNS * C + ch];
+#pragma unroll
+                for (int k = 0; k < GN_MAXNS; ++k) if (k < NS) s0 += y[k] * u[k * C];
+              }
+              acc[ps] += s0;
+            }
           }
         }
         __syncthreads();
       }
-      if (pvalid) dX[(base + p0 + pl) * C + ch] = acc;
+      if (active) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int pi = ps * PC + pl;
+          if (ps < NPASS && pi < npb) dX[(base + pblk + pi) * C + ch] = acc[ps];
+        }
+      }
     }
   }
 }
@@ -640,7 +672,8 @@ int nq_gn_quad_backward(const void* main_set, const void* qint_set, const int32_
   if (M.n <= 0 || T <= 0 || KQ <= 0) return NQ_OK;
   hipLaunchKernelGGL(k_gn_quad_bwd_u, GN_GRID((long)M.n * KQ * C), M, Q, dS, C, NS, KQ, scale, scratch);
   NQ_LAUNCH_CHECK();
-  if (C <= 64 && g_gn_quad_variant == 1) hipLaunchKernelGGL(k_gn_quad_bwd_x_atom, dim3(n_atoms), dim3(256), 0, st, M, Q, tin_ptr, scratch, C, NS, KQ, dx);
+  if (C <= 64 && g_gn_quad_variant == 1) hipLaunchKernelGGL(k_gn_quad_bwd_x_atom, dim3(n_atoms), dim3(256), sizeof(float) * (GQ_UC * GN_MAXNS * C + GQ_PB * GQ_UC * GN_MAXNS + 5 * (GQ_PB + GQ_UC)),
+                                                        st, M, Q, tin_ptr, scratch, C, NS, KQ, dx);
   else hipLaunchKernelGGL(k_gn_quad_bwd_x, GN_GRID(T * C), M, Q, tin_ptr, scratch, C, NS, KQ, dx);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
