@@ -155,8 +155,9 @@ def bench_gemnet(args, rank, world, local_dev, dev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    bf = None
+    bf = b8 = None
     if world == 1 and not args.no_roofline:
+        b8 = BG.run(8, args.steps, args.warmup, kernels=False, device=dev) if mol != 8 else None
         bf = BG.run(mol, args.steps, args.warmup, kernels=False, device=dev, precision="bf16")
         bf = {"what": "same step with the Dense products (forward, input and weight gradients) on bf16 MFMA, fp32 accumulation, fp32 sums over edges / triplets / "
                       "quadruplets, fp32 master weights and optimizer -- the mode BASELINE.json names for this configuration; not parity-grade (operands rounded to bf16)",
@@ -169,7 +170,8 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
-               "parity": rec.get("parity"), "bf16_mode": bf}
+               "parity": rec.get("parity"), "bf16_mode": bf,
+               "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

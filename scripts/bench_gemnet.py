@@ -1,6 +1,6 @@
 """GemNet-OC (BASELINE.json configs[2]: config/model/gemnet-oc.yaml -- 4 blocks, atom 256 / edge 512, 128 radial / 7 spherical functions, 12 A cutoffs,
 neighbour caps 30 / 20 / 8, quadruplet + atom-edge + edge-atom + atom-atom interactions, direct coupled forces; AdamW(amsgrad, betas 0.9/0.95, lr 1e-3),
-loss = L1(E) + 100 * L2(F)) training-step timing on one MI355X in fp32: graphs -> forward -> loss -> backward -> AdamW, on synthetic drug-like
+loss = L1(E) + 100 * L2(F), gradient-norm clip 10.0, config/gemnet-oc.yaml: batch_size 8) training-step timing on one MI355X in fp32: graphs -> forward -> loss -> backward -> AdamW, on synthetic drug-like
 conformers already resident in HBM.  ``run()`` is what ``bench.py --model gemnet`` calls.
 
     python scripts/bench_gemnet.py [--molecules 16] [--steps 10] [--warmup 3] [--kernels] [--cpu-baseline]
@@ -74,6 +74,7 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         loss.backward()
         if world > 1:
             nqdist.allreduce_mean_(flat.flat.grad)
+        flat.clip_grad_norm_(10.0)                                     # config/gemnet-oc.yaml:19-20 (gradient_clip_val 10.0, norm)
         opt.step()
         return loss
 
@@ -90,7 +91,7 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     dt = time.perf_counter() - t0
     G = net.get_graphs_and_indices(batches[0])
     out = {"workload": "GemNet-OC (config/model/gemnet-oc.yaml: 4 blocks, atom 256 / edge 512, 128 rbf, 7 spherical, 12 A cutoffs, caps 30/20/8, all four extra "
-                       "interactions, direct coupled forces) train step: graphs, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
+                       "interactions, direct coupled forces) train step: graphs, forward, L1(E) + 100 L2(F), backward, clip 10.0, AdamW(amsgrad); synthetic ~42-atom conformers",
            "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N,
            "edges": {"a2a": G.Ea2a, "main": G.Em, "a2ee2a": G.Ea, "qint": G.Eq, "qint_x_main_rows": G.Tin}, "parameters": net.num_params, "_dt": dt,
            "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
