@@ -91,9 +91,11 @@ _SN = {"sn_filter1": lambda N, E: E / 2 * (F * 4 + 128.0), "sn_filter1_tan": lam
 
 
 def pmc_traffic_bytes(kernel_prefix, batch):
-    """HBM bytes per launch from the committed PMC summary (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the
+    """HBM bytes per launch from the committed PMC summary (profiles/r02_pmc_traffic.json, else r01; FETCH_SIZE doubled per the
     gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported), only if it was taken at this batch size."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -155,9 +157,13 @@ def bench_gemnet(args, rank, world, local_dev, dev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    bf = b8 = None
+    bf = b8 = big = None
     if world == 1 and not args.no_roofline:
         b8 = BG.run(8, args.steps, args.warmup, kernels=False, device=dev) if mol != 8 else None
+        big = {}
+        for prec in ("f32", "bf16"):
+            r64 = BG.run(64, 4, 3, kernels=False, device=dev, precision=prec)
+            big[prec] = {k: r64[k] for k in ("value", "unit", "ms_per_step", "atoms")}
         bf = BG.run(mol, args.steps, args.warmup, kernels=False, device=dev, precision="bf16")
         bf = {"what": "same step with the Dense products (forward, input and weight gradients) on bf16 MFMA, fp32 accumulation, fp32 sums over edges / triplets / "
                       "quadruplets, fp32 master weights and optimizer -- the mode BASELINE.json names for this configuration; not parity-grade (operands rounded to bf16)",
@@ -171,7 +177,8 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
                "parity": rec.get("parity"), "bf16_mode": bf,
-               "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
+               "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
+               "batch_64": big if bf is not None else None}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -533,7 +540,7 @@ def main():
         torch.cuda.empty_cache()
         import bench_gemnet as BG
         g16 = BG.run(16, 5, 2, kernels=True, device=dev)
-        g16b = BG.run(16, 5, 2, kernels=False, device=dev, precision="bf16")
+        g16b = BG.run(16, 5, 4, kernels=False, device=dev, precision="bf16")
         g16.pop("_dt", None)
         gemnet = {"workload": g16.pop("workload"), "batch16": g16,
                   "batch16_bf16_gemms": {k: g16b[k] for k in ("value", "unit", "ms_per_step", "dtype", "final_loss")},
