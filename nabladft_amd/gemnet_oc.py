@@ -992,6 +992,7 @@ class GemNetOC(torch.nn.Module):
                  atom_interaction: bool = False, scale_basis: bool = False, num_elements: int = 83, otf_graph: bool = False,
                  scale_file: Optional[str] = None) -> None:
         super().__init__()
+        _PACKED.clear()               # packed bf16 weights are keyed by address + version: a new model may reuse the addresses of a freed one
         for ok, what in ((num_targets == 1, "num_targets != 1"), (not use_pbc, "periodic boundary conditions"), (regress_forces and direct_forces,
                          "forces by back-propagation (direct_forces=False)"), (enforce_max_neighbors_strictly, "enforce_max_neighbors_strictly=False"),
                          (not scale_backprop_forces, "scale_backprop_forces"), (extensive, "extensive=False"), (scale_file is None, "scale_file"),

@@ -90,3 +90,30 @@ def test_fused_step_two_ranks_overlapped_allreduce(tmp_path):
     expect = ((g2[0] + g2[1]) / 2).cpu()
     got = r0["overlap"]["grad"]
     assert float((got - expect).abs().max()) <= 2e-6 * float(expect.abs().max())
+
+
+def _gemnet_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    import torch.distributed as dist
+    from nabladft_amd import dist as nqdist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_gemnet as BG
+    nqdist.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    BG.CFG = dict(BG.CFG, num_blocks=1, emb_size_atom=64, emb_size_edge=64, num_radial=32, emb_size_trip_in=16, emb_size_trip_out=16, emb_size_quad_in=8,
+                  emb_size_quad_out=8, emb_size_aint_in=16, emb_size_aint_out=16, emb_size_rbf=8, emb_size_cbf=8, emb_size_sbf=8, num_spherical=4)
+    rec = BG.run(molecules=2, steps=2, warmup=1, kernels=False, device=torch.device("cuda:0"), world=world, rank=rank,
+                 sync=lambda: (torch.cuda.synchronize(), dist.barrier(), torch.cuda.synchronize()))
+    torch.save({"loss": rec["final_loss"], "value": rec["value"]}, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gemnet_data_parallel_two_ranks(tmp_path):
+    """bench_gemnet.run under 2 ranks (the path `bench.py --model gemnet --gpus N` takes): parameters are broadcast, the flat gradient is averaged, both ranks
+    finish; each rank sees its own conformers (different losses), so this checks plumbing, not numbers."""
+    world, port = 2, _free_port()
+    mp.spawn(_gemnet_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert r0["value"] > 0 and r1["value"] > 0 and r0["loss"] == r0["loss"] and r1["loss"] == r1["loss"] and r0["loss"] != r1["loss"]
