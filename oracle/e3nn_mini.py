@@ -275,8 +275,7 @@ def spherical_harmonics(l, x, normalize, normalization="integral"):
         ls = list(l)
     if normalize:
         x = torch.nn.functional.normalize(x, dim=-1)
-    else:
-        raise NotImplementedError("only normalize=True is used by QHNet (qhnet.py:266-271)")
+    # normalize=False (escn.py:170-176): the harmonic POLYNOMIALS on the raw vector, |x|^l Y_l(x / |x|) -- the recursion below is homogeneous of degree l
     ys = _sh_unit(max(ls), x)
     fac = {"component": lambda k: math.sqrt(2 * k + 1), "norm": lambda k: 1.0, "integral": lambda k: math.sqrt((2 * k + 1) / (4 * math.pi))}[normalization]
     return torch.cat([ys[k] * fac(k) for k in ls], dim=-1)
@@ -539,6 +538,75 @@ class FullyConnectedNet(nn.Sequential):
             var_in = var_out
 
 
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# angles and S2 grids (used by the eSCN fixtures: escn/so3.py:380-381,453-470) -- restated from e3nn 0.5.1's documented conventions [memory], PARITY UNPINNED:
+#   angles_to_matrix(a, b, c) = Ry(a) Rx(b) Ry(c);  xyz_to_angles: beta = acos(y), alpha = atan2(x, z);  grid: beta_b = (b + 1/2) pi / B, alpha_a = 2 pi a / A;
+#   ToS2Grid (normalization="integral") samples the integral-normalised real harmonics; FromS2Grid integrates with the equiangular quadrature weights of
+#   Driscoll-Healy type, so that from_grid(to_grid(x)) = x for l <= lmax when B >= 2 (lmax + 1).  The classes expose the factors ``shb`` / ``sha`` whose
+#   contraction the reference forms (escn/so3.py:457,467); here the factorisation is the trivial one (sha = identity over the longitudes).
+def xyz_to_angles(xyz):
+    xyz = torch.nn.functional.normalize(xyz, p=2, dim=-1).clamp(-1, 1)
+    return torch.atan2(xyz[..., 0], xyz[..., 2]), torch.acos(xyz[..., 1])
+
+
+def _rot_x(a):
+    c, s, o, z = a.cos(), a.sin(), torch.ones_like(a), torch.zeros_like(a)
+    return torch.stack([torch.stack([o, z, z], -1), torch.stack([z, c, -s], -1), torch.stack([z, s, c], -1)], -2)
+
+
+def _rot_y(a):
+    c, s, o, z = a.cos(), a.sin(), torch.ones_like(a), torch.zeros_like(a)
+    return torch.stack([torch.stack([c, z, s], -1), torch.stack([z, o, z], -1), torch.stack([-s, z, c], -1)], -2)
+
+
+def angles_to_matrix(alpha, beta, gamma):
+    alpha, beta, gamma = torch.broadcast_tensors(alpha, beta, gamma)
+    return _rot_y(alpha) @ _rot_x(beta) @ _rot_y(gamma)
+
+
+def s2_grid(res_beta, res_alpha):
+    betas = (torch.arange(res_beta, dtype=torch.float64) + 0.5) / res_beta * math.pi
+    alphas = torch.arange(res_alpha, dtype=torch.float64) / res_alpha * 2 * math.pi
+    return betas, alphas
+
+
+def s2_quadrature_weights(res_beta):
+    """Weights w_b of the equiangular grid beta_b = (b + 1/2) pi / B (B even) with sum_b w_b f(beta_b) = int_0^pi f sin(beta) d beta for band-limited f
+    (Driscoll & Healy 1994): w_b = (2 / (B/2)) sin(beta_b) sum_{k < B/2} sin((2k + 1) beta_b) / (2k + 1) ... normalised to sum to 2."""
+    half = res_beta // 2
+    betas, _ = s2_grid(res_beta, 1)
+    k = torch.arange(half, dtype=torch.float64)
+    w = torch.stack([(2.0 / half) * torch.sin(b) * (torch.sin((2 * k + 1) * b) / (2 * k + 1)).sum() for b in betas])
+    return w * (2.0 / w.sum())
+
+
+def _s2_samples(lmax, res_beta, res_alpha):
+    betas, alphas = s2_grid(res_beta, res_alpha)
+    b, a = torch.meshgrid(betas, alphas, indexing="ij")
+    xyz = torch.stack([b.sin() * a.sin(), b.cos(), b.sin() * a.cos()], dim=-1)                      # e3nn's angles_to_xyz
+    return spherical_harmonics(list(range(lmax + 1)), xyz, True, "integral")                          # [B, A, (lmax+1)^2]
+
+
+class ToS2Grid(nn.Module):
+    def __init__(self, lmax=None, res=None, normalization="component", dtype=None, device=None):
+        super().__init__()
+        assert normalization == "integral", "only the normalisation eSCN uses is restated"
+        Y = _s2_samples(lmax, res[0], res[1]).to(torch.get_default_dtype())
+        self.register_buffer("sha", torch.eye(res[1], dtype=Y.dtype))                                # [a, m]
+        self.register_buffer("shb", Y.permute(1, 0, 2).contiguous())                                 # [m, b, i]
+
+
+class FromS2Grid(nn.Module):
+    def __init__(self, res=None, lmax=None, normalization="component", lmax_in=None, dtype=None, device=None):
+        super().__init__()
+        assert normalization == "integral" and res[0] % 2 == 0
+        Y = _s2_samples(lmax, res[0], res[1])
+        w = s2_quadrature_weights(res[0]) * (2 * math.pi / res[1])                                    # d(cos beta) d(alpha) per grid point
+        F = (Y * w[:, None, None]).to(torch.get_default_dtype())
+        self.register_buffer("sha", torch.eye(res[1], dtype=F.dtype))                                # [a, m]
+        self.register_buffer("shb", F.permute(1, 0, 2).contiguous())                                 # [m, b, i]
+
+
 def install():
     """Registers this module as ``e3nn`` / ``e3nn.o3`` / ``e3nn.nn`` in sys.modules (fixture generation only)."""
     import sys
@@ -546,7 +614,8 @@ def install():
     me = sys.modules[__name__]
     e3 = types.ModuleType("e3nn")
     o3 = types.ModuleType("e3nn.o3")
-    for name in ("Irrep", "Irreps", "wigner_3j", "spherical_harmonics", "TensorProduct", "ElementwiseTensorProduct", "Norm", "Linear"):
+    for name in ("Irrep", "Irreps", "wigner_3j", "spherical_harmonics", "TensorProduct", "ElementwiseTensorProduct", "Norm", "Linear", "xyz_to_angles",
+                 "angles_to_matrix", "ToS2Grid", "FromS2Grid"):
         setattr(o3, name, getattr(me, name))
     nn_mod = types.ModuleType("e3nn.nn")
     nn_mod.FullyConnectedNet = FullyConnectedNet
