@@ -425,6 +425,27 @@ int nq_gn_lincomb(const float* a, const float* b, float alpha, float beta, int64
 int nq_gn_ssilu_backward(const float* z, const float* g, float scale, int64_t n, float* out, void* stream);
 int nq_gn_embed_grad(const int32_t* z, const float* g, int32_t N, int32_t num_elements, int32_t C, float* dW, void* stream);
 
+/* ---- eSCN building blocks (reference nablaDFT/escn/escn.py, so3.py) --------------------------------------------------- */
+/* Directed radius graph of escn.py:253-255 (radius_graph(pos, r, batch, max_num_neighbors)): per target atom the first K atoms of its molecule (index
+ * order) with d^2 < r^2.  Pass 1 (count): deg [N], ptr [N+1], *E_host (synchronises).  Pass 2 (fill): src, dst [E], geom [E][4] = {pos[j] - pos[i], |.|}. */
+int nq_es_graph_count(const float* pos, const int32_t* mol_ptr, const int32_t* atom_mol, int32_t N, double cutoff, int32_t K, int32_t* deg, int32_t* ptr,
+                      int32_t* E_host, void* stream);
+int nq_es_graph_fill(const float* pos, const int32_t* mol_ptr, const int32_t* atom_mol, int32_t N, double cutoff, int32_t K, const int32_t* ptr, int32_t* src,
+                     int32_t* dst, float* geom, void* stream);
+/* Edge rotation matrices rot [E][3][3] (escn.py:435-487; deterministic helper axis instead of the reference's random vector: same model output). */
+int nq_es_frames(const float* geom, int32_t E, float* rot, void* stream);
+/* Wigner-D rows (so3.py:377-425): W [E][n_red][n_full], row b = row red_row[b] of the degree-red_l[b] block D^l = Z(alpha) J_l Z(beta) J_l Z(gamma);
+ * J: the J_l matrices back to back (J_offset[l]); scratch f32[3 E]. */
+int nq_es_wigner(const float* rot, int32_t E, const float* J, const int32_t* J_offset, const int32_t* red_l, const int32_t* red_row, int32_t n_red, int32_t n_full,
+                 int32_t lmax, float* scratch, float* W, void* stream);
+/* GaussianSmearing (smearing.py:14-31): out[e][k] = exp(coeff (geom[e][3] - offset[k])^2). */
+int nq_es_smearing(const float* geom, int64_t E, int32_t K, const float* offset, float coeff, float* out, void* stream);
+/* One small matrix per row times the row's [coefficients][channels] block (SO3_Embedding._rotate / _rotate_inv / to_grid / from_grid, so3.py:265-375):
+ * transpose == 0: out[o][i][c] (+)= sum_s R_o[i][s] X_r[s][c];  else out[o][s][c] (+)= sum_i R_o[i][s] X_r[i][c];  R_o = R + o * r_stride (0: shared),
+ * r = index ? index[o] : o; strides in floats; R is I x NSS. */
+int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride, const int32_t* index, float* out, int64_t out_stride, int64_t n, int32_t I,
+             int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate, void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

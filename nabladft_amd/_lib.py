@@ -145,6 +145,12 @@ SYMBOLS = {
     "nq_weight_grad_bf16_scratch_bytes": (_SZ, [_I64, _I32, _I32]),
     "nq_linear_weight_grad_bf16": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_gn_embed_grad": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "nq_es_graph_count": (C.c_int, [_P, _P, _P, _I32, _D, _I32, _P, _P, C.POINTER(C.c_int32), _P]),
+    "nq_es_graph_fill": (C.c_int, [_P, _P, _P, _I32, _D, _I32, _P, _P, _P, _P, _P]),
+    "nq_es_frames": (C.c_int, [_P, _I32, _P, _P]),
+    "nq_es_wigner": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "nq_es_smearing": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P]),
+    "nq_rowop": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

@@ -1,0 +1,274 @@
+// eSCN building blocks (reference /root/reference/nablaDFT/escn/escn.py, so3.py):
+//   escn.py:253-255,435-487   directed radius graph (first K sources per target in index order), edge vectors / distances, edge rotation matrices
+//   so3.py:377-425            Wigner-D matrices from the rotation matrices: D^l = Z(alpha) J_l Z(beta) J_l Z(gamma), written directly as the rows the SO(2)
+//                             convolution keeps (|m| <= mmax, m-primary order of CoefficientMapping, so3.py:23-118)
+//   so3.py:265-300,361-375    SO3_Embedding._rotate / _rotate_inv / to_grid / from_grid and the point sampling of escn.py:399-407: all are "one small
+//                             matrix per row times the row's [coefficients x channels] block" -> k_rowop_*: per-row or shared matrix, optional gather of
+//                             the row from node storage, strided outputs, optional accumulation
+//   smearing.py:14-31         GaussianSmearing
+// The dense layers in between run on the fp32 MFMA GEMMs (gemm.hip).  Sums are in a fixed order; nothing here uses atomics.
+#include "common.h"
+
+typedef unsigned long long es_u64;
+__device__ __forceinline__ es_u64 es_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+__device__ __forceinline__ float es_sqrt_rn(float x) {
+  if (!(x > 0.0f)) return 0.0f;
+  const float s = __builtin_sqrtf(x);
+  const float r = fmaf(-s, s, x);
+  return fmaf(r, 0.5f / s, s);
+}
+
+// ---- directed radius graph: one wavefront per target atom, candidates = the atoms of its molecule in index order, strict d^2 < r^2, first K kept ---------
+__global__ __launch_bounds__(64) void k_es_graph(const float* __restrict__ pos, const int* __restrict__ mol_ptr, const int* __restrict__ atom_mol, float r2, int K,
+                                                 const int* __restrict__ ptr, int* __restrict__ deg, int* __restrict__ src, int* __restrict__ dst,
+                                                 float4* __restrict__ geom) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int g = atom_mol[i], a0 = mol_ptr[g], a1 = mol_ptr[g + 1];
+  const float xi = pos[3 * (long)i], yi = pos[3 * (long)i + 1], zi = pos[3 * (long)i + 2];
+  int kept = 0;
+  const int base = ptr ? ptr[i] : 0;
+  for (int j0 = a0; j0 < a1 && kept < K; j0 += 64) {
+    const int j = j0 + lane;
+    bool in = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (j < a1 && j != i) {
+      dx = pos[3 * (long)j] - xi; dy = pos[3 * (long)j + 1] - yi; dz = pos[3 * (long)j + 2] - zi;     // edge_distance_vec = pos[j] - pos[i] (escn.py:282)
+      float s = __fmul_rn(dx, dx);
+      s = __fadd_rn(s, __fmul_rn(dy, dy));
+      s = __fadd_rn(s, __fmul_rn(dz, dz));
+      in = s < r2;
+    }
+    const es_u64 m = __ballot(in);
+    const int rank = kept + __popcll(m & es_below(lane));
+    if (in && rank < K && src) {
+      float s = __fmul_rn(dx, dx);                    // distance as torch.norm evaluates it on the CPU (see gemnet_graph.hip: k_gn_geom)
+      s = fmaf(dy, dy, s);
+      s = fmaf(dz, dz, s);
+      const int slot = base + rank;
+      src[slot] = j; dst[slot] = i;
+      geom[slot] = make_float4(dx, dy, dz, es_sqrt_rn(s));
+    }
+    kept = min(K, kept + __popcll(m));
+  }
+  if (lane == 0 && deg) deg[i] = kept;
+}
+__global__ __launch_bounds__(1024) void k_es_scan(const int* __restrict__ in, int n, int* __restrict__ out) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    int s = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(s, off, 64); if (lane >= off) s += t; }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int p = carry;
+    for (int w = 0; w < wave; ++w) p += wsum[w];
+    if (i < n) out[i] = p + s - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = p + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
+// ---- edge frames (escn.py:435-487).  The reference draws a random helper vector per edge; any helper not parallel to the edge gives the same model output
+// (the SO(2) convolution commutes with rotations about the edge), so the helper here is the coordinate axis least aligned with the edge: deterministic. --------
+__global__ void k_es_frames(const float4* __restrict__ geom, int E, float* __restrict__ rot) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float4 v = geom[e];
+  const float inv = 1.0f / v.w;
+  const float nx0 = v.x * inv, nx1 = v.y * inv, nx2 = v.z * inv;
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+  const float a0 = fabsf(nx0), a1 = fabsf(nx1), a2 = fabsf(nx2);
+  if (a0 <= a1 && a0 <= a2) h0 = 1.f; else if (a1 <= a2) h1 = 1.f; else h2 = 1.f;
+  float z0 = nx1 * h2 - nx2 * h1, z1 = nx2 * h0 - nx0 * h2, z2 = nx0 * h1 - nx1 * h0;       // norm_z = normalize(norm_x x helper)
+  float n = rsqrtf(z0 * z0 + z1 * z1 + z2 * z2);
+  z0 *= n; z1 *= n; z2 *= n;
+  float y0 = nx1 * z2 - nx2 * z1, y1 = nx2 * z0 - nx0 * z2, y2 = nx0 * z1 - nx1 * z0;       // norm_y = normalize(norm_x x norm_z), then negated
+  n = rsqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+  y0 *= -n; y1 *= -n; y2 *= -n;
+  float* r = rot + 9 * (long)e;      // edge_rot_mat = transpose([norm_z | norm_x | norm_y] as columns): rows are norm_z, norm_x, norm_y
+  r[0] = z0; r[1] = z1; r[2] = z2; r[3] = nx0; r[4] = nx1; r[5] = nx2; r[6] = y0; r[7] = y1; r[8] = y2;
+}
+
+// ---- Euler angles of the frames (so3.py:378-383 with e3nn's y-polar conventions) ----------------------------------------------------------------------------
+__global__ void k_es_angles(const float* __restrict__ rot, int E, float* __restrict__ ang) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float* R = rot + 9 * (long)e;
+  float x0 = R[1], x1 = R[4], x2 = R[7];                           // R @ (0, 1, 0)
+  const float n = rsqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+  x0 *= n; x1 *= n; x2 *= n;
+  x1 = fminf(1.f, fmaxf(-1.f, x1));
+  const float beta = acosf(x1), alpha = atan2f(x0, x2);
+  // first row of (Ry(alpha) Rx(beta))^T R: Ry Rx has first column (cos a, 0, -sin a)
+  const float ca = cosf(alpha), sa = sinf(alpha);
+  const float m00 = ca * R[0] - sa * R[6], m02 = ca * R[2] - sa * R[8];
+  ang[3 * (long)e] = alpha; ang[3 * (long)e + 1] = beta; ang[3 * (long)e + 2] = atan2f(m02, m00);
+}
+
+// ---- Wigner rows: W[e][b][:] = row red_row[b] of block l = red_l[b] of D(e), placed at the columns of that block (zero elsewhere) ----------------------------
+#define ES_MAXL 6
+__global__ void k_es_wigner(const float* __restrict__ ang, int E, const float* __restrict__ Jall, const int* __restrict__ Joff, const int* __restrict__ red_l,
+                            const int* __restrict__ red_row, int n_red, int n_full, float* __restrict__ W) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)E * n_red) return;
+  const int e = (int)(t / n_red), b = (int)(t - (long)e * n_red);
+  const int l = red_l[b], i = red_row[b], w = 2 * l + 1;
+  const float alpha = ang[3 * (long)e], beta = ang[3 * (long)e + 1], gamma = ang[3 * (long)e + 2];
+  const float* J = Jall + Joff[l];
+  float A[2 * ES_MAXL + 1], B[2 * ES_MAXL + 1], Cc[2 * ES_MAXL + 1];
+  const float fi = (float)(l - i);
+  const float ci = cosf(fi * alpha), si = sinf(fi * alpha);
+  // row i of Z(alpha) J: Z[i][i] = cos(f_i a), Z[i][2l - i] = sin(f_i a) (the diagonal wins at i = l)
+  for (int p = 0; p < w; ++p) A[p] = (i == l ? 1.f : ci) * J[i * w + p] + (i == l ? 0.f : si * J[(2 * l - i) * w + p]);
+  // times Z(beta): (A Z)[q] = A[q] cos(f_q b) + A[2l - q] sin(f_{2l-q} b)
+  for (int q = 0; q < w; ++q) {
+    const float fq = (float)(l - q);
+    B[q] = q == l ? A[q] : A[q] * cosf(fq * beta) + A[2 * l - q] * sinf(-fq * beta);
+  }
+  for (int q = 0; q < w; ++q) {
+    float s = 0.f;
+    for (int p = 0; p < w; ++p) s += B[p] * J[p * w + q];
+    Cc[q] = s;
+  }
+  float* out = W + ((long)e * n_red + b) * n_full;
+  for (int q = 0; q < n_full; ++q) out[q] = 0.f;
+  for (int q = 0; q < w; ++q) {
+    const float fq = (float)(l - q);
+    out[l * l + q] = q == l ? Cc[q] : Cc[q] * cosf(fq * gamma) + Cc[2 * l - q] * sinf(-fq * gamma);
+  }
+}
+
+// ---- GaussianSmearing: out[e][k] = exp(coeff (d_e - offset_k)^2) -------------------------------------------------------------------------------------------
+__global__ void k_es_smear(const float4* __restrict__ geom, long E, int K, const float* __restrict__ offset, float coeff, float* __restrict__ out) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= E * K) return;
+  const long e = t / K; const int k = (int)(t - e * K);
+  const float x = geom[e].w - offset[k];
+  out[t] = expf(coeff * x * x);
+}
+
+// ---- row operators ---------------------------------------------------------------------------------------------------------------------------------------------
+// forward:   out[o][i][c] (+)= sum_s R_o[i][s] X_row(o)[s][c]          R_o = R + o * r_stride (r_stride 0: one shared matrix), row(o) = index ? index[o] : o
+// transpose: out[o][s][c] (+)= sum_i R_o[i][s] Y[o][i][c]
+// One workgroup per row; the matrix and the row block are staged in LDS.
+struct RowOp { const float* R; long r_stride; const float* X; long x_stride; const int* index; float* out; long out_stride; int I, NSS, C, accumulate; };
+
+__global__ __launch_bounds__(256) void k_rowop_fwd(RowOp p) {
+  extern __shared__ __attribute__((aligned(16))) float es_lds[];
+  float* sR = es_lds; float* sX = es_lds + p.I * p.NSS;
+  const long o = blockIdx.x;
+  const float* R = p.R + o * p.r_stride;
+  const float* X = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
+  for (int t = threadIdx.x; t < p.I * p.NSS; t += 256) sR[t] = R[t];
+  for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) sX[t] = X[t];
+  __syncthreads();
+  float* out = p.out + o * p.out_stride;
+  for (int t = threadIdx.x; t < p.I * p.C; t += 256) {
+    const int i = t / p.C, ch = t - i * p.C;
+    float acc = 0.f;
+    for (int k = 0; k < p.NSS; ++k) acc += sR[i * p.NSS + k] * sX[k * p.C + ch];
+    out[t] = p.accumulate ? out[t] + acc : acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_rowop_tr(RowOp p) {
+  extern __shared__ __attribute__((aligned(16))) float es_lds[];
+  float* sR = es_lds; float* sY = es_lds + p.I * p.NSS;
+  const long o = blockIdx.x;
+  const float* R = p.R + o * p.r_stride;
+  const float* Y = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
+  for (int t = threadIdx.x; t < p.I * p.NSS; t += 256) sR[t] = R[t];
+  for (int t = threadIdx.x; t < p.I * p.C; t += 256) sY[t] = Y[t];
+  __syncthreads();
+  float* out = p.out + o * p.out_stride;
+  for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) {
+    const int k = t / p.C, ch = t - k * p.C;
+    float acc = 0.f;
+    for (int i = 0; i < p.I; ++i) acc += sR[i * p.NSS + k] * sY[i * p.C + ch];
+    out[t] = p.accumulate ? out[t] + acc : acc;
+  }
+}
+
+// =========================================================================================================================================================
+#define ES_GRID(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256), 0, st
+
+extern "C" {
+
+/* Pass 1 (src == NULL): degrees -> ptr (exclusive scan), returns E in *E_host (synchronises).  Pass 2: fills src / dst / geom [E][4] = {pos[j] - pos[i], |.|}. */
+int nq_es_graph_count(const float* pos, const int32_t* mol_ptr, const int32_t* atom_mol, int32_t N, double cutoff, int32_t K, int32_t* deg, int32_t* ptr,
+                      int32_t* E_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_graph_count");
+  if (!pos || !mol_ptr || !atom_mol || !deg || !ptr || !E_host || N <= 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  const float r2 = (float)(cutoff * cutoff);
+  hipLaunchKernelGGL(k_es_graph, dim3(N), dim3(64), 0, st, pos, mol_ptr, atom_mol, r2, K, nullptr, deg, nullptr, nullptr, nullptr);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_es_scan, dim3(1), dim3(1024), 0, st, deg, N, ptr);
+  NQ_LAUNCH_CHECK();
+  NQ_HIP(hipMemcpyAsync(E_host, ptr + N, sizeof(int), hipMemcpyDeviceToHost, st));
+  NQ_HIP(hipStreamSynchronize(st));
+  return NQ_OK;
+}
+int nq_es_graph_fill(const float* pos, const int32_t* mol_ptr, const int32_t* atom_mol, int32_t N, double cutoff, int32_t K, const int32_t* ptr, int32_t* src,
+                     int32_t* dst, float* geom, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_graph_fill");
+  if (!pos || !ptr || !src || !dst || !geom) return nq_fail(NQ_ERR_ARG, "null argument");
+  hipLaunchKernelGGL(k_es_graph, dim3(N), dim3(64), 0, st, pos, mol_ptr, atom_mol, (float)(cutoff * cutoff), K, ptr, nullptr, src, dst, (float4*)geom);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_es_frames(const float* geom, int32_t E, float* rot, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_frames");
+  if (E <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_es_frames, ES_GRID((long)E), (const float4*)geom, E, rot);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+/* rot [E][3][3] -> W [E][n_red][n_full]; J: the (2l+1)^2 matrices of l = 0..lmax back to back, J_offset[l] their starts; red_l / red_row [n_red]: degree and
+ * row inside the degree's block of every kept coefficient (in the order the caller wants them, e.g. m-primary); scratch: f32[3 E]. */
+int nq_es_wigner(const float* rot, int32_t E, const float* J, const int32_t* J_offset, const int32_t* red_l, const int32_t* red_row, int32_t n_red, int32_t n_full,
+                 int32_t lmax, float* scratch, float* W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_wigner");
+  if (lmax > ES_MAXL) return nq_fail(NQ_ERR_ARG, "lmax %d > %d", lmax, ES_MAXL);
+  if (E <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_es_angles, ES_GRID((long)E), rot, E, scratch);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_es_wigner, ES_GRID((long)E * n_red), scratch, E, J, J_offset, red_l, red_row, n_red, n_full, W);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+int nq_es_smearing(const float* geom, int64_t E, int32_t K, const float* offset, float coeff, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_smear");
+  if (E <= 0) return NQ_OK;
+  hipLaunchKernelGGL(k_es_smear, ES_GRID(E * K), (const float4*)geom, (long)E, K, offset, coeff, out);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+/* transpose == 0: out[o][i][c] (+)= sum_s R_o[i][s] X_row(o)[s][c];  transpose != 0: out[o][s][c] (+)= sum_i R_o[i][s] X_row(o)[i][c].  Strides in floats. */
+int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride, const int32_t* index, float* out, int64_t out_stride, int64_t n, int32_t I,
+             int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, transpose ? "rowop_tr" : "rowop_fwd");
+  if (n <= 0) return NQ_OK;
+  if (!R || !X || !out) return nq_fail(NQ_ERR_ARG, "null argument");
+  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB): split the matrix rows", I, NSS, C, lds);
+  RowOp p{R, (long)r_stride, X, (long)x_stride, index, out, (long)out_stride, I, NSS, C, accumulate};
+  if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+}  // extern "C"
