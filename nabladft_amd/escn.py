@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, cg
-from .gemnet_oc import _DenseFn, _EmbedFn, _MulFn, _SegSumFn, _gather_raw, _new, _segsum_raw, _st, lin
+from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _gather_raw, _new, _segsum_raw, _st, lin
 from .qhnet import _ActFn, _LinearBiasFn, _MatmulFn, _f32
 
 
@@ -154,6 +154,31 @@ def _silu(x):
     return _ActFn.apply(x, 0, 1.0)
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """W[idx]; the adjoint is a chain of fixed-order segment sums ``levels`` = [(order, ptr, n), ...] (no atomics).  Edge embeddings reduce in two steps
+    (edges -> their atom -> the atom's element): a one-step sum over ~10 k edges per element would leave one thread per channel walking the whole list."""
+
+    @staticmethod
+    def forward(ctx, W, idx, levels):
+        W = _f32(W)
+        ctx.levels = levels
+        return _gather_raw(W, idx, None, idx.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        for order, ptr, n in ctx.levels:
+            g = _segsum_raw(g, order, ptr, n, g.shape[1])
+        return g, None, None
+
+
+def _inverse_lists(idx, n):
+    """(order, ptr) int32: positions sorted (stably) by index value, and the start of every value's run."""
+    order = torch.sort(idx.long(), stable=True).indices.to(torch.int32)
+    ptr = torch.cat([idx.new_zeros(1, dtype=torch.int64), torch.bincount(idx.long(), minlength=n).cumsum(0)]).to(torch.int32)
+    return order, ptr
+
+
 class _Linear(torch.nn.Module):
     """torch.nn.Linear's parameters (reference initialisation) on the MFMA GEMM; ``act`` fuses SiLU."""
 
@@ -168,8 +193,7 @@ class _Linear(torch.nn.Module):
 
     def forward(self, x, act=False):
         if self.bias is None:
-            y = _DenseFn.apply(x, self.weight, False)
-            return _silu(y) if act else y
+            return _DenseFn.apply(x, self.weight, 1.0 if act else False)          # SiLU in the GEMM epilogue
         return _LinearBiasFn.apply(x, self.weight, self.bias, act)
 
 
@@ -204,8 +228,8 @@ class EdgeBlock(torch.nn.Module):
 
     def forward(self, x_dist, G):
         x = self.fc1_dist(x_dist)
-        x = lin(x, _EmbedFn.apply(self.source_embedding.weight, G.z_src, G.z_src1))
-        x = lin(x, _EmbedFn.apply(self.target_embedding.weight, G.z_dst, G.z_dst1))
+        x = lin(x, _EmbeddingFn.apply(self.source_embedding.weight, G.z_src, [G.src_inverse + (G.N,), G.z_inverse]))
+        x = lin(x, _EmbeddingFn.apply(self.target_embedding.weight, G.z_dst, [G.dst_inverse + (G.N,), G.z_inverse]))
         return self.fc1_edge_attr(_silu(x), act=True)
 
 
@@ -423,13 +447,11 @@ class eSCN(torch.nn.Module):
                                     _lib.ptr(scratch), _lib.ptr(G.wigner), _st()))
         # inverse lists for the adjoints of the two gathers: the edges are sorted by target; by source through a stable sort of the source column
         G.dst_inverse = (None, ptr)
-        order = torch.sort(G.src.long(), stable=True).indices.to(torch.int32)
-        src_ptr = torch.cat([counts.new_zeros(1), torch.bincount(G.src.long(), minlength=N).cumsum(0)]).to(torch.int32)
-        G.src_inverse = (order, src_ptr)
-        z = data.z.long()
-        G.z = z.to(torch.int32)
+        G.src_inverse = _inverse_lists(G.src, N)
+        G.z = data.z.to(torch.int32).contiguous()
         G.z_src, G.z_dst = G.z[G.src.long()].contiguous(), G.z[G.dst.long()].contiguous()
-        G.z1, G.z_src1, G.z_dst1 = G.z + 1, G.z_src + 1, G.z_dst + 1                                  # nq_gn_embed_grad counts rows with z == t + 1
+        T = self.max_num_elements
+        G.z_inverse = _inverse_lists(G.z, T) + (T,)
         G.x_dist = self.distance_expansion(G.geom)
         return G
 
@@ -439,7 +461,7 @@ class eSCN(torch.nn.Module):
         G = self.build_graph(data, edge_rot_mat)
         K = self._constants(data.pos.device)
         Cc, nf = self.sphere_channels, K.order.n_full
-        emb = _EmbedFn.apply(self.sphere_embedding.weight, G.z, G.z1)                                   # [N, C] -> the l = 0 coefficient (escn.py:333-341)
+        emb = _EmbeddingFn.apply(self.sphere_embedding.weight, G.z, [G.z_inverse])                                   # [N, C] -> the l = 0 coefficient (escn.py:333-341)
         x = torch.cat([emb, emb.new_zeros(G.N, (nf - 1) * Cc)], dim=1)
         layers = []
         for i, blk in enumerate(self.layer_blocks):

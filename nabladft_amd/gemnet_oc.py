@@ -248,10 +248,11 @@ class _DenseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, act):
+        """act: False / 0 = identity, True = ScaledSiLU (silu / 0.6), a float s = s * silu (1.0: plain SiLU, escn.py)."""
         x, W = _f32(x), _f32(W)
-        ctx.act = act
-        if act:
-            pre, y = _gemm_act(x, W, None, 0.0, _SSILU)
+        ctx.act = _SSILU if act is True else float(act)
+        if ctx.act:
+            pre, y = _gemm_act(x, W, None, 0.0, ctx.act)
             ctx.save_for_backward(x, W, pre)
             return y
         M, K = x.shape
@@ -271,7 +272,7 @@ class _DenseFn(torch.autograd.Function):
         g = _f32(g)
         if ctx.act:
             x, W, pre = ctx.saved_tensors
-            g = _ssilu_bwd(pre, g, 1.0)
+            g = _ssilu_bwd(pre, g, ctx.act / _SSILU)
         else:
             x, W = ctx.saved_tensors
         gx = _dgrad(g, W) if ctx.needs_input_grad[0] else None

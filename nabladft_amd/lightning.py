@@ -184,6 +184,11 @@ class GemNetOCLightning(_Task):
         return self(data)
 
 
+class eSCNLightning(GemNetOCLightning):
+    """escn/escn.py:1006-1159: the same wrapper contract as GemNetOCLightning (energy / forces dict, L1 + L2Loss, learning rate logged on the step);
+    ``net`` = nabladft_amd.escn.eSCN."""
+
+
 class QHNetLightning(_Task):
     """``net`` is ``nabladft_amd.qhnet.QHNet``.  Losses that declare ``packed = True`` (nabladft_amd.hamiltonian.HamiltonianLoss) get the
     diagonal blocks packed molecule after molecule -- prediction and target -- and never see the block_diag matrix; any other loss (e.g. the

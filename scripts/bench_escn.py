@@ -1,0 +1,156 @@
+"""eSCN (BASELINE.json configs[4]: config/model/escn-oc.yaml -- 8 layers, lmax 6 / mmax 2, 128 sphere channels, 256 hidden, cutoff 8 A, 40 neighbours,
+128 sphere samples; AdamW(amsgrad, betas 0.9/0.95, lr 1e-3), loss = L1(E) + 100 * L2(F); config/escn-oc.yaml: batch_size 8, no gradient clip) training-step
+timing on one MI355X in fp32: graph + frames + Wigner rows -> forward -> loss -> backward -> AdamW, on synthetic drug-like conformers already resident in HBM.
+
+    python scripts/bench_escn.py [--molecules 16] [--steps 10] [--warmup 3] [--kernels] [--cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CFG = dict(num_targets=1, use_pbc=False, regress_forces=True, otf_graph=True, use_grid=True, distance_function="gaussian", basis_width_scalar=1.0,
+           show_timing_info=False, max_neighbors=40, cutoff=8.0, max_num_elements=65, num_layers=8, lmax_list=[6], mmax_list=[2], sphere_channels=128,
+           hidden_channels=256, edge_channels=128, num_sphere_samples=128, distance_resolution=0.02)          # config/model/escn-oc.yaml:5-25
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+class Batch:
+    pass
+
+
+def synthetic_batch(molecules, seed, device):
+    import torch
+    from nabladft_amd.synth import gen_conformers
+    pos, z, batch, y, f = gen_conformers(seed, molecules)
+    b = Batch()
+    b.pos, b.z, b.batch, b.y, b.forces = pos.to(device), z.to(device), batch.to(device), y.to(device), f.to(device)
+    return b
+
+
+def build(device, seed=23):
+    import torch
+    from nabladft_amd.escn import eSCN
+    torch.manual_seed(seed)
+    return eSCN(**CFG).to(device)
+
+
+def loss_fn(E, F, b):
+    import torch
+    return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()
+
+
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+    import torch
+    from nabladft_amd import _lib, gemnet_oc
+    from nabladft_amd import dist as nqdist
+    from nabladft_amd.trainer import FlatParameters
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    net = build(dev)
+    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    flat = FlatParameters(net.parameters())
+    opt = torch.optim.AdamW([flat.flat], lr=1e-3, betas=(0.9, 0.95), amsgrad=True, weight_decay=0)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        flat.zero_grad()
+        E, F = net(b)
+        loss = loss_fn(E, F, b)
+        loss.backward()
+        if world > 1:
+            nqdist.allreduce_mean_(flat.flat.grad)
+        opt.step()
+        return loss
+
+    sync = sync or torch.cuda.synchronize
+    if world > 1:
+        nqdist.broadcast_(flat.flat.data)
+    for i in range(warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    G = net.build_graph(batches[0])
+    out = {"workload": "eSCN (config/model/escn-oc.yaml: 8 layers, lmax 6 / mmax 2, 128 sphere channels, 256 hidden, cutoff 8 A, 40 neighbours, 128 sphere samples) train "
+                       "step: graph, frames, Wigner rows, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N, "edges": G.E,
+           "parameters": net.num_params, "_dt": dt, "final_loss": float(loss.detach()), "dtype": "f32", "data": "synthetic",
+           "parity": "pinned to the reference eSCN classes run on CPU (tests/golden/escn_*.npz); the five e3nn symbols under them are restated (unpinned), the Wigner "
+                     "J matrices equal the reference's Jd.pt"}
+    if kernels:
+        gemnet_oc.GEMM_FLOPS[0] = 0.0
+        step(0)
+        fwd_flops = gemnet_oc.GEMM_FLOPS[0]
+        gemnet_oc.GEMM_FLOPS[0] = None
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        ks = sorted(((k, v[0] / steps, v[1] // steps) for k, v in prof.items()), key=lambda x: -x[1])
+        out["device_ms_per_step_nq_kernels"] = sum(v[0] for v in prof.values()) / steps
+        out["kernel_ms_per_step"] = {k: [round(ms, 4), int(n)] for k, ms, n in ks[:24]}
+        gemm_ms = sum(ms for k, ms, _ in ks if k.startswith("gemm"))
+        out["gemm_ms_per_step"] = gemm_ms
+        out["dense_flops_counted_per_step"] = 3.0 * fwd_flops             # only the bias-free layers are counted by the hook (the biased ones are small)
+        ach = 3.0 * fwd_flops / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_gemm (SO(2) convolution and grid MLP layers, fp32 MFMA)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "gemm_ms_per_step": gemm_ms, "flops_per_step": 3.0 * fwd_flops}
+    return out
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """oracle/escn_ref.py (torch CPU, fp32; pinned to the reference classes' golden vectors) forward + loss + backward on ONE synthetic conformer."""
+    import torch
+    from nabladft_amd.escn import eSCN
+    from nabladft_amd.synth import gen_conformers
+    from oracle import escn_ref as R
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pos, z, batch, y, f = gen_conformers(101, 1)
+    torch.manual_seed(23)
+    net = eSCN(**CFG)
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, p in net.named_parameters():
+        if p.requires_grad:
+            P[k].requires_grad_(True)
+    del net
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        E, F = R.forward(P, CFG, pos, z, [pos.shape[0]])
+        R.loss(E, F, y, f).backward()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 3:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"1 synthetic conformer ({pos.shape[0]} atoms), eSCN yaml configuration, forward + loss + backward of oracle/escn_ref.py, mean of {n} steps, "
+                      f"torch {torch.__version__} CPU fp32, no optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--molecules", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kernels", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    out = run(a.molecules, a.steps, a.warmup, a.kernels)
+    if a.cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

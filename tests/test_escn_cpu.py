@@ -52,3 +52,29 @@ def test_full_configuration_surface():
         eSCN(**dict(FULL, use_pbc=True))
     with pytest.raises(NotImplementedError):
         eSCN(**dict(FULL, lmax_list=[4, 2], mmax_list=[2, 2]))
+
+
+def test_oracle_restatement_matches_the_reference_fixtures():
+    """oracle/escn_ref.py (checker of smoke / cpu_baseline) against the golden vectors of the real classes: fp64 to round-off with the fixture's frames,
+    and the deterministic frames give the same function up to eSCN's own grid-sampling error."""
+    from oracle import escn_ref as R
+    d = np.load(os.path.join(GOLD, "escn_small.npz"))
+    P = {k[6:]: torch.tensor(d[k]).double() for k in d.files if k.startswith("state:")}
+    P["distance_expansion.offset"] = torch.linspace(0.0, SMALL["cutoff"], int(SMALL["cutoff"] / SMALL["distance_resolution"]), dtype=torch.float64)
+    P["sphere_points"], P["sphharm_weights.0"] = R.sphere_constants(SMALL, torch.float64)         # built in the run's dtype by the reference
+    train = list(d["param_names"])
+    for k in train:
+        P[k].requires_grad_(True)
+    pos, z = torch.tensor(d["pos"]).double(), torch.tensor(d["z"])
+    E, F = R.forward(P, SMALL, pos, z, list(d["sizes"]), rot=torch.tensor(d["edge_rot_mat"]).double())
+    assert np.abs(E.detach().numpy() - d["f64:E"]).max() < 1e-6 * np.abs(d["f64:E"]).max()
+    assert np.abs(F.detach().numpy() - d["f64:F"]).max() < 1e-6 * np.abs(d["f64:F"]).max()
+    L = R.loss(E, F, torch.tensor(d["y"]).double(), torch.tensor(d["f_target"]).double())
+    L.backward()
+    for k in train:
+        ref = d["f64:grad:" + k]
+        g = np.zeros_like(ref) if P[k].grad is None else P[k].grad.numpy()
+        assert np.abs(g - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1e-30), k
+    with torch.no_grad():
+        E2, F2 = R.forward(P, SMALL, pos, z, list(d["sizes"]))
+    assert np.abs(F2.numpy() - d["f64:F"]).max() < 3e-4 * np.abs(d["f64:F"]).max()
