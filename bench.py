@@ -185,6 +185,40 @@ def bench_gemnet(args, rank, world, local_dev, dev):
         dist.destroy_process_group()
 
 
+def bench_escn(args, rank, world, local_dev, dev):
+    """--model escn: BASELINE.json configs[4] (config/model/escn-oc.yaml) through scripts/bench_escn.py; same JSON contract, conformer-steps/s, fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_escn as BE
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    mol = args.batch if args.batch != 2048 else 16
+    rec = BE.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
+    t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    b8 = BE.run(8, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != 8 else None
+    if rank == 0:
+        cpu = BE.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
+        out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
+                          "edges": rec["edges"], "parallelism": f"dp{world}"},
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "parity": rec.get("parity"),
+               "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_qhnet(args, rank, world, local_dev, dev):
     """--model qhnet: BASELINE.json configs[3] (config/qhnet.yaml) through scripts/bench_qhnet.py; same JSON contract, conformer-steps/s."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -225,6 +259,7 @@ WORKLOADS = {
                   "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
     "qhnet": "QHNet (config/qhnet.yaml) Hamiltonian training step -- see scripts/bench_qhnet.py",
     "gemnet": "GemNet-OC (config/model/gemnet-oc.yaml) energy + direct forces training step -- see scripts/bench_gemnet.py",
+    "escn": "eSCN (config/model/escn-oc.yaml) energy + direct forces training step -- see scripts/bench_escn.py",
     "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
 }
@@ -363,6 +398,8 @@ def main():
         return bench_qhnet(args, rank, world, local_dev, dev)
     if args.model == "gemnet":
         return bench_gemnet(args, rank, world, local_dev, dev)
+    if args.model == "escn":
+        return bench_escn(args, rank, world, local_dev, dev)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
     model, step = build_step(args.model, dev)
     batches = make_batches(1 + rank, 4, args.batch, dev)
@@ -546,6 +583,15 @@ def main():
                   "batch16_bf16_gemms": {k: g16b[k] for k in ("value", "unit", "ms_per_step", "dtype", "final_loss")},
                   "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
+    escn = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+        # BASELINE.json configs[4] (eSCN, config/model/escn-oc.yaml, fp32) in the same record
+        torch.cuda.empty_cache()
+        import bench_escn as BE
+        e16 = BE.run(16, 3, 2, kernels=True, device=dev)
+        e16.pop("_dt", None)
+        escn = {"workload": e16.pop("workload"), "batch16": e16, "cpu_baseline": None if args.no_cpu_baseline else BE.cpu_baseline(seconds_budget=10.0)}
+
     if rank == 0:
         out = {
             "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
@@ -561,6 +607,7 @@ def main():
             "sibling_config": other,
             "hamiltonian": hamiltonian,
             "gemnet_oc": gemnet,
+            "escn": escn,
             "reference_batch_size_32": small,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)

@@ -10,6 +10,7 @@ echo "== smoke";  timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -6 |
 echo "== bench default"; S=$(date +%s); timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "wall $(( $(date +%s) - S )) s" | tee $OUT/bench_default.wall
 echo "== bench qhnet";   timeout 900 python bench.py --model qhnet > $OUT/bench_qhnet.json 2> $OUT/bench_qhnet.err
 echo "== bench gemnet";  timeout 900 python bench.py --model gemnet > $OUT/bench_gemnet.json 2> $OUT/bench_gemnet.err
+echo "== bench escn";    timeout 900 python bench.py --model escn --steps 5 --warmup 2 > $OUT/bench_escn.json 2> $OUT/bench_escn.err
 cp gpurun_out/kernel_events.txt $OUT/ 2>/dev/null
 prof() {  # name, command...
   local name=$1; shift
@@ -22,6 +23,7 @@ prof() {  # name, command...
 echo "== rocprof painn";  prof painn_b2048 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
 echo "== rocprof qhnet";  prof qhnet_b16 python scripts/bench_qhnet.py --molecules 16 --steps 5 --warmup 2
 echo "== rocprof gemnet"; prof gemnet_b16_f32 python scripts/bench_gemnet.py --molecules 16 --steps 5 --warmup 2
+prof escn_b16 python scripts/bench_escn.py --molecules 16 --steps 3 --warmup 1
 prof gemnet_b16_bf16 python scripts/bench_gemnet.py --molecules 16 --steps 5 --warmup 2 --precision bf16
 echo "== pmc painn"
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write

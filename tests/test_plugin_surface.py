@@ -330,3 +330,51 @@ def test_gemnet_oc_config_instantiates_with_the_reference_state_dict_surface():
         d = type("D", (), {})()
         d.pos, d.z, d.batch = torch.zeros(3, 3), torch.ones(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)
         task.net(d)
+
+
+ESCN_YAML = """
+_target_: nabladft_amd.eSCNLightning
+model_name: "ESCN-OC"
+net:
+  _target_: nabladft_amd.eSCN
+  num_targets: 1
+  max_num_elements: 65
+  num_layers: 8
+  lmax_list: [6]
+  mmax_list: [2]
+  sphere_channels: 128
+  hidden_channels: 256
+  edge_channels: 128
+  use_grid: true
+  num_sphere_samples: 128
+  distance_function: gaussian
+  regress_forces: true
+  otf_graph: true
+  use_pbc: false
+  cutoff: 8.0
+  max_neighbors: 40
+  basis_width_scalar: 1.0
+  distance_resolution: 0.02
+  show_timing_info: false
+optimizer: {_target_: torch.optim.AdamW, _partial_: true, amsgrad: true, betas: [0.9, 0.95], lr: 1.0e-3, weight_decay: 0}
+lr_scheduler: {_target_: torch.optim.lr_scheduler.ReduceLROnPlateau, _partial_: true, factor: 0.8, patience: 10}
+losses:
+  energy: {_target_: torch.nn.L1Loss}
+  forces: {_target_: nabladft_amd.L2Loss}
+loss_coefs: {energy: 1.0, forces: 100.0}
+metric: null
+"""
+
+
+def test_escn_config_instantiates():
+    """config/model/escn-oc.yaml with the `_target_` lines pointed at this package."""
+    import nabladft_amd as nq
+    from nabladft_amd.config import instantiate
+    task = instantiate(yaml.safe_load(ESCN_YAML))
+    assert isinstance(task, nq.eSCNLightning) and isinstance(task.net, nq.eSCN) and task.net.num_params == 34332032
+    assert all(k.startswith("net.") for k in task.state_dict())
+    assert task.configure_optimizers()["optimizer"].defaults["amsgrad"]
+    with pytest.raises(RuntimeError, match="MI355X"):
+        d = type("D", (), {})()
+        d.pos, d.z, d.batch = torch.zeros(3, 3), torch.ones(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)
+        task.net(d)
