@@ -203,6 +203,11 @@ def bench_escn(args, rank, world, local_dev, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     b8 = BE.run(8, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != 8 else None
+    bf = None
+    if world == 1 and not args.no_roofline:
+        bf = BE.run(mol, args.steps, args.warmup + 2, kernels=False, device=dev, precision="bf16")
+        bf = {"what": "same step with the bias-free Dense products (SO(2) convolutions, grid MLP) on bf16 MFMA, fp32 accumulation; not parity-grade",
+              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"]}
     if rank == 0:
         cpu = BE.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
@@ -211,7 +216,7 @@ def bench_escn(args, rank, world, local_dev, dev):
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
-               "parity": rec.get("parity"),
+               "parity": rec.get("parity"), "bf16_mode": bf,
                "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
         print(json.dumps(out))
     if world > 1:

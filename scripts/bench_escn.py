@@ -44,9 +44,12 @@ def loss_fn(E, F, b):
     return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()
 
 
-def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32"):
+    """precision "bf16": the bias-free Dense products (the SO(2) convolutions and the grid MLP: >95 % of the flops) on bf16 MFMA with fp32 accumulation
+    (nabladft_amd.gemnet_oc.set_gemm_precision); everything else fp32."""
     import torch
     from nabladft_amd import _lib, gemnet_oc
+    gemnet_oc.set_gemm_precision(precision)
     from nabladft_amd import dist as nqdist
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
@@ -81,7 +84,7 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     out = {"workload": "eSCN (config/model/escn-oc.yaml: 8 layers, lmax 6 / mmax 2, 128 sphere channels, 256 hidden, cutoff 8 A, 40 neighbours, 128 sphere samples) train "
                        "step: graph, frames, Wigner rows, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
            "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N, "edges": G.E,
-           "parameters": net.num_params, "_dt": dt, "final_loss": float(loss.detach()), "dtype": "f32", "data": "synthetic",
+           "parameters": net.num_params, "_dt": dt, "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
            "parity": "pinned to the reference eSCN classes run on CPU (tests/golden/escn_*.npz); the five e3nn symbols under them are restated (unpinned), the Wigner "
                      "J matrices equal the reference's Jd.pt"}
     if kernels:
@@ -105,6 +108,7 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         ach = 3.0 * fwd_flops / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_gemm (SO(2) convolution and grid MLP layers, fp32 MFMA)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "gemm_ms_per_step": gemm_ms, "flops_per_step": 3.0 * fwd_flops}
+    gemnet_oc.set_gemm_precision("f32")
     return out
 
 
@@ -145,8 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kernels", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
     a = ap.parse_args()
-    out = run(a.molecules, a.steps, a.warmup, a.kernels)
+    out = run(a.molecules, a.steps, a.warmup, a.kernels, precision=a.precision)
     if a.cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
