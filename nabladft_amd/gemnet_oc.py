@@ -83,7 +83,11 @@ def build_graphs(pos, batch, z, cutoff, cutoff_qint, cutoff_aeaint, cutoff_aint,
     t = nl.t
     dev = pos.device
     N, E = nl.N, nl.E
-    max_deg = int(t["deg"].max().item())
+    mp = t["mol_ptr"].long()
+    per_mol = t["row_ptr"].long()[mp[1:]] - t["row_ptr"].long()[mp[:-1]]
+    max_deg, min_mol = (int(v) for v in torch.stack([t["deg"].max().long(), per_mol.min()]).tolist())      # one host read for both checks
+    if min_mol == 0:
+        raise ValueError("An image has no neighbors")                # gemnet_oc.py:821-825 (a molecule without any pair inside the cutoff)
     if max_deg > max_neighbors_aint:
         raise NotImplementedError(f"an atom has {max_deg} neighbours within cutoff_aint but max_neighbors_aint = {max_neighbors_aint}: the reference's "
                                   "radius_graph truncation by source order is not implemented")
@@ -672,6 +676,11 @@ class AtomEmbedding(torch.nn.Module):
 
     def forward(self, G):
         z = G.t["z"]
+        if not getattr(G, "z_checked", False):                              # one host read per batch: an atomic number outside the table would read out of bounds
+            lo, hi = (int(v) for v in torch.stack([z.min(), z.max()]).tolist())
+            if lo < 1 or hi > self.embeddings.num_embeddings:
+                raise IndexError(f"atomic numbers {lo}..{hi} outside 1..{self.embeddings.num_embeddings} (num_elements)")
+            G.z_checked = True
         return _EmbedFn.apply(self.embeddings.weight, (z - 1).contiguous(), z)
 
 

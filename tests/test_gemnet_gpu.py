@@ -321,3 +321,28 @@ def test_bf16_gemm_matches_bf16_rounded_operands_and_model_stays_close(small, fu
     den = sum(float((v ** 2).sum()) for v in g0.values())
     assert (num / den) ** 0.5 < 5e-2                                   # whole-gradient relative deviation of the bf16 step
     assert float((E1 - E0).abs().max()) > 0.0                           # the mode really took another path
+
+
+def test_invalid_inputs_fail_loudly(small):
+    """Out-of-table atomic numbers and a molecule without neighbours raise instead of reading out of bounds / silently producing zeros."""
+    dev = torch.device("cuda:0")
+    net = build(SMALL, small, dev, True)
+    data = Data(small, dev)
+    bad = Data(small, dev)
+    bad.z = data.z.clone()
+    bad.z[3] = 99
+    with pytest.raises(IndexError):
+        net(bad)
+    far = Data(small, dev)
+    far.pos = data.pos.clone()
+    far.pos[: int(small["sizes"][0])] *= 100.0                       # first molecule blown up: no pair inside the cutoffs
+    with pytest.raises((ValueError, IndexError)):
+        net(far)
+    from nabladft_amd.escn import eSCN
+    from tests.test_escn_cpu import SMALL as ES
+    es = eSCN(**ES).to(dev)
+    bad.z[3] = 77
+    with pytest.raises(IndexError):
+        es(bad)
+    with pytest.raises((ValueError, IndexError)):
+        es(far)
