@@ -446,6 +446,13 @@ int nq_es_smearing(const float* geom, int64_t E, int32_t K, const float* offset,
 int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride, const int32_t* index, float* out, int64_t out_stride, int64_t n, int32_t I,
              int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate, void* stream);
 
+/* nq_rowop with one side living in per-block tensors (the m-blocks an SO(2) layer consumes / produces): seg_side 0 = the I side (rows of R), 1 = the S side
+ * (columns); seg_rows[nseg] (host) rows per block, seg_ptrs[nseg] (host array of device pointers) the contiguous [n][rows_k][C] tensors; x_or_out / stride: the
+ * other side (transpose == 0: S side in, I side out; else I side in, S side out).  nseg <= 8. */
+int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t stride, const int32_t* index, int32_t seg_side, int32_t nseg,
+                    const int32_t* seg_rows, float* const* seg_ptrs, int64_t n, int32_t I, int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate,
+                    void* stream);
+
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */
 int nq_loss_l1_l2(const float* energy, const float* y, int32_t B, const float* forces, const float* f_target, int32_t N, float coef_e,

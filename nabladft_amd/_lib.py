@@ -151,6 +151,7 @@ SYMBOLS = {
     "nq_es_wigner": (C.c_int, [_P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "nq_es_smearing": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P]),
     "nq_rowop": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "nq_rowop_blocks": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

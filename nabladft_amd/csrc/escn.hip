@@ -159,23 +159,38 @@ __global__ void k_es_smear(const float4* __restrict__ geom, long E, int K, const
 // forward:   out[o][i][c] (+)= sum_s R_o[i][s] X_row(o)[s][c]          R_o = R + o * r_stride (r_stride 0: one shared matrix), row(o) = index ? index[o] : o
 // transpose: out[o][s][c] (+)= sum_i R_o[i][s] Y[o][i][c]
 // One workgroup per row; the matrix and the row block are staged in LDS.
-struct RowOp { const float* R; long r_stride; const float* X; long x_stride; const int* index; float* out; long out_stride; int I, NSS, C, accumulate; };
+#define ROWOP_MAXSEG 8
+// A "segmented" side: the rows [seg_start[k], seg_start[k+1]) of that side live in their own contiguous tensor seg_ptr[k] ([n][rows_k][C]) -- the m-blocks of
+// an SO(2) layer -- instead of one [n][rows][C] tensor.
+struct RowSeg { int n; int start[ROWOP_MAXSEG + 1]; float* ptr[ROWOP_MAXSEG]; };
+struct RowOp { const float* R; long r_stride; const float* X; long x_stride; const int* index; float* out; long out_stride; int I, NSS, C, accumulate;
+               RowSeg segI, segS; };
+
+__device__ __forceinline__ float* rowseg_addr(const RowSeg& sg, long o, int row, int C) {
+  int k = 0;
+  while (k + 1 < sg.n && row >= sg.start[k + 1]) ++k;
+  return sg.ptr[k] + (o * (sg.start[k + 1] - sg.start[k]) + (row - sg.start[k])) * C;
+}
 
 __global__ __launch_bounds__(256) void k_rowop_fwd(RowOp p) {
   extern __shared__ __attribute__((aligned(16))) float es_lds[];
   float* sR = es_lds; float* sX = es_lds + p.I * p.NSS;
   const long o = blockIdx.x;
   const float* R = p.R + o * p.r_stride;
-  const float* X = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
   for (int t = threadIdx.x; t < p.I * p.NSS; t += 256) sR[t] = R[t];
-  for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) sX[t] = X[t];
+  if (p.segS.n) {                                   // input rows (the s side) come from the per-block tensors
+    for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) { const int k = t / p.C; sX[t] = rowseg_addr(p.segS, o, k, p.C)[t - k * p.C]; }
+  } else {
+    const float* X = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
+    for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) sX[t] = X[t];
+  }
   __syncthreads();
-  float* out = p.out + o * p.out_stride;
   for (int t = threadIdx.x; t < p.I * p.C; t += 256) {
     const int i = t / p.C, ch = t - i * p.C;
     float acc = 0.f;
     for (int k = 0; k < p.NSS; ++k) acc += sR[i * p.NSS + k] * sX[k * p.C + ch];
-    out[t] = p.accumulate ? out[t] + acc : acc;
+    float* dst = p.segI.n ? rowseg_addr(p.segI, o, i, p.C) + ch : p.out + o * p.out_stride + t;
+    *dst = p.accumulate ? *dst + acc : acc;
   }
 }
 __global__ __launch_bounds__(256) void k_rowop_tr(RowOp p) {
@@ -183,16 +198,20 @@ __global__ __launch_bounds__(256) void k_rowop_tr(RowOp p) {
   float* sR = es_lds; float* sY = es_lds + p.I * p.NSS;
   const long o = blockIdx.x;
   const float* R = p.R + o * p.r_stride;
-  const float* Y = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
   for (int t = threadIdx.x; t < p.I * p.NSS; t += 256) sR[t] = R[t];
-  for (int t = threadIdx.x; t < p.I * p.C; t += 256) sY[t] = Y[t];
+  if (p.segI.n) {                                   // input rows (the i side) come from the per-block tensors
+    for (int t = threadIdx.x; t < p.I * p.C; t += 256) { const int i = t / p.C; sY[t] = rowseg_addr(p.segI, o, i, p.C)[t - i * p.C]; }
+  } else {
+    const float* Y = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
+    for (int t = threadIdx.x; t < p.I * p.C; t += 256) sY[t] = Y[t];
+  }
   __syncthreads();
-  float* out = p.out + o * p.out_stride;
   for (int t = threadIdx.x; t < p.NSS * p.C; t += 256) {
     const int k = t / p.C, ch = t - k * p.C;
     float acc = 0.f;
     for (int i = 0; i < p.I; ++i) acc += sR[i * p.NSS + k] * sY[i * p.C + ch];
-    out[t] = p.accumulate ? out[t] + acc : acc;
+    float* dst = p.segS.n ? rowseg_addr(p.segS, o, k, p.C) + ch : p.out + o * p.out_stride + t;
+    *dst = p.accumulate ? *dst + acc : acc;
   }
 }
 
@@ -264,7 +283,36 @@ int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride,
   if (!R || !X || !out) return nq_fail(NQ_ERR_ARG, "null argument");
   const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
   if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB): split the matrix rows", I, NSS, C, lds);
-  RowOp p{R, (long)r_stride, X, (long)x_stride, index, out, (long)out_stride, I, NSS, C, accumulate};
+  RowOp p{R, (long)r_stride, X, (long)x_stride, index, out, (long)out_stride, I, NSS, C, accumulate, {}, {}};
+  p.segI.n = p.segS.n = 0;
+  if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+/* nq_rowop with one side split into per-block tensors (the m-blocks of an SO(2) layer): seg_side 0 = the I side (rows of R), 1 = the S side (columns of R);
+ * seg_rows[nseg] rows per block, seg_ptrs[nseg] device pointers of the contiguous [n][rows_k][C] tensors (HOST arrays).  The other side is x_or_out:
+ * transpose == 0: S side is the input, I side the output; transpose != 0: I side is the input, S side the output. */
+int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t stride, const int32_t* index, int32_t seg_side, int32_t nseg,
+                    const int32_t* seg_rows, float* const* seg_ptrs, int64_t n, int32_t I, int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate,
+                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, transpose ? "rowop_tr" : "rowop_fwd");
+  if (n <= 0) return NQ_OK;
+  if (!R || !x_or_out || !seg_rows || !seg_ptrs || nseg < 1 || nseg > ROWOP_MAXSEG) return nq_fail(NQ_ERR_ARG, "bad argument");
+  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB)", I, NSS, C, lds);
+  RowOp p{R, (long)r_stride, nullptr, 0, index, nullptr, 0, I, NSS, C, accumulate, {}, {}};
+  p.segI.n = p.segS.n = 0;
+  RowSeg& sg = seg_side == 0 ? p.segI : p.segS;
+  sg.n = nseg;
+  int tot = 0;
+  for (int k = 0; k < nseg; ++k) { sg.start[k] = tot; tot += seg_rows[k]; sg.ptr[k] = seg_ptrs[k]; }
+  sg.start[nseg] = tot;
+  if (tot != (seg_side == 0 ? I : NSS)) return nq_fail(NQ_ERR_ARG, "rowop: block rows sum to %d, expected %d", tot, seg_side == 0 ? I : NSS);
+  const bool seg_is_input = (transpose != 0) == (seg_side == 0);          // fwd: input = S side; tr: input = I side
+  if (seg_is_input) { p.out = x_or_out; p.out_stride = stride; }
+  else { p.X = x_or_out; p.x_stride = stride; }
   if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
   NQ_LAUNCH_CHECK();

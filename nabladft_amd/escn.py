@@ -129,6 +129,59 @@ def _rowop(R, r_stride, X, x_stride, index, n, I, NSS, Cc, transpose):
     return out
 
 
+def _rowop_blocks(R, r_stride, other, index, seg_side, rows, blocks, n, I, NSS, Cc, transpose):
+    """One launch of the row operator with one side in per-block tensors (csrc/escn.hip: nq_rowop_blocks)."""
+    k = len(rows)
+    seg_rows = (C.c_int32 * k)(*rows)
+    seg_ptrs = (C.c_void_p * k)(*[b.data_ptr() for b in blocks])
+    _lib.check(_lib.load().nq_rowop_blocks(_lib.ptr(R), r_stride, _lib.ptr(other), other.shape[1], None if index is None else _lib.ptr(index), seg_side, k, seg_rows,
+                                           seg_ptrs, n, I, NSS, Cc, int(transpose), 0, _st()))
+
+
+class _BlocksOutFn(torch.autograd.Function):
+    """(out_b) = op(R, X) with the segmented side as the OUTPUT: rotation into the edge frame (rows of R = the m-blocks) and from-grid (columns of R = the
+    m-blocks) write the blocks the SO(2) layers consume as separate contiguous tensors, in one pass over X.  Adjoint: _BlocksInFn, other orientation."""
+
+    @staticmethod
+    def forward(ctx, X, R, r_stride, I, NSS, Cc, transpose, seg_side, rows, index, inverse, n):
+        X = _f32(X)
+        ctx.meta = (R, r_stride, I, NSS, Cc, transpose, seg_side, rows, index, inverse, n, X.shape[0])
+        outs = [_new(n, r * Cc, like=X) for r in rows]
+        _rowop_blocks(R, r_stride, X, index, seg_side, rows, outs, n, I, NSS, Cc, transpose)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        R, r_stride, I, NSS, Cc, transpose, seg_side, rows, index, inverse, n, n_src = ctx.meta
+        gs = [_f32(g) for g in gs]
+        dX = _new(n, (I if transpose else NSS) * Cc, like=gs[0])
+        _rowop_blocks(R, r_stride, dX, None, seg_side, rows, gs, n, I, NSS, Cc, not transpose)
+        if index is not None:
+            order, ptr = inverse
+            dX = _segsum_raw(dX, order, ptr, n_src, dX.shape[1])
+        return (dX,) + (None,) * 11
+
+
+class _BlocksInFn(torch.autograd.Function):
+    """out = op(R, (X_b)) with the segmented side as the INPUT (rotate back, to-grid)."""
+
+    @staticmethod
+    def forward(ctx, R, r_stride, I, NSS, Cc, transpose, seg_side, rows, n, *Xs):
+        Xs = [_f32(x) for x in Xs]
+        ctx.meta = (R, r_stride, I, NSS, Cc, transpose, seg_side, rows, n)
+        out = _new(n, (NSS if transpose else I) * Cc, like=Xs[0])
+        _rowop_blocks(R, r_stride, out, None, seg_side, rows, Xs, n, I, NSS, Cc, transpose)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        R, r_stride, I, NSS, Cc, transpose, seg_side, rows, n = ctx.meta
+        g = _f32(g)
+        outs = [_new(n, r * Cc, like=g) for r in rows]
+        _rowop_blocks(R, r_stride, g, None, seg_side, rows, outs, n, I, NSS, Cc, not transpose)
+        return (None,) * 9 + tuple(outs)
+
+
 class _RowFn(torch.autograd.Function):
     """out[o] = R_o X_r(o) (transpose False) or R_o^T X_r(o) (True); R constant (per-row ``r_stride`` = I * NSS or shared 0).  With ``index`` the rows are
     gathered from node storage and the adjoint is summed back over ``inverse`` = (order, ptr) of the index."""
@@ -271,18 +324,12 @@ class SO2Block(torch.nn.Module):
         self.fc2_m0 = _Linear(hidden_channels, n0, bias=False)
         self.so2_conv = torch.nn.ModuleList([SO2Conv(m, sphere_channels, hidden_channels, edge_channels, lmax, mmax) for m in range(1, mmax + 1)])
 
-    def forward(self, x, x_edge, order):
-        """x: [E, n_red * C] in m-primary order -> same layout."""
-        Cc = self.C
-        n0 = order.m_size[0] * Cc
-        parts = [self.fc2_m0(_MulFn.apply(self.fc1_m0(x[:, :n0].contiguous()), self.fc1_dist0(x_edge, act=True)))]
-        off = n0
+    def forward(self, blocks, x_edge):
+        """blocks: [m = 0 | +1 | -1 | +2 | -2 ...] each [E, n_m * C] (contiguous, straight from the rotation) -> the same list."""
+        out = [self.fc2_m0(_MulFn.apply(self.fc1_m0(blocks[0]), self.fc1_dist0(x_edge, act=True)))]
         for m, conv in enumerate(self.so2_conv, start=1):
-            nm = order.m_size[m] * Cc
-            re, im = conv(x[:, off:off + nm].contiguous(), x[:, off + nm:off + 2 * nm].contiguous(), x_edge)
-            parts += [re, im]
-            off += 2 * nm
-        return torch.cat(parts, dim=1)
+            out += list(conv(blocks[2 * m - 1], blocks[2 * m], x_edge))
+        return out
 
 
 class MessageBlock(torch.nn.Module):
@@ -296,17 +343,19 @@ class MessageBlock(torch.nn.Module):
 
     def forward(self, x, G, K):
         """x: [N, n_full * C] -> messages summed per target atom, [N, n_full * C]."""
-        o, Cc = K.order, K.C
+        Cc = K.C
         x_edge = self.edge_block(G.x_dist, G)
-        rs = o.n_red * o.n_full
-        xs = _RowFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, G.src, G.src_inverse, G.E)        # rotate into the edge frame, |m| <= mmax rows
-        xt = _RowFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, G.dst, G.dst_inverse, G.E)
-        y = lin(self.so2_block_source(xs, x_edge, o), self.so2_block_target(xt, x_edge, o))
-        # point-wise SiLU on the (lmax, mmax) grid (so3.py:301-318), matrices with their columns in m-primary order
-        grid = _RowFn.apply(y, K.to_grid_red, 0, K.to_grid_red.shape[0], o.n_red, Cc, False, None, None, G.E)
-        y = _RowFn.apply(_silu(grid), K.from_grid_red, 0, K.from_grid_red.shape[0], o.n_red, Cc, True, None, None, G.E)
-        y = _RowFn.apply(y, G.wigner, rs, o.n_red, o.n_full, Cc, True, None, None, G.E)                       # rotate back (wigner_inv = transpose)
-        return _SegSumFn.apply(y, G.ptr, G.dst, G.N)                                                       # _reduce_edge: sum over the target's in-edges
+        o = K.order
+        rs, rows = o.n_red * o.n_full, K.block_rows
+        xs = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.src, G.src_inverse, G.E)     # rotate into the edge frame: one tensor per m-block
+        xt = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.dst, G.dst_inverse, G.E)
+        ys = [lin(a, b) for a, b in zip(self.so2_block_source(list(xs), x_edge), self.so2_block_target(list(xt), x_edge))]
+        # point-wise SiLU on the (lmax, mmax) grid (so3.py:301-318), grid matrices with their columns in m-primary order
+        ng = K.to_grid_red.shape[0]
+        grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Cc, False, 1, rows, G.E, *ys)
+        ys = _BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Cc, True, 1, rows, None, None, G.E)
+        y = _BlocksInFn.apply(G.wigner, rs, o.n_red, o.n_full, Cc, True, 0, rows, G.E, *ys)                              # rotate back (wigner_inv = transpose)
+        return _SegSumFn.apply(y, G.ptr, G.dst, G.N)                                   # _reduce_edge: sum over the target's in-edges
 
 
 class LayerBlock(torch.nn.Module):
@@ -406,6 +455,8 @@ class eSCN(torch.nn.Module):
             for k, v in self._const.items():
                 setattr(K, k, v.to(dev))
             K.order, K.C, K.device = self._order, self.sphere_channels, dev
+            o = self._order
+            K.block_rows = [o.m_size[0]] + [o.m_size[m] for m in range(1, o.mmax + 1) for _ in (0, 1)]           # rows of every m-block: m = 0, +1, -1, +2, -2, ...
             self._dev_const = K
         return self._dev_const
 
