@@ -500,11 +500,10 @@ class eSCN(torch.nn.Module):
         G.dst_inverse = (None, ptr)
         G.src_inverse = _inverse_lists(G.src, N)
         G.z = data.z.to(torch.int32).contiguous()
-        lo, hi, iso = (int(v) for v in torch.stack([G.z.min().long(), G.z.max().long(), deg.min().long()]).tolist())      # one host read for the three checks
+        lo, hi = (int(v) for v in torch.stack([G.z.min().long(), G.z.max().long()]).tolist())      # one host read: an index outside the table would read out of bounds
         if lo < 0 or hi >= self.max_num_elements:
             raise IndexError(f"atomic numbers {lo}..{hi} outside 0..{self.max_num_elements - 1} (max_num_elements)")
-        if iso == 0:
-            raise ValueError("an atom has no neighbour within the cutoff (the reference's edge-frame construction fails on such input too)")
+        # atoms without any neighbour are legal (as in the reference): their message is zero
         G.z_src, G.z_dst = G.z[G.src.long()].contiguous(), G.z[G.dst.long()].contiguous()
         T = self.max_num_elements
         G.z_inverse = _inverse_lists(G.z, T) + (T,)
