@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 8
+#define NQ_ABI_VERSION 9
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -316,7 +316,8 @@ int nq_packed_act0(const float* x, const float* alpha, const float* beta, int64_
 int nq_packed_act0_backward(const float* x, const float* alpha, const float* beta, const float* grad_y, int64_t rows, int32_t ncomp, int32_t F, int32_t kind,
                             float* grad_x, float* grad_alpha_rows, float* grad_beta_rows, void* stream);
 
-/* PhiSNet SphericalLinear (phisnet/nn/modules/spherical_linear.py:50-59) on packed irreps tensors x, y: [rows][(order+1)^2][F]: one Linear per order,
+/* PhiSNet SphericalLinear (phisnet/nn/modules/spherical_linear.py:50-59; also EquiformerV2's SO3_LinearV2,
+ * equiformer_v2/so3.py:587-625, order <= 6) on packed irreps tensors x, y: [rows][(order+1)^2][F]: one Linear per order,
  * y_L = x_L W_L^T (+ bias0 on the scalars), W: HOST array of order+1 device pointers to [Fout][Fin] matrices.  Forward and input gradient are one launch
  * for all orders; the weight gradient is one split-K contraction per order (scratch: nq_sph_weight_grad_scratch_floats floats; fixed summation order). */
 int nq_sph_linear_forward(const float* x, const float* const* W_host, const float* bias0, float* y, int64_t rows, int32_t order, int32_t Fin, int32_t Fout,
@@ -452,6 +453,39 @@ int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride,
 int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t stride, const int32_t* index, int32_t seg_side, int32_t nseg,
                     const int32_t* seg_rows, float* const* seg_ptrs, int64_t n, int32_t I, int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate,
                     void* stream);
+
+/* ---- EquiformerV2 building blocks (reference nablaDFT/equiformer_v2/; the graph, rotations, S2 grids and SO(2) GEMMs are the eSCN entries
+ * above, SO3_LinearV2 is nq_sph_linear_*) ------------------------------------------------------------------------------------------------------------------ */
+/* torch.nn.LayerNorm over rows of width W (radial_function.py:20, transformer_block.py:151): rows may be strided (x_stride / y_stride floats); stats [rows][2]
+ * (mean, rstd) out.  Backward: grad_x, grad_weight [W], grad_bias [W] (fixed summation order); scratch nq_eq_layernorm_scratch_floats floats. */
+int nq_eq_layernorm_forward(const float* x, int64_t x_stride, const float* weight, const float* bias, int64_t rows, int32_t W, float eps, float* y, int64_t y_stride,
+                            float* stats, void* stream);
+size_t nq_eq_layernorm_scratch_floats(int64_t rows, int32_t W);
+int nq_eq_layernorm_backward(const float* x, int64_t x_stride, const float* weight, const float* grad_y, int64_t g_stride, const float* stats, int64_t rows, int32_t W,
+                             float* grad_x, int64_t gx_stride, float* grad_weight, float* grad_bias, float* scratch, void* stream);
+/* EquivariantLayerNormArraySphericalHarmonics (layer_norm.py:117-215, normalization "component", std_balance_degrees): x, y [N][(lmax+1)^2][C]; LayerNorm
+ * (w0, b0) on the scalars; all l > 0 scaled by (mean_c sum_i balance_weight[i] x_ic^2 + eps)^-1/2 affine_weight[l-1][c]; stats [N][3] out; 1 <= lmax <= 6. */
+int nq_eq_norm_sh_forward(const float* x, const float* w0, const float* b0, const float* affine_weight, const float* balance_weight, int64_t N, int32_t lmax,
+                          int32_t C, float eps, float* y, float* stats, void* stream);
+size_t nq_eq_norm_sh_scratch_floats(int64_t N, int32_t lmax, int32_t C);
+int nq_eq_norm_sh_backward(const float* x, const float* w0, const float* affine_weight, const float* balance_weight, const float* grad_y, const float* stats,
+                           int64_t N, int32_t lmax, int32_t C, float* grad_x, float* grad_w0, float* grad_b0, float* grad_affine_weight, float* scratch,
+                           void* stream);
+/* Attention logits (transformer_block.py:343-350; activation.py:52-61): z[e][h] = sum_a alpha_dot[h][a] SmoothLeakyReLU_0.2(x[e][h][a]). */
+int nq_eq_logits_forward(const float* x, const float* alpha_dot, int64_t E, int32_t H, int32_t A, float* z, void* stream);
+size_t nq_eq_logits_scratch_floats(int64_t E, int32_t H, int32_t A);
+int nq_eq_logits_backward(const float* x, const float* alpha_dot, const float* grad_z, int64_t E, int32_t H, int32_t A, float* grad_x, float* grad_alpha_dot,
+                          float* scratch, void* stream);
+/* torch_geometric.utils.softmax(z, edge_index[1]) (transformer_block.py:352) for edges sorted by target: the in-edges of atom n are [ptr[n], ptr[n+1]). */
+int nq_eq_softmax_forward(const float* z, const int32_t* ptr, int64_t N, int32_t H, float* out, void* stream);
+int nq_eq_softmax_backward(const float* y, const float* grad_y, const int32_t* ptr, int64_t N, int32_t H, float* grad_z, void* stream);
+/* Messages times attention weights (transformer_block.py:357-370) on the per-block tensors x_b [E][rows_b][H V] (host arrays of device pointers, nseg <= 8),
+ * alpha [E][H].  grad == NULL: out_b = x_b alpha.  Else out_b = grad_b alpha and (grad_alpha != NULL) grad_alpha [E][H] = sum_b sum_rows,v grad_b x_b. */
+int nq_eq_head_scale(int32_t nseg, const int32_t* rows, const float* const* x, const float* const* grad, const float* alpha, int64_t E, int32_t H, int32_t V,
+                     float* const* out, float* grad_alpha, void* stream);
+/* out[n][i][c] = x[n][i][c] * row_scale[row_index ? row_index[n] : n] * coef_scale[i] (nullable factors): the rescale of SO3_Rotation.rotate_inv
+ * (so3.py:121-136,338-343) and GraphDropPath (drop.py:57-71). */
+int nq_eq_scale(const float* x, const float* row_scale, const int32_t* row_index, const float* coef_scale, int64_t N, int32_t I, int32_t C, float* out, void* stream);
 
 /* ---- loss / optimizer ------------------------------------------------------------------------ */
 /* loss[1] = coef_e * mean|E-y| + coef_f * mean_i ||F_i - Ft_i||_2 ; grad_energy[B], grad_forces[N][3] */

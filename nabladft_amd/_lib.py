@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -152,6 +152,19 @@ SYMBOLS = {
     "nq_es_smearing": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P]),
     "nq_rowop": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "nq_rowop_blocks": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "nq_eq_layernorm_forward": (C.c_int, [_P, _I64, _P, _P, _I64, _I32, _F, _P, _I64, _P, _P]),
+    "nq_eq_layernorm_scratch_floats": (_SZ, [_I64, _I32]),
+    "nq_eq_layernorm_backward": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
+    "nq_eq_norm_sh_forward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
+    "nq_eq_norm_sh_scratch_floats": (_SZ, [_I64, _I32, _I32]),
+    "nq_eq_norm_sh_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "nq_eq_logits_forward": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_eq_logits_scratch_floats": (_SZ, [_I64, _I32, _I32]),
+    "nq_eq_logits_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "nq_eq_softmax_forward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "nq_eq_softmax_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P]),
+    "nq_eq_head_scale": (C.c_int, [_I32, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "nq_eq_scale": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_loss_l1_l2": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_loss_mse": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),

@@ -41,7 +41,7 @@ struct GemmArgs {
   // (r, m) = (q / w, q % w), w = 2L+1, stored at packed row r * ncomp + L*L + m
   int rm_rows, rm_ncomp, rm_w, rm_base;   // RM == 2 (weight gradient of one order): w / base given here
   int rm_s;                               // RM == 3 (weight gradients of all orders): splits per component; blockIdx.z = component * rm_s + split
-  const float* Bz[5];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
+  const float* Bz[7];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
   const float* resid; float ea, eb;       // EPI_SILU_RES (resid nullable, same leading dimension as C)
 };
 __device__ __forceinline__ long rm_row(int q, int w, int ncomp, int base) { return (long)(q / w) * ncomp + base + q % w; }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   // row maps (see GemmArgs): RM 1 = all orders in one launch (blockIdx.z = L; A rows and C rows mapped), RM 2 = one order, reduction index mapped
   const int zc = RM == 3 ? (int)blockIdx.z / p.rm_s : 0;                                   // RM 3: packed component this split belongs to
-  const int zL = RM == 3 ? (zc >= 16 ? 4 : zc >= 9 ? 3 : zc >= 4 ? 2 : zc >= 1 ? 1 : 0) : (int)blockIdx.z;
+  const int zL = RM == 3 ? (zc >= 36 ? 6 : zc >= 25 ? 5 : zc >= 16 ? 4 : zc >= 9 ? 3 : zc >= 4 ? 2 : zc >= 1 ? 1 : 0) : (int)blockIdx.z;
   const int mw = RM == 1 || RM == 3 ? 2 * zL + 1 : p.rm_w, mn = p.rm_ncomp, mb = RM == 1 || RM == 3 ? zL * zL : p.rm_base;
   const int Meff = RM == 1 ? p.rm_rows * mw : p.M;
   const float* const Bsrc = RM == 1 ? p.Bz[blockIdx.z] : p.B;
@@ -534,7 +534,7 @@ int nq_reduce_partials(hipStream_t st, const float* part, int nsplit, long strid
 // x, y: [rows][(order+1)^2][F]; one weight matrix per order.  Forward and input gradient: ONE launch for all orders (blockIdx.z = L, rows of
 // order L found through the row map) instead of order+1 GEMMs on gathered copies; weight gradient: one split-K launch per order.
 static int sph_check(long rows, int order, int Fin, int Fout) {
-  if (order < 0 || order > 4) return nq_fail(NQ_ERR_ARG, "spherical linear: order must be in 0..4");
+  if (order < 0 || order > 6) return nq_fail(NQ_ERR_ARG, "spherical linear: order must be in 0..6");
   if (rows < 0 || rows * (2L * order + 1) > 2000000000L || Fin <= 0 || Fout <= 0) return nq_fail(NQ_ERR_ARG, "spherical linear: bad sizes");
   return NQ_OK;
 }
@@ -546,7 +546,7 @@ static int sph_tn_splits(long rows, int ncomp) {
   if (s > by_rows) s = by_rows;
   return (int)(s < 1 ? 1 : s);
 }
-struct SphOut { float* out[5]; };
+struct SphOut { float* out[7]; };
 // out[L][i] = sum over the (2L+1) * s partial slabs of order L, in slab order (deterministic)
 __global__ void k_reduce_grouped(const float* __restrict__ part, int s, long cnt, SphOut o) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -587,11 +587,22 @@ def _s2_samples(lmax, res_beta, res_alpha):
     return spherical_harmonics(list(range(lmax + 1)), xyz, True, "integral")                          # [B, A, (lmax+1)^2]
 
 
+def _s2_degree_factor(lmax, normalization):
+    """Per-coefficient factor a_l of ToS2Grid relative to the integral-normalised harmonics (FromS2Grid divides by it, so from_grid(to_grid(x)) = x in every
+    normalisation): "integral" 1; "component" sqrt(4 pi / ((2l + 1)(lmax + 1))) -- unit-variance coefficients give a unit-variance signal; "norm"
+    sqrt(4 pi / (lmax + 1)).  [memory of e3nn 0.5.1's s2grid.py, PARITY UNPINNED; EquiformerV2 uses "component", equiformer_v2_oc20.py:282]"""
+    assert normalization in ("integral", "component", "norm")
+    f = []
+    for l in range(lmax + 1):
+        a = {"integral": 1.0, "component": math.sqrt(4 * math.pi / ((2 * l + 1) * (lmax + 1))), "norm": math.sqrt(4 * math.pi / (lmax + 1))}[normalization]
+        f += [a] * (2 * l + 1)
+    return torch.tensor(f, dtype=torch.float64)
+
+
 class ToS2Grid(nn.Module):
     def __init__(self, lmax=None, res=None, normalization="component", dtype=None, device=None):
         super().__init__()
-        assert normalization == "integral", "only the normalisation eSCN uses is restated"
-        Y = _s2_samples(lmax, res[0], res[1]).to(torch.get_default_dtype())
+        Y = (_s2_samples(lmax, res[0], res[1]) * _s2_degree_factor(lmax, normalization)).to(torch.get_default_dtype())
         self.register_buffer("sha", torch.eye(res[1], dtype=Y.dtype))                                # [a, m]
         self.register_buffer("shb", Y.permute(1, 0, 2).contiguous())                                 # [m, b, i]
 
@@ -599,8 +610,8 @@ class ToS2Grid(nn.Module):
 class FromS2Grid(nn.Module):
     def __init__(self, res=None, lmax=None, normalization="component", lmax_in=None, dtype=None, device=None):
         super().__init__()
-        assert normalization == "integral" and res[0] % 2 == 0
-        Y = _s2_samples(lmax, res[0], res[1])
+        assert res[0] % 2 == 0
+        Y = _s2_samples(lmax, res[0], res[1]) / _s2_degree_factor(lmax, normalization)
         w = s2_quadrature_weights(res[0]) * (2 * math.pi / res[1])                                    # d(cos beta) d(alpha) per grid point
         F = (Y * w[:, None, None]).to(torch.get_default_dtype())
         self.register_buffer("sha", torch.eye(res[1], dtype=F.dtype))                                # [a, m]
