@@ -185,10 +185,14 @@ def bench_gemnet(args, rank, world, local_dev, dev):
         dist.destroy_process_group()
 
 
-def bench_escn(args, rank, world, local_dev, dev):
-    """--model escn: BASELINE.json configs[4] (config/model/escn-oc.yaml) through scripts/bench_escn.py; same JSON contract, conformer-steps/s, fp32."""
+def bench_escn(args, rank, world, local_dev, dev, which="escn"):
+    """--model escn / equiformer: BASELINE.json configs[4] (config/model/escn-oc.yaml, config/model/equiformer_v2_oc20.yaml) through scripts/bench_escn.py /
+    scripts/bench_equiformer.py; same JSON contract, conformer-steps/s, fp32."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import bench_escn as BE
+    import bench_escn
+    import bench_equiformer
+    BE = bench_escn if which == "escn" else bench_equiformer
+    ref_batch = 8 if which == "escn" else 2                       # config/escn-oc.yaml:11, config/equiformer_v2_oc20.yaml:11
 
     def sync():
         torch.cuda.synchronize()
@@ -202,7 +206,7 @@ def bench_escn(args, rank, world, local_dev, dev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    b8 = BE.run(8, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != 8 else None
+    b8 = BE.run(ref_batch, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != ref_batch else None
     bf = None
     if world == 1 and not args.no_roofline:
         bf = BE.run(mol, args.steps, args.warmup + 2, kernels=False, device=dev, precision="bf16")
@@ -217,7 +221,7 @@ def bench_escn(args, rank, world, local_dev, dev):
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
                "parity": rec.get("parity"), "bf16_mode": bf,
-               "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
+               f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -265,6 +269,7 @@ WORKLOADS = {
     "qhnet": "QHNet (config/qhnet.yaml) Hamiltonian training step -- see scripts/bench_qhnet.py",
     "gemnet": "GemNet-OC (config/model/gemnet-oc.yaml) energy + direct forces training step -- see scripts/bench_gemnet.py",
     "escn": "eSCN (config/model/escn-oc.yaml) energy + direct forces training step -- see scripts/bench_escn.py",
+    "equiformer": "EquiformerV2 (config/model/equiformer_v2_oc20.yaml) energy + direct forces training step -- see scripts/bench_equiformer.py",
     "painn-spk": "PaiNN (config/painn.yaml -> schnetpack PaiNN F=128 L=6 R=100 rc=5A cosine cutoff, Atomwise+Forces; restated, parity unpinned) "
                  "energy+forces train step incl. neighbour list, MSE+MSE loss, grad all-reduce, no clip, AdamW lr 1e-4 wd 0.01",
 }
@@ -403,8 +408,8 @@ def main():
         return bench_qhnet(args, rank, world, local_dev, dev)
     if args.model == "gemnet":
         return bench_gemnet(args, rank, world, local_dev, dev)
-    if args.model == "escn":
-        return bench_escn(args, rank, world, local_dev, dev)
+    if args.model in ("escn", "equiformer"):
+        return bench_escn(args, rank, world, local_dev, dev, which=args.model)
     torch.manual_seed(23)                                       # config/painn-oc.yaml:38 seed
     model, step = build_step(args.model, dev)
     batches = make_batches(1 + rank, 4, args.batch, dev)
@@ -588,7 +593,7 @@ def main():
                   "batch16_bf16_gemms": {k: g16b[k] for k in ("value", "unit", "ms_per_step", "dtype", "final_loss")},
                   "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
-    escn = None
+    escn = equiformer = None
     if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
         # BASELINE.json configs[4] (eSCN, config/model/escn-oc.yaml, fp32) in the same record
         torch.cuda.empty_cache()
@@ -596,6 +601,12 @@ def main():
         e16 = BE.run(16, 3, 2, kernels=True, device=dev)
         e16.pop("_dt", None)
         escn = {"workload": e16.pop("workload"), "batch16": e16, "cpu_baseline": None if args.no_cpu_baseline else BE.cpu_baseline(seconds_budget=10.0)}
+        # ... and its second model, EquiformerV2 (config/model/equiformer_v2_oc20.yaml, fp32, training mode)
+        torch.cuda.empty_cache()
+        import bench_equiformer as BQ2
+        q16 = BQ2.run(16, 3, 2, kernels=True, device=dev)
+        q16.pop("_dt", None)
+        equiformer = {"workload": q16.pop("workload"), "batch16": q16, "cpu_baseline": None if args.no_cpu_baseline else BQ2.cpu_baseline(seconds_budget=8.0)}
 
     if rank == 0:
         out = {
@@ -613,6 +624,7 @@ def main():
             "hamiltonian": hamiltonian,
             "gemnet_oc": gemnet,
             "escn": escn,
+            "equiformer_v2": equiformer,
             "reference_batch_size_32": small,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)

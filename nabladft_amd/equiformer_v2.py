@@ -32,6 +32,23 @@ _AVG_NUM_NODES = 39.65745326960467          # equiformer_v2_oc20.py:47-48
 _AVG_DEGREE = 19.16009564536883
 
 
+class CosineLRLambda:
+    """lr_scheduler.py:33-50 (the ``lr_lambda`` of config/model/equiformer_v2_oc20.yaml:47-55): linear warm-up from ``warmup_factor`` to 1 over ``warmup_epochs``
+    steps, then half a cosine down to ``lr_min_factor`` at ``epochs``."""
+
+    def __init__(self, scheduler_params) -> None:
+        self.warmup_epochs, self.lr_warmup_factor = scheduler_params["warmup_epochs"], scheduler_params["warmup_factor"]
+        self.max_epochs, self.lr_min_factor = scheduler_params["epochs"], scheduler_params["lr_min_factor"]
+
+    def __call__(self, current_step: int) -> float:
+        if current_step <= self.warmup_epochs:
+            a = current_step / float(self.warmup_epochs)
+            return self.lr_warmup_factor * (1.0 - a) + a
+        if current_step >= self.max_epochs:
+            return self.lr_min_factor
+        return self.lr_min_factor + 0.5 * (1 - self.lr_min_factor) * (1 + math.cos(math.pi * current_step / self.max_epochs))
+
+
 # ---- autograd wrappers of csrc/equiformer.hip ----------------------------------------------------------------------------------------------------------------
 class _LayerNormFn(torch.autograd.Function):
     """torch.nn.LayerNorm over the last axis of x [rows, W]."""

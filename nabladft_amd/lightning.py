@@ -189,6 +189,12 @@ class eSCNLightning(GemNetOCLightning):
     ``net`` = nabladft_amd.escn.eSCN."""
 
 
+class EquiformerV2_OC20_Lightning(GemNetOCLightning):
+    """equiformer_v2/equiformer_v2_oc20.py:643-817: the same wrapper contract (energy / forces dict, 2 L1 + 100 L2Loss per config/model/equiformer_v2_oc20.yaml,
+    learning rate logged on the step); ``net`` = nabladft_amd.equiformer_v2.EquiformerV2_OC20; the yaml's LambdaLR takes
+    ``nabladft_amd.equiformer_v2.CosineLRLambda``."""
+
+
 class QHNetLightning(_Task):
     """``net`` is ``nabladft_amd.qhnet.QHNet``.  Losses that declare ``packed = True`` (nabladft_amd.hamiltonian.HamiltonianLoss) get the
     diagonal blocks packed molecule after molecule -- prediction and target -- and never see the block_diag matrix; any other loss (e.g. the

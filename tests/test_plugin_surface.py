@@ -378,3 +378,74 @@ def test_escn_config_instantiates():
         d = type("D", (), {})()
         d.pos, d.z, d.batch = torch.zeros(3, 3), torch.ones(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)
         task.net(d)
+
+
+EQUIFORMER_YAML = """
+_target_: nabladft_amd.EquiformerV2_OC20_Lightning
+model_name: "Equiformer-v2"
+net:
+  _target_: nabladft_amd.EquiformerV2_OC20
+  otf_graph: true
+  num_layers: 12
+  sphere_channels: 128
+  attn_hidden_channels: 64
+  num_heads: 8
+  attn_alpha_channels: 64
+  attn_value_channels: 16
+  ffn_hidden_channels: 128
+  norm_type: 'layer_norm_sh'
+  lmax_list: [6]
+  mmax_list: [2]
+  num_sphere_samples: 128
+  edge_channels: 128
+  use_atom_edge_embedding: true
+  share_atom_edge_embedding: false
+  distance_function: 'gaussian'
+  num_distance_basis: 512
+  attn_activation: 'silu'
+  use_s2_act_attn: false
+  use_attn_renorm: true
+  ffn_activation: 'silu'
+  use_gate_act: false
+  use_grid_mlp: true
+  use_sep_s2_act: true
+  alpha_drop: 0.1
+  drop_path_rate: 0.05
+  proj_drop: 0.0
+  weight_init: 'uniform'
+  regress_forces: true
+  use_pbc: false
+  max_neighbors: 30
+  max_radius: 12.0
+  max_num_elements: 65
+optimizer: {_target_: torch.optim.AdamW, _partial_: true, lr: 0.0004, weight_decay: 0.001}
+lr_scheduler:
+  _target_: torch.optim.lr_scheduler.LambdaLR
+  _partial_: true
+  lr_lambda:
+    _target_: nabladft_amd.equiformer_v2.CosineLRLambda
+    scheduler_params: {warmup_factor: 0.2, warmup_epochs: 0.1, epochs: 1000, lr_min_factor: 0.01}
+losses:
+  energy: {_target_: torch.nn.L1Loss}
+  forces: {_target_: nabladft_amd.L2Loss}
+loss_coefs: {energy: 2.0, forces: 100.0}
+metric: null
+"""
+
+
+def test_equiformer_config_instantiates():
+    """config/model/equiformer_v2_oc20.yaml with the `_target_` lines pointed at this package."""
+    import nabladft_amd as nq
+    from nabladft_amd.config import instantiate
+    task = instantiate(yaml.safe_load(EQUIFORMER_YAML))
+    assert isinstance(task, nq.EquiformerV2_OC20_Lightning) and isinstance(task.net, nq.EquiformerV2_OC20) and task.net.num_params == 83072002
+    assert all(k.startswith("net.") for k in task.state_dict())
+    opt = task.configure_optimizers()
+    assert opt["optimizer"].defaults["weight_decay"] == 0.001
+    sched = opt["lr_scheduler"]["scheduler"]
+    lam = sched.lr_lambdas[0]
+    assert abs(lam(0) - 0.2) < 1e-12 and abs(lam(500) - (0.01 + 0.5 * 0.99)) < 1e-12 and lam(1000) == 0.01
+    with pytest.raises(RuntimeError, match="MI355X"):
+        d = type("D", (), {})()
+        d.pos, d.z, d.batch = torch.zeros(3, 3), torch.ones(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)
+        task.net(d)
