@@ -454,6 +454,17 @@ int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t s
                     const int32_t* seg_rows, float* const* seg_ptrs, int64_t n, int32_t I, int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate,
                     void* stream);
 
+/* Rotations that use the degree-block structure of the Wigner rows (235 of 29 x 49 entries at lmax 6 / mmax 2), no LDS.  nq_es_rotate (SO3_Embedding._rotate):
+ * block(i)[o][row][c_off + c] = sum_k W_o[i][l_i^2 + k] x[index ? index[o] : o][l_i^2 + k][c]; red_l [n_red] (HOST) = degree of every kept row, rows in W's
+ * order; blocks = nseg contiguous tensors [E][seg_rows_k][c_stride] (HOST arrays; two rotations may fill two channel halves of one block).
+ * nq_es_rotate_back (_rotate_inv fused with _reduce_edge): out[n][s][c] = coef_scale[s] sum_{q in [ptr[n], ptr[n+1])} sum_i W_o[i][s] block(i)[o][row][c_off + c],
+ * o = order ? order[q] : q; ptr == NULL: one output row per edge; coef_scale nullable. */
+int nq_es_rotate(const float* W, int64_t w_stride, const float* x, int64_t x_stride, const int32_t* index, int32_t nseg, const int32_t* seg_rows,
+                 float* const* seg_ptrs, int32_t c_stride, int32_t c_off, int64_t E, const int32_t* red_l, int32_t n_red, int32_t lmax, int32_t C, void* stream);
+int nq_es_rotate_back(const float* W, int64_t w_stride, int32_t nseg, const int32_t* seg_rows, float* const* seg_ptrs, int32_t c_stride, int32_t c_off,
+                      const int32_t* ptr, const int32_t* order, const float* coef_scale, float* out, int64_t n_out, const int32_t* red_l, int32_t n_red,
+                      int32_t lmax, int32_t C, void* stream);
+
 /* ---- EquiformerV2 building blocks (reference nablaDFT/equiformer_v2/; the graph, rotations, S2 grids and SO(2) GEMMs are the eSCN entries
  * above, SO3_LinearV2 is nq_sph_linear_*) ------------------------------------------------------------------------------------------------------------------ */
 /* torch.nn.LayerNorm over rows of width W (radial_function.py:20, transformer_block.py:151): rows may be strided (x_stride / y_stride floats); stats [rows][2]

@@ -152,6 +152,8 @@ SYMBOLS = {
     "nq_es_smearing": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P]),
     "nq_rowop": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "nq_rowop_blocks": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "nq_es_rotate": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _P, _I32, _I32, _I64, _P, _I32, _I32, _I32, _P]),
+    "nq_es_rotate_back": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _P]),
     "nq_eq_layernorm_forward": (C.c_int, [_P, _I64, _P, _P, _I64, _I32, _F, _P, _I64, _P, _P]),
     "nq_eq_layernorm_scratch_floats": (_SZ, [_I64, _I32]),
     "nq_eq_layernorm_backward": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),

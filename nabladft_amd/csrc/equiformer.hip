@@ -57,16 +57,24 @@ __global__ __launch_bounds__(256) void k_eq_ln_bwd(const float* __restrict__ x, 
   float* o = gx + r * gx_stride;
   for (int c = lane; c < W; c += 64) { const float gh = gr[c] * w[c], xh = (xr[c] - st.x) * st.y; o[c] = st.y * (gh - a - xh * bsum); }
 }
-// parameter gradients: part[chunk][0][c] = sum_r g xhat, part[chunk][1][c] = sum_r g over the chunk's rows (in row order); thread = column
-__global__ __launch_bounds__(256) void k_eq_ln_wgrad(const float* __restrict__ x, long x_stride, const float* __restrict__ g, long g_stride,
-                                                     const float2* __restrict__ stats, long rows, int W, int rows_per_chunk, float* __restrict__ part) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= W) return;
+// parameter gradients: part[chunk][0][c] = sum_r g xhat, part[chunk][1][c] = sum_r g over the chunk's rows; 64 columns x 16 row lanes per workgroup (lane j takes
+// the rows r0 + j, r0 + j + 16, ...; the partial sums are added in lane order)
+__global__ __launch_bounds__(1024) void k_eq_ln_wgrad(const float* __restrict__ x, long x_stride, const float* __restrict__ g, long g_stride,
+                                                      const float2* __restrict__ stats, long rows, int W, int rows_per_chunk, float* __restrict__ part) {
+  __shared__ float red[2][16][64];
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
   const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   float gw = 0.f, gb = 0.f;
-  for (long r = r0; r < r1; ++r) { const float2 st = stats[r]; const float gv = g[r * g_stride + c]; gw += gv * (x[r * x_stride + c] - st.x) * st.y; gb += gv; }
-  part[((long)blockIdx.x * 2) * W + c] = gw;
-  part[((long)blockIdx.x * 2 + 1) * W + c] = gb;
+  if (c < W)
+    for (long r = r0 + j; r < r1; r += 16) { const float2 st = stats[r]; const float gv = g[r * g_stride + c]; gw += gv * (x[r * x_stride + c] - st.x) * st.y; gb += gv; }
+  red[0][j][lane] = gw; red[1][j][lane] = gb;
+  __syncthreads();
+  if (j < 2 && c < W) {
+    float a = 0.f;
+    for (int k = 0; k < 16; ++k) a += red[j][k][lane];
+    part[((long)blockIdx.x * 2 + j) * W + c] = a;
+  }
 }
 // out[i] = sum_k part[k * stride + i] in k order, i < cnt
 __global__ void k_eq_reduce(const float* __restrict__ part, int nparts, long stride, long cnt, float* __restrict__ out) {
@@ -261,7 +269,8 @@ int nq_eq_layernorm_forward(const float* x, int64_t x_stride, const float* weigh
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
-size_t nq_eq_layernorm_scratch_floats(int64_t rows, int32_t W) { return (size_t)nq_cdiv(rows, nq_cdiv(rows, 256) < 64 ? 64 : nq_cdiv(rows, 256)) * 2 * W + 64; }
+static int ln_rows_per_chunk(long rows) { const int per = nq_cdiv(rows, 128); return per < 64 ? 64 : per; }        // <= 128 chunks of >= 64 rows
+size_t nq_eq_layernorm_scratch_floats(int64_t rows, int32_t W) { return (size_t)nq_cdiv(rows, ln_rows_per_chunk(rows)) * 2 * W + 64; }
 /* grad_x (strided like x), grad_weight [W], grad_bias [W]; scratch: nq_eq_layernorm_scratch_floats(rows, W) floats. */
 int nq_eq_layernorm_backward(const float* x, int64_t x_stride, const float* weight, const float* grad_y, int64_t g_stride, const float* stats, int64_t rows, int32_t W,
                              float* grad_x, int64_t gx_stride, float* grad_weight, float* grad_bias, float* scratch, void* stream) {
@@ -276,9 +285,9 @@ int nq_eq_layernorm_backward(const float* x, int64_t x_stride, const float* weig
   hipLaunchKernelGGL(k_eq_ln_bwd, dim3(nq_cdiv(rows, 4)), dim3(256), 0, st, x, (long)x_stride, weight, grad_y, (long)g_stride, (const float2*)stats, (long)rows, W,
                      grad_x, (long)gx_stride);
   NQ_LAUNCH_CHECK();
-  const int per = nq_cdiv(rows, 256) < 64 ? 64 : nq_cdiv(rows, 256);        // <= 256 chunks of >= 64 rows
+  const int per = ln_rows_per_chunk(rows);
   const int chunks = nq_cdiv(rows, per);
-  hipLaunchKernelGGL(k_eq_ln_wgrad, dim3(chunks, nq_cdiv(W, 256)), dim3(256), 0, st, x, (long)x_stride, grad_y, (long)g_stride, (const float2*)stats, (long)rows, W,
+  hipLaunchKernelGGL(k_eq_ln_wgrad, dim3(chunks, nq_cdiv(W, 64)), dim3(1024), 0, st, x, (long)x_stride, grad_y, (long)g_stride, (const float2*)stats, (long)rows, W,
                      per, scratch);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_eq_reduce, EQ_GRID((long)W), scratch, chunks, (long)2 * W, (long)W, grad_weight);        // part[k][0][c] at k * 2W + c

@@ -215,6 +215,112 @@ __global__ __launch_bounds__(256) void k_rowop_tr(RowOp p) {
   }
 }
 
+// ---- rotations with the block structure of the Wigner matrices ------------------------------------------------------------------------------------------------
+// Row i of an edge's Wigner block (degree l_i) touches only the 2 l_i + 1 coefficients of that degree: 235 of the 29 x 49 entries at lmax 6 / mmax 2.  One
+// workgroup per edge (or per node when the transposed form also sums over a node's edges), thread = channel: the coefficients of one degree sit in registers,
+// the matrix entries are wavefront-uniform loads; no LDS.  The edge-frame side lives in per-m-block tensors [n][rows_k][c_stride] at channel offset c_off
+// (two rotations can fill the two halves of one concatenated block).
+#define ROT_MAXROWS 13
+struct RotArgs {
+  const float* W; long w_stride;                 // per-edge rows [.][n_full]
+  const float* X; long x_stride; const int* index;   // forward input: [.][n_full][C], row of edge o = index ? index[o] : o
+  float* out;                                    // transposed output [n_out][n_full][C]
+  const int* ptr; const int* order;              // transposed: out row n sums the edges order[q] (or q), q in [ptr[n], ptr[n+1]); ptr null: n is the edge
+  const float* coef_scale;                       // transposed: optional factor per output coefficient
+  int n_full, lmax, C, c_stride, c_off;
+  int nrows[ES_MAXL + 1];
+  unsigned char rows[ES_MAXL + 1][ROT_MAXROWS];  // reduced rows of every degree
+  unsigned char seg_of[64], row_in_seg[64];
+  int seg_rows[ROWOP_MAXSEG];
+  float* seg_ptr[ROWOP_MAXSEG];
+};
+__device__ __forceinline__ float* rot_addr(const RotArgs& p, long o, int i) {
+  const int sg = p.seg_of[i];
+  return p.seg_ptr[sg] + (o * p.seg_rows[sg] + p.row_in_seg[i]) * (long)p.c_stride + p.c_off;
+}
+__global__ __launch_bounds__(256) void k_es_rot_fwd(RotArgs p) {
+  const long o = blockIdx.x;
+  const float* __restrict__ R = p.W + o * p.w_stride;
+  const float* __restrict__ X = p.X + (p.index ? (long)p.index[o] : o) * p.x_stride;
+  for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+#pragma unroll
+    for (int l = 0; l <= ES_MAXL; ++l) {
+      if (l <= p.lmax) {
+        float x[2 * ES_MAXL + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * l + 1; ++k) x[k] = X[(long)(l * l + k) * p.C + ch];
+        for (int r = 0; r < p.nrows[l]; ++r) {
+          const int i = p.rows[l][r];
+          const float* __restrict__ Rr = R + i * p.n_full + l * l;
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 2 * l + 1; ++k) acc = fmaf(Rr[k], x[k], acc);
+          rot_addr(p, o, i)[ch] = acc;
+        }
+      }
+    }
+  }
+}
+// grid (output rows, degrees): the workgroup (n, l) owns the 2l + 1 output coefficients of degree l (7x the parallelism of one workgroup per output row; the
+// degrees touch disjoint matrix entries and block rows, so nothing is read twice)
+template <int L>
+__device__ __forceinline__ void rot_tr_degree(const RotArgs& p, long n, long q0, long q1) {
+  for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+    float acc[2 * L + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * L + 1; ++k) acc[k] = 0.f;
+    for (long q = q0; q < q1; ++q) {
+      const long o = p.order ? (long)p.order[q] : q;
+      const float* __restrict__ R = p.W + o * p.w_stride + L * L;
+      for (int r = 0; r < p.nrows[L]; ++r) {
+        const int i = p.rows[L][r];
+        const float y = rot_addr(p, o, i)[ch];
+        const float* __restrict__ Rr = R + i * p.n_full;
+#pragma unroll
+        for (int k = 0; k < 2 * L + 1; ++k) acc[k] = fmaf(Rr[k], y, acc[k]);
+      }
+    }
+    float* out = p.out + (n * (long)p.n_full + L * L) * p.C + ch;
+#pragma unroll
+    for (int k = 0; k < 2 * L + 1; ++k) out[(long)k * p.C] = p.coef_scale ? acc[k] * p.coef_scale[L * L + k] : acc[k];
+  }
+}
+__global__ __launch_bounds__(256) void k_es_rot_tr(RotArgs p) {
+  const long n = blockIdx.x;
+  long q0 = n, q1 = n + 1;
+  if (p.ptr) { q0 = p.ptr[n]; q1 = p.ptr[n + 1]; }
+  switch (blockIdx.y) {
+    case 0: rot_tr_degree<0>(p, n, q0, q1); break;
+    case 1: rot_tr_degree<1>(p, n, q0, q1); break;
+    case 2: rot_tr_degree<2>(p, n, q0, q1); break;
+    case 3: rot_tr_degree<3>(p, n, q0, q1); break;
+    case 4: rot_tr_degree<4>(p, n, q0, q1); break;
+    case 5: rot_tr_degree<5>(p, n, q0, q1); break;
+    default: rot_tr_degree<6>(p, n, q0, q1); break;
+  }
+}
+static int rot_setup(RotArgs& p, const float* W, int64_t w_stride, int32_t nseg, const int32_t* seg_rows, float* const* seg_ptrs, int32_t c_stride, int32_t c_off,
+                     const int32_t* red_l, int32_t n_red, int32_t lmax, int32_t C) {
+  if (!W || !seg_rows || !seg_ptrs || !red_l || nseg < 1 || nseg > ROWOP_MAXSEG || n_red < 1 || n_red > 64 || lmax < 0 || lmax > ES_MAXL || C < 1 ||
+      c_off < 0 || c_off + C > c_stride)
+    return nq_fail(NQ_ERR_ARG, "rotate: bad argument");
+  p = RotArgs{};
+  p.W = W; p.w_stride = (long)w_stride; p.n_full = (lmax + 1) * (lmax + 1); p.lmax = lmax; p.C = C; p.c_stride = c_stride; p.c_off = c_off;
+  int tot = 0;
+  for (int k = 0; k < nseg; ++k) {
+    if (!seg_ptrs[k] || seg_rows[k] < 1) return nq_fail(NQ_ERR_ARG, "rotate: bad block %d", k);
+    p.seg_rows[k] = seg_rows[k]; p.seg_ptr[k] = seg_ptrs[k];
+    for (int r = 0; r < seg_rows[k] && tot < 64; ++r, ++tot) { p.seg_of[tot] = (unsigned char)k; p.row_in_seg[tot] = (unsigned char)r; }
+  }
+  if (tot != n_red) return nq_fail(NQ_ERR_ARG, "rotate: block rows sum to %d, expected %d", tot, n_red);
+  for (int i = 0; i < n_red; ++i) {
+    const int l = red_l[i];
+    if (l < 0 || l > lmax || p.nrows[l] >= ROT_MAXROWS) return nq_fail(NQ_ERR_ARG, "rotate: bad degree list");
+    p.rows[l][p.nrows[l]++] = (unsigned char)i;
+  }
+  return NQ_OK;
+}
+
 // =========================================================================================================================================================
 #define ES_GRID(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256), 0, st
 
@@ -315,6 +421,39 @@ int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t s
   else { p.X = x_or_out; p.x_stride = stride; }
   if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* Rotation into the edge frame with the degree-block structure of W (SO3_Embedding._rotate, so3.py:265-283): for every edge o and kept row i (degree
+ * red_l[i], HOST array, rows in the order of W): block(i)[o][row][c_off + c] = sum_k W_o[i][l^2 + k] x[index ? index[o] : o][l^2 + k][c], k < 2l + 1.
+ * Blocks: nseg contiguous tensors [E][seg_rows_k][c_stride] (HOST arrays).  W_o = W + o * w_stride, rows of n_full = (lmax+1)^2 floats. */
+int nq_es_rotate(const float* W, int64_t w_stride, const float* x, int64_t x_stride, const int32_t* index, int32_t nseg, const int32_t* seg_rows,
+                 float* const* seg_ptrs, int32_t c_stride, int32_t c_off, int64_t E, const int32_t* red_l, int32_t n_red, int32_t lmax, int32_t C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_rotate");
+  if (E <= 0) return NQ_OK;
+  if (!x) return nq_fail(NQ_ERR_ARG, "rotate: null input");
+  RotArgs p;
+  NQ_TRY(rot_setup(p, W, w_stride, nseg, seg_rows, seg_ptrs, c_stride, c_off, red_l, n_red, lmax, C));
+  p.X = x; p.x_stride = (long)x_stride; p.index = index;
+  hipLaunchKernelGGL(k_es_rot_fwd, dim3((unsigned)E), dim3(C >= 256 ? 256 : (C + 63) / 64 * 64), 0, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+/* The transposed rotation (rotate_inv, so3.py:285-300) fused with the sum over edges: out[n][s][c] = coef_scale[s] * sum_{q in [ptr[n], ptr[n+1])}
+ * sum_i W_o[i][s] block(i)[o][row][c_off + c], o = order ? order[q] : q (ptr == NULL: n_out edges, no sum).  coef_scale nullable. */
+int nq_es_rotate_back(const float* W, int64_t w_stride, int32_t nseg, const int32_t* seg_rows, float* const* seg_ptrs, int32_t c_stride, int32_t c_off,
+                      const int32_t* ptr, const int32_t* order, const float* coef_scale, float* out, int64_t n_out, const int32_t* red_l, int32_t n_red,
+                      int32_t lmax, int32_t C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "es_rotate_back");
+  if (n_out <= 0) return NQ_OK;
+  if (!out) return nq_fail(NQ_ERR_ARG, "rotate_back: null output");
+  RotArgs p;
+  NQ_TRY(rot_setup(p, W, w_stride, nseg, seg_rows, seg_ptrs, c_stride, c_off, red_l, n_red, lmax, C));
+  p.out = out; p.ptr = ptr; p.order = order; p.coef_scale = coef_scale;
+  hipLaunchKernelGGL(k_es_rot_tr, dim3((unsigned)n_out, lmax + 1), dim3(C >= 256 ? 256 : (C + 63) / 64 * 64), 0, st, p);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -23,7 +23,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _EmbeddingFn, _RowFn, _silu, eSCN, j_matrices, s2_grids)
+from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _EmbeddingFn, _RotateBackFn, _RotateFn, _RowFn, _silu, eSCN, j_matrices,
+                   s2_grids)
 from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _new, _st, lin
 from .phisnet import _SphLinearFn
 from .qhnet import _LinearBiasFn, _f32
@@ -478,12 +479,10 @@ class SO2EquivariantGraphAttention(nn.Module):
         """x [N, n_full * C] -> [N, n_full * output_channels]."""
         Cc, Hc, H, A, V = self.sphere_channels, self.hidden_channels, self.num_heads, self.attn_alpha_channels, self.attn_value_channels
         E, o = G.E, K.order
-        rs, rows = o.n_red * o.n_full, K.block_rows
+        rows = K.block_rows
         x_edge = _edge_scalars(self, G)
-        # source and target embeddings rotated into the edge frame, concatenated along the channel (transformer_block.py:210-236)
-        xs = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.src, G.src_inverse, E)
-        xt = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.dst, G.dst_inverse, E)
-        msg = [torch.cat([a.view(E, r, Cc), b.view(E, r, Cc)], dim=2).view(E, r * 2 * Cc) for a, b, r in zip(xs, xt, rows)]
+        # source and target embeddings rotated into the edge frame, side by side along the channel (transformer_block.py:210-236): blocks [E, rows, 2C]
+        msg = list(_RotateFn.apply(x, G, K, Cc, [(G.src, G.src_inverse), (G.dst, G.dst_inverse)]))
         msg, extra = self.so2_conv_1(msg, x_edge)
         # attention weights (transformer_block.py:343-356)
         xa = extra[:, :H * A].contiguous().view(E * H, A)
@@ -500,9 +499,7 @@ class SO2EquivariantGraphAttention(nn.Module):
         msg[0] = torch.cat([gating, msg[0][:, Hc:]], dim=1)
         msg = self.so2_conv_2(msg, None)
         msg = _HeadScaleFn.apply(alpha, rows, H, V, *msg)
-        y = _BlocksInFn.apply(G.wigner, rs, o.n_red, o.n_full, H * V, True, 0, rows, E, *msg)           # rotate back
-        y = _SegSumFn.apply(y, G.ptr, G.dst, G.N)                                                      # _reduce_edge
-        y = _ScaleFn.apply(y, None, None, K.coef_scale, o.n_full, H * V)                               # rotate_inv's rescale (so3.py:121-136)
+        y = _RotateBackFn.apply(G, K, H * V, K.coef_scale, rows, *msg)       # rotate back with rotate_inv's rescale (so3.py:121-136) + _reduce_edge, one pass
         return self.proj(y)
 
 
@@ -618,9 +615,8 @@ class EdgeDegreeEmbedding(nn.Module):
     def forward(self, G, K):
         o, Cc = K.order, self.sphere_channels
         h = self.rad_func(_edge_scalars(self, G))                                                       # [E, (lmax + 1) * C]: the m = 0 block
-        y = _RowFn.apply(h, G.wigner, o.n_red * o.n_full, o.m_size[0], o.n_full, Cc, True, None, None, G.E)   # the m = 0 rows lead every edge's Wigner block
-        y = _SegSumFn.apply(y, G.ptr, G.dst, G.N)
-        return _ScaleFn.apply(y, None, None, K.coef_scale_degree, o.n_full, Cc)                        # rotate_inv's rescale / rescale_factor
+        # the m = 0 rows lead every edge's Wigner block: rotate back + sum over in-edges, scaled by rotate_inv's rescale / rescale_factor
+        return _RotateBackFn.apply(G, K, Cc, K.coef_scale_degree, [o.m_size[0]], h)
 
 
 class _Consts:

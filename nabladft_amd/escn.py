@@ -207,6 +207,79 @@ def _silu(x):
     return _ActFn.apply(x, 0, 1.0)
 
 
+def _rot_args(K, rows, blocks):
+    k = len(rows)
+    n_red = sum(rows)
+    return (k, (C.c_int32 * k)(*rows), (C.c_void_p * k)(*[b.data_ptr() for b in blocks]), (C.c_int32 * n_red)(*K.red_l_host[:n_red]), n_red)
+
+
+class _RotateFn(torch.autograd.Function):
+    """Node embedding x [n, n_full * C] -> the edge-frame embedding as per-m blocks (SO3_Embedding._rotate + _m_primary): ``sources`` = [(index, (order, ptr)), ...]
+    gathers whose rotated rows fill consecutive channel slots of the blocks (one source: eSCN; source and target: EquiformerV2's concatenated message,
+    transformer_block.py:210-236).  Uses the degree-block structure of the Wigner rows (nq_es_rotate).  Adjoint: nq_es_rotate_back summed over every node's
+    edges through the inverse lists, in list order (no atomics, no per-edge intermediate)."""
+
+    @staticmethod
+    def forward(ctx, x, G, K, Cc, sources):
+        x = _f32(x)
+        o, rows, E = K.order, K.block_rows, G.E
+        cs = len(sources) * Cc
+        blocks = [_new(E, r * cs, like=x) for r in rows]
+        k, rows_c, ptrs, red_l, n_red = _rot_args(K, rows, blocks)
+        for slot, (index, _) in enumerate(sources):
+            _lib.check(_lib.load().nq_es_rotate(_lib.ptr(G.wigner), o.n_red * o.n_full, _lib.ptr(x), o.n_full * Cc, _lib.ptr(index), k, rows_c, ptrs, cs, slot * Cc, E,
+                                                red_l, n_red, o.lmax, Cc, _st()))
+        ctx.meta = (G, K, Cc, sources, x.shape[0])
+        return tuple(blocks)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        G, K, Cc, sources, n_src = ctx.meta
+        o, rows = K.order, K.block_rows
+        gs = [_f32(g) for g in gs]
+        cs = len(sources) * Cc
+        k, rows_c, ptrs, red_l, n_red = _rot_args(K, rows, gs)
+        dX = None
+        for slot, (_, (order, ptr)) in enumerate(sources):
+            part = _new(n_src, o.n_full * Cc, like=gs[0])
+            _lib.check(_lib.load().nq_es_rotate_back(_lib.ptr(G.wigner), o.n_red * o.n_full, k, rows_c, ptrs, cs, slot * Cc, _lib.ptr(ptr), _lib.ptr(order), None,
+                                                     _lib.ptr(part), n_src, red_l, n_red, o.lmax, Cc, _st()))
+            dX = part if dX is None else lin(dX, part)
+        return dX, None, None, None, None
+
+
+class _RotateBackFn(torch.autograd.Function):
+    """Per-m blocks of the edge-frame messages -> rotated back and summed over the in-edges of every target atom: [N, n_full * C] (_rotate_inv + _reduce_edge in
+    one pass); ``coef_scale`` [n_full] (or None) multiplies the output coefficients (EquiformerV2's rotate_inv rescale).  ``rows`` may cover only the leading
+    blocks (the m = 0 block of the edge-degree embedding)."""
+
+    @staticmethod
+    def forward(ctx, G, K, Cc, coef_scale, rows, *blocks):
+        blocks = [_f32(b) for b in blocks]
+        o = K.order
+        out = _new(G.N, o.n_full * Cc, like=blocks[0])
+        k, rows_c, ptrs, red_l, n_red = _rot_args(K, rows, blocks)
+        _lib.check(_lib.load().nq_es_rotate_back(_lib.ptr(G.wigner), o.n_red * o.n_full, k, rows_c, ptrs, Cc, 0, _lib.ptr(G.ptr), None, _lib.ptr(coef_scale),
+                                                 _lib.ptr(out), G.N, red_l, n_red, o.lmax, Cc, _st()))
+        ctx.meta = (G, K, Cc, coef_scale, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        G, K, Cc, coef_scale, rows = ctx.meta
+        o = K.order
+        g = _f32(g)
+        if coef_scale is not None:
+            gs = torch.empty_like(g)
+            _lib.check(_lib.load().nq_eq_scale(_lib.ptr(g), None, None, _lib.ptr(coef_scale), g.shape[0], o.n_full, Cc, _lib.ptr(gs), _st()))
+            g = gs
+        outs = [_new(G.E, r * Cc, like=g) for r in rows]
+        k, rows_c, ptrs, red_l, n_red = _rot_args(K, rows, outs)
+        _lib.check(_lib.load().nq_es_rotate(_lib.ptr(G.wigner), o.n_red * o.n_full, _lib.ptr(g), o.n_full * Cc, _lib.ptr(G.dst), k, rows_c, ptrs, Cc, 0, G.E, red_l,
+                                            n_red, o.lmax, Cc, _st()))
+        return (None,) * 5 + tuple(outs)
+
+
 class _EmbeddingFn(torch.autograd.Function):
     """W[idx]; the adjoint is a chain of fixed-order segment sums ``levels`` = [(order, ptr, n), ...] (no atomics).  Edge embeddings reduce in two steps
     (edges -> their atom -> the atom's element): a one-step sum over ~10 k edges per element would leave one thread per channel walking the whole list."""
@@ -346,16 +419,15 @@ class MessageBlock(torch.nn.Module):
         Cc = K.C
         x_edge = self.edge_block(G.x_dist, G)
         o = K.order
-        rs, rows = o.n_red * o.n_full, K.block_rows
-        xs = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.src, G.src_inverse, G.E)     # rotate into the edge frame: one tensor per m-block
-        xt = _BlocksOutFn.apply(x, G.wigner, rs, o.n_red, o.n_full, Cc, False, 0, rows, G.dst, G.dst_inverse, G.E)
+        rows = K.block_rows
+        xs = _RotateFn.apply(x, G, K, Cc, [(G.src, G.src_inverse)])                        # rotate into the edge frame: one tensor per m-block
+        xt = _RotateFn.apply(x, G, K, Cc, [(G.dst, G.dst_inverse)])
         ys = [lin(a, b) for a, b in zip(self.so2_block_source(list(xs), x_edge), self.so2_block_target(list(xt), x_edge))]
         # point-wise SiLU on the (lmax, mmax) grid (so3.py:301-318), grid matrices with their columns in m-primary order
         ng = K.to_grid_red.shape[0]
         grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Cc, False, 1, rows, G.E, *ys)
         ys = _BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Cc, True, 1, rows, None, None, G.E)
-        y = _BlocksInFn.apply(G.wigner, rs, o.n_red, o.n_full, Cc, True, 0, rows, G.E, *ys)                              # rotate back (wigner_inv = transpose)
-        return _SegSumFn.apply(y, G.ptr, G.dst, G.N)                                   # _reduce_edge: sum over the target's in-edges
+        return _RotateBackFn.apply(G, K, Cc, None, rows, *ys)                          # rotate back (wigner_inv = transpose) + _reduce_edge over the target's in-edges
 
 
 class LayerBlock(torch.nn.Module):
@@ -457,6 +529,7 @@ class eSCN(torch.nn.Module):
             K.order, K.C, K.device = self._order, self.sphere_channels, dev
             o = self._order
             K.block_rows = [o.m_size[0]] + [o.m_size[m] for m in range(1, o.mmax + 1) for _ in (0, 1)]           # rows of every m-block: m = 0, +1, -1, +2, -2, ...
+            K.red_l_host = [l for l, _ in o.m_primary]                  # degree of every kept Wigner row (host side of nq_es_rotate)
             self._dev_const = K
         return self._dev_const
 
