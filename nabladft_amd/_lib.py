@@ -219,8 +219,9 @@ def profile_enable(on: bool):
     load().nq_profile_enable(1 if on else 0)
 
 
-def profile_read(cap=256, stride=64):
-    """-> {name: (total_ms, launches)} of everything recorded since the last read."""
+def profile_read(cap=4096, stride=64):
+    """-> {name: (total_ms, launches)} of everything recorded since the last read (``cap`` distinct names: a process that ran several models has one name per
+    GEMM shape of each of them -- 256 was too few for the default bench record, which dropped EquiformerV2's weight-gradient GEMMs from its table)."""
     names = C.create_string_buffer(cap * stride)
     tot = (C.c_double * cap)()
     cnt = (C.c_int64 * cap)()
