@@ -80,9 +80,13 @@ __global__ __launch_bounds__(1024) void k_eq_ln_wgrad(const float* __restrict__ 
 __global__ void k_eq_reduce(const float* __restrict__ part, int nparts, long stride, long cnt, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
-  float s = 0.f;
-  for (int k = 0; k < nparts; ++k) s += part[(long)k * stride + i];
-  out[i] = s;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                               // four independent chains (fixed association), loads in flight together
+  int k = 0;
+  for (; k + 3 < nparts; k += 4) {
+    a0 += part[(long)k * stride + i]; a1 += part[(long)(k + 1) * stride + i]; a2 += part[(long)(k + 2) * stride + i]; a3 += part[(long)(k + 3) * stride + i];
+  }
+  for (; k < nparts; ++k) a0 += part[(long)k * stride + i];
+  out[i] = (a0 + a1) + (a2 + a3);
 }
 
 // ---- EquivariantLayerNormArraySphericalHarmonics: x [N][I][C], I = (lmax+1)^2; one workgroup per atom, thread = channel (blockDim = C rounded up to 64) ----

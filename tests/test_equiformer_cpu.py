@@ -28,6 +28,7 @@ def test_state_dict_surface_and_helper_buffers_match_the_reference_run():
     assert list(sd.keys()) == list(d["state_keys"])                                          # 1137 keys incl. the buffers of the shared helper modules, same order
     assert [",".join(map(str, v.shape)) for v in sd.values()] == list(d["state_shapes"])
     assert [n for n, p in net.named_parameters() if p.requires_grad] == list(d["param_names"])
+    assert len(net.no_weight_decay()) == 67                                                  # known answer: the reference's no_weight_decay() on this configuration
     params = set(d["param_names"].tolist())
     checked = 0
     for k in d.files:
@@ -60,6 +61,9 @@ def test_full_configuration_surface():
     net = EquiformerV2_OC20(**FULL)
     assert net.num_params == 83072002 and list(net.state_dict().keys()) == list(d["state_keys"])
     assert [",".join(map(str, v.shape)) for v in net.state_dict().values()] == list(d["state_shapes"])
+    nwd = net.no_weight_decay()                                                             # the reference method on this configuration: same rule, 12 blocks
+    assert "blocks.0.ga.alpha_norm.weight" in nwd and "blocks.3.norm_1.affine_weight" in nwd and "blocks.0.ga.proj.bias" in nwd
+    assert "blocks.0.ga.proj.weight" not in nwd and "blocks.0.ga.alpha_dot" not in nwd and "sphere_embedding.weight" not in nwd
     for bad in (dict(use_pbc=True), dict(lmax_list=[4, 2], mmax_list=[2, 2]), dict(norm_type="rms_norm_sh"), dict(use_gate_act=True), dict(use_grid_mlp=False),
                 dict(share_atom_edge_embedding=True)):
         with pytest.raises(NotImplementedError):
