@@ -96,3 +96,22 @@ def test_oracle_restatement_matches_the_reference_fixtures():
     with torch.no_grad():
         E2, F2 = R.forward(P, SMALL, torch.tensor(d["pos"], dtype=dt), torch.tensor(d["z"]), d["sizes"].tolist())
     assert abs(rel(E2, d["f64:E"]) - 0.008421122999490679) < 1e-9 and abs(rel(F2, d["f64:F"]) - 0.3463934802847423) < 1e-9   # the REAL class with frames(vec)
+
+
+def test_oracle_restatement_yaml_configuration():
+    """The restatement at config/model/equiformer_v2_oc20.yaml (83.1 M parameters, deterministic weights of oracle/equiformer_params.py) against E / F of the
+    real reference's fp64 run on the 20- and 46-atom molecules (the cap of 30 neighbours binds)."""
+    from oracle import equiformer_ref as R
+    from oracle.equiformer_params import make_state
+    from nabladft_amd.equiformer_v2 import EquiformerV2_OC20
+    d = np.load(os.path.join(GOLD, "equiformer_full.npz"))
+    net = EquiformerV2_OC20(**FULL)
+    names = [(k, tuple(v.shape)) for k, v in net.named_parameters()]
+    assert [n for n, _ in names] == list(d["param_names"])
+    dt = torch.float64
+    P = {k: v.to(dt) for k, v in make_state(names, int(d["seed"])).items()}
+    del net
+    with torch.no_grad():
+        E, F = R.forward(P, FULL, torch.tensor(d["pos"], dtype=dt), torch.tensor(d["z"]), d["sizes"].tolist(), rot=torch.tensor(d["edge_rot_mat"], dtype=dt))
+    assert np.abs(E.numpy() - d["f64:E"]).max() < 1e-10 * np.abs(d["f64:E"]).max()
+    assert np.abs(F.numpy() - d["f64:F"]).max() < 1e-10 * np.abs(d["f64:F"]).max()
