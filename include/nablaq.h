@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 9
+#define NQ_ABI_VERSION 10
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -548,6 +548,10 @@ int nq_linear_input_grad_epi(const float* G, const float* W, float* C, int32_t M
 int nq_linear_input_grad_bf16_epi(const float* G, const void* WbT, float* C, int32_t M, int32_t N, int32_t K, const float* aux, float alpha, float beta,
                                   int32_t mode, void* stream);
 /* gW[N,K] = G[rows,N]^T X[rows,K]; scratch: f32[nq_weight_grad_scratch_floats(rows,N,K)] */
+/* out[c] = sum over rows of A[r][c] (row stride lda floats) in a fixed order (per-chunk partial sums, then the chunks in order): the bias gradient of a
+ * Linear layer (torch.nn.Linear backward); scratch: nq_column_sum_scratch_floats(rows, cols) floats. */
+size_t nq_column_sum_scratch_floats(int64_t rows, int32_t cols);
+int nq_column_sum(const float* A, int64_t rows, int32_t cols, int64_t lda, float* out, float* scratch, void* stream);
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
 

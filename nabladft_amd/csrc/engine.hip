@@ -672,6 +672,11 @@ int nq_linear_input_grad_epi(const float* G, const float* Wt, float* C, int32_t 
   if (!G || !Wt || !C || !aux || (mode != 1 && mode != 2)) return nq_fail(NQ_ERR_ARG, "bad argument");
   return nq_gemm_nn_epi((hipStream_t)stream, G, Wt, C, M, N, K, aux, alpha, beta, mode);
 }
+size_t nq_column_sum_scratch_floats(int64_t rows, int32_t cols) { return nq_colsum_scratch_floats((long)rows, cols); }
+int nq_column_sum(const float* A, int64_t rows, int32_t cols, int64_t lda, float* out, float* scratch, void* stream) {
+  if (!A || !out || !scratch || cols < 1 || lda < cols) return nq_fail(NQ_ERR_ARG, "column_sum: bad argument");
+  return nq_colsum((hipStream_t)stream, A, (long)rows, cols, (int)lda, out, scratch);
+}
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K) { return nq_gemm_tn_scratch_floats(rows, N, K); }
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream) {
   return nq_gemm_tn((hipStream_t)stream, G, X, gW, rows, N, K, N, K, scratch);

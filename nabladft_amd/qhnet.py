@@ -170,7 +170,10 @@ class _LinearBiasFn(torch.autograd.Function):
         gW = torch.empty_like(W)
         scr = torch.empty(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, device=x.device, dtype=torch.float32)
         _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
-        return gx, gW, g.sum(0), None
+        gb = torch.empty(N, device=g.device, dtype=torch.float32)
+        cs = torch.empty(int(lib.nq_column_sum_scratch_floats(M, N)) + 64, device=g.device, dtype=torch.float32)
+        _lib.check(lib.nq_column_sum(_lib.ptr(g), M, N, N, _lib.ptr(gb), _lib.ptr(cs), _lib.stream_ptr()))      # bias gradient: fixed-order column sums
+        return gx, gW, gb, None
 
 
 class _ActFn(torch.autograd.Function):
