@@ -424,13 +424,15 @@ struct SideStream {
 enum { SB_GY = 0, SB_GQ, SB_GU, SB_GXH, SB_GH, SB_GPHI, SB_GBR };
 static hipStream_t g_side_stream = nullptr;
 static std::vector<hipEvent_t> g_side_events;
-static SideStream side_stream_for(hipStream_t main) {
+static SideStream side_stream_for(hipStream_t main, int n_atoms) {
   SideStream s;
   s.main = main; s.pool = &g_side_events;
-  // Measured (profiles/r02_side_stream_ab.txt, 2048 conformers / step): 60.5 ms with the side stream vs 60.1 ms without -- every kernel of the sweep
-  // already fills the chip, concurrency only adds scheduling noise.  Kept as an opt-in (NQ_SIDE_STREAM=1) for small batches / other shapes.
-  const char* on = getenv("NQ_SIDE_STREAM");
-  if (!(on && on[0] == '1')) return s;
+  // Measured (profiles/r02_side_stream_ab.txt): at 2048 conformers / step 60.5 ms with the side stream vs 60.1 ms without -- every kernel of the sweep already
+  // fills the chip, concurrency only adds scheduling noise; at 32 conformers (1.3 k atoms, the step is a chain of ~330 small dependent kernels) 4.40 vs 4.71 ms,
+  // at 256 conformers 11.57 vs 11.78 ms: the weight gradients leave the critical path.  Default: on up to 16 k atoms; NQ_SIDE_STREAM=0 / 1 forces it.
+  const char* env = getenv("NQ_SIDE_STREAM");
+  const bool want = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : n_atoms <= 16384;
+  if (!want) return s;
   if (!g_side_stream && hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) { g_side_stream = nullptr; return s; }
   s.side = g_side_stream; s.on = true;
   return s;
@@ -520,7 +522,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   if (seeded) NQ_HIP(hipMemsetAsync(ws + W.gte, 0, (size_t)N * sizeof(float), st));   // no Edot term
   r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
   NQ_TRY(nq_readout_rev(st, r, true));
-  SideStream ss = side_stream_for(st);
+  SideStream ss = side_stream_for(st, N);
   hipStream_t sd = ss.fork();          // sd == st when the side stream is off
   NQ_TRY(nq_colsum(sd, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(sd, ws + W.ge, N, 1, 1, gp + P.o2, scr));
