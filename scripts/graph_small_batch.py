@@ -6,13 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import nabladft_amd as nq
 from nabladft_amd import painn as P, trainer as T
-from oracle import painn_ref as R          # parameter generator only (measurement script, not product)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda:0")
-cfg = R.PaiNNConfig(hidden_channels=128, num_layers=6, num_rbf=100, cutoff=5.0, max_neighbors=100)
-model = nq.PaiNN(cfg.hidden_channels, cfg.num_layers, cfg.num_rbf, cfg.cutoff, cfg.max_neighbors, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5},
-                 True, False, False, True, cfg.num_elements).to(dev)
+CUTOFF, MAX_NEIGHBORS = 5.0, 100                                            # config/model/painn-oc.yaml
+model = nq.PaiNN(128, 6, 100, CUTOFF, MAX_NEIGHBORS, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100).to(dev)
 from nabladft_amd.synth import gen_conformers
 pos, z, batch, y, f = gen_conformers(7, B)
 b = nq.Batch(pos, z, batch, y, f).to(dev)
@@ -25,7 +23,7 @@ for _ in range(50):
     step(b)
 torch.cuda.synchronize()
 eager = (time.perf_counter() - t0) / 50
-nl = P.build_neighbor_list(b.pos, b.batch, b.z, cfg.cutoff, cfg.max_neighbors, b.ptr)
+nl = P.build_neighbor_list(b.pos, b.batch, b.z, CUTOFF, MAX_NEIGHBORS, b.ptr)
 orig = T.build_neighbor_list
 T.build_neighbor_list = lambda *a, **k: nl
 try:
