@@ -692,7 +692,9 @@ class EquiformerV2_OC20(nn.Module):
                            to_grid_red=f32(Tr[:, perm]), from_grid_red=f32(Fr[:, perm]), to_grid_full=f32(Tf), from_grid_full=f32(Ff),
                            coef_scale=f32(scale), coef_scale_degree=f32(scale / self.avg_degree))
         self._order = o
+        self._grid_perm = perm
         self._dev_const = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: setattr(module, "_dev_const", None))
 
     # ---- reference initialisation (equiformer_v2_oc20.py:588-612) ----
     def _init_weights(self, m):
@@ -731,7 +733,22 @@ class EquiformerV2_OC20(nn.Module):
                     out.add(f"{mname}.{pname}")
         return out
 
-    _constants = eSCN._constants
+    def _constants(self, dev):
+        """The kernel constants on ``dev``.  The S2-grid matrices are taken from the model's own ``SO3_grid`` buffers (reordered to the kernels' m-primary columns):
+        freshly constructed they are this package's matrices, after ``load_state_dict`` of a reference checkpoint they are the matrices e3nn gave the reference, so a
+        loaded model evaluates the grids the checkpoint was trained with (the one place where the restated e3nn arithmetic could differ in the last digits)."""
+        fresh = self._dev_const is None or self._dev_const.device != dev
+        K = eSCN._constants(self, dev)
+        if fresh:
+            lmax, mmax = self.lmax_list[0], self.mmax_list[0]
+            red, full = self.SO3_grid[lmax][mmax], self.SO3_grid[lmax][lmax]
+            perm = torch.tensor(self._grid_perm, dtype=torch.long)
+            flat = lambda m: m.detach().to(device=dev, dtype=torch.float32).reshape(-1, m.shape[-1])                    # noqa: E731
+            K.to_grid_red = flat(red.to_grid_mat)[:, perm.to(dev)].contiguous()
+            K.from_grid_red = flat(red.from_grid_mat)[:, perm.to(dev)].contiguous()
+            K.to_grid_full, K.from_grid_full = flat(full.to_grid_mat).contiguous(), flat(full.from_grid_mat).contiguous()
+        return K
+
     build_graph = eSCN.build_graph                      # radius graph + frames + Wigner rows + the inverse lists of the gathers (escn.py / equiformer: same stage)
 
     def forward(self, data, edge_rot_mat=None, return_intermediates: bool = False):

@@ -115,3 +115,24 @@ def test_oracle_restatement_yaml_configuration():
         E, F = R.forward(P, FULL, torch.tensor(d["pos"], dtype=dt), torch.tensor(d["z"]), d["sizes"].tolist(), rot=torch.tensor(d["edge_rot_mat"], dtype=dt))
     assert np.abs(E.numpy() - d["f64:E"]).max() < 1e-10 * np.abs(d["f64:E"]).max()
     assert np.abs(F.numpy() - d["f64:F"]).max() < 1e-10 * np.abs(d["f64:F"]).max()
+
+
+def test_grid_constants_follow_the_state_dict():
+    """The kernels' S2-grid matrices come from the model's SO3_grid buffers: identical to the package's own matrices after construction (bit for bit), and the
+    checkpoint's matrices after load_state_dict (a reference checkpoint carries the matrices e3nn produced for it)."""
+    from nabladft_amd.equiformer_v2 import EquiformerV2_OC20
+    net = EquiformerV2_OC20(**SMALL)
+    cpu = torch.device("cpu")
+    K = net._constants(cpu)
+    for k in ("to_grid_red", "from_grid_red", "to_grid_full", "from_grid_full"):
+        assert torch.equal(getattr(K, k), net._const[k]), k
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for k in sd:                                                                            # the helper modules are shared: every alias of the buffer, as in a real checkpoint
+        if k.endswith("SO3_grid.3.2.to_grid_mat"):
+            sd[k] = sd[k] * 1.25
+        if k.endswith("SO3_grid.3.3.from_grid_mat"):
+            sd[k] = sd[k] + 0.5
+    net.load_state_dict(sd)
+    K2 = net._constants(cpu)
+    assert torch.allclose(K2.to_grid_red, net._const["to_grid_red"] * 1.25) and torch.equal(K2.from_grid_red, net._const["from_grid_red"])
+    assert torch.allclose(K2.from_grid_full, net._const["from_grid_full"] + 0.5) and torch.equal(K2.to_grid_full, net._const["to_grid_full"])
