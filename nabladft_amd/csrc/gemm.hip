@@ -13,8 +13,9 @@
 // 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Both operands are staged in LDS k-major
 // ([BK][BM+pad]) so that the MFMA operand fetch (lane l: row l&31, k = l>>5) is a conflict-free
 // ds_read_b32 of 32 consecutive floats per half-wave.
-#include "common.h"
+#include "gemm_tile.h"   // round 3: the persistent, double-buffered tile engine k_gemm2 (every launch whose operands are 16-byte friendly)
 
+// ---- generic kernels (round 1): operands that are not 16-byte friendly (odd K / leading dimensions) and the row-mapped spherical launches ----
 #define BM 128
 #define BN 128
 // BKT (template parameter of the kernels) = K depth of one staged tile: 32 by default; the input-gradient (NN) launches use 16 -- half the
@@ -26,24 +27,6 @@
 #define GEMM_OCC
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4, EPI_DSILU = 5, EPI_RES = 6 };   // 4: C = v, C2 = ea * resid + eb * silu(v)
-
-struct GemmArgs {
-  const float* A; const float* B; float* C; const float* bias; float* C2;
-  int M, N, K, lda, ldb, ldc;
-  int k_per_split;       // EPI_PARTIAL: K range per blockIdx.z
-  long part_stride;      // EPI_PARTIAL: floats between partial slabs
-  float* bpart;          // EPI_PARTIAL, optional: per-split column sums of A over rows < brows (bias gradient), [splits][M]
-  int brows;
-  // spherical (row-mapped) launches: the operands are packed irreps tensors [rows][ncomp][F]; the logical row q of order L is the pair
-  // (r, m) = (q / w, q % w), w = 2L+1, stored at packed row r * ncomp + L*L + m
-  int rm_rows, rm_ncomp, rm_w, rm_base;   // RM == 2 (weight gradient of one order): w / base given here
-  int rm_s;                               // RM == 3 (weight gradients of all orders): splits per component; blockIdx.z = component * rm_s + split
-  const float* Bz[7];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
-  const float* resid; float ea, eb;       // EPI_SILU_RES (resid nullable, same leading dimension as C)
-};
 __device__ __forceinline__ long rm_row(int q, int w, int ncomp, int base) { return (long)(q / w) * ncomp + base + q % w; }
 
 // K-contiguous source (element (r, k) at src[r*ld + k]) -> LDS tile[k][r], stride LDS_KC
@@ -379,6 +362,40 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
   if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// ---- round-3 tile engine: eligibility, tile choice, launch -----------------------------------------------------------------------------
+// k_gemm2 reads both operands with 16-byte buffer loads and 32-bit offsets from the tile origin.
+template <bool A_KC, bool B_KC>
+static bool gemm2_ok(const GemmArgs& p, long kspan) {
+  if (g_gemm_variant & 16) return false;   // A/B switch: force the generic kernels
+  if ((reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.B) & 15) || (p.lda & 3) || (p.ldb & 3)) return false;
+  if ((A_KC || B_KC) && (p.K & 3)) return false;   // K-contiguous operand: whole float4s along k
+  if (!A_KC && (p.M & 3)) return false;            // MN-contiguous operands: whole float4s along m / n
+  if (!B_KC && (p.N & 3)) return false;
+  // 32-bit byte offsets inside one tile / k span
+  if (!A_KC && kspan * p.lda * 4 >= 0x7fffffffL) return false;
+  if (!B_KC && kspan * p.ldb * 4 >= 0x7fffffffL) return false;
+  if ((A_KC && 128L * p.lda * 4 >= 0x7fffffffL) || (B_KC && 128L * p.ldb * 4 >= 0x7fffffffL) || 128L * p.ldc * 4 >= 0x7fffffffL) return false;
+  return true;
+}
+// Tile choice by the load of the busiest CU (tiles are dealt round-robin): 128x128 (8 wavefronts, 2 workgroups per CU) runs ~10 % more flops per
+// CU-cycle than 64x64 (4 wavefronts, 4 per CU) but quantises coarser -- [20480 x 256] x [256 x 256] is 320 big tiles = 2 on the busiest CU, or
+// 1280 small ones = 5 quarter-size tiles (measured 0.043 vs 0.032 ms, scripts/lab/gemm_lab.hip).
+static bool gemm2_small_tiles(int M, int N, int splits) {
+  const long t128 = (long)nq_cdiv(M, 128) * nq_cdiv(N, 128) * splits, t64 = (long)nq_cdiv(M, 64) * nq_cdiv(N, 64) * splits;
+  const double c128 = (double)((t128 + 255) / 256), c64 = (double)((t64 + 255) / 256) / (4.0 * 0.9);
+  return c64 < c128;
+}
+template <bool A_KC, bool B_KC, int EPI>
+static void launch_gemm2(hipStream_t st, const GemmArgs& p, int splits) {
+  if (gemm2_small_tiles(p.M, p.N, splits)) {
+    const long tiles = (long)nq_cdiv(p.M, 64) * nq_cdiv(p.N, 64) * splits;
+    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 64, 64, 32, 2, 2, 4>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, p);
+  } else {
+    const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
+    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 128, 128, 32, 4, 2, 4>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(512), 0, st, p);
+  }
+}
+
 // ---- host launchers ------------------------------------------------------------------------
 int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K,
                int lda, int ldw, int ldc, const char* tag) {
@@ -386,6 +403,12 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm2_ok<true, true>(p, K)) {
+    if (C2_silu) launch_gemm2<true, true, EPI_SILU>(st, p, 1);
+    else launch_gemm2<true, true, EPI_STORE>(st, p, 1);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
     dim3 gs(nq_cdiv(M, SM), nq_cdiv(N, SM), 1);
     if (C2_silu) hipLaunchKernelGGL((k_gemm_small<true, EPI_SILU>), gs, dim3(256), 0, st, p);
@@ -408,6 +431,11 @@ int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, flo
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, nullptr, C2, M, N, K, K, K, N, 0, 0, nullptr, 0};
   p.resid = resid; p.ea = ea; p.eb = eb;
+  if (gemm2_ok<true, true>(p, K)) {
+    launch_gemm2<true, true, EPI_SILU_RES>(st, p, 1);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
     dim3 gs(nq_cdiv(M, SM), nq_cdiv(N, SM), 1);
     hipLaunchKernelGGL((k_gemm_small<true, EPI_SILU_RES>), gs, dim3(256), 0, st, p);
@@ -426,6 +454,12 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   NQ_PROF(st, nm__);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm2_ok<true, false>(p, Nout)) {
+    if (accumulate) launch_gemm2<true, false, EPI_ACC>(st, p, 1);
+    else launch_gemm2<true, false, EPI_STORE>(st, p, 1);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm_is_small(M, Kin) && !(g_gemm_variant & 8)) {
     dim3 gs(nq_cdiv(M, SM), nq_cdiv(Kin, SM), 1);
     if (accumulate) hipLaunchKernelGGL((k_gemm_small<false, EPI_ACC>), gs, dim3(256), 0, st, p);
@@ -447,6 +481,12 @@ int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
   p.resid = aux; p.ea = ea; p.eb = eb;
+  if (gemm2_ok<true, false>(p, Nout)) {
+    if (mode == 1) launch_gemm2<true, false, EPI_DSILU>(st, p, 1);
+    else launch_gemm2<true, false, EPI_RES>(st, p, 1);
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm_is_small(M, Kin) && !(g_gemm_variant & 8)) {
     dim3 gs(nq_cdiv(M, SM), nq_cdiv(Kin, SM), 1);
     if (mode == 1) hipLaunchKernelGGL((k_gemm_small<false, EPI_DSILU>), gs, dim3(256), 0, st, p);
@@ -463,16 +503,14 @@ int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int
 // out[Mo, No] = sum_{r<rows} GY[r, Mo] * X[r, No];  scratch must hold nq_gemm_tn_scratch_floats()
 // Split count for the weight-gradient contraction: enough workgroups to fill 256 CUs (~768) given the number
 // of 128x128 output tiles, but at least 512 rows per split so the 64-KB partial slab stays amortised.
-#ifndef NQ_TN_TARGET
-#define NQ_TN_TARGET 768   // workgroups aimed at by the row split (512: U, V1 -5..-7 %, W2, V2 +7..+10 %: no net gain)
-#endif
+// Split count of the weight-gradient contraction: the persistent engine keeps 2 workgroups of 8 wavefronts per CU = 512 slots; as many
+// (output tile, row range) items as fit WITHOUT exceeding them (one item more would cost a whole extra round), at least 128 rows per split.
 static int tn_splits(long rows, int Mo, int No) {
   const long tiles = (long)nq_cdiv(Mo, BM) * nq_cdiv(No, BN);
-  long s = (NQ_TN_TARGET + tiles - 1) / tiles;
+  long s = 512 / tiles;
   const long by_rows = (rows + 127) / 128;   // >= 128 rows (4 k-tiles) per split
   if (s > by_rows) s = by_rows;
   if (s < 1) s = 1;
-  if (s > 512) s = 512;
   return (int)s;
 }
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No) * ((size_t)Mo * No + Mo); }
@@ -492,14 +530,15 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   kper = (kper + 31) / 32 * 32;   // whole k-tiles (BKT = 32 for the TN launches)
   float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
   GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
-  dim3 grid(nq_cdiv(Mo, BM), nq_cdiv(No, BN), ns);
-  launch_gemm<false, false, EPI_PARTIAL>(st, grid, p);
+  const int nse = nq_cdiv(rows, kper);   // splits that actually hold rows (<= ns); only their slabs are reduced
+  if (gemm2_ok<false, false>(p, kper)) launch_gemm2<false, false, EPI_PARTIAL>(st, p, nse);
+  else launch_gemm<false, false, EPI_PARTIAL>(st, dim3(nq_cdiv(Mo, BM), nq_cdiv(No, BN), nse), p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, ns, cnt, cnt, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, nse, cnt, cnt, out);
   NQ_LAUNCH_CHECK();
   if (bias_out) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Mo, 64)), dim3(64), 0, st, bpart, ns, (long)Mo, (long)Mo, bias_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Mo, 64)), dim3(64), 0, st, bpart, nse, (long)Mo, (long)Mo, bias_out);
     NQ_LAUNCH_CHECK();
   }
   return NQ_OK;

@@ -113,6 +113,49 @@ def test_gemm_forward_and_grads(M, N, K):
     assert rel_err(gW.cpu().numpy(), (G.double().T @ A.double()).numpy()) < 3e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (130, 68, 36), (70000, 256, 128), (5000, 512, 256), (257, 3, 64)])
+def test_gemm_fused_epilogues(M, N, K):
+    """Dense + ScaledSiLU + residual (forward) and the two adjoint epilogues of the input-gradient product, ragged and multi-tile shapes
+    (70000 x 256: every persistent workgroup walks several tiles; N = 3: the generic kernel)."""
+    from nabladft_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    R, G = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    aux = torch.randn(M, K, generator=g)
+    Ad, Wd, Rd, Gd, auxd = A.to(dev), W.to(dev), R.to(dev), G.to(dev), aux.to(dev)
+    pre, act = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    st = _lib.stream_ptr()
+    ref = A.double() @ W.double().T
+    for resid in (Rd, None):
+        _lib.check(lib.nq_linear_forward_act(_lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(pre), _lib.ptr(act), None if resid is None else _lib.ptr(resid), 0.75, 1.25, M, N, K, st))
+        want = 1.25 * torch.nn.functional.silu(ref) + (0.75 * R.double() if resid is not None else 0.0)
+        assert rel_err(pre.cpu().numpy(), ref.numpy()) < 2e-6
+        assert rel_err(act.cpu().numpy(), want.numpy()) < 2e-6
+    gx = torch.empty(M, K, device=dev)
+    refx = G.double() @ W.double()
+    _lib.check(lib.nq_linear_input_grad_epi(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(gx), M, N, K, _lib.ptr(auxd), 0.0, 0.6, 1, st))
+    z = aux.double()
+    sg = torch.sigmoid(z)
+    assert rel_err(gx.cpu().numpy(), (0.6 * refx * (sg * (1 + z * (1 - sg)))).numpy()) < 3e-6
+    _lib.check(lib.nq_linear_input_grad_epi(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(gx), M, N, K, _lib.ptr(auxd), 0.7, 0.0, 2, st))
+    assert rel_err(gx.cpu().numpy(), (0.7 * z + refx).numpy()) < 2e-6
+
+
+def test_gemm_rows_do_not_depend_on_the_batch():
+    """A row's result is the same whatever else is in the batch (fixed k order, no split over K on the forward layouts) -- the tile engine picks
+    64x64 or 128x128 tiles from the problem size; both must produce identical bits."""
+    from nabladft_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(50000, 128, generator=g).to(dev), (torch.randn(256, 128, generator=g) * 0.1).to(dev)
+    st = _lib.stream_ptr()
+    big, small = torch.empty(50000, 256, device=dev), torch.empty(700, 256, device=dev)
+    _lib.check(lib.nq_linear_forward(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(big), None, 50000, 256, 128, st))
+    _lib.check(lib.nq_linear_forward(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(small), None, 700, 256, 128, st))
+    assert torch.equal(big[:700], small)
+
+
 def test_weight_grad_many_rows_deterministic():
     from nabladft_amd import _lib
     lib, dev = _lib.load(), _dev()
