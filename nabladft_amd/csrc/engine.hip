@@ -22,6 +22,8 @@ int nq_fail(int code, const char* fmt, ...) {
 
 // ---- profiler ---------------------------------------------------------------------------------------
 #include <map>
+#include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 int nq_profile_on = 0;
@@ -400,13 +402,19 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
 // optimiser does.  They are issued on a second HIP stream and run under the critical path (input-gradient GEMMs, node kernels, message sweeps),
 // which leaves matrix-core and bandwidth gaps: the dual message kernel waits on gathers for half of its cycles.  Ordering is by events: a side
 // launch waits for its producer on the main stream; the main stream waits before it overwrites a buffer the side stream may still read.
-// One process drives one GPU from one thread (SURVEY.md 8b threading): the stream and the event pool are process-global.
+// The side stream and its event pool belong to one (device, main stream) pair (a process that drives two GPUs, or two streams from two threads, gets
+// one pair each); an early error return between fork() and join() still joins (destructor), so a stream capture is never left forked.
 struct SideStream {
   hipStream_t main = nullptr, side = nullptr;
   bool on = false;
   std::vector<hipEvent_t>* pool = nullptr;
   size_t used = 0;
+  bool forked = false, joined = false;
   hipEvent_t last_read[8] = {};
+  SideStream() = default;
+  SideStream(const SideStream&) = delete;
+  SideStream& operator=(const SideStream&) = delete;
+  ~SideStream() { if (on && forked && !joined) join(); }
   hipEvent_t next() {
     if (used == pool->size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; pool->push_back(e); }
     return (*pool)[used++];
@@ -415,27 +423,35 @@ struct SideStream {
     if (!on) return main;
     hipEvent_t e = next();
     (void)hipEventRecord(e, main); (void)hipStreamWaitEvent(side, e, 0);
+    forked = true; joined = false;
     return side;
   }
   void read_by_side(int buf) { if (on) { hipEvent_t e = next(); (void)hipEventRecord(e, side); last_read[buf] = e; } }
   void before_main_writes(int buf) { if (on && last_read[buf]) { (void)hipStreamWaitEvent(main, last_read[buf], 0); last_read[buf] = nullptr; } }
-  void join() { if (on) { hipEvent_t e = next(); (void)hipEventRecord(e, side); (void)hipStreamWaitEvent(main, e, 0); } }
+  void join() { if (on) { hipEvent_t e = next(); (void)hipEventRecord(e, side); (void)hipStreamWaitEvent(main, e, 0); joined = true; } }
 };
 enum { SB_GY = 0, SB_GQ, SB_GU, SB_GXH, SB_GH, SB_GPHI, SB_GBR };
-static hipStream_t g_side_stream = nullptr;
-static std::vector<hipEvent_t> g_side_events;
-static SideStream side_stream_for(hipStream_t main, int n_atoms) {
-  SideStream s;
-  s.main = main; s.pool = &g_side_events;
+struct SidePool { hipStream_t side = nullptr; std::vector<hipEvent_t> events; };
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SidePool*> g_side_pools;
+static void side_stream_init(SideStream& s, hipStream_t main, int n_atoms) {
+  s.main = main;
   // Measured (profiles/r02_side_stream_ab.txt): at 2048 conformers / step 60.5 ms with the side stream vs 60.1 ms without -- every kernel of the sweep already
   // fills the chip, concurrency only adds scheduling noise; at 32 conformers (1.3 k atoms, the step is a chain of ~330 small dependent kernels) 4.40 vs 4.71 ms,
   // at 256 conformers 11.57 vs 11.78 ms: the weight gradients leave the critical path.  Default: on up to 16 k atoms; NQ_SIDE_STREAM=0 / 1 forces it.
   const char* env = getenv("NQ_SIDE_STREAM");
   const bool want = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : n_atoms <= 16384;
-  if (!want) return s;
-  if (!g_side_stream && hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) { g_side_stream = nullptr; return s; }
-  s.side = g_side_stream; s.on = true;
-  return s;
+  if (!want) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  SidePool*& pool = g_side_pools[std::make_pair(dev, main)];
+  if (!pool) {
+    SidePool* p = new SidePool();
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { delete p; return; }
+    pool = p;
+  }
+  s.side = pool->side; s.pool = &pool->events; s.on = true;
 }
 
 static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
@@ -522,7 +538,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   if (seeded) NQ_HIP(hipMemsetAsync(ws + W.gte, 0, (size_t)N * sizeof(float), st));   // no Edot term
   r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
   NQ_TRY(nq_readout_rev(st, r, true));
-  SideStream ss = side_stream_for(st, N);
+  SideStream ss;
+  side_stream_init(ss, st, N);
   hipStream_t sd = ss.fork();          // sd == st when the side stream is off
   NQ_TRY(nq_colsum(sd, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(sd, ws + W.ge, N, 1, 1, gp + P.o2, scr));

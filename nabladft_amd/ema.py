@@ -39,6 +39,17 @@ class ExponentialMovingAverage:
     def shadow_params(self):
         return self._views
 
+    def _resolve(self, parameters):
+        """The parameter list an operation acts on: the tracked one, or a caller-supplied list of the SAME length (torch_ema raises on a mismatch;
+        zip() would silently truncate)."""
+        if parameters is None:
+            return self._params
+        params = [p for p in parameters if p.requires_grad]
+        if len(params) != len(self._views):
+            raise ValueError(f"Number of parameters passed as argument ({len(params)}) is different from number of shadow parameters maintained by this "
+                             f"ExponentialMovingAverage ({len(self._views)})")
+        return params
+
     def _rebind(self):
         o = 0
         self._views = []
@@ -47,7 +58,7 @@ class ExponentialMovingAverage:
             o += p.numel()
 
     def update(self, parameters: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
-        params = self._params if parameters is None else [p for p in parameters if p.requires_grad]
+        params = self._resolve(parameters)
         decay = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
@@ -60,19 +71,19 @@ class ExponentialMovingAverage:
                     s.sub_((1.0 - decay) * (s - p.detach()))
 
     def copy_to(self, parameters: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
-        params = self._params if parameters is None else [p for p in parameters if p.requires_grad]
+        params = self._resolve(parameters)
         with torch.no_grad():
             for s, p in zip(self._views, params):
                 p.data.copy_(s)
 
     def store(self, parameters: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
-        params = self._params if parameters is None else [p for p in parameters if p.requires_grad]
+        params = self._resolve(parameters)
         self._stored = [p.detach().clone() for p in params]
 
     def restore(self, parameters: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
         if self._stored is None:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
-        params = self._params if parameters is None else [p for p in parameters if p.requires_grad]
+        params = self._resolve(parameters)
         with torch.no_grad():
             for c, p in zip(self._stored, params):
                 p.data.copy_(c)
@@ -89,8 +100,14 @@ class ExponentialMovingAverage:
             self._stored = None
 
     def to(self, device=None, dtype=None) -> None:
+        """Moves the shadow buffer AND any store()d copies (restore() after a device move must not copy across devices).  The shadow is kept in fp32
+        whatever the parameters' dtype (an average of low-precision weights loses its small increments): a `dtype` other than float32 is refused."""
+        if dtype is not None and dtype != torch.float32:
+            raise ValueError("the EMA shadow is kept in float32")
         self._flat = self._flat.to(device=device)
         self._rebind()
+        if self._stored is not None:
+            self._stored = [c.to(device=device) for c in self._stored]
 
     def state_dict(self) -> dict:
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": [v.clone() for v in self._views], "collected_params": self._stored}
@@ -100,4 +117,5 @@ class ExponentialMovingAverage:
         with torch.no_grad():
             for v, s in zip(self._views, state_dict["shadow_params"]):
                 v.copy_(s)
-        self._stored = state_dict.get("collected_params")
+        stored = state_dict.get("collected_params")
+        self._stored = None if stored is None else [c.to(device=self._flat.device) for c in stored]

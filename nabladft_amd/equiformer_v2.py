@@ -25,6 +25,7 @@ from torch import nn
 from . import _lib
 from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _EmbeddingFn, _RotateBackFn, _RotateFn, _RowFn, _silu, eSCN, j_matrices,
                    s2_grids)
+from . import gemnet_oc as _gemnet
 from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _new, _st, lin
 from .phisnet import _SphLinearFn
 from .qhnet import _LinearBiasFn, _f32
@@ -623,6 +624,11 @@ class _Consts:
     pass
 
 
+def _drop_device_constants(module, incompatible_keys):
+    """load_state_dict post-hook: the kernels' constant tables are rebuilt from the (possibly replaced) SO3_grid buffers on the next forward."""
+    module._dev_const = None
+
+
 class EquiformerV2_OC20(nn.Module):
     """equiformer_v2/equiformer_v2_oc20.py:51-640 (constructor arguments :121-160)."""
 
@@ -694,7 +700,7 @@ class EquiformerV2_OC20(nn.Module):
         self._order = o
         self._grid_perm = perm
         self._dev_const = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: setattr(module, "_dev_const", None))
+        self.register_load_state_dict_post_hook(_drop_device_constants)   # module-level function: a lambda here would make the model unpicklable
 
     # ---- reference initialisation (equiformer_v2_oc20.py:588-612) ----
     def _init_weights(self, m):
@@ -752,6 +758,7 @@ class EquiformerV2_OC20(nn.Module):
     build_graph = eSCN.build_graph                      # radius graph + frames + Wigner rows + the inverse lists of the gathers (escn.py / equiformer: same stage)
 
     def forward(self, data, edge_rot_mat=None, return_intermediates: bool = False):
+        _gemnet.weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.EquiformerV2_OC20 runs on MI355X only: tensors must be on a cuda (HIP) device")
         G = self.build_graph(data, edge_rot_mat)

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, cg
+from . import gemnet_oc as _gemnet
 from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _gather_raw, _new, _segsum_raw, _st, lin
 from .qhnet import _ActFn, _LinearBiasFn, _MatmulFn, _f32
 
@@ -584,6 +585,7 @@ class eSCN(torch.nn.Module):
         return G
 
     def forward(self, data, edge_rot_mat=None, return_layers: bool = False):
+        _gemnet.weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.eSCN runs on MI355X only: tensors must be on a cuda (HIP) device")
         G = self.build_graph(data, edge_rot_mat)

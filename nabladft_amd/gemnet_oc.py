@@ -154,6 +154,15 @@ def _new(*shape, like):
 _SSILU = 1.0 / 0.6       # ScaledSiLU (layers/base_layers.py:61-71)
 _PRECISION = ["f32"]
 _PACKED = {}
+_EPOCH = [0]
+
+
+def weights_epoch_advance() -> None:
+    """Marks every packed bf16 weight copy stale.  Called at the start of each model forward: between two forwards the optimizer, an EMA swap or a
+    load_state_dict may have rewritten the parameters IN PLACE -- FlatParameters points `p.data` at slices of one flat buffer and the fused AdamW /
+    `ema.copy_to` write through raw pointers, none of which moves `p._version`, so a version-keyed cache would keep serving the initial weights.
+    The backward of the same step re-uses the copies packed in its forward (same epoch)."""
+    _EPOCH[0] += 1
 
 
 def set_gemm_precision(mode: str) -> None:
@@ -164,18 +173,19 @@ def set_gemm_precision(mode: str) -> None:
         raise ValueError(mode)
     _PRECISION[0] = mode
     _PACKED.clear()
+    weights_epoch_advance()
 
 
 def _packed(W):
-    """(Wb [N, K], WbT [K, N]) bf16 copies of a weight, refreshed when the parameter (or the flat buffer it lives in) was modified in place."""
+    """(Wb [N, K], WbT [K, N]) bf16 copies of a weight, packed once per weights epoch (= once per model forward, see weights_epoch_advance)."""
     key = (W.data_ptr(), tuple(W.shape))
     ent = _PACKED.get(key)
-    if ent is None or ent[0] != W._version:
+    if ent is None or ent[0] != _EPOCH[0]:
         N, K = W.shape
         Wb = torch.empty(N, K, device=W.device, dtype=torch.bfloat16)
         WbT = torch.empty(K, N, device=W.device, dtype=torch.bfloat16)
         _lib.check(_lib.load().nq_bf16_pack(_lib.ptr(W), N, K, _lib.ptr(Wb), _lib.ptr(WbT), _st()))
-        ent = (W._version, Wb, WbT)
+        ent = (_EPOCH[0], Wb, WbT)
         _PACKED[key] = ent
     return ent[1], ent[2]
 
@@ -1002,7 +1012,8 @@ class GemNetOC(torch.nn.Module):
                  atom_interaction: bool = False, scale_basis: bool = False, num_elements: int = 83, otf_graph: bool = False,
                  scale_file: Optional[str] = None) -> None:
         super().__init__()
-        _PACKED.clear()               # packed bf16 weights are keyed by address + version: a new model may reuse the addresses of a freed one
+        _PACKED.clear()               # packed bf16 weights are keyed by address: a new model may reuse the addresses of a freed one
+        weights_epoch_advance()
         for ok, what in ((num_targets == 1, "num_targets != 1"), (not use_pbc, "periodic boundary conditions"), (regress_forces and direct_forces,
                          "forces by back-propagation (direct_forces=False)"), (enforce_max_neighbors_strictly, "enforce_max_neighbors_strictly=False"),
                          (not scale_backprop_forces, "scale_backprop_forces"), (extensive, "extensive=False"), (scale_file is None, "scale_file"),
@@ -1105,6 +1116,7 @@ class GemNetOC(torch.nn.Module):
         return B
 
     def forward(self, data, return_intermediates: bool = False):
+        weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.GemNetOC runs on MI355X only: tensors must be on a cuda (HIP) device")
         G = self.get_graphs_and_indices(data)

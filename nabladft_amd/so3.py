@@ -374,8 +374,9 @@ class ExponentialBernsteinRadialBasisFunctions(nn.Module):
         nn.init.constant_(self._alpha, float(x + torch.log(-torch.expm1(-x))))          # softplus_inverse (phisnet/nn/functional.py)
 
     def _tables32(self, device):
-        """float32 device copies of the buffers the kernels read, rebuilt only when the module's buffers change (dtype / device moves)."""
-        key = (self.logc.data_ptr(), str(device))
+        """float32 device copies of the buffers the kernels read, rebuilt when the module's buffers change: dtype / device moves (new storage) and
+        in-place writes such as load_state_dict (same storage, new version counters)."""
+        key = (self.logc.data_ptr(), str(device), self.logc._version, self.n._version, self.v._version, self.cutoff._version)
         if getattr(self, "_t32_key", None) != key:
             self._t32 = tuple(t.to(device=device, dtype=torch.float32).contiguous() for t in (self.logc, self.n, self.v))
             self._cutoff_f = float(self.cutoff)

@@ -136,3 +136,20 @@ def test_grid_constants_follow_the_state_dict():
     K2 = net._constants(cpu)
     assert torch.allclose(K2.to_grid_red, net._const["to_grid_red"] * 1.25) and torch.equal(K2.from_grid_red, net._const["from_grid_red"])
     assert torch.allclose(K2.from_grid_full, net._const["from_grid_full"] + 0.5) and torch.equal(K2.to_grid_full, net._const["to_grid_full"])
+
+
+def test_model_pickles():
+    """torch.save(model) / ddp_spawn pickle the module: its load_state_dict post-hook must be a module-level function (it was a lambda)."""
+    import io
+    import pickle
+    from nabladft_amd.equiformer_v2 import EquiformerV2_OC20
+    net = EquiformerV2_OC20(**SMALL)
+    net2 = pickle.loads(pickle.dumps(net))
+    assert list(net2.state_dict().keys()) == list(net.state_dict().keys())
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    net3 = torch.load(buf, weights_only=False)
+    net3._dev_const = "stale"
+    net3.load_state_dict(net.state_dict())
+    assert net3._dev_const is None                                                          # the hook survived the round trip

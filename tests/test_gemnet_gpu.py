@@ -323,6 +323,56 @@ def test_bf16_gemm_matches_bf16_rounded_operands_and_model_stays_close(small, fu
     assert float((E1 - E0).abs().max()) > 0.0                           # the mode really took another path
 
 
+def test_bf16_weights_follow_in_place_optimizer_updates(small):
+    """FlatParameters + AdamW rewrite the parameters through one flat buffer (no per-parameter version bump): the bf16 weight copies must be re-packed
+    every forward.  Three optimiser steps in bf16 must move the forward output and track the same three steps in fp32."""
+    from nabladft_amd import gemnet_oc
+    from nabladft_amd.trainer import FlatParameters
+    dev = torch.device("cuda:0")
+    cfg = dict(SMALL, emb_size_atom=64, emb_size_edge=64, emb_size_trip_in=32, emb_size_trip_out=32, emb_size_quad_in=32, emb_size_quad_out=32,
+               emb_size_aint_in=32, emb_size_aint_out=32)                  # contraction sizes that are multiples of 32 -> the bf16 kernels really run
+    base = Data(small, dev)
+
+    class Rep:                                                              # >= 256 rows per Dense product: 8 copies of the fixture's molecules
+        pass
+    rep = Rep()
+    reps = 8
+    nmol = int(base.batch.max()) + 1
+    rep.pos = torch.cat([base.pos + 50.0 * i for i in range(reps)])
+    rep.z = base.z.repeat(reps)
+    rep.batch = torch.cat([base.batch + nmol * i for i in range(reps)])
+    cnt = torch.bincount(rep.batch)
+    rep.ptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)])
+    rep.y = torch.zeros(nmol * reps, device=dev)
+    rep.forces = torch.zeros_like(rep.pos)
+    outs = {}
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(3)
+        net = gemnet_oc.GemNetOC(**cfg).to(dev)
+        gemnet_oc.set_gemm_precision(mode)
+        try:
+            flat = FlatParameters(net.parameters())
+            opt = torch.optim.AdamW([flat.flat], lr=1e-2, weight_decay=0)
+            seq = []
+            for _ in range(3):
+                flat.zero_grad()
+                E, F = net(rep)
+                seq.append(E.detach().clone())
+                ((E - 1.0) ** 2).mean().add((F ** 2).mean()).backward()
+                opt.step()
+            with torch.no_grad():
+                seq.append(net(rep)[0].clone())
+        finally:
+            gemnet_oc.set_gemm_precision("f32")
+        outs[mode] = seq
+    f, b = outs["f32"], outs["bf16"]
+    scale = float(f[0].abs().max()) + 1e-6
+    assert float((b[0] - b[1]).abs().max()) > 1e-3 * scale and float((b[2] - b[3]).abs().max()) > 1e-4 * scale      # every step changed what the bf16 forward sees
+    move = float((f[3] - f[0]).abs().max())
+    assert move > 1e-2 * scale                                              # the three fp32 steps moved the energies visibly ...
+    assert float((b[3] - f[3]).abs().max()) < 0.25 * move + 3e-2 * scale    # ... and the bf16 run followed them (stale weights would stay at step 0)
+
+
 def test_invalid_inputs_fail_loudly(small):
     """Out-of-table atomic numbers and a molecule without neighbours raise instead of reading out of bounds / silently producing zeros."""
     dev = torch.device("cuda:0")

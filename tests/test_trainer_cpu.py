@@ -55,3 +55,39 @@ def test_flat_parameters_survive_optimizer_zero_grad():
     net.zero_grad(set_to_none=True)                    # detaches the per-parameter views: must be reported, not silently accepted
     with pytest.raises(RuntimeError):
         fp.clip_grad_norm_(1.0)
+
+
+def test_ema_follows_torch_ema_semantics():
+    """nabladft_amd.ema (torch_ema restated, qhnet.py:459-536): warm-up decay, store / copy_to / restore, and the argument checks torch_ema has
+    (a parameter list of the wrong length must raise instead of being zip-truncated; to() moves the stored copies too)."""
+    import pytest
+    from nabladft_amd.ema import ExponentialMovingAverage
+    torch.manual_seed(0)
+    net = torch.nn.Linear(4, 3)
+    ema = ExponentialMovingAverage(net.parameters(), decay=0.9)
+    w0 = net.weight.detach().clone()
+    with torch.no_grad():
+        net.weight.add_(1.0)
+    ema.update()
+    d = min(0.9, 2.0 / 11.0)                                              # (1 + n) / (10 + n) at n = 1
+    assert torch.allclose(ema.shadow_params[0], w0 + (1.0 - d) * 1.0, atol=1e-6)
+    with pytest.raises(ValueError):
+        ema.update([net.weight])                                          # one parameter instead of two
+    with pytest.raises(ValueError):
+        ema.copy_to(list(net.parameters()) + [torch.nn.Parameter(torch.zeros(1))])
+    with pytest.raises(RuntimeError):
+        ema.restore()
+    live = net.weight.detach().clone()
+    with ema.average_parameters():
+        assert torch.allclose(net.weight, ema.shadow_params[0])
+    assert torch.equal(net.weight, live)
+    ema.store()
+    ema.to(torch.device("cpu"))                                           # stored copies travel with the shadow
+    assert all(c.device.type == "cpu" for c in ema._stored)
+    with pytest.raises(ValueError):
+        ema.to(dtype=torch.float16)
+    sd = ema.state_dict()
+    ema2 = ExponentialMovingAverage(net.parameters(), decay=0.5)
+    ema2.load_state_dict(sd)
+    assert ema2.decay == 0.9 and ema2.num_updates == 1 and torch.equal(ema2.shadow_params[1], ema.shadow_params[1])
+    ema2.restore()
