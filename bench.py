@@ -91,12 +91,10 @@ _SN = {"sn_filter1": lambda N, E: E / 2 * (F * 4 + 128.0), "sn_filter1_tan": lam
 
 
 def pmc_traffic_bytes(kernel_prefix, batch):
-    """HBM bytes per launch from the committed PMC summary (profiles/r02_pmc_traffic.json, else r01; FETCH_SIZE doubled per the
+    """HBM bytes per launch from the newest committed PMC summary (profiles/r0N_pmc_traffic.json; FETCH_SIZE doubled per the
     gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported), only if it was taken at this batch size."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    if path is None:
         return None
     with open(path) as fh:
         rec = json.load(fh)
@@ -140,6 +138,27 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
             "avg_launch_ms": avg_ms, "launches_per_step": launches}
 
 
+# fp32 operations per (directed edge, channel) of the message-path kernels, counted from csrc/edge.hip (FMA = 2): the 13-tap filter is 39 FMA + 3 mul
+# (phi) or 78 FMA + 6 mul (phi and psi); then the per-edge message arithmetic of each flavour; the dual reverse runs its second direction on half of the edges;
+# k_gwr_sorted: 26 FMA per (pair, column) = 13 per directed edge and column, three column parts.
+_MSG_FLOP_PER_EDGE_CHANNEL = {"msgf_fwd": 81 + 16, "msgf_tan": 162 + 39, "msgf_rev_force": 162 + 39, "msgf_rev_dual": 162 + 103 + 27, "gwr_sorted": 3 * 26}
+
+
+def step_bounds(kernels, n_atoms, E, batch, ms_per_step):
+    """Step-level roofs of the PaiNN training step: the fp32 arithmetic the step executes (GEMM flops from the role tags of every GEMM launch of the step +
+    the message-path kernels' VALU flops) against the 157.3 TFLOP/s fp32 peak (matrix cores and VALU have the SAME fp32 peak on gfx950), and SURVEY 8(d)'s
+    17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger of the two times is the roof that binds."""
+    gemm = sum(gemm_flops(k, n_atoms, E, n) * n for k, _, n in kernels if k.startswith("gemm"))
+    msg = sum(_MSG_FLOP_PER_EDGE_CHANNEL[k] * float(E) * F * n for k, _, n in kernels if k in _MSG_FLOP_PER_EDGE_CHANNEL)
+    t_fp32 = (gemm + msg) / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
+    t_hbm = 17.8e6 * batch / (HBM_PEAK_GBS * 1e9) * 1e3
+    bind = "fp32" if t_fp32 >= t_hbm else "hbm"
+    return {"flops_per_step": gemm + msg, "gemm_flops_per_step": gemm, "message_valu_flops_per_step": msg, "fp32_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+            "fp32_bound_ms": t_fp32, "hbm_bound_ms": t_hbm, "binding_roof": bind, "achieved_TFLOPs": (gemm + msg) / (ms_per_step * 1e-3) / 1e12,
+            "frac_of_fp32_roof": t_fp32 / ms_per_step, "frac_of_hbm_roof": t_hbm / ms_per_step, "frac_of_binding_roof": max(t_fp32, t_hbm) / ms_per_step,
+            "note": "exact-fp32 arithmetic makes the step FLOP-bound: the HBM fraction cannot exceed hbm_bound_ms / fp32_bound_ms"}
+
+
 def bench_gemnet(args, rank, world, local_dev, dev):
     """--model gemnet: BASELINE.json configs[2] (config/model/gemnet-oc.yaml) through scripts/bench_gemnet.py; same JSON contract, conformer-steps/s, fp32."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -164,10 +183,11 @@ def bench_gemnet(args, rank, world, local_dev, dev):
         for prec in ("f32", "bf16"):
             r64 = BG.run(64, 4, 3, kernels=False, device=dev, precision=prec)
             big[prec] = {k: r64[k] for k in ("value", "unit", "ms_per_step", "atoms")}
-        bf = BG.run(mol, args.steps, args.warmup, kernels=False, device=dev, precision="bf16")
+        bf = BG.run(mol, args.steps, args.warmup, kernels=True, device=dev, precision="bf16")
         bf = {"what": "same step with the Dense products (forward, input and weight gradients) on bf16 MFMA, fp32 accumulation, fp32 sums over edges / triplets / "
                       "quadruplets, fp32 master weights and optimizer -- the mode BASELINE.json names for this configuration; not parity-grade (operands rounded to bf16)",
-              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"]}
+              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"], "roofline": bf.get("roofline"),
+              "kernel_ms_per_step": bf.get("kernel_ms_per_step")}
     if rank == 0:
         cpu = BG.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
@@ -211,7 +231,8 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
     if world == 1 and not args.no_roofline:
         bf = BE.run(mol, args.steps, args.warmup + 2, kernels=False, device=dev, precision="bf16")
         bf = {"what": "same step with the bias-free Dense products (SO(2) convolutions, grid MLP) on bf16 MFMA, fp32 accumulation; not parity-grade",
-              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"]}
+              "value": bf["value"], "unit": bf["unit"], "ms_per_step": bf["ms_per_step"], "final_loss": bf["final_loss"], "roofline": bf.get("roofline"),
+              "kernel_ms_per_step": bf.get("kernel_ms_per_step")}
     if rank == 0:
         cpu = BE.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
@@ -462,6 +483,7 @@ def main():
         E = n_edges
         roofline = roofline_record(dom, avg_ms, dom_launches, n_atoms, E, args.batch)
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
+        roofline["step"] = step_bounds(kernels, n_atoms, E, args.batch, 1e3 * dt / args.steps)
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -587,10 +609,10 @@ def main():
         torch.cuda.empty_cache()
         import bench_gemnet as BG
         g16 = BG.run(16, 5, 2, kernels=True, device=dev)
-        g16b = BG.run(16, 5, 4, kernels=False, device=dev, precision="bf16")
+        g16b = BG.run(16, 5, 4, kernels=True, device=dev, precision="bf16")
         g16.pop("_dt", None)
         gemnet = {"workload": g16.pop("workload"), "batch16": g16,
-                  "batch16_bf16_gemms": {k: g16b[k] for k in ("value", "unit", "ms_per_step", "dtype", "final_loss")},
+                  "batch16_bf16_gemms": {k: g16b.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "final_loss", "roofline", "gemm_bf16_ms_per_step")},
                   "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
     escn = equiformer = None

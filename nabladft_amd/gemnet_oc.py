@@ -144,6 +144,7 @@ def build_graphs(pos, batch, z, cutoff, cutoff_qint, cutoff_aeaint, cutoff_aint,
 # ============================================================================================================================================
 # autograd wrappers of the C entry points (no CPU path)
 # ============================================================================================================================================
+GEMM_BYTES = [None]      # bench hook: compulsory HBM bytes of the same products (operands read once, result written once; weights 2 B in the bf16 mode)
 GEMM_FLOPS = [None]      # bench hook: set GEMM_FLOPS[0] = 0.0 to accumulate 2*M*N*K of every dense product of the forward pass (backward = 2x that)
 
 
@@ -207,6 +208,8 @@ def _gemm_act(x, W, resid, alpha, beta):
                                                      float(alpha), float(beta), M, N, K, _st()))
     if GEMM_FLOPS[0] is not None:
         GEMM_FLOPS[0] += 2.0 * M * N * K
+    if GEMM_BYTES[0] is not None:
+        GEMM_BYTES[0] += 4.0 * M * K + 8.0 * M * N + (2.0 if _use_bf16(M, K) else 4.0) * N * K      # x read, pre and out written, W read
     return pre, out
 
 
@@ -278,6 +281,8 @@ class _DenseFn(torch.autograd.Function):
             _lib.check(_lib.load().nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(pre), None, M, N, K, _st()))
         if GEMM_FLOPS[0] is not None:
             GEMM_FLOPS[0] += 2.0 * M * N * K
+        if GEMM_BYTES[0] is not None:
+            GEMM_BYTES[0] += 4.0 * M * K + 4.0 * M * N + (2.0 if _use_bf16(M, K) else 4.0) * N * K
         ctx.save_for_backward(x, W)
         return pre
 

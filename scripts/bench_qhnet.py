@@ -65,8 +65,8 @@ def gemm_flops_per_step(net, N, E, P):
 def pmc_traffic_bytes(kernel_prefix, molecules):
     """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r02_pmc_traffic_qhnet.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), only if it was taken at this batch size."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_qhnet.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_qhnet.json") for r in (3, 2)) if os.path.exists(q)), None)
+    if path is None:
         return None
     with open(path) as fh:
         rec = json.load(fh)
@@ -151,18 +151,24 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
         fl = gemm_flops_per_step(net, N, E, P)
         dom, dom_ms, dom_n = ks[0]
         C = net.hs
-        # per-row algorithmic bytes: both weight factors (+ their adjoints in the reverse kernels), the gathered irreps rows and the row written
-        alg = {"qh_tp_uuu_fwd": P * (2 * 65 * C + 3 * 25 * C) * 4.0, "qh_tp_uuu_bwd": P * (4 * 65 * C + 5 * 25 * C) * 4.0,
-               "qh_tp_uvu_fwd": E * (2 * 42 * C + 2 * 25 * C) * 4.0, "qh_tp_uvu_bwd": E * (4 * 42 * C + 3 * 25 * C) * 4.0,
-               "qh_exp_fwd": P * (8320 + 800 + 1024) * 4.0, "qh_exp_bwd": P * (2 * 8320 + 1600 + 1024) * 4.0}
-        if dom in alg:
-            per_launch = alg[dom]
+        # per-launch bytes.  COMPULSORY (what must cross HBM however the step is fused) = the irreps rows read and written per (pair / edge) row;
+        # the per-row weight factors ([rows, paths * C], written by the generator GEMMs and re-read here, plus their adjoints in the reverse kernels)
+        # are MATERIALISED INTERMEDIATES of the current, unfused formulation: reported separately, never part of `achieved` / `frac`.
+        comp = {"qh_tp_uuu_fwd": P * (3 * 25 * C) * 4.0, "qh_tp_uuu_bwd": P * (5 * 25 * C) * 4.0,
+                "qh_tp_uvu_fwd": E * (2 * 25 * C) * 4.0, "qh_tp_uvu_bwd": E * (3 * 25 * C) * 4.0,
+                "qh_exp_fwd": P * (800 + 1024) * 4.0, "qh_exp_bwd": P * (1600 + 1024) * 4.0}
+        mat = {"qh_tp_uuu_fwd": P * (2 * 65 * C) * 4.0, "qh_tp_uuu_bwd": P * (4 * 65 * C) * 4.0, "qh_tp_uvu_fwd": E * (2 * 42 * C) * 4.0,
+               "qh_tp_uvu_bwd": E * (4 * 42 * C) * 4.0, "qh_exp_fwd": P * 8320 * 4.0, "qh_exp_bwd": P * 2 * 8320 * 4.0}
+        if dom in comp:
+            per_launch = comp[dom]
             avg_ms = dom_ms / max(dom_n, 1)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
             traffic = pmc_traffic_bytes(_KERNEL_OF.get(dom, dom), molecules)
             out["roofline"] = {"kernel": _KERNEL_OF.get(dom, dom) + ">", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-                               "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms, "launches_per_step": dom_n}
+                               "algorithmic_bytes_per_launch": per_launch, "materialised_intermediate_bytes_per_launch": mat[dom],
+                               "frac_incl_materialised_intermediates": (per_launch + mat[dom]) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "avg_launch_ms": avg_ms, "launches_per_step": dom_n}
         else:
             ach = fl / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
             out["roofline"] = {"kernel": "k_gemm (weight generators [rows,128]x[128,8320] and heads)", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
