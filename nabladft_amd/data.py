@@ -149,10 +149,10 @@ class _Staging:
 
 # ---- epoch plan + overlapped feed ---------------------------------------------------------------------------------------------
 def epoch_plan(sizes: torch.Tensor, batch_size: int, shuffle: bool, seed: int, epoch: int, rank: int = 0, world: int = 1,
-               drop_last: bool = False) -> List[torch.Tensor]:
+               drop_last: bool = False, cost_model: str = "painn") -> List[torch.Tensor]:
     """Conformer indices of every step of one epoch for this rank.  All ranks draw the same permutation (seed, epoch), cut it
-    into global batches of ``batch_size * world`` and split each by estimated cost (``dist.shard_by_cost``: edges ~ n^2 up to
-    the cutoff sphere) so that every rank runs the same number of steps with balanced work -- one molecule = one graph, no
+    into global batches of ``batch_size * world`` and split each by estimated cost (``dist.shard_by_cost`` with the model's proxy,
+    ``dist.COST_MODELS``: n * min(n - 1, K) edges for neighbour-capped graphs, n (n - 1) pairs for the Hamiltonian models) so that every rank runs the same number of steps with balanced work -- one molecule = one graph, no
     collective besides the gradient all-reduce."""
     from .dist import shard_by_cost
     m = sizes.shape[0]
@@ -170,7 +170,7 @@ def epoch_plan(sizes: torch.Tensor, batch_size: int, shuffle: bool, seed: int, e
         if world == 1:
             steps.append(chunk)
         else:
-            parts = shard_by_cost(sizes[chunk].tolist(), world)
+            parts = shard_by_cost(sizes[chunk].tolist(), world, cost_model)
             steps.append(chunk[torch.as_tensor(parts[rank], dtype=torch.long)])
     return steps
 
@@ -180,9 +180,10 @@ class ArenaLoader:
     stream, one event per batch; the consumer stream waits on the event only (no host synchronisation)."""
 
     def __init__(self, arena: ConformerArena, batch_size: int, device, shuffle: bool = True, seed: int = 0, rank: int = 0, world: int = 1,
-                 drop_last: bool = False, depth: int = 2):
+                 drop_last: bool = False, depth: int = 2, cost_model: str = "painn"):
         self.arena, self.batch_size, self.device = arena, batch_size, torch.device(device)
         self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, seed, rank, world, drop_last
+        self.cost_model = cost_model          # dist.COST_MODELS key: how the per-rank split of a global batch weighs a conformer of n atoms
         self.epoch = 0
         self.gpu = self.device.type == "cuda"
         if self.gpu:
@@ -195,7 +196,7 @@ class ArenaLoader:
         self.epoch = epoch
 
     def __len__(self):
-        return len(epoch_plan(self.arena.sizes, self.batch_size, False, 0, 0, self.rank, self.world, self.drop_last))
+        return len(epoch_plan(self.arena.sizes, self.batch_size, False, 0, 0, self.rank, self.world, self.drop_last, self.cost_model))
 
     def _stage(self, conformers, slot):
         if not self.gpu:
@@ -212,7 +213,7 @@ class ArenaLoader:
         return db, ev
 
     def __iter__(self) -> Iterator[Batch]:
-        plan = epoch_plan(self.arena.sizes, self.batch_size, self.shuffle, self.seed, self.epoch, self.rank, self.world, self.drop_last)
+        plan = epoch_plan(self.arena.sizes, self.batch_size, self.shuffle, self.seed, self.epoch, self.rank, self.world, self.drop_last, self.cost_model)
         self.epoch += 1
         if not plan:
             return

@@ -79,3 +79,26 @@ def gen_conformers(seed: int, n_mol: int, size="drug", dtype=torch.float32):
     y = torch.tensor(rng.normal(0, 1, size=n_mol).astype(np.float32)).to(dtype)
     f = torch.tensor(rng.normal(0, 0.05, size=(pos.shape[0], 3)).astype(np.float32)).to(dtype)
     return pos, z, batch, y, f
+
+
+def take_conformers(pos, z, batch, y, f, idx):
+    """The conformers `idx` (ascending list) of a batch, renumbered 0..len(idx)-1."""
+    idx_t = torch.as_tensor(list(idx), dtype=torch.long)
+    n_mol = int(y.shape[0])
+    new_id = torch.full((n_mol,), -1, dtype=torch.long)
+    new_id[idx_t] = torch.arange(idx_t.shape[0])
+    keep = new_id[batch] >= 0
+    return pos[keep], z[keep], new_id[batch[keep]], y[idx_t], f[keep]
+
+
+def gen_rank_conformers(seed: int, per_rank: int, world: int = 1, rank: int = 0, size="drug", cost_model: str = "n2"):
+    """What one rank of a data-parallel job trains on: every rank draws the SAME global batch of per_rank * world conformers (same seed) and keeps its
+    share of the cost-balanced partition (dist.shard_by_cost with the model's proxy) -- one molecule = one graph, nothing else is exchanged.
+    Returns ((pos, z, batch, y, forces), predicted spread of the per-rank cost)."""
+    from .dist import predicted_spread, shard_by_cost
+    data = gen_conformers(seed, per_rank * world, size)
+    if world == 1:
+        return data, 0.0
+    sizes = torch.bincount(data[2], minlength=per_rank * world).tolist()
+    parts = shard_by_cost(sizes, world, cost_model)
+    return take_conformers(*data, parts[rank]), predicted_spread(sizes, world, cost_model)

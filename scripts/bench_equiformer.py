@@ -36,7 +36,7 @@ def loss_fn(E, F, b):
     return 2.0 * (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()
 
 
-def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32"):
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32", size="drug"):
     import torch
     from nabladft_amd import _lib, gemnet_oc
     gemnet_oc.set_gemm_precision(precision)
@@ -44,7 +44,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
     net = build(dev)
-    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    # every rank draws the same global batch of `molecules` x world conformers and keeps its cost-balanced share (dist.shard_by_cost, proxy "equiformer_v2")
+    batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "equiformer_v2") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=4e-4, weight_decay=1e-3)
 
@@ -74,7 +75,9 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     out = {"workload": "EquiformerV2 (config/model/equiformer_v2_oc20.yaml: 12 blocks, lmax 6 / mmax 2, 128 sphere channels, 8 heads, cutoff 12 A, 30 neighbours) train step "
                        "in training mode (attention dropout, drop-path): graph, frames, Wigner rows, forward, 2 L1(E) + 100 L2(F), backward, AdamW; synthetic ~42-atom "
                        "conformers",
-           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N, "edges": G.E,
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "sizes": str(size),
+           "load_balance": {"cost_model": "equiformer_v2", "this_run_predicted_spread": getattr(batches[0], "cost_spread", 0.0),
+                            "predicted_spread_8_ranks_10_to_90_atoms_by_conformers_per_rank": nqdist.spread_table("equiformer_v2")}, "atoms": G.N, "edges": G.E,
            "parameters": net.num_params, "_dt": dt, "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
            "parity": "pinned to the reference EquiformerV2 classes run on CPU in eval mode (tests/golden/equiformer_*.npz); the four e3nn symbols under them are "
                      "restated (unpinned), the Wigner J matrices equal the reference's Jd.pt"}

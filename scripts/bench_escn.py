@@ -23,12 +23,14 @@ class Batch:
     pass
 
 
-def synthetic_batch(molecules, seed, device):
+def synthetic_batch(molecules, seed, device, world=1, rank=0, size="drug", cost_model="escn"):
     import torch
-    from nabladft_amd.synth import gen_conformers
-    pos, z, batch, y, f = gen_conformers(seed, molecules)
+    from nabladft_amd.synth import gen_rank_conformers
+    (pos, z, batch, y, f), spread = gen_rank_conformers(seed, molecules, world, rank, size, cost_model)
+    molecules = int(y.shape[0])          # this rank's share of the cost-balanced global batch
     b = Batch()
     b.pos, b.z, b.batch, b.y, b.forces = pos.to(device), z.to(device), batch.to(device), y.to(device), f.to(device)
+    b.cost_spread = spread
     return b
 
 
@@ -44,7 +46,7 @@ def loss_fn(E, F, b):
     return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()
 
 
-def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32"):
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32", size="drug"):
     """precision "bf16": the bias-free Dense products (the SO(2) convolutions and the grid MLP: >95 % of the flops) on bf16 MFMA with fp32 accumulation
     (nabladft_amd.gemnet_oc.set_gemm_precision); everything else fp32."""
     import torch
@@ -54,7 +56,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
     net = build(dev)
-    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    # every rank draws the same global batch of `molecules` x world conformers and keeps its cost-balanced share (dist.shard_by_cost, proxy "escn")
+    batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "escn") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=1e-3, betas=(0.9, 0.95), amsgrad=True, weight_decay=0)
 
@@ -83,7 +86,9 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     G = net.build_graph(batches[0])
     out = {"workload": "eSCN (config/model/escn-oc.yaml: 8 layers, lmax 6 / mmax 2, 128 sphere channels, 256 hidden, cutoff 8 A, 40 neighbours, 128 sphere samples) train "
                        "step: graph, frames, Wigner rows, forward, L1(E) + 100 L2(F), backward, AdamW(amsgrad); synthetic ~42-atom conformers",
-           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N, "edges": G.E,
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "sizes": str(size),
+           "load_balance": {"cost_model": "escn", "this_run_predicted_spread": getattr(batches[0], "cost_spread", 0.0),
+                            "predicted_spread_8_ranks_10_to_90_atoms_by_conformers_per_rank": nqdist.spread_table("escn")}, "atoms": G.N, "edges": G.E,
            "parameters": net.num_params, "_dt": dt, "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
            "parity": "pinned to the reference eSCN classes run on CPU (tests/golden/escn_*.npz); the five e3nn symbols under them are restated (unpinned), the Wigner "
                      "J matrices equal the reference's Jd.pt"}

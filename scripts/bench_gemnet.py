@@ -32,14 +32,16 @@ class Batch:
     pass
 
 
-def synthetic_batch(molecules, seed, device):
+def synthetic_batch(molecules, seed, device, world=1, rank=0, size="drug", cost_model="gemnet_oc"):
     import torch
-    from nabladft_amd.synth import gen_conformers
-    pos, z, batch, y, f = gen_conformers(seed, molecules)
+    from nabladft_amd.synth import gen_rank_conformers
+    (pos, z, batch, y, f), spread = gen_rank_conformers(seed, molecules, world, rank, size, cost_model)
+    molecules = int(y.shape[0])          # this rank's share of the cost-balanced global batch
     b = Batch()
     b.pos, b.z, b.batch, b.y, b.forces = pos.to(device), z.to(device), batch.to(device), y.to(device), f.to(device)
     cnt = torch.bincount(batch, minlength=molecules)
     b.ptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)]).to(device)
+    b.cost_spread = spread
     return b
 
 
@@ -55,7 +57,7 @@ def loss_fn(E, F, b):
     return (E - b.y).abs().mean() + 100.0 * torch.linalg.vector_norm(F - b.forces, dim=-1).mean()          # config/model/gemnet-oc.yaml:78-85
 
 
-def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32"):
+def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, precision="f32", size="drug"):
     import torch
     from nabladft_amd import _lib, gemnet_oc
     gemnet_oc.set_gemm_precision(precision)
@@ -63,7 +65,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     from nabladft_amd.trainer import FlatParameters
     dev = device or torch.device("cuda", torch.cuda.current_device())
     net = build(dev)
-    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    # every rank draws the same global batch of `molecules` x world conformers and keeps its cost-balanced share (dist.shard_by_cost, proxy "gemnet_oc")
+    batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "gemnet_oc") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=1e-3, betas=(0.9, 0.95), amsgrad=True, weight_decay=0)
 
@@ -93,7 +96,9 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     G = net.get_graphs_and_indices(batches[0])
     out = {"workload": "GemNet-OC (config/model/gemnet-oc.yaml: 4 blocks, atom 256 / edge 512, 128 rbf, 7 spherical, 12 A cutoffs, caps 30/20/8, all four extra "
                        "interactions, direct coupled forces) train step: graphs, forward, L1(E) + 100 L2(F), backward, clip 10.0, AdamW(amsgrad); synthetic ~42-atom conformers",
-           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": G.N,
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "sizes": str(size),
+           "load_balance": {"cost_model": "gemnet_oc", "this_run_predicted_spread": getattr(batches[0], "cost_spread", 0.0),
+                            "predicted_spread_8_ranks_10_to_90_atoms_by_conformers_per_rank": nqdist.spread_table("gemnet_oc")}, "atoms": G.N,
            "edges": {"a2a": G.Ea2a, "main": G.Em, "a2ee2a": G.Ea, "qint": G.Eq, "qint_x_main_rows": G.Tin}, "parameters": net.num_params, "_dt": dt,
            "final_loss": float(loss.detach()), "dtype": precision, "data": "synthetic",
            "parity": "pinned to the reference GemNetOC classes run on CPU (tests/golden/gemnet_*.npz); torch_scatter / torch_sparse / torch_cluster restated"}

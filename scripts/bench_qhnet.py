@@ -28,16 +28,18 @@ class Batch:
     pass
 
 
-def synthetic_batch(molecules, seed, device):
+def synthetic_batch(molecules, seed, device, world=1, rank=0, size="drug", cost_model="qhnet"):
     """``molecules`` drug-like conformers of the bench generator (nabladft_amd/synth.py, Angstrom) in bohr, as a PyG-style batch."""
     import torch
-    from nabladft_amd.synth import gen_conformers
-    pos, z, batch, _, _ = gen_conformers(seed, molecules)
+    from nabladft_amd.synth import gen_rank_conformers
+    (pos, z, batch, _, _), spread = gen_rank_conformers(seed, molecules, world, rank, size, cost_model)
+    molecules = int(torch.bincount(batch).shape[0])          # this rank's share of the cost-balanced global batch
     b = Batch()
     b.pos, b.z, b.batch = (pos * BOHR).to(device), z.to(device), batch.to(device)
     cnt = torch.bincount(batch, minlength=molecules)
     b.ptr = torch.cat([cnt.new_zeros(1), cnt.cumsum(0)]).to(device)
     b.num_nodes = int(pos.shape[0])
+    b.cost_spread = spread
     return b
 
 
@@ -82,7 +84,7 @@ _KERNEL_OF = {"qh_tp_uuu_fwd": "k_qh_tp<0, false, false", "qh_tp_uuu_bwd": "k_qh
               "qh_tp_uvu_bwd": "k_qh_tp<1, true, true", "qh_exp_fwd": "k_qh_exp_fwd", "qh_exp_bwd": "k_qh_exp_bwd"}
 
 
-def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None):
+def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, world=1, rank=0, sync=None, size="drug"):
     """One rank's share of the job: ``molecules`` conformers per step on this GPU; with world > 1 the flat gradient is all-reduced (mean) each step
     (conformers are independent graphs: data-parallel, no other collective).  Returns the record with THIS rank's wall time in ``_dt``."""
     import torch
@@ -93,7 +95,8 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
     dev = device or torch.device("cuda", torch.cuda.current_device())
     net = build(dev)
     from nabladft_amd import dist as nqdist
-    batches = [synthetic_batch(molecules, (seed + 17 * rank) * 100 + k, dev) for k in range(4)]
+    # every rank draws the same global batch of `molecules` x world conformers and keeps its cost-balanced share (dist.shard_by_cost, proxy "qhnet")
+    batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "qhnet") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=5e-4, betas=(0.9, 0.95), amsgrad=True)
     ema = ExponentialMovingAverage([flat.flat], decay=0.9999)
@@ -131,7 +134,9 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
     N, E, P = b0.num_nodes, int(b0.edge_index.shape[1]), int(b0.full_edge_index.shape[1])
     out = {"workload": "QHNet (config/qhnet.yaml: lmax 4, hidden 128, bottleneck 32, 5 layers, 32 rbf, cutoff 12 bohr, def2-SVP blocks) train step: graphs, "
                        "forward, HamiltonianLoss on the packed blocks, backward, AdamW(amsgrad), EMA; synthetic ~42-atom conformers in bohr",
-           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "atoms": N,
+           "value": molecules * steps / dt, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt / steps, "molecules_per_step": molecules, "sizes": str(size),
+           "load_balance": {"cost_model": "qhnet", "this_run_predicted_spread": getattr(batches[0], "cost_spread", 0.0),
+                            "predicted_spread_8_ranks_10_to_90_atoms_by_conformers_per_rank": nqdist.spread_table("qhnet")}, "atoms": N,
            "edges_within_cutoff": E, "ordered_pairs": P, "orbitals": int(net.last_plan.m_total), "parameters": net.get_number_of_parameters(),
            "_dt": dt, "final_loss": float(loss), "dtype": "f32", "data": "synthetic", "parity": "pinned to the reference QHNet classes; e3nn arithmetic restated (unpinned)"}
     if kernels:

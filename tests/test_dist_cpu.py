@@ -77,6 +77,26 @@ def test_shard_by_cost_balanced_and_complete():
         assert all(s == sorted(s) for s in shards)
 
 
+def test_cost_proxies_balance_the_10_to_90_atom_mix_for_every_model():
+    """BASELINE.json configs[4]: "mixed molecule sizes 10-90 atoms (load-balance stress)".  For every model's cost proxy the greedy partition of a global
+    batch over 8 ranks stays within 5 % of the mean from 16 conformers per rank on (pure arithmetic, no GPU needed), and the proxies differ the way the
+    graphs do: a neighbour-capped model weighs a 90-atom molecule ~9x a 10-atom one, the pair models ~90x."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    for model in ("painn", "escn", "equiformer_v2", "gemnet_oc", "qhnet", "phisnet"):
+        for per_rank in (16, 32, 64):
+            sizes = rng.integers(10, 91, size=8 * per_rank).tolist()
+            shards = nqdist.shard_by_cost(sizes, 8, model)
+            assert sorted(i for s in shards for i in s) == list(range(len(sizes)))
+            assert nqdist.predicted_spread(sizes, 8, model) <= 0.05, (model, per_rank, nqdist.predicted_spread(sizes, 8, model))
+    assert 8.0 < nqdist.conformer_cost(90, "escn") / nqdist.conformer_cost(10, "escn") < 35.0
+    assert 80.0 < nqdist.conformer_cost(90, "qhnet") / nqdist.conformer_cost(10, "qhnet") < 100.0
+    # the n^2 proxy mis-balances a capped model: partition by n^2, evaluate with the capped cost
+    sizes = rng.integers(10, 91, size=128).tolist()
+    parts = nqdist.shard_by_cost(sizes, 8, "n2")
+    loads = [sum(nqdist.conformer_cost(sizes[i], "equiformer_v2") for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) - 1.0 > nqdist.predicted_spread(sizes, 8, "equiformer_v2")
+
+
 def test_bench_never_calls_a_training_step_on_one_rank_only():
     """bench.py: a training step contains the gradient all-reduce, so inside main() every call of step()/step2() must be reached by ALL
     ranks or be guarded by ``world == 1`` (a rank-0-only instrumented pass once deadlocked every multi-GPU run)."""
