@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 10
+#define NQ_ABI_VERSION 11
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -518,6 +518,9 @@ int nq_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
  * terminated), total milliseconds, launch count}, clears the records and returns the number of names. */
 void nq_profile_enable(int32_t on);
 int nq_profile_read(char* names_host, int32_t name_stride, double* total_ms_host, int64_t* counts_host, int32_t cap);
+/* As nq_profile_read, plus flops_host[i] (nullable) = arithmetic of the launches of name i: the dense-product launchers record 2 M N K per call, so a
+ * class's TFLOP/s is flops / time without re-deriving shapes from names (every other launcher records 0).  ABI 11. */
+int nq_profile_read2(char* names_host, int32_t name_stride, double* total_ms_host, int64_t* counts_host, double* flops_host, int32_t cap);
 
 /* Tuning hook (process-global): GEMM kernel variant, bit0 = 8 wavefronts per 128x128 tile, bit1 = register prefetch. */
 void nq_set_gemm_variant(int32_t variant);

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -174,6 +174,7 @@ SYMBOLS = {
     "nq_adamw_step": (C.c_int, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _F, _F, _I32, _P, _P]),
     "nq_profile_enable": (None, [_I32]),
     "nq_profile_read": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "nq_profile_read2": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I32]),
     "nq_set_gemm_variant": (None, [_I32]),
     "nq_linear_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
@@ -222,14 +223,15 @@ def profile_enable(on: bool):
 
 
 def profile_read(cap=4096, stride=64):
-    """-> {name: (total_ms, launches)} of everything recorded since the last read (``cap`` distinct names: a process that ran several models has one name per
+    """-> {name: (total_ms, launches, flops)} of everything recorded since the last read; flops = 2 M N K summed over the launches of a dense-product class, 0 for other kernels (``cap`` distinct names: a process that ran several models has one name per
     GEMM shape of each of them -- 256 was too few for the default bench record, which dropped EquiformerV2's weight-gradient GEMMs from its table)."""
     names = C.create_string_buffer(cap * stride)
     tot = (C.c_double * cap)()
     cnt = (C.c_int64 * cap)()
-    n = load().nq_profile_read(names, stride, tot, cnt, cap)
+    fl = (C.c_double * cap)()
+    n = load().nq_profile_read2(names, stride, tot, cnt, fl, cap)
     out = {}
     for i in range(min(n, cap)):
         nm = names.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode()
-        out[nm] = (tot[i], cnt[i])
+        out[nm] = (tot[i], cnt[i], fl[i])
     return out

@@ -43,9 +43,11 @@ struct NqProfScope {
   hipStream_t st; int slot;
   NqProfScope(hipStream_t s, const char* name);
   ~NqProfScope();
+  void add_flops(double f);   // arithmetic of this launch (GEMM launchers: 2 M N K), summed per name and returned by nq_profile_read2
 };
 extern int nq_profile_on;
 #define NQ_PROF(st, name) NqProfScope nq_prof_scope__((st), (name))
+#define NQ_PROF_FLOPS(f) do { if (nq_profile_on) nq_prof_scope__.add_flops((double)(f)); } while (0)
 
 // ---- device math ---------------------------------------------------------------------------
 __device__ __forceinline__ float nq_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }

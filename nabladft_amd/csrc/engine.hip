@@ -27,7 +27,7 @@ int nq_fail(int code, const char* fmt, ...) {
 #include <string>
 #include <vector>
 int nq_profile_on = 0;
-struct ProfRec { hipEvent_t a, b; int name_id; };
+struct ProfRec { hipEvent_t a, b; int name_id;  double flops = 0.0; };
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::string> g_prof_names;
 static std::map<std::string, int> g_prof_ids;
@@ -45,6 +45,9 @@ NqProfScope::NqProfScope(hipStream_t s, const char* name) : st(s), slot(-1) {
 }
 NqProfScope::~NqProfScope() {
   if (slot >= 0) (void)hipEventRecord(g_prof_recs[slot].b, st);
+}
+void NqProfScope::add_flops(double f) {
+  if (slot >= 0) g_prof_recs[slot].flops += f;
 }
 
 // ---- parameter layout --------------------------------------------------------------------------
@@ -173,13 +176,13 @@ int nq_abi_version(void) { return NQ_ABI_VERSION; }
 void nq_profile_enable(int32_t on) { nq_profile_on = on; }
 // Synchronises the device, folds all recorded event pairs into per-name totals and clears them.
 // Fills up to `cap` entries; returns the number of distinct names.
-int nq_profile_read(char* names, int32_t name_stride, double* total_ms, int64_t* counts, int32_t cap) {
+int nq_profile_read2(char* names, int32_t name_stride, double* total_ms, int64_t* counts, double* flops, int32_t cap) {
   (void)hipDeviceSynchronize();
-  std::vector<double> tot(g_prof_names.size(), 0.0);
+  std::vector<double> tot(g_prof_names.size(), 0.0), fl(g_prof_names.size(), 0.0);
   std::vector<long long> cnt(g_prof_names.size(), 0);
   for (auto& r : g_prof_recs) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot[r.name_id] += ms; cnt[r.name_id] += 1; }
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot[r.name_id] += ms; cnt[r.name_id] += 1; fl[r.name_id] += r.flops; }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof_recs.clear();
@@ -187,8 +190,12 @@ int nq_profile_read(char* names, int32_t name_stride, double* total_ms, int64_t*
   for (int i = 0; i < n && i < cap; ++i) {
     snprintf(names + (size_t)i * name_stride, name_stride, "%s", g_prof_names[i].c_str());
     total_ms[i] = tot[i]; counts[i] = cnt[i];
+    if (flops) flops[i] = fl[i];
   }
   return n;
+}
+int nq_profile_read(char* names, int32_t name_stride, double* total_ms, int64_t* counts, int32_t cap) {
+  return nq_profile_read2(names, name_stride, total_ms, counts, nullptr, cap);
 }
 const char* nq_last_error(void) { return nq_err_buf; }
 

@@ -401,6 +401,7 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
                int lda, int ldw, int ldc, const char* tag) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * N * K);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
   if (gemm2_ok<true, true>(p, K)) {
@@ -428,6 +429,7 @@ int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, flo
                    const char* tag) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * N * K);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, nullptr, C2, M, N, K, K, K, N, 0, 0, nullptr, 0};
   p.resid = resid; p.ea = ea; p.eb = eb;
@@ -452,6 +454,7 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
                int accumulate, const char* tag) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
   if (gemm2_ok<true, false>(p, Nout)) {
@@ -478,6 +481,7 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:[n=%d,k=%d]", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
   p.resid = aux; p.ea = ea; p.eb = eb;
@@ -519,6 +523,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
                const char* tag, float* bias_out, long bias_rows) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_tn:%s[%dx%d]", tag ? tag : "", Mo, No); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * rows * Mo * No);
   if (rows <= 0) {
     NQ_HIP(hipMemsetAsync(out, 0, sizeof(float) * Mo * No, st));
     if (bias_out) NQ_HIP(hipMemsetAsync(bias_out, 0, sizeof(float) * Mo, st));
@@ -608,6 +613,7 @@ int nq_sph_linear_forward(const float* x, const float* const* W_host, const floa
   if (!x || !W_host || !y) return nq_fail(NQ_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "sph_linear_fwd");
+  NQ_PROF_FLOPS(2.0 * rows * (order + 1) * (order + 1) * Fin * Fout);
   if (rows == 0) return NQ_OK;
   const int ncomp = (order + 1) * (order + 1);
   GemmArgs p{};
@@ -628,6 +634,7 @@ int nq_sph_linear_input_grad(const float* gy, const float* const* W_host, float*
   if (!gy || !W_host || !gx) return nq_fail(NQ_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "sph_linear_bwd_x");
+  NQ_PROF_FLOPS(2.0 * rows * (order + 1) * (order + 1) * Fin * Fout);
   if (rows == 0) return NQ_OK;
   const int ncomp = (order + 1) * (order + 1);
   GemmArgs p{};
@@ -654,6 +661,7 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
   if (!gy || !x || !gW_host || !scratch) return nq_fail(NQ_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "sph_linear_bwd_w");
+  NQ_PROF_FLOPS(2.0 * rows * (order + 1) * (order + 1) * Fin * Fout);
   const int ncomp = (order + 1) * (order + 1);
   GemmArgs p{};
   for (int L = 0; L <= order; ++L) {

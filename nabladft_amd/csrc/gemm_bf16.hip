@@ -184,6 +184,7 @@ static int hb_launch(hipStream_t st, const float* A, const void* B, float* C, fl
                      int accumulate, const char* kind, int mode = 0) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_bf16_%s:[n=%d,k=%d]", kind, N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * N * K);
   if (M <= 0) return NQ_OK;
   if (K % HB_BK != 0 || N <= 0) return nq_fail(NQ_ERR_ARG, "bf16 gemm: K = %d must be a multiple of %d", K, HB_BK);
   HbArgs p{A, (const __bf16*)B, C, C2, resid, ea, eb, M, N, K, K, K, N, nullptr, 0, 0};
@@ -236,6 +237,7 @@ int nq_linear_weight_grad_bf16(const float* G, const float* X, float* gW, int64_
   hipStream_t st = (hipStream_t)stream;
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_bf16_tn:[%dx%d]", N, K); else nm__[0] = 0;
   NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * rows * N * K);
   if (!G || !X || !gW || !scratch || rows <= 0) return nq_fail(NQ_ERR_ARG, "bad argument");
   long Mp; int ns, ks;
   hb_wgrad_plan(rows, N, K, &Mp, &ns, &ks);

@@ -120,9 +120,10 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         ks = sorted(((k, v[0] / steps, v[1] // steps) for k, v in prof.items()), key=lambda x: -x[1])
         out["device_ms_per_step_nq_kernels"] = tot
         out["kernel_ms_per_step"] = {k: [round(ms, 4), int(n)] for k, ms, n in ks[:24]}
-        gemm_ms = sum(ms for k, ms, _ in ks if k.startswith("gemm") or k.startswith("bf16"))
+        gemm_ms = sum(v[0] for k, v in prof.items() if v[2] > 0 or k.startswith("bf16")) / steps      # dense products (+ the per-forward bf16 weight re-pack)
+        out["gemm_classes_TFLOPs"] = {k: round(v[2] / max(v[0], 1e-9) / 1e9, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]) if v[2] > 0}
         out["gemm_bf16_ms_per_step"] = sum(ms for k, ms, _ in ks if "bf16" in k)
-        fl = 3.0 * fwd_flops                                                # forward + input gradient + weight gradient of every Dense (batch 0's sizes)
+        fl = sum(v[2] for v in prof.values()) / steps                      # exact: every dense launcher records its 2 M N K (nq_profile_read2)
         by = 3.0 * fwd_bytes                                                # each of the three products reads two operands and writes one of the same sizes
         ach = fl / (max(gemm_ms, 1e-9) * 1e-3) / 1e12
         if precision == "bf16":

@@ -152,8 +152,9 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
         out["kernel_ms_per_step"] = {k: [round(ms, 4), int(n)] for k, ms, n in ks[:16]}
         # roofline of the dominant class.  The [P, 128] x [128, 8320] generators are MFMA-bound; the Clebsch-Gordan kernels stream the
         # per-pair weight arrays: algorithmic bytes = weights read (2 factors) + irreps in / out per row.
-        gemm_ms = sum(ms for k, ms, _ in ks if k.startswith("gemm") or k.startswith("linear"))
-        fl = gemm_flops_per_step(net, N, E, P)
+        gemm_ms = sum(v[0] for v in prof.values() if v[2] > 0) / steps      # every dense launcher (incl. the row-mapped spherical linears) records 2 M N K
+        out["gemm_classes_TFLOPs"] = {k: round(v[2] / max(v[0], 1e-9) / 1e9, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]) if v[2] > 0}
+        fl = sum(v[2] for v in prof.values()) / steps
         dom, dom_ms, dom_n = ks[0]
         C = net.hs
         # per-launch bytes.  COMPULSORY (what must cross HBM however the step is fused) = the irreps rows read and written per (pair / edge) row;
