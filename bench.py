@@ -144,11 +144,14 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
 _MSG_FLOP_PER_EDGE_CHANNEL = {"msgf_fwd": 81 + 16, "msgf_tan": 162 + 39, "msgf_rev_force": 162 + 39, "msgf_rev_dual": 162 + 103 + 27, "gwr_sorted": 3 * 26}
 
 
-def step_bounds(kernels, n_atoms, E, batch, ms_per_step):
+def step_bounds(kernels, n_atoms, E, batch, ms_per_step, prof=None, steps=1):
     """Step-level roofs of the PaiNN training step: the fp32 arithmetic the step executes (GEMM flops from the role tags of every GEMM launch of the step +
     the message-path kernels' VALU flops) against the 157.3 TFLOP/s fp32 peak (matrix cores and VALU have the SAME fp32 peak on gfx950), and SURVEY 8(d)'s
     17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger of the two times is the roof that binds."""
-    gemm = sum(gemm_flops(k, n_atoms, E, n) * n for k, _, n in kernels if k.startswith("gemm"))
+    if prof is not None:      # exact: every dense launcher records its 2 M N K with the event pair (nq_profile_read2)
+        gemm = sum(v[2] for v in prof.values()) / steps
+    else:
+        gemm = sum(gemm_flops(k, n_atoms, E, n) * n for k, _, n in kernels if k.startswith("gemm"))
     msg = sum(_MSG_FLOP_PER_EDGE_CHANNEL[k] * float(E) * F * n for k, _, n in kernels if k in _MSG_FLOP_PER_EDGE_CHANNEL)
     t_fp32 = (gemm + msg) / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
     t_hbm = 17.8e6 * batch / (HBM_PEAK_GBS * 1e9) * 1e3
@@ -157,6 +160,18 @@ def step_bounds(kernels, n_atoms, E, batch, ms_per_step):
             "fp32_bound_ms": t_fp32, "hbm_bound_ms": t_hbm, "binding_roof": bind, "achieved_TFLOPs": (gemm + msg) / (ms_per_step * 1e-3) / 1e12,
             "frac_of_fp32_roof": t_fp32 / ms_per_step, "frac_of_hbm_roof": t_hbm / ms_per_step, "frac_of_binding_roof": max(t_fp32, t_hbm) / ms_per_step,
             "note": "exact-fp32 arithmetic makes the step FLOP-bound: the HBM fraction cannot exceed hbm_bound_ms / fp32_bound_ms"}
+
+
+def _graph_replay(which):
+    """scripts/bench_graphed.py: the step at the reference's batch size on one PREPARED batch, eager and as a replayed HIP graph (is the step host-bound?)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import gc
+    import bench_graphed
+    gc.collect()                                           # no autograd graph of an earlier eager step may be alive during the capture
+    try:
+        return bench_graphed.run(which)
+    except Exception as e:                                 # a failed capture must not cost the record its other numbers
+        return {"error": repr(e)[:300]}
 
 
 def bench_gemnet(args, rank, world, local_dev, dev):
@@ -198,6 +213,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
                "parity": rec.get("parity"), "bf16_mode": bf,
                "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
+               "reference_batch_size_8_prepared_eager_vs_graph_replay": _graph_replay("gemnet") if world == 1 and not args.no_roofline else None,
                "batch_64": big if bf is not None else None}
         print(json.dumps(out))
     if world > 1:
@@ -242,7 +258,8 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
                "parity": rec.get("parity"), "bf16_mode": bf,
-               f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")}}
+               f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
+               f"reference_batch_size_{ref_batch}_prepared_eager_vs_graph_replay": _graph_replay(which) if world == 1 and not args.no_roofline else None}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -275,7 +292,8 @@ def bench_qhnet(args, rank, world, local_dev, dev):
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "ordered_pairs": rec["ordered_pairs"], "edges_within_cutoff": rec["edges_within_cutoff"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
-               "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")}}
+               "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
+               "reference_batch_size_2_prepared_eager_vs_graph_replay": _graph_replay("qhnet") if world == 1 and not args.no_roofline else None}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -483,7 +501,7 @@ def main():
         E = n_edges
         roofline = roofline_record(dom, avg_ms, dom_launches, n_atoms, E, args.batch)
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
-        roofline["step"] = step_bounds(kernels, n_atoms, E, args.batch, 1e3 * dt / args.steps)
+        roofline["step"] = step_bounds(kernels, n_atoms, E, args.batch, 1e3 * dt / args.steps, prof, args.steps)
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

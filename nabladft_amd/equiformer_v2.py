@@ -755,13 +755,18 @@ class EquiformerV2_OC20(nn.Module):
             K.to_grid_full, K.from_grid_full = flat(full.to_grid_mat).contiguous(), flat(full.from_grid_mat).contiguous()
         return K
 
+    prepare = eSCN.prepare                              # data.prepared = net.prepare(data): forward without host synchronisation (trainer.GraphedStep)
     build_graph = eSCN.build_graph                      # radius graph + frames + Wigner rows + the inverse lists of the gathers (escn.py / equiformer: same stage)
 
     def forward(self, data, edge_rot_mat=None, return_intermediates: bool = False):
         _gemnet.weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.EquiformerV2_OC20 runs on MI355X only: tensors must be on a cuda (HIP) device")
-        G = self.build_graph(data, edge_rot_mat)
+        G = getattr(data, "prepared", None)            # build_graph(data) done ahead: the forward then issues no host synchronisation (HIP-graph capture)
+        if G is None:
+            G = self.build_graph(data, edge_rot_mat)
+        elif G.N != int(data.pos.shape[0]):
+            raise ValueError("data.prepared belongs to another batch")
         K = self._constants(data.pos.device)
         Cc, nf = self.sphere_channels, K.order.n_full
         emb = _EmbeddingFn.apply(self.sphere_embedding.weight, G.z, [G.z_inverse])                     # the l = 0 coefficient (equiformer_v2_oc20.py:517-530)

@@ -534,6 +534,11 @@ class eSCN(torch.nn.Module):
             self._dev_const = K
         return self._dev_const
 
+    def prepare(self, data, edge_rot_mat=None):
+        """Graph, frames, Wigner rows and index lists of a batch (all host reads of the step happen here).  ``data.prepared = net.prepare(data)`` makes
+        ``forward(data)`` free of host synchronisation: a training step on that batch can be captured into a HIP graph (trainer.GraphedStep)."""
+        return self.build_graph(data, edge_rot_mat)
+
     def build_graph(self, data, edge_rot_mat=None):
         """radius graph + frames + Wigner rows (escn.py:313-325)."""
         lib = _lib.load()
@@ -588,7 +593,11 @@ class eSCN(torch.nn.Module):
         _gemnet.weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.eSCN runs on MI355X only: tensors must be on a cuda (HIP) device")
-        G = self.build_graph(data, edge_rot_mat)
+        G = getattr(data, "prepared", None)            # build_graph(data) done ahead: the forward then issues no host synchronisation (HIP-graph capture)
+        if G is None:
+            G = self.build_graph(data, edge_rot_mat)
+        elif G.N != int(data.pos.shape[0]):
+            raise ValueError("data.prepared belongs to another batch")
         K = self._constants(data.pos.device)
         Cc, nf = self.sphere_channels, K.order.n_full
         emb = _EmbeddingFn.apply(self.sphere_embedding.weight, G.z, [G.z_inverse])                                   # [N, C] -> the l = 0 coefficient (escn.py:333-341)

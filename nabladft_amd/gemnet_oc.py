@@ -1120,11 +1120,23 @@ class GemNetOC(torch.nn.Module):
              "a2a_rad": self.mlp_rbf_aint(self.radial_basis_aint(t["geom"]))}
         return B
 
+    def prepare(self, data):
+        """The four graphs, their index lists and the atomic-number range check of a batch (every host read of the step happens here).
+        ``data.prepared = net.prepare(data)`` makes ``forward(data)`` free of host synchronisation (trainer.GraphedStep can capture the step)."""
+        G = self.get_graphs_and_indices(data)
+        with torch.no_grad():
+            self.atom_emb(G)                            # runs the range check once (sets G.z_checked)
+        return G
+
     def forward(self, data, return_intermediates: bool = False):
         weights_epoch_advance()   # bf16 weight copies are re-packed once per forward (parameters may have been updated in place)
         if not data.pos.is_cuda:
             raise RuntimeError("nabladft_amd.GemNetOC runs on MI355X only: tensors must be on a cuda (HIP) device")
-        G = self.get_graphs_and_indices(data)
+        G = getattr(data, "prepared", None)            # prepare(data) done ahead: the forward then issues no host synchronisation (HIP-graph capture)
+        if G is None:
+            G = self.get_graphs_and_indices(data)
+        elif G.N != int(data.pos.shape[0]):
+            raise ValueError("data.prepared belongs to another batch")
         B = self.get_bases(G)
         NS = self.num_spherical
         h = self.atom_emb(G)

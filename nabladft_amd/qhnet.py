@@ -701,17 +701,40 @@ class QHNet(nn.Module):
         return data.z.squeeze(), csr.edge_index, rbf, sh, transpose_index(ptr)
 
     def _graphs(self, data):
+        """The two neighbour structures (index arrays + geometry; no learnable parameter involved)."""
         g = _Graphs()
         g.conv = self._csr(data, self.max_radius)
-        g.edge_attr, g.edge_sh = self._edge_features(g.conv)
         g.full = self._csr(data, 10000)
-        g.full_edge_attr, g.full_edge_sh = self._edge_features(g.full)
         return g
 
+    def _features(self, g):
+        """Radial basis (learnable exponent: part of every step's autograd graph, never cached across steps) and harmonics of both edge sets."""
+        g.edge_attr, g.edge_sh = self._edge_features(g.conv)
+        g.full_edge_attr, g.full_edge_sh = self._edge_features(g.full)
+
     # -- forward -------------------------------------------------------------------------------------------------------------------------------
-    def forward(self, data, keep_blocks=False, packed=False):
+    def prepare(self, data):
+        """Everything of a batch that is built with host reads: the two neighbour structures (edge counts come back to the host to size the per-edge tensors)
+        and the matrix-assembly tables.  Pass the result as ``data.prepared`` and ``forward`` issues no host synchronisation at all -- a training step on
+        that batch can then be captured into a HIP graph (trainer.GraphedStep; the edge sets depend on the positions, so a prepared batch is tied to its
+        geometry, not only to its composition)."""
         _require_gpu(data.pos)
         g = self._graphs(data)
+        z = data.z.squeeze().long()
+        g.plan = self._asm.plan(z, data.ptr.to(z.device), g.full.edge_index)
+        g.ptr = data.ptr.to(data.pos.device)
+        g.transpose = transpose_index(g.ptr)
+        g.n_atoms = int(data.pos.shape[0])
+        return g
+
+    def forward(self, data, keep_blocks=False, packed=False):
+        _require_gpu(data.pos)
+        g = getattr(data, "prepared", None)
+        if g is None:
+            g = self.prepare(data)
+        elif g.n_atoms != int(data.pos.shape[0]):
+            raise ValueError("data.prepared belongs to another batch")
+        self._features(g)
         z = data.z.squeeze().long()
         node_attr = self.node_embedding(z)
         data.node_attr, data.edge_index, data.edge_attr, data.edge_sh = node_attr, g.conv.edge_index, g.edge_attr, g.edge_sh
@@ -729,11 +752,10 @@ class QHNet(nn.Module):
         diag = self.expand_ii[name](fii, _mlp(self.fc_ii[name], node_attr), _mlp(self.fc_ii_bias[name], node_attr))
         nondiag = self.expand_ij[name](fij, self._pair_head(self.fc_ij[name], node_attr, g.full), self._pair_head(self.fc_ij_bias[name], node_attr, g.full))
         if keep_blocks:
-            ptr = data.ptr.to(data.pos.device)
-            t = transpose_index(ptr)
+            t = g.transpose
             return {"hamiltonian_diagonal_blocks": diag + diag.transpose(-1, -2),
                     "hamiltonian_non_diagonal_blocks": nondiag + nondiag[t].transpose(-1, -2)}
-        plan = self._asm.plan(z, data.ptr.to(z.device), data.full_edge_index)
+        plan = g.plan
         H = self._asm.assemble(plan, diag, nondiag, symmetrize=True)          # build_final_matrix + H + H^T (qhnet.py:234-237)
         self.last_plan = plan
         if packed:

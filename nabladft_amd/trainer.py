@@ -291,7 +291,9 @@ class GraphedStep:
     step is a thousand small launches issued from Python autograd (PhiSNet: ~1000, device busy 45 % of the wall time) the host disappears from the
     critical path.  Requirements: ``fn()`` must not synchronise with the host (prepared batch composition, device-side scalars), must read its inputs
     from tensors that keep their addresses (update them in place between replays) and must use capturable optimiser settings
-    (``torch.optim.Adam(..., capturable=True)``).  ``fn`` returns a tensor (the loss) that is refreshed by every replay."""
+    (``torch.optim.Adam(..., capturable=True)``).  ``fn`` returns a tensor (the loss) that is refreshed by every replay.  Drop every reference to
+    results of earlier EAGER calls of ``fn`` (e.g. a kept loss tensor) before constructing this: their autograd graph keeps AccumulateGrad nodes of the
+    default stream alive, and touching those from the capture stream aborts the capture."""
 
     def __init__(self, fn, warmup: int = 3):
         self.fn = fn
