@@ -215,6 +215,116 @@ __global__ __launch_bounds__(256) void k_rowop_tr(RowOp p) {
   }
 }
 
+// ---- shared-matrix row operator on the matrix cores -----------------------------------------------------------------------------------------------------------
+// The S2-grid transforms (to_grid / from_grid, so3.py:301-375) and the sphere-point sampling apply ONE constant matrix to every edge / node row: per row o an
+// [M x K] x [K x C] product with M, K = (grid points, coefficients) or the reverse.  k_rowop_* does it with two LDS reads per FMA (measured 12 TFLOP/s on the
+// per-edge grid activations: 38 ms of the 177-ms eSCN step); here the constant matrix sits in LDS as the MFMA A operand for the lifetime of a persistent
+// workgroup, the row's block X_o (B operand) is staged once per row, and v_mfma_f32_32x32x2_f32 does the arithmetic (exact f32, fixed k order).
+//   forward   (TR = false): out[o][i][c] = sum_s R[i][s] X_o[s][c]      M = I,   K = NSS
+//   transpose (TR = true):  out[o][s][c] = sum_i R[i][s] X_o[i][c]      M = NSS, K = I
+// One work item = (row o, slice of CS <= 128 channels); the M x CS result is MT x CS/32 tiles of 32 x 32, dealt round-robin to the 4 wavefronts.
+#define RMM_MAXT 6
+typedef float es_f32x16 __attribute__((ext_vector_type(16)));
+template <bool TR, int TW>   // TW = tiles per wavefront (a wavefront whose last tile does not exist recomputes the previous one and does not store it)
+__global__ __launch_bounds__(256) void k_rowmm(RowOp p, int CS, long n_items) {
+  extern __shared__ __attribute__((aligned(16))) float es_lds[];
+  const int M = TR ? p.NSS : p.I, K = TR ? p.I : p.NSS;
+  const int MT = (M + 31) >> 5, Kp = (K + 1) & ~1, KS = Kp + 1, NTc = CS >> 5, nsl = p.C / CS, CS4 = CS >> 2;
+  float* sA = es_lds;                       // [MT*32][KS]: A(m, k), zero outside M x K; KS odd: the 32 rows of a fragment hit 32 banks
+  float* sB = es_lds + ((MT * 32 * KS + 3) & ~3);   // [max(Kp, MT*32)][CS]: the row block X_o, then the result tile on its way out
+  for (int t = threadIdx.x; t < MT * 32 * KS; t += 256) {
+    const int m = t / KS, k = t - m * KS;
+    sA[t] = (m < M && k < K) ? (TR ? p.R[(long)k * p.NSS + m] : p.R[(long)m * p.NSS + k]) : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int ntiles = MT * NTc;
+  int aoff[TW], boff[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    const int tile = min(wave + 4 * t, ntiles - 1), mt = tile / NTc, nt = tile - mt * NTc;
+    aoff[t] = (mt * 32 + r) * KS + h;
+    boff[t] = h * CS + nt * 32 + r;
+  }
+  const RowSeg& in_seg = TR ? p.segI : p.segS;
+  const RowSeg& out_seg = TR ? p.segS : p.segI;
+  for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const long o = item / nsl;
+    const int c0 = (int)(item - o * nsl) * CS;
+    __syncthreads();                        // sA staged / the previous item's fragments read before sB is overwritten
+    const float* xrow = p.X ? p.X + (p.index ? (long)p.index[o] : o) * p.x_stride : nullptr;
+    for (int t = threadIdx.x; t < Kp * CS4; t += 256) {
+      const int k = t / CS4, q = t - k * CS4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K) {
+        const float* src = in_seg.n ? rowseg_addr(in_seg, o, k, p.C) : xrow + (long)k * p.C;
+        v = *reinterpret_cast<const float4*>(src + c0 + 4 * q);
+      }
+      *reinterpret_cast<float4*>(sB + k * CS + 4 * q) = v;
+    }
+    __syncthreads();
+    es_f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    for (int j = 0; j < Kp; j += 2) {
+#pragma unroll
+      for (int t = 0; t < TW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[aoff[t] + j], sB[boff[t] + j * CS], acc[t], 0, 0, 0);
+    }
+    // result: accumulators -> LDS (the B buffer is free once every wavefront has left the k loop) -> coalesced 16-byte stores, one row resolution per float4
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < ntiles) {                     // wave-uniform
+        const int mt = tile / NTc, nt = tile - mt * NTc;
+        float* so = sB + (mt * 32 + 4 * h) * CS + nt * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) so[((q & 3) + 8 * (q >> 2)) * CS] = acc[t][q];
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < M * CS4; t += 256) {
+      const int m = t / CS4, q = t - m * CS4;
+      float* dst = out_seg.n ? rowseg_addr(out_seg, o, m, p.C) : p.out + o * p.out_stride + (long)m * p.C;
+      *reinterpret_cast<float4*>(dst + c0 + 4 * q) = *reinterpret_cast<const float4*>(sB + m * CS + 4 * q);
+    }
+  }
+}
+// eligibility and launch of the matrix-core form (shared matrix, no accumulation into the output, whole 32-channel groups, LDS and register budget)
+static bool rowmm_plan(const RowOp& p, long r_stride, int transpose, int* CS, size_t* lds) {
+  if (r_stride != 0 || p.accumulate || (p.C & 31)) return false;
+  const int M = transpose ? p.NSS : p.I, K = transpose ? p.I : p.NSS;
+  const int MT = (M + 31) / 32, Kp = (K + 1) & ~1, KS = Kp + 1;
+  int cs = p.C % 128 == 0 ? 128 : (p.C % 64 == 0 ? 64 : 32);
+  while (cs > 32 && (MT * (cs / 32) + 3) / 4 > RMM_MAXT) cs >>= 1;
+  if ((MT * (cs / 32) + 3) / 4 > RMM_MAXT) return false;
+  const size_t need = sizeof(float) * ((size_t)((MT * 32 * KS + 3) & ~3) + (size_t)(Kp > MT * 32 ? Kp : MT * 32) * cs);
+  if (need > 150 * 1024) return false;
+  *CS = cs; *lds = need;
+  return true;
+}
+static int rowmm_launch(hipStream_t st, const RowOp& p, long n, int transpose, int CS, size_t lds) {
+  const long items = n * (p.C / CS);
+  const int per_cu = (int)(lds > 75 * 1024 ? 1 : (160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds));
+  const long grid = items < 256L * per_cu ? items : 256L * per_cu;
+  const int M = transpose ? p.NSS : p.I;
+  const int tw = (((M + 31) / 32) * (CS / 32) + 3) / 4;
+#define RMM_GO(TRV, TWV)                                                                                                                          \
+  do {                                                                                                                                            \
+    if (lds > 64 * 1024) NQ_HIP(hipFuncSetAttribute((const void*)k_rowmm<TRV, TWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    hipLaunchKernelGGL((k_rowmm<TRV, TWV>), dim3((unsigned)grid), dim3(256), lds, st, p, CS, items);                                              \
+  } while (0)
+#define RMM_TW(TRV)                                                                                                                               \
+  switch (tw) { case 1: RMM_GO(TRV, 1); break; case 2: RMM_GO(TRV, 2); break; case 3: RMM_GO(TRV, 3); break; case 4: RMM_GO(TRV, 4); break;       \
+                case 5: RMM_GO(TRV, 5); break; default: RMM_GO(TRV, 6); break; }
+  if (transpose) { RMM_TW(true) } else { RMM_TW(false) }
+#undef RMM_TW
+#undef RMM_GO
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
 // ---- rotations with the block structure of the Wigner matrices ------------------------------------------------------------------------------------------------
 // Row i of an edge's Wigner block (degree l_i) touches only the 2 l_i + 1 coefficients of that degree: 235 of the 29 x 49 entries at lmax 6 / mmax 2.  One
 // workgroup per edge (or per node when the transposed form also sums over a node's edges), thread = channel: the coefficients of one degree sit in registers,
@@ -387,10 +497,14 @@ int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride,
   NQ_PROF(st, transpose ? "rowop_tr" : "rowop_fwd");
   if (n <= 0) return NQ_OK;
   if (!R || !X || !out) return nq_fail(NQ_ERR_ARG, "null argument");
-  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
-  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB): split the matrix rows", I, NSS, C, lds);
   RowOp p{R, (long)r_stride, X, (long)x_stride, index, out, (long)out_stride, I, NSS, C, accumulate, {}, {}};
   p.segI.n = p.segS.n = 0;
+  {
+    int CS; size_t l2;
+    if (rowmm_plan(p, (long)r_stride, transpose, &CS, &l2)) return rowmm_launch(st, p, (long)n, transpose, CS, l2);
+  }
+  const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB): split the matrix rows", I, NSS, C, lds);
   if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
   NQ_LAUNCH_CHECK();
@@ -407,7 +521,6 @@ int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t s
   if (n <= 0) return NQ_OK;
   if (!R || !x_or_out || !seg_rows || !seg_ptrs || nseg < 1 || nseg > ROWOP_MAXSEG) return nq_fail(NQ_ERR_ARG, "bad argument");
   const size_t lds = sizeof(float) * ((size_t)I * NSS + (size_t)(transpose ? I : NSS) * C);
-  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB)", I, NSS, C, lds);
   RowOp p{R, (long)r_stride, nullptr, 0, index, nullptr, 0, I, NSS, C, accumulate, {}, {}};
   p.segI.n = p.segS.n = 0;
   RowSeg& sg = seg_side == 0 ? p.segI : p.segS;
@@ -419,6 +532,11 @@ int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t s
   const bool seg_is_input = (transpose != 0) == (seg_side == 0);          // fwd: input = S side; tr: input = I side
   if (seg_is_input) { p.out = x_or_out; p.out_stride = stride; }
   else { p.X = x_or_out; p.x_stride = stride; }
+  {
+    int CS; size_t l2;
+    if (rowmm_plan(p, (long)r_stride, transpose, &CS, &l2)) return rowmm_launch(st, p, (long)n, transpose, CS, l2);
+  }
+  if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB)", I, NSS, C, lds);
   if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
   NQ_LAUNCH_CHECK();

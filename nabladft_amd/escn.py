@@ -113,13 +113,31 @@ class CoefficientOrder:
 _LDS_FLOATS = 15 * 1024          # per-call LDS budget of nq_rowop (60 kB)
 
 
+def _rowmm_ok(r_stride, I, NSS, Cc, transpose):
+    """Mirror of csrc/escn.hip: rowmm_plan -- a shared matrix (r_stride 0) with whole 32-channel groups runs on the matrix cores with the WHOLE matrix
+    resident in LDS (no splitting of its rows); same budget arithmetic as the C side."""
+    if r_stride != 0 or Cc % 32:
+        return False
+    M, K = (NSS, I) if transpose else (I, NSS)
+    MT, Kp = (M + 31) // 32, (K + 1) & ~1
+    cs = 128 if Cc % 128 == 0 else (64 if Cc % 64 == 0 else 32)
+    while cs > 32 and (MT * (cs // 32) + 3) // 4 > 6:
+        cs //= 2
+    if (MT * (cs // 32) + 3) // 4 > 6:
+        return False
+    return 4 * (((MT * 32 * (Kp + 1) + 3) & ~3) + max(Kp, MT * 32) * cs) <= 150 * 1024
+
+
 def _rowop(R, r_stride, X, x_stride, index, n, I, NSS, Cc, transpose):
-    """nq_rowop with the matrix rows split so that (matrix chunk + row block) fits the LDS budget: forward chunks write disjoint output rows, transposed
-    chunks accumulate."""
+    """nq_rowop.  Shared matrices go to the MFMA row operator in one call; per-row matrices use the LDS kernel with the matrix rows split so that
+    (matrix chunk + row block) fits its LDS budget: forward chunks write disjoint output rows, transposed chunks accumulate."""
     lib = _lib.load()
     out = _new(n, (NSS if transpose else I) * Cc, like=X)
-    step = max(1, (_LDS_FLOATS // (NSS + Cc)) if transpose else (_LDS_FLOATS - NSS * Cc) // NSS)
     idx = None if index is None else _lib.ptr(index)
+    if _rowmm_ok(r_stride, I, NSS, Cc, transpose):
+        _lib.check(lib.nq_rowop(_lib.ptr(R), r_stride, _lib.ptr(X), x_stride, idx, _lib.ptr(out), (NSS if transpose else I) * Cc, n, I, NSS, Cc, int(transpose), 0, _st()))
+        return out
+    step = max(1, (_LDS_FLOATS // (NSS + Cc)) if transpose else (_LDS_FLOATS - NSS * Cc) // NSS)
     for a in range(0, I, step):
         rows = min(step, I - a)
         Rp = R.data_ptr() + 4 * a * NSS

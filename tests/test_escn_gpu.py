@@ -126,3 +126,33 @@ def test_equivariance_and_reproducibility():
         assert (E1 - E0).abs().max() < 2e-2 * float(E0.abs().max()) and (F1 - F0 @ q.T).abs().max() < 5e-2 * float(F0.abs().max())
         E2, F2 = net(data)
         assert torch.equal(E2, E0) and torch.equal(F2, F0)
+
+
+@pytest.mark.parametrize("I,NSS,Cc,n", [(70, 29, 128, 300), (182, 49, 128, 37), (128, 49, 128, 50), (70, 29, 256, 64), (14, 9, 64, 1000), (70, 29, 16, 20)])
+def test_row_operator_shared_matrix_on_the_matrix_cores(I, NSS, Cc, n):
+    """nq_rowop / nq_rowop_blocks with a shared matrix (the S2-grid transforms and the sphere sampling): MFMA kernel (channels in whole groups of 32) and the
+    LDS kernel (the 16-channel case) against float64 einsum, both orientations, contiguous and per-m-block operands, gathered rows."""
+    from nabladft_amd import escn as ES
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(I * 7 + NSS)
+    R = torch.randn(I, NSS, generator=g)
+    X = torch.randn(n, NSS, Cc, generator=g)
+    Y = torch.randn(n, I, Cc, generator=g)
+    idx = torch.randint(0, n, (n,), generator=g)
+    Rd, Xd, Yd, idxd = R.to(dev), X.to(dev).reshape(n, -1), Y.to(dev).reshape(n, -1), idx.to(dev).to(torch.int32)
+    fwd = ES._rowop(Rd, 0, Xd, Xd.shape[1], None, n, I, NSS, Cc, False).view(n, I, Cc)
+    assert rel(fwd.cpu().numpy(), torch.einsum("is,nsc->nic", R.double(), X.double()).numpy()) < 3e-6
+    tr = ES._rowop(Rd, 0, Yd, Yd.shape[1], None, n, I, NSS, Cc, True).view(n, NSS, Cc)
+    assert rel(tr.cpu().numpy(), torch.einsum("is,nic->nsc", R.double(), Y.double()).numpy()) < 3e-6
+    gat = ES._rowop(Rd, 0, Xd, Xd.shape[1], idxd, n, I, NSS, Cc, False).view(n, I, Cc)
+    assert rel(gat.cpu().numpy(), torch.einsum("is,nsc->nic", R.double(), X[idx].double()).numpy()) < 3e-6
+    # the S side split into three block tensors (m-blocks): as input of the forward form and as output of the transposed form
+    rows = [NSS - 2 * (NSS // 3), NSS // 3, NSS // 3]
+    cuts = np.cumsum([0] + rows)
+    blocks = [X[:, cuts[k]:cuts[k + 1]].contiguous().to(dev) for k in range(3)]
+    out = torch.empty(n, I * Cc, device=dev)
+    ES._rowop_blocks(Rd, 0, out, None, 1, rows, blocks, n, I, NSS, Cc, False)
+    assert rel(out.view(n, I, Cc).cpu().numpy(), torch.einsum("is,nsc->nic", R.double(), X.double()).numpy()) < 3e-6
+    outs = [torch.empty(n, r, Cc, device=dev) for r in rows]
+    ES._rowop_blocks(Rd, 0, Yd, None, 1, rows, outs, n, I, NSS, Cc, True)
+    assert rel(torch.cat(outs, dim=1).cpu().numpy(), torch.einsum("is,nic->nsc", R.double(), Y.double()).numpy()) < 3e-6
