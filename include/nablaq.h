@@ -436,7 +436,8 @@ int nq_es_graph_fill(const float* pos, const int32_t* mol_ptr, const int32_t* at
 /* Edge rotation matrices rot [E][3][3] (escn.py:435-487; deterministic helper axis instead of the reference's random vector: same model output). */
 int nq_es_frames(const float* geom, int32_t E, float* rot, void* stream);
 /* Wigner-D rows (so3.py:377-425): W [E][n_red][n_full], row b = row red_row[b] of the degree-red_l[b] block D^l = Z(alpha) J_l Z(beta) J_l Z(gamma);
- * J: the J_l matrices back to back (J_offset[l]); scratch f32[3 E]. */
+ * J: the J_l matrices back to back (J_offset[l]); scratch: 8-byte aligned, 3 E doubles (the Euler angles and all trigonometry are evaluated in float64:
+ * the rows are then exact to float32 rounding, the reference's float32 evaluation carries several 1e-6 near the polar axis). */
 int nq_es_wigner(const float* rot, int32_t E, const float* J, const int32_t* J_offset, const int32_t* red_l, const int32_t* red_row, int32_t n_red, int32_t n_full,
                  int32_t lmax, float* scratch, float* W, void* stream);
 /* GaussianSmearing (smearing.py:14-31): out[e][k] = exp(coeff (geom[e][3] - offset[k])^2). */

@@ -98,51 +98,54 @@ __global__ void k_es_frames(const float4* __restrict__ geom, int E, float* __res
 }
 
 // ---- Euler angles of the frames (so3.py:378-383 with e3nn's y-polar conventions) ----------------------------------------------------------------------------
-__global__ void k_es_angles(const float* __restrict__ rot, int E, float* __restrict__ ang) {
+// Evaluated in float64: beta = acos(x_y) loses digits like 1 / sqrt(1 - x_y^2) for edges close to the polar axis, and every Wigner entry is a product of
+// cos / sin of up to l = 6 times these angles.  In float32 (what the reference's CPU run does) the rows carry errors of several 1e-6, which the network
+// passes on to the forces at the 1e-5 level; in float64 the rows are exact to float32 rounding at the cost of ~30 double-precision sincos per row, once per batch.
+__global__ void k_es_angles(const float* __restrict__ rot, int E, double* __restrict__ ang) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float* R = rot + 9 * (long)e;
-  float x0 = R[1], x1 = R[4], x2 = R[7];                           // R @ (0, 1, 0)
-  const float n = rsqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+  double x0 = R[1], x1 = R[4], x2 = R[7];                          // R @ (0, 1, 0)
+  const double n = 1.0 / sqrt(x0 * x0 + x1 * x1 + x2 * x2);
   x0 *= n; x1 *= n; x2 *= n;
-  x1 = fminf(1.f, fmaxf(-1.f, x1));
-  const float beta = acosf(x1), alpha = atan2f(x0, x2);
+  x1 = fmin(1.0, fmax(-1.0, x1));
+  const double beta = acos(x1), alpha = atan2(x0, x2);
   // first row of (Ry(alpha) Rx(beta))^T R: Ry Rx has first column (cos a, 0, -sin a)
-  const float ca = cosf(alpha), sa = sinf(alpha);
-  const float m00 = ca * R[0] - sa * R[6], m02 = ca * R[2] - sa * R[8];
-  ang[3 * (long)e] = alpha; ang[3 * (long)e + 1] = beta; ang[3 * (long)e + 2] = atan2f(m02, m00);
+  const double ca = cos(alpha), sa = sin(alpha);
+  const double m00 = ca * R[0] - sa * R[6], m02 = ca * R[2] - sa * R[8];
+  ang[3 * (long)e] = alpha; ang[3 * (long)e + 1] = beta; ang[3 * (long)e + 2] = atan2(m02, m00);
 }
 
 // ---- Wigner rows: W[e][b][:] = row red_row[b] of block l = red_l[b] of D(e), placed at the columns of that block (zero elsewhere) ----------------------------
 #define ES_MAXL 6
-__global__ void k_es_wigner(const float* __restrict__ ang, int E, const float* __restrict__ Jall, const int* __restrict__ Joff, const int* __restrict__ red_l,
+__global__ void k_es_wigner(const double* __restrict__ ang, int E, const float* __restrict__ Jall, const int* __restrict__ Joff, const int* __restrict__ red_l,
                             const int* __restrict__ red_row, int n_red, int n_full, float* __restrict__ W) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)E * n_red) return;
   const int e = (int)(t / n_red), b = (int)(t - (long)e * n_red);
   const int l = red_l[b], i = red_row[b], w = 2 * l + 1;
-  const float alpha = ang[3 * (long)e], beta = ang[3 * (long)e + 1], gamma = ang[3 * (long)e + 2];
+  const double alpha = ang[3 * (long)e], beta = ang[3 * (long)e + 1], gamma = ang[3 * (long)e + 2];
   const float* J = Jall + Joff[l];
-  float A[2 * ES_MAXL + 1], B[2 * ES_MAXL + 1], Cc[2 * ES_MAXL + 1];
-  const float fi = (float)(l - i);
-  const float ci = cosf(fi * alpha), si = sinf(fi * alpha);
+  double A[2 * ES_MAXL + 1], B[2 * ES_MAXL + 1], Cc[2 * ES_MAXL + 1];
+  const double fi = (double)(l - i);
+  const double ci = cos(fi * alpha), si = sin(fi * alpha);
   // row i of Z(alpha) J: Z[i][i] = cos(f_i a), Z[i][2l - i] = sin(f_i a) (the diagonal wins at i = l)
-  for (int p = 0; p < w; ++p) A[p] = (i == l ? 1.f : ci) * J[i * w + p] + (i == l ? 0.f : si * J[(2 * l - i) * w + p]);
+  for (int p = 0; p < w; ++p) A[p] = (i == l ? 1.0 : ci) * (double)J[i * w + p] + (i == l ? 0.0 : si * (double)J[(2 * l - i) * w + p]);
   // times Z(beta): (A Z)[q] = A[q] cos(f_q b) + A[2l - q] sin(f_{2l-q} b)
   for (int q = 0; q < w; ++q) {
-    const float fq = (float)(l - q);
-    B[q] = q == l ? A[q] : A[q] * cosf(fq * beta) + A[2 * l - q] * sinf(-fq * beta);
+    const double fq = (double)(l - q);
+    B[q] = q == l ? A[q] : A[q] * cos(fq * beta) + A[2 * l - q] * sin(-fq * beta);
   }
   for (int q = 0; q < w; ++q) {
-    float s = 0.f;
-    for (int p = 0; p < w; ++p) s += B[p] * J[p * w + q];
+    double s = 0.0;
+    for (int p = 0; p < w; ++p) s += B[p] * (double)J[p * w + q];
     Cc[q] = s;
   }
   float* out = W + ((long)e * n_red + b) * n_full;
   for (int q = 0; q < n_full; ++q) out[q] = 0.f;
   for (int q = 0; q < w; ++q) {
-    const float fq = (float)(l - q);
-    out[l * l + q] = q == l ? Cc[q] : Cc[q] * cosf(fq * gamma) + Cc[2 * l - q] * sinf(-fq * gamma);
+    const double fq = (double)(l - q);
+    out[l * l + q] = (float)(q == l ? Cc[q] : Cc[q] * cos(fq * gamma) + Cc[2 * l - q] * sin(-fq * gamma));
   }
 }
 
@@ -476,9 +479,11 @@ int nq_es_wigner(const float* rot, int32_t E, const float* J, const int32_t* J_o
   NQ_PROF(st, "es_wigner");
   if (lmax > ES_MAXL) return nq_fail(NQ_ERR_ARG, "lmax %d > %d", lmax, ES_MAXL);
   if (E <= 0) return NQ_OK;
-  hipLaunchKernelGGL(k_es_angles, ES_GRID((long)E), rot, E, scratch);
+  if (reinterpret_cast<uintptr_t>(scratch) & 7) return nq_fail(NQ_ERR_ARG, "es_wigner: scratch must be 8-byte aligned (3 E doubles)");
+  double* ang = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(k_es_angles, ES_GRID((long)E), rot, E, ang);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_es_wigner, ES_GRID((long)E * n_red), scratch, E, J, J_offset, red_l, red_row, n_red, n_full, W);
+  hipLaunchKernelGGL(k_es_wigner, ES_GRID((long)E * n_red), ang, E, J, J_offset, red_l, red_row, n_red, n_full, W);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -590,7 +590,7 @@ class eSCN(torch.nn.Module):
         K = self._constants(dev)
         o = K.order
         G.wigner = torch.empty(E, o.n_red * o.n_full, device=dev, dtype=torch.float32)
-        scratch = torch.empty(3 * E, device=dev, dtype=torch.float32)
+        scratch = torch.empty(3 * E, device=dev, dtype=torch.float64)          # Euler angles, evaluated in float64 (csrc/escn.hip: k_es_angles)
         _lib.check(lib.nq_es_wigner(_lib.ptr(G.rot), E, _lib.ptr(K.J), _lib.ptr(K.J_off), _lib.ptr(K.red_l), _lib.ptr(K.red_row), o.n_red, o.n_full, o.lmax,
                                     _lib.ptr(scratch), _lib.ptr(G.wigner), _st()))
         # inverse lists for the adjoints of the two gathers: the edges are sorted by target; by source through a stable sort of the source column

@@ -286,6 +286,84 @@ class FlatParameters:
         return norm
 
 
+class OverlappedAllReduce:
+    """Data-parallel gradient averaging for the autograd-driven models, overlapped with the backward pass: the flat gradient buffer is cut into buckets of
+    consecutive parameters (~``bucket_bytes`` each); a ``post_accumulate_grad`` hook counts a bucket's parameters down and, when the last one has its
+    gradient, starts the bucket's all-reduce on a side stream while autograd keeps running the rest of the backward on the main stream
+    (FusedTrainStep._backward_overlapped does the same for the fused PaiNN engine, per layer).  ``finish()`` -- call it after ``loss.backward()`` --
+    launches the buckets whose parameters received no gradient this step, waits for all of them, and divides by the world size.  The result equals
+    ``dist.allreduce_mean_(flat.grad)`` (same per-element sums; reference semantics: Lightning DDPStrategy, nablaDFT/utils/pipelines.py:65-68).
+    Payloads here are 88-332 MB per step (21.9-83.1 M parameters): at xGMI ring rates 1-2 ms that would otherwise sit after the backward."""
+
+    def __init__(self, flat: "FlatParameters", bucket_bytes: int = 32 << 20, group=None):
+        import torch.distributed as dist
+        self.flat, self.group, self.dist = flat, group, dist
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = []                                   # [lo, hi, n_params]
+        self._bucket_of = {}
+        lo = o = 0
+        count = 0
+        for p in flat.params:
+            o += p.numel()
+            count += 1
+            self._bucket_of[id(p)] = len(self.buckets)
+            if (o - lo) * 4 >= bucket_bytes:
+                self.buckets.append([lo, o, count])
+                lo, count = o, 0
+        if count:
+            self.buckets.append([lo, o, count])
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._cuda = flat.flat.is_cuda
+        self._comm = torch.cuda.Stream(device=flat.flat.device) if self._cuda else None
+        self._handles = []
+        if self.world > 1:
+            for p in flat.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def _hook(self, p):
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        lo, hi, _ = self.buckets[b]
+        view = self.flat.flat.grad[lo:hi]
+        if self._cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())       # the accumulations into this slice are on the stream autograd runs this node on
+            self._comm.wait_event(ready)
+            with torch.cuda.stream(self._comm):
+                self._works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """After backward: every bucket reduced, the flat gradient holds the mean over ranks; counters re-armed for the next step."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):              # parameters without a gradient this step never fire their hook
+                self._launch(b)
+            for w in self._works:
+                w.wait()
+            if self._cuda:
+                torch.cuda.current_stream().wait_stream(self._comm)
+            self.flat.flat.grad.mul_(1.0 / self.world)
+        self._works = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        return self.flat.flat.grad
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 class GraphedStep:
     """A whole training step -- zero the gradients, forward, loss, backward, clip, optimiser -- captured ONCE into a HIP graph and replayed: for models whose
     step is a thousand small launches issued from Python autograd (PhiSNet: ~1000, device busy 45 % of the wall time) the host disappears from the

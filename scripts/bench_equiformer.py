@@ -48,6 +48,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "equiformer_v2") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=4e-4, weight_decay=1e-3)
+    from nabladft_amd.trainer import OverlappedAllReduce
+    ov = OverlappedAllReduce(flat) if world > 1 else None     # gradient buckets reduced on a side stream while the backward is still running
 
     def step(i):
         b = batches[i % len(batches)]
@@ -55,8 +57,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         E, F = net(b)
         loss = loss_fn(E, F, b)
         loss.backward()
-        if world > 1:
-            nqdist.allreduce_mean_(flat.flat.grad)
+        if ov is not None:
+            ov.finish()                                   # bucketed all-reduce started by the hooks during backward; mean over ranks
         opt.step()
         return loss
 

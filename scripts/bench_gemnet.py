@@ -69,6 +69,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
     batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "gemnet_oc") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=1e-3, betas=(0.9, 0.95), amsgrad=True, weight_decay=0)
+    from nabladft_amd.trainer import OverlappedAllReduce
+    ov = OverlappedAllReduce(flat) if world > 1 else None     # gradient buckets reduced on a side stream while the backward is still running
 
     def step(i):
         b = batches[i % len(batches)]
@@ -76,8 +78,8 @@ def run(molecules=16, steps=10, warmup=3, kernels=True, device=None, seed=1, wor
         E, F = net(b)
         loss = loss_fn(E, F, b)
         loss.backward()
-        if world > 1:
-            nqdist.allreduce_mean_(flat.flat.grad)
+        if ov is not None:
+            ov.finish()                                   # bucketed all-reduce started by the hooks during backward; mean over ranks
         flat.clip_grad_norm_(10.0)                                     # config/gemnet-oc.yaml:19-20 (gradient_clip_val 10.0, norm)
         opt.step()
         return loss

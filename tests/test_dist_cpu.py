@@ -120,3 +120,55 @@ def test_bench_never_calls_a_training_step_on_one_rank_only():
             node = parent
         gated = [c for c in conds if "rank == 0" in c]
         assert all("world == 1" in c for c in gated), (call.lineno, conds)
+
+
+# ---- bucketed all-reduce overlapped with backward (trainer.OverlappedAllReduce), world 2 and 3 over gloo ------------------------------------------------
+def _mlp(seed):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.SiLU(), torch.nn.Linear(33, 19), torch.nn.SiLU(), torch.nn.Linear(19, 1))
+    unused = torch.nn.Linear(3, 3)                          # parameters that never receive a gradient: their bucket must still be reduced (zeros)
+    return net, unused
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    nqdist.init_from_env(backend="gloo")
+    from nabladft_amd.trainer import FlatParameters, OverlappedAllReduce
+    net, unused = _mlp(0)
+    flat = FlatParameters(list(net.parameters()) + list(unused.parameters()))
+    ov = OverlappedAllReduce(flat, bucket_bytes=600)        # several buckets over ~1.6 k parameters
+    assert len(ov.buckets) >= 3
+    net2, unused2 = _mlp(0)                                 # the same model without hooks: local gradient -> one flat all-reduce
+    flat2 = FlatParameters(list(net2.parameters()) + list(unused2.parameters()))
+    g = torch.Generator().manual_seed(10 + rank)
+    outs = []
+    for step in range(2):                                   # two steps: the counters re-arm
+        x = torch.randn(16, 7, generator=g)
+        flat.zero_grad()
+        net(x).pow(2).mean().backward()                     # buckets start reducing (in place) while autograd is still running
+        got = ov.finish().clone()
+        flat2.zero_grad()
+        net2(x).pow(2).mean().backward()
+        ref = flat2.flat.grad.clone()
+        nqdist.allreduce_mean_(ref)
+        outs.append((got, ref))
+    torch.save(outs, os.path.join(out_dir, f"ov{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_allreduce_equals_one_flat_allreduce(tmp_path):
+    for world in (2, 3):
+        port = _free_port()
+        mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        res = [torch.load(tmp_path / f"ov{r}.pt") for r in range(world)]
+        for step in range(2):
+            for r in range(world):
+                got, ref = res[r][step]
+                if world == 2:
+                    assert torch.equal(got, ref)            # two addends: the sum does not depend on how the collective chunks the buffer
+                else:
+                    assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())      # ring order differs with the chunking: last-bit differences
+                assert torch.equal(got, res[0][step][0])    # every rank holds the same mean
+            assert float(res[0][step][0].abs().max()) > 0

@@ -117,3 +117,26 @@ def test_gemnet_data_parallel_two_ranks(tmp_path):
     mp.spawn(_gemnet_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
     assert r0["value"] > 0 and r1["value"] > 0 and r0["loss"] == r0["loss"] and r1["loss"] == r1["loss"] and r0["loss"] != r1["loss"]
+
+
+@pytest.mark.parametrize("model", ["painn-oc", "qhnet", "gemnet", "escn", "equiformer"])
+def test_bench_eight_rank_rehearsal(model, tmp_path):
+    """Deadlock / plumbing guard for the driver's multi-GPU run: ``bench.py --gpus 8`` launched exactly as the driver launches it (torch.distributed.run, one
+    process per rank), here with 8 gloo ranks sharing the one GPU of the test box and one tiny step.  Checks the contract of the JSON line and that every
+    rank reaches every collective (barriers, bucketed gradient all-reduce overlapped with backward, max-over-ranks timing).  No scaling number comes out of
+    this: RCCL / xGMI are not involved."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NQ_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "4" if model == "painn-oc" else "1", "--model", model,
+           "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 1 and rec["scaling"] == "weak" and rec["unit"] == "conformer-steps/s" and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "dp8"

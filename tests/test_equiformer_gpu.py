@@ -14,6 +14,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 from oracle.equiformer_params import make_state, probe_direction  # noqa: E402
 from tests.test_equiformer_cpu import FULL, SMALL  # noqa: E402
 from tests.test_escn_gpu import Data, rel  # noqa: E402
+from tests.helpers import assert_parity  # noqa: E402
 
 
 def build(cfg, d, dev):
@@ -44,7 +45,8 @@ def test_graph_wigner_and_stages_small():
         ref64 = d["f64:" + k].reshape(G.N, -1)
         own = rel(d["f32:" + k].reshape(G.N, -1), ref64)
         assert rel(rec[k].cpu().numpy(), ref64) < max(2e-5, 3 * own), k
-    assert rel(E.cpu().numpy(), d["f64:E"]) < 2e-5 and rel(F.cpu().numpy(), d["f64:F"]) < 2e-5
+    assert_parity("equiformer_small E", E.cpu().numpy(), d["f64:E"], d["f32:E"])
+    assert_parity("equiformer_small F", F.cpu().numpy(), d["f64:F"], d["f32:F"])
 
 
 def test_gradients_small():
@@ -77,10 +79,11 @@ def test_full_configuration():
     for k in ("embed", "block0", "block11"):
         got = rec[k].detach().cpu().numpy().reshape(G.N, -1, C)[::5, :, ::8]
         assert rel(got, d["f32:" + k]) < 5e-5, k
-    assert rel(E.detach().cpu().numpy(), d["f64:E"]) < 5e-5 and rel(F.detach().cpu().numpy(), d["f64:F"]) < 5e-5
+    assert_parity("equiformer_full E", E.detach().cpu().numpy(), d["f64:E"], d["f32:E"])
+    assert_parity("equiformer_full F", F.detach().cpu().numpy(), d["f64:F"], d["f32:F"])
     loss = _loss(E, F, data)
     loss.backward()
-    assert abs(float(loss.detach()) - float(d["f64:loss"])) < 5e-5 * abs(float(d["f64:loss"]))
+    assert_parity("equiformer_full loss", float(loss.detach()), d["f64:loss"], d["f32:loss"])
     names = list(d["param_names"])
     n64, p64, p32 = d["f64:grad_norm"], d["f64:grad_probe"], d["f32:grad_probe"]
     params = dict(net.named_parameters())

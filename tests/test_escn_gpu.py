@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden")
 from oracle.escn_params import make_state, probe_direction  # noqa: E402
 from tests.test_escn_cpu import FULL, SMALL  # noqa: E402
+from tests.helpers import assert_parity  # noqa: E402
 
 
 class Data:
@@ -58,7 +59,9 @@ def test_graph_wigner_and_layers_small():
         ref64 = d[f"f64:layer{i}"].reshape(G.N, -1)
         own = rel(d[f"f32:layer{i}"].reshape(G.N, -1), ref64)
         assert rel(x.cpu().numpy(), ref64) < max(2e-5, 3 * own), i
-    assert rel(E.cpu().numpy(), d["f64:E"]) < 2e-5 and rel(F.cpu().numpy(), d["f64:F"]) < 2e-5
+        assert_parity(f"escn_small layer{i}", x.cpu().numpy(), ref64, d[f"f32:layer{i}"].reshape(G.N, -1), floor=2e-5, factor=3.0)
+    assert_parity("escn_small E", E.cpu().numpy(), d["f64:E"], d["f32:E"])
+    assert_parity("escn_small F", F.cpu().numpy(), d["f64:F"], d["f32:F"])
     # the model's own deterministic frames give the same function (the SO(2) convolution commutes with rotations about the edge)
     with torch.no_grad():
         E2, F2 = net(data)
@@ -96,10 +99,11 @@ def test_full_configuration():
     for k, x in (("layer0", layers[0]), ("layer7", layers[7])):
         got = x.detach().cpu().numpy().reshape(G.N, -1, C)[::5, :, ::8]
         assert rel(got, d["f32:" + k]) < 5e-5, k
-    assert rel(E.detach().cpu().numpy(), d["f64:E"]) < 5e-5 and rel(F.detach().cpu().numpy(), d["f64:F"]) < 5e-5
+    assert_parity("escn_full E", E.detach().cpu().numpy(), d["f64:E"], d["f32:E"])
+    assert_parity("escn_full F", F.detach().cpu().numpy(), d["f64:F"], d["f32:F"])
     loss = _loss(E, F, data)
     loss.backward()
-    assert abs(float(loss.detach()) - float(d["f64:loss"])) < 5e-5 * abs(float(d["f64:loss"]))
+    assert_parity("escn_full loss", float(loss.detach()), d["f64:loss"], d["f32:loss"])
     names = list(d["param_names"])
     n64, p64, p32 = d["f64:grad_norm"], d["f64:grad_probe"], d["f32:grad_probe"]
     params = dict(net.named_parameters())
