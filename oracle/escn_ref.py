@@ -88,8 +88,9 @@ def s2(lmax, mmax, dtype):
     return T.to(dtype), (T * w.repeat_interleave(na)[:, None]).to(dtype)
 
 
-def forward(P, cfg, pos, z, sizes, rot=None):
-    """P: state dict (reference names); returns (energy [B], forces [N, 3])."""
+def forward(P, cfg, pos, z, sizes, rot=None, probe=None):
+    """P: state dict (reference names); returns (energy [B], forces [N, 3]).  probe: optional dict that receives intermediates (final embedding, sphere-point
+    features, per-point force magnitudes) for error localisation."""
     dt = pos.dtype
     lmax, mmax, C = cfg["lmax_list"][0], cfg["mmax_list"][0], cfg["sphere_channels"]
     nf = (lmax + 1) ** 2
@@ -157,6 +158,8 @@ def forward(P, cfg, pos, z, sizes, rot=None):
     energy = e.new_zeros(B).index_add_(0, batch, e) * 0.001
     f = lin("force_block.fc3", act(lin("force_block.fc2", act(lin("force_block.fc1", x_pt))))).view(N, n_pts, 1)
     forces = (f * sp.view(1, n_pts, 3)).sum(1) / n_pts
+    if probe is not None:
+        probe.update(x=x.detach(), x_pt=x_pt.detach(), f=f.detach().view(N, n_pts), e_pt=e.detach())
     return energy, forces
 
 
