@@ -210,7 +210,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
-               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
                "parity": rec.get("parity"), "bf16_mode": bf,
                "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
                "reference_batch_size_8_prepared_eager_vs_graph_replay": _graph_replay("gemnet") if world == 1 and not args.no_roofline else None,
@@ -256,7 +256,7 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
-               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
                "parity": rec.get("parity"), "bf16_mode": bf,
                f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
                f"reference_batch_size_{ref_batch}_prepared_eager_vs_graph_replay": _graph_replay(which) if world == 1 and not args.no_roofline else None}
@@ -291,7 +291,7 @@ def bench_qhnet(args, rank, world, local_dev, dev):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "ordered_pairs": rec["ordered_pairs"], "edges_within_cutoff": rec["edges_within_cutoff"], "parallelism": f"dp{world}"},
-               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"),
+               "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
                "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
                "reference_batch_size_2_prepared_eager_vs_graph_replay": _graph_replay("qhnet") if world == 1 and not args.no_roofline else None}
         print(json.dumps(out))
