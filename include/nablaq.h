@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 11
+#define NQ_ABI_VERSION 12
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -454,6 +454,12 @@ int nq_rowop(const float* R, int64_t r_stride, const float* X, int64_t x_stride,
 int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t stride, const int32_t* index, int32_t seg_side, int32_t nseg,
                     const int32_t* seg_rows, float* const* seg_ptrs, int64_t n, int32_t I, int32_t NSS, int32_t C, int32_t transpose, int32_t accumulate,
                     void* stream);
+/* Fused S2 activation of the SO(2) message blocks (escn/so3.py:301-318 to_grid / from_grid around the point-wise SiLU; equiformer_v2/activation.py:155-176):
+ * y_blocks = from_grid(SiLU(to_grid(x_blocks))) in ONE kernel on the matrix cores, the [n][G][C] grid tensor never reaches memory; backward != 0: dx_blocks from
+ * (x_blocks, dy_blocks) with the grid recomputed.  T, F: [G][S] to_grid / from_grid matrices; blocks: nseg contiguous tensors [n][seg_rows[k]][C] (HOST arrays of
+ * device pointers), S = sum seg_rows.  Requires C % 64 == 0, S <= 32, G <= 96 (NQ_ERR_ARG otherwise). */
+int nq_s2_activation_blocks(const float* T, const float* F, int32_t G, int32_t S, int32_t C, int64_t n, int32_t nseg, const int32_t* seg_rows, float* const* x_ptrs,
+                            float* const* gy_ptrs, float* const* out_ptrs, int32_t backward, void* stream);
 
 /* Rotations that use the degree-block structure of the Wigner rows (235 of 29 x 49 entries at lmax 6 / mmax 2), no LDS.  nq_es_rotate (SO3_Embedding._rotate):
  * block(i)[o][row][c_off + c] = sum_k W_o[i][l_i^2 + k] x[index ? index[o] : o][l_i^2 + k][c]; red_l [n_red] (HOST) = degree of every kept row, rows in W's

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -152,6 +152,7 @@ SYMBOLS = {
     "nq_es_smearing": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P]),
     "nq_rowop": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "nq_rowop_blocks": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
+    "nq_s2_activation_blocks": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I32, _P, _P, _P, _P, _I32, _P]),
     "nq_column_sum_scratch_floats": (_SZ, [_I64, _I32]),
     "nq_column_sum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _P]),
     "nq_es_rotate": (C.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _P, _I32, _I32, _I64, _P, _I32, _I32, _I32, _P]),

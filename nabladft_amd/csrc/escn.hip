@@ -328,6 +328,116 @@ static int rowmm_launch(hipStream_t st, const RowOp& p, long n, int transpose, i
   return NQ_OK;
 }
 
+// ---- fused S2 activation on the matrix cores: to_grid -> SiLU -> from_grid in one kernel (so3.py:301-318, activation.py:155-176) --------------------------------
+// y[o][s'][c] = sum_i F[i][s'] silu( sum_s T[i][s] x[o][s][c] ): per edge the [G x C] grid tensor (5x the coefficient tensor: 0.97 GB per eSCN layer at 16
+// conformers, written, read, written and read again by the three separate kernels) never leaves the registers.  One work item = (edge o, 128 channels); wavefront
+// w owns channels 32 w .. 32 w + 31 and ALL MT grid-row tiles of them:
+//   product 1  Gr = T x        MT accumulators of 32 x 32 (A = T from LDS, B = x_o from LDS)
+//   SiLU on the accumulators
+//   product 2  y = F^T silu(Gr): the accumulators ARE the B operands -- MFMA(q) of tile mt contracts the two grid rows its lanes hold in register q
+//              (rows 32 mt + rho(q, h), rho = (q&3) + 8 (q>>2) + 4 h), the A operand F^T[s'][that row] comes from LDS.  No data movement between the products.
+// Backward (BWD): dGr = (F dy) * silu'(T x) with both products in the same register layout, dx = T^T dGr by the same accumulator-as-operand product.
+// T, F: [G][S] row-major (to_grid / from_grid matrices, columns in the order of the blocks); x, y (and dy, dx): per-block tensors (RowSeg over the S side).
+template <int MT, bool BWD>
+__global__ __launch_bounds__(256) void k_s2act(const float* __restrict__ T, const float* __restrict__ F, RowSeg xin, RowSeg gyin, RowSeg out, int G, int S, int C,
+                                              int CS, long n_items) {
+  extern __shared__ __attribute__((aligned(16))) float es_lds[];
+  // CS = 128: one item (edge, 128 channels) per pass, wavefront w owns channels 32 w..; CS = 64: TWO items per pass, wavefronts {0,1} / {2,3} own one each
+  const int CS4 = CS >> 2, wpi = CS >> 5, nsub = 4 / wpi;            // float4 per row, wavefronts per item, items per pass
+  const int Sp = (S + 1) & ~1, KS1 = Sp + 1, KS2 = MT * 32 + 1, nsl = C / CS;
+  float* sT = es_lds;                                   // [MT*32][KS1]  A(m = i, k = s) = T[i][s]
+  float* sF = sT + MT * 32 * KS1;                       // BWD only: same image of F
+  float* sM2 = sF + (BWD ? MT * 32 * KS1 : 0);          // [32][KS2]     A(m = s, k = i) = (BWD ? T : F)[i][s]
+  float* sX = sM2 + ((32 * KS2 + 3) & ~3);              // [nsub][32][CS] x rows (zero beyond S); the result tiles on their way out
+  float* sY = sX + 32 * 128;                            // BWD only: dy rows
+  for (int t = threadIdx.x; t < MT * 32 * KS1; t += 256) {
+    const int i = t / KS1, k = t - i * KS1;
+    const bool in = i < G && k < S;
+    sT[t] = in ? T[(long)i * S + k] : 0.f;
+    if (BWD) sF[t] = in ? F[(long)i * S + k] : 0.f;
+  }
+  for (int t = threadIdx.x; t < 32 * KS2; t += 256) {
+    const int sr = t / KS2, i = t - sr * KS2;
+    sM2[t] = (sr < S && i < G) ? (BWD ? T : F)[(long)i * S + sr] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int sub = wave / wpi, wcol = (wave - sub * wpi) * 32;
+  // the A operands of the SECOND product are the same for every item: 16 MT registers per lane for the lifetime of the workgroup (no LDS read per MFMA)
+  // (not in the 3-tile backward: its two accumulator sets leave no room -- 282 registers would halve the resident wavefronts)
+  constexpr bool HOIST = false;   // see the note at the pass loop
+  float a2[HOIST ? MT : 1][16];
+  if (HOIST) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a2[m][q] = sM2[r * KS2 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h];
+  }
+  const long n_pass = (n_items + nsub - 1) / nsub;
+  // (tried and measured slower: A operands of the second product resident in registers, and the next pass's rows prefetched into registers under the
+  // MFMAs -- both cost resident workgroups (186-282 registers), and this kernel lives on the overlap BETWEEN workgroups: 0.63-0.74 / 1.0-1.3 ms per launch vs
+  // < 0.6 / 0.93 ms forward / backward for 27 k edges x 128 channels.  It runs at ~43 % of its MFMA floor: 93 / 138 MFMAs per item of which 27 % are padding.)
+  for (long pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) {               // 32 rows x 128 floats of staging: [sub][k][CS]
+      const int k = t >> 5, c4 = t & 31, sb = c4 / CS4, q = c4 - sb * CS4;
+      const long item = pass * nsub + sb;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+      if (k < S && item < n_items) {
+        const long o = item / nsl;
+        const int c0 = (int)(item - o * nsl) * CS;
+        v = *reinterpret_cast<const float4*>(rowseg_addr(xin, o, k, C) + c0 + 4 * q);
+        if (BWD) w = *reinterpret_cast<const float4*>(rowseg_addr(gyin, o, k, C) + c0 + 4 * q);
+      }
+      *reinterpret_cast<float4*>(sX + (sb * 32 + k) * CS + 4 * q) = v;
+      if (BWD) *reinterpret_cast<float4*>(sY + (sb * 32 + k) * CS + 4 * q) = w;
+    }
+    __syncthreads();
+    es_f32x16 gr[MT], da[BWD ? MT : 1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { gr[m][q] = 0.f; if (BWD) da[m][q] = 0.f; }
+    const int bo = (sub * 32 + h) * CS + wcol + r;
+#pragma unroll 3
+    for (int j = 0; j < Sp; j += 2) {
+      const float bx = sX[bo + j * CS];
+      float by = 0.f;
+      if (BWD) by = sY[bo + j * CS];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        gr[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[(m * 32 + r) * KS1 + h + j], bx, gr[m], 0, 0, 0);
+        if (BWD) da[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sF[(m * 32 + r) * KS1 + h + j], by, da[m], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gr[m][q] = BWD ? da[m][q] * nq_dsilu(gr[m][q]) : nq_silu(gr[m][q]);
+    es_f32x16 res;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) res[q] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        res = __builtin_amdgcn_mfma_f32_32x32x2f32(HOIST ? a2[HOIST ? m : 0][q] : sM2[r * KS2 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h], gr[m][q], res, 0, 0, 0);
+    __syncthreads();                                    // every wavefront has left the x rows: the buffer takes the result tiles
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sX[(sub * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * CS + wcol + r] = res[q];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+      const int k = t >> 5, c4 = t & 31, sb = c4 / CS4, q = c4 - sb * CS4;
+      const long item = pass * nsub + sb;
+      if (k < S && item < n_items) {
+        const long o = item / nsl;
+        const int c0 = (int)(item - o * nsl) * CS;
+        *reinterpret_cast<float4*>(rowseg_addr(out, o, k, C) + c0 + 4 * q) = *reinterpret_cast<const float4*>(sX + (sb * 32 + k) * CS + 4 * q);
+      }
+    }
+  }
+}
+
 // ---- rotations with the block structure of the Wigner matrices ------------------------------------------------------------------------------------------------
 // Row i of an edge's Wigner block (degree l_i) touches only the 2 l_i + 1 coefficients of that degree: 235 of the 29 x 49 entries at lmax 6 / mmax 2.  One
 // workgroup per edge (or per node when the transposed form also sums over a node's edges), thread = channel: the coefficients of one degree sit in registers,
@@ -544,6 +654,43 @@ int nq_rowop_blocks(const float* R, int64_t r_stride, float* x_or_out, int64_t s
   if (lds > 64 * 1024) return nq_fail(NQ_ERR_ARG, "rowop: I=%d NSS=%d C=%d needs %zu bytes of LDS (> 64 kB)", I, NSS, C, lds);
   if (transpose) hipLaunchKernelGGL(k_rowop_tr, dim3((unsigned)n), dim3(256), lds, st, p);
   else hipLaunchKernelGGL(k_rowop_fwd, dim3((unsigned)n), dim3(256), lds, st, p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* Fused S2 activation (to_grid -> SiLU -> from_grid; backward != 0: its adjoint with the grid recomputed) on per-block tensors: nseg blocks of seg_rows[k] rows
+ * ([n][rows_k][C] each, HOST arrays of device pointers); T, F: [G][S] with S = sum of seg_rows.  Requires C % 64 == 0, S <= 32, G <= 96 (else NQ_ERR_ARG: the
+ * caller falls back to nq_rowop_blocks + the activation kernel). */
+int nq_s2_activation_blocks(const float* T, const float* F, int32_t G, int32_t S, int32_t C, int64_t n, int32_t nseg, const int32_t* seg_rows, float* const* x_ptrs,
+                            float* const* gy_ptrs, float* const* out_ptrs, int32_t backward, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, backward ? "s2act_bwd" : "s2act_fwd");
+  if (n <= 0) return NQ_OK;
+  if (!T || !F || !seg_rows || !x_ptrs || !out_ptrs || (backward && !gy_ptrs) || nseg < 1 || nseg > ROWOP_MAXSEG) return nq_fail(NQ_ERR_ARG, "s2 activation: bad argument");
+  if ((C & 63) || S > 32 || G > 96 || S < 1 || G < 1) return nq_fail(NQ_ERR_ARG, "s2 activation: needs C %% 64 == 0, S <= 32, G <= 96 (C=%d S=%d G=%d)", C, S, G);
+  const int CS = (C & 127) ? 64 : 128;
+  RowSeg sx{}, sg{}, so{};
+  int tot = 0;
+  for (int k = 0; k < nseg; ++k) {
+    sx.start[k] = sg.start[k] = so.start[k] = tot; tot += seg_rows[k];
+    sx.ptr[k] = x_ptrs[k]; sg.ptr[k] = backward ? gy_ptrs[k] : nullptr; so.ptr[k] = out_ptrs[k];
+  }
+  sx.start[nseg] = sg.start[nseg] = so.start[nseg] = tot;
+  sx.n = sg.n = so.n = nseg;
+  if (tot != S) return nq_fail(NQ_ERR_ARG, "s2 activation: block rows sum to %d, expected %d", tot, S);
+  const int MT = (G + 31) / 32, Sp = (S + 1) & ~1, KS1 = Sp + 1, KS2 = MT * 32 + 1;
+  const size_t lds = sizeof(float) * ((size_t)MT * 32 * KS1 * (backward ? 2 : 1) + (size_t)((32 * KS2 + 3) & ~3) + (size_t)32 * 128 * (backward ? 2 : 1));
+  const long items = n * (C / CS), passes = (items + (128 / CS) - 1) / (128 / CS);
+  const int per_cu = (int)(160 * 1024 / lds > 4 ? 4 : (160 * 1024 / lds < 1 ? 1 : 160 * 1024 / lds));
+  const long grid = passes < 256L * per_cu ? passes : 256L * per_cu;
+#define S2_GO(MTV, BW)                                                                                                                             \
+  do {                                                                                                                                             \
+    if (lds > 64 * 1024) NQ_HIP(hipFuncSetAttribute((const void*)k_s2act<MTV, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL((k_s2act<MTV, BW>), dim3((unsigned)grid), dim3(256), lds, st, T, F, sx, sg, so, G, S, C, CS, items);                            \
+  } while (0)
+  if (backward) { if (MT == 1) S2_GO(1, true); else if (MT == 2) S2_GO(2, true); else S2_GO(3, true); }
+  else { if (MT == 1) S2_GO(1, false); else if (MT == 2) S2_GO(2, false); else S2_GO(3, false); }
+#undef S2_GO
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

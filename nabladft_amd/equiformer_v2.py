@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _EmbeddingFn, _RotateBackFn, _RotateFn, _RowFn, _silu, eSCN, j_matrices,
+from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _S2ActBlocksFn, s2_activation_fusable, _EmbeddingFn, _RotateBackFn, _RotateFn, _RowFn, _silu, eSCN, j_matrices,
                    s2_grids)
 from . import gemnet_oc as _gemnet
 from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _new, _st, lin
@@ -495,8 +495,11 @@ class SO2EquivariantGraphAttention(nn.Module):
         # separable S2 activation (activation.py:155-176): SiLU on the (lmax, mmax) grid, scalars replaced by SiLU(gating scalars)
         gating = _silu(extra[:, H * A:].contiguous())
         ng = K.to_grid_red.shape[0]
-        grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Hc, False, 1, rows, E, *msg)
-        msg = list(_BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Hc, True, 1, rows, None, None, E))
+        if s2_activation_fusable(K.to_grid_red, rows, Hc):
+            msg = list(_S2ActBlocksFn.apply(K.to_grid_red, K.from_grid_red, rows, E, Hc, *msg))      # to_grid -> SiLU -> from_grid in one kernel, grid in registers
+        else:
+            grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Hc, False, 1, rows, E, *msg)
+            msg = list(_BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Hc, True, 1, rows, None, None, E))
         msg[0] = torch.cat([gating, msg[0][:, Hc:]], dim=1)
         msg = self.so2_conv_2(msg, None)
         msg = _HeadScaleFn.apply(alpha, rows, H, V, *msg)

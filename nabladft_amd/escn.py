@@ -201,6 +201,41 @@ class _BlocksInFn(torch.autograd.Function):
         return (None,) * 9 + tuple(outs)
 
 
+def s2_activation_fusable(T, rows, Cc):
+    """Mirror of csrc/escn.hip: nq_s2_activation_blocks' requirements (whole groups of 64 channels, <= 32 coefficients, <= 96 grid points)."""
+    return Cc % 64 == 0 and sum(rows) <= 32 and T.shape[0] <= 96
+
+
+class _S2ActBlocksFn(torch.autograd.Function):
+    """(y_b) = from_grid(SiLU(to_grid((x_b)))) on per-m-block tensors in ONE kernel (csrc/escn.hip: k_s2act): the [E, grid, C] tensor of the point-wise
+    activation (so3.py:301-318; 5x the coefficient tensor) is neither written nor kept for the backward, which recomputes it from the saved coefficient blocks."""
+
+    @staticmethod
+    def forward(ctx, T, F, rows, n, Cc, *xs):
+        xs = [_f32(x) for x in xs]
+        outs = [_new(n, r * Cc, like=xs[0]) for r in rows]
+        _S2ActBlocksFn._launch(T, F, rows, n, Cc, xs, None, outs, 0)
+        ctx.meta = (T, F, rows, n, Cc)
+        ctx.save_for_backward(*xs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        T, F, rows, n, Cc = ctx.meta
+        xs = ctx.saved_tensors
+        gs = [torch.zeros_like(x) if g is None else _f32(g) for g, x in zip(gs, xs)]
+        dxs = [_new(n, r * Cc, like=xs[0]) for r in rows]
+        _S2ActBlocksFn._launch(T, F, rows, n, Cc, list(xs), gs, dxs, 1)
+        return (None,) * 5 + tuple(dxs)
+
+    @staticmethod
+    def _launch(T, F, rows, n, Cc, xs, gs, outs, backward):
+        k = len(rows)
+        arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])          # noqa: E731
+        _lib.check(_lib.load().nq_s2_activation_blocks(_lib.ptr(T), _lib.ptr(F), T.shape[0], sum(rows), Cc, n, k, (C.c_int32 * k)(*rows), arr(xs),
+                                                       None if gs is None else arr(gs), arr(outs), backward, _st()))
+
+
 class _RowFn(torch.autograd.Function):
     """out[o] = R_o X_r(o) (transpose False) or R_o^T X_r(o) (True); R constant (per-row ``r_stride`` = I * NSS or shared 0).  With ``index`` the rows are
     gathered from node storage and the adjoint is summed back over ``inverse`` = (order, ptr) of the index."""
@@ -444,8 +479,11 @@ class MessageBlock(torch.nn.Module):
         ys = [lin(a, b) for a, b in zip(self.so2_block_source(list(xs), x_edge), self.so2_block_target(list(xt), x_edge))]
         # point-wise SiLU on the (lmax, mmax) grid (so3.py:301-318), grid matrices with their columns in m-primary order
         ng = K.to_grid_red.shape[0]
-        grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Cc, False, 1, rows, G.E, *ys)
-        ys = _BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Cc, True, 1, rows, None, None, G.E)
+        if s2_activation_fusable(K.to_grid_red, rows, Cc):
+            ys = _S2ActBlocksFn.apply(K.to_grid_red, K.from_grid_red, rows, G.E, Cc, *ys)            # to_grid -> SiLU -> from_grid, the grid stays in registers
+        else:
+            grid = _BlocksInFn.apply(K.to_grid_red, 0, ng, o.n_red, Cc, False, 1, rows, G.E, *ys)
+            ys = _BlocksOutFn.apply(_silu(grid), K.from_grid_red, 0, ng, o.n_red, Cc, True, 1, rows, None, None, G.E)
         return _RotateBackFn.apply(G, K, Cc, None, rows, *ys)                          # rotate back (wigner_inv = transpose) + _reduce_edge over the target's in-edges
 
 

@@ -56,6 +56,27 @@ __global__ void k_reduce(const float* part, int nsplit, long stride, long count,
   out[i] = (s0 + s1) + (s2 + s3);
 }
 
+// calibration: back-to-back v_mfma_f32_32x32x2_f32 on registers only (no LDS, no memory): the matrix-pipe ceiling of THIS box under sustained load (DVFS included)
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters, float a0, float b0) {
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[(long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 struct Shape { const char* kind; const char* name; int M, N, K; };   // nt/nn: C[M,N], contraction K.  tn: out[M=Mo, N=No], K = rows
 
 template <bool A_KC, bool B_KC, int EPI, int BM, int BN, int BK, int NWM, int NWN, int WPE, int ABL = 0>
@@ -70,6 +91,22 @@ struct Variant { std::string name; std::function<void()> run; bool check; };
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
   hipStream_t st; CK(hipStreamCreate(&st));
+  {   // matrix-pipe ceiling: 256 CUs x (1, 2, 4) workgroups of 4 waves, 4 independent accumulators, ~0.2 s of sustained MFMA issue in total
+    float* sink; CK(hipMalloc(&sink, 1024 * 256 * 4 * sizeof(float)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int wg = 1; wg <= 4; wg *= 2) {
+      const int iters = 4000;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_mfma_peak<4>, dim3(256 * wg), dim3(256), 0, st, sink, iters, 0.5f, 0.25f);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double fl = 2.0 * 32 * 32 * 2 * 4.0 * iters * 4 * 256 * wg;
+        if (rep == 2) printf("# pure MFMA 32x32x2 f32, %d workgroup(s) of 4 waves per CU, %.2f ms: %.1f TFLOP/s  (157.3 = 2.4 GHz x 64 flop/clk/SIMD x 1024 SIMDs)\n", wg, ms, fl / ms * 1e-9);
+      }
+    }
+    CK(hipFree(sink));
+  }
   std::vector<Shape> shapes = {
       // PaiNN step at B = 2048 (N = 85576 atoms)
       {"nt", "painn W1", 85576, 128, 128}, {"nt", "painn W2", 85576, 384, 128}, {"nt", "painn U", 256728, 256, 128}, {"nt", "painn V1", 85576, 128, 256},

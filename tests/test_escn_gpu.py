@@ -160,3 +160,28 @@ def test_row_operator_shared_matrix_on_the_matrix_cores(I, NSS, Cc, n):
     outs = [torch.empty(n, r, Cc, device=dev) for r in rows]
     ES._rowop_blocks(Rd, 0, Yd, None, 1, rows, outs, n, I, NSS, Cc, True)
     assert rel(torch.cat(outs, dim=1).cpu().numpy(), torch.einsum("is,nic->nsc", R.double(), Y.double()).numpy()) < 3e-6
+
+
+@pytest.mark.parametrize("G,rows,Cc,n", [(70, [7, 12, 10], 128, 500), (70, [7, 12, 10], 256, 33), (40, [5, 8, 6], 128, 100), (96, [8, 14, 10], 128, 17), (70, [7, 12, 10], 64, 301),
+                                         (70, [7, 12, 10], 192, 20)])
+def test_fused_s2_activation_blocks(G, rows, Cc, n):
+    """to_grid -> SiLU -> from_grid in one kernel (k_s2act: the grid tensor lives in MFMA accumulators) against float64 torch: outputs and the gradient w.r.t.
+    every input block (the backward recomputes the grid)."""
+    from nabladft_amd import escn as ES
+    dev = torch.device("cuda:0")
+    S = sum(rows)
+    g = torch.Generator().manual_seed(G + 3 * Cc + n)
+    T, F = torch.randn(G, S, generator=g) * 0.5, torch.randn(G, S, generator=g) * 0.5
+    xs = [torch.randn(n, r, Cc, generator=g) for r in rows]
+    ws = [torch.randn(n, r, Cc, generator=g) for r in rows]
+    assert ES.s2_activation_fusable(T, rows, Cc)
+    xd = [x.to(dev).reshape(n, -1).requires_grad_(True) for x in xs]
+    ys = ES._S2ActBlocksFn.apply(T.to(dev), F.to(dev), rows, n, Cc, *xd)
+    sum((y * w.to(dev).reshape(n, -1)).sum() for y, w in zip(ys, ws)).backward()
+    X = torch.cat(xs, dim=1).double().requires_grad_(True)
+    Y = torch.einsum("is,nic->nsc", F.double(), torch.nn.functional.silu(torch.einsum("is,nsc->nic", T.double(), X)))
+    (Y * torch.cat(ws, dim=1).double()).sum().backward()
+    cuts = np.cumsum([0] + rows)
+    for k, (y, x) in enumerate(zip(ys, xd)):
+        assert rel(y.detach().view(n, rows[k], Cc).cpu().numpy(), Y[:, cuts[k]:cuts[k + 1]].detach().numpy()) < 3e-6, k
+        assert rel(x.grad.view(n, rows[k], Cc).cpu().numpy(), X.grad[:, cuts[k]:cuts[k + 1]].numpy()) < 5e-6, k
