@@ -361,7 +361,11 @@ class _LinFn(torch.autograd.Function):
     def backward(ctx, g):
         alpha, beta, has_b = ctx.ab
         g = _f32(g)
-        return (_lin_raw(g, None, alpha, 0.0) if ctx.needs_input_grad[0] else None), (_lin_raw(g, None, beta, 0.0) if has_b and ctx.needs_input_grad[1] else None), None, None
+        # a unit coefficient passes the incoming gradient on unchanged (no copy: nothing downstream writes into its incoming gradient, and autograd only accumulates
+        # in place into buffers it owns alone) -- the residual sums and the source + target sums of the SO(2) blocks are all 1 * a + 1 * b
+        ga = (g if alpha == 1.0 else _lin_raw(g, None, alpha, 0.0)) if ctx.needs_input_grad[0] else None
+        gb = (g if beta == 1.0 else _lin_raw(g, None, beta, 0.0)) if has_b and ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
 
 
 def lin(a, b=None, alpha=1.0, beta=1.0):
