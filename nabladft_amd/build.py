@@ -28,7 +28,7 @@ def _newer(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "lanes.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(CSRC, "cg_l4.inc"), os.path.join(os.path.dirname(HERE), "include", "nablaq.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "lanes.h"), os.path.join(CSRC, "gemm_tile.h"), os.path.join(CSRC, "gemm_split.h"), os.path.join(CSRC, "cg_l4.inc"), os.path.join(os.path.dirname(HERE), "include", "nablaq.h")]
     objs, procs = [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))

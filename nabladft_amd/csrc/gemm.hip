@@ -14,6 +14,7 @@
 // ([BK][BM+pad]) so that the MFMA operand fetch (lane l: row l&31, k = l>>5) is a conflict-free
 // ds_read_b32 of 32 consecutive floats per half-wave.
 #include "gemm_tile.h"   // round 3: the persistent, double-buffered tile engine k_gemm2 (every launch whose operands are 16-byte friendly)
+#include "gemm_split.h"  // round 3: the same skeleton on the bf16 matrix pipe, every f32 value split exactly into three bf16 pieces (large launches)
 
 // ---- generic kernels (round 1): operands that are not 16-byte friendly (odd K / leading dimensions) and the row-mapped spherical launches ----
 #define BM 128
@@ -396,6 +397,35 @@ static void launch_gemm2(hipStream_t st, const GemmArgs& p, int splits) {
   }
 }
 
+// ---- split-bf16 engine (gemm_split.h): f32-accurate products on the bf16 matrix pipe, 128 x 128 tiles only -------------------------------------------
+// Taken when the problem gives every CU work in 128 x 128 tiles (measured, scripts/lab/gemm_lab.hip: 1.3-1.7x the exact-f32 engine there); small
+// problems stay on k_gemm2's 64 x 64 tiles.  nq_set_gemm_variant(32) (or NQ_GEMM_F32=1 in the environment) keeps every product on v_mfma_f32_32x32x2_f32.
+static bool gemm3_disabled() {
+  static const int env = [] { const char* e = getenv("NQ_GEMM_F32"); return (e && e[0] && e[0] != '0') ? 1 : 0; }();
+  return env || (g_gemm_variant & 32);
+}
+template <bool A_KC, bool B_KC>
+static bool gemm3_ok(const GemmArgs& p, long kspan, int splits) {
+  if (gemm3_disabled() || !gemm2_ok<A_KC, B_KC>(p, kspan)) return false;
+  return (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits >= 192;
+}
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
+  using SA = SplitStage<A_KC, 128, 16, 256>;
+  using SB = SplitStage<B_KC, 128, 16, 256>;
+  constexpr int lds = 2 * (SA::BYTES + SB::BYTES) + (EPI == EPI_PARTIAL ? 4 * 128 * 4 : 0);
+  static bool prepared[64] = {};   // per device: more than 64 KB of LDS has to be granted once per function
+  int dev = 0;
+  NQ_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !prepared[dev]) {
+    NQ_HIP(hipFuncSetAttribute((const void*)k_gemm3<A_KC, B_KC, EPI, 16, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < 64) prepared[dev] = true;
+  }
+  const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
+  hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 16, 2, 6>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), lds, st, p);
+  return NQ_OK;
+}
+
 // ---- host launchers ------------------------------------------------------------------------
 int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K,
                int lda, int ldw, int ldc, const char* tag) {
@@ -404,6 +434,12 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   NQ_PROF_FLOPS(2.0 * M * N * K);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm3_ok<true, true>(p, K, 1)) {
+    if (C2_silu) NQ_TRY((launch_gemm3<true, true, EPI_SILU>(st, p, 1)));
+    else NQ_TRY((launch_gemm3<true, true, EPI_STORE>(st, p, 1)));
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm2_ok<true, true>(p, K)) {
     if (C2_silu) launch_gemm2<true, true, EPI_SILU>(st, p, 1);
     else launch_gemm2<true, true, EPI_STORE>(st, p, 1);
@@ -433,6 +469,11 @@ int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, flo
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, nullptr, C2, M, N, K, K, K, N, 0, 0, nullptr, 0};
   p.resid = resid; p.ea = ea; p.eb = eb;
+  if (gemm3_ok<true, true>(p, K, 1)) {
+    NQ_TRY((launch_gemm3<true, true, EPI_SILU_RES>(st, p, 1)));
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm2_ok<true, true>(p, K)) {
     launch_gemm2<true, true, EPI_SILU_RES>(st, p, 1);
     NQ_LAUNCH_CHECK();
@@ -457,6 +498,12 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
+  if (gemm3_ok<true, false>(p, Nout, 1)) {
+    if (accumulate) NQ_TRY((launch_gemm3<true, false, EPI_ACC>(st, p, 1)));
+    else NQ_TRY((launch_gemm3<true, false, EPI_STORE>(st, p, 1)));
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm2_ok<true, false>(p, Nout)) {
     if (accumulate) launch_gemm2<true, false, EPI_ACC>(st, p, 1);
     else launch_gemm2<true, false, EPI_STORE>(st, p, 1);
@@ -485,6 +532,12 @@ int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
   p.resid = aux; p.ea = ea; p.eb = eb;
+  if (gemm3_ok<true, false>(p, Nout, 1)) {
+    if (mode == 1) NQ_TRY((launch_gemm3<true, false, EPI_DSILU>(st, p, 1)));
+    else NQ_TRY((launch_gemm3<true, false, EPI_RES>(st, p, 1)));
+    NQ_LAUNCH_CHECK();
+    return NQ_OK;
+  }
   if (gemm2_ok<true, false>(p, Nout)) {
     if (mode == 1) launch_gemm2<true, false, EPI_DSILU>(st, p, 1);
     else launch_gemm2<true, false, EPI_RES>(st, p, 1);
@@ -536,7 +589,8 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
   GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
   const int nse = nq_cdiv(rows, kper);   // splits that actually hold rows (<= ns); only their slabs are reduced
-  if (gemm2_ok<false, false>(p, kper)) launch_gemm2<false, false, EPI_PARTIAL>(st, p, nse);
+  if (gemm3_ok<false, false>(p, kper, nse)) NQ_TRY((launch_gemm3<false, false, EPI_PARTIAL>(st, p, nse)));
+  else if (gemm2_ok<false, false>(p, kper)) launch_gemm2<false, false, EPI_PARTIAL>(st, p, nse);
   else launch_gemm<false, false, EPI_PARTIAL>(st, dim3(nq_cdiv(Mo, BM), nq_cdiv(No, BN), nse), p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;

@@ -1,0 +1,317 @@
+// f32 products on the bf16 matrix pipe: every f32 operand value is split EXACTLY into three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits,
+// round-to-nearest at every step, the remainders x - h and x - h - m are exact in f32), while its tile is staged into LDS; the product of two values is
+// then the sum of the piece products  h h' + h m' + m h' + h l' + l h' + m m'  (the three dropped terms are <= 3 * 2^-24 |x y|, below the rounding of an
+// f32 product-sum), each accumulated in f32 by v_mfma_f32_32x32x16_bf16.  One such instruction contracts 16 k's in 32 cycles where the exact-f32
+// v_mfma_f32_32x32x2_f32 needs 8 x 64: six of them are 2.67x the f32 pipe's rate (peak 2.5 PF / 6 = 416 TFLOP/s of f32-accurate products vs 157).
+// TERMS = 9 keeps all piece products (the exact 48-bit product, summed in f32).
+//
+// Same skeleton as k_gemm2 (gemm_tile.h): persistent workgroups over (tile, k-tile) steps, two LDS buffers, one barrier per k-tile, buffer-descriptor
+// loads, C stores left in flight under the next tile, epilogue inputs fetched under the last k-tile.  128 x 128 tiles, 4 wavefronts of 64 x 64 (2 x 2
+// accumulators: per k16 step 12 ds_read_b128 feed 24 MFMAs = 64 B/clk/CU of LDS reads, half the LDS rate).
+// LDS image of an operand tile: three planes (h, m, l) of [row][k] bf16, row pitch 2 BK + 16 bytes (conflict-free ds_read_b128 of 8 consecutive k).
+//   KC source ([row][k] in memory): a thread loads 8 consecutive k of one row, splits, writes one ds_write_b128 per plane.
+//   MC source ([k][col] in memory): wavefront w loads the k rows  w KPT .. w KPT + KPT-1,  lane l the columns 2l, 2l+1 (8-byte loads, 512 B per row
+//   and wavefront); the thread then holds KPT consecutive k of two columns = one ds_write_b64/b128 per column and plane (the transposition costs nothing).
+// Inf / NaN: a non-finite operand value gives NaN (inf - inf in the split) where the f32 pipe would give inf.
+#pragma once
+#include "gemm_tile.h"
+
+typedef __bf16 sp_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sp_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned sp_pack(float a, float b) {
+  sp_bf2 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+template <bool CHEAP = false>
+__device__ __forceinline__ void sp_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  if (CHEAP) { h = m = l = (__float_as_uint(x0) >> 16) | (__float_as_uint(x1) & 0xffff0000u); return; }
+  h = sp_pack(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = sp_pack(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = sp_pack(s0, s1);
+}
+
+template <bool KC, int ROWS, int BK, int NT>
+struct SplitStage {
+  static constexpr int PITCH = BK * 2 + 16;
+  static constexpr int PLANE = ROWS * PITCH;
+  static constexpr int BYTES = 3 * PLANE;
+  static constexpr int LPR = BK / 8;                   // KC: lanes per row, 8 k each
+  static constexpr int RPP = NT / LPR;                 // KC: rows per pass
+  static constexpr int NP = KC ? ROWS / RPP : 1;       // KC: passes
+  static constexpr int KPT = BK / (NT / 64);           // MC: k rows per wavefront
+  static constexpr int NREG = KC ? NP * 8 : KPT * 2;
+  static_assert(KC || ROWS == 128, "MC staging: 64 lanes x 2 columns");
+  static_assert(!KC || ROWS % RPP == 0, "KC staging");
+  static_assert(KPT == 4 || KPT == 8, "MC staging: 4 or 8 k per wavefront");
+
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t descriptor(const float* __restrict__ src, long ld, int r0, int R, int kbeg, int kend) {
+    const float* base = KC ? src + (long)r0 * ld + kbeg : src + (long)kbeg * ld + r0;
+    const long rr = min(R - r0, ROWS), kl = kend - kbeg;
+    const long bytes = (KC ? (rr - 1) * ld + kl : (kl - 1) * ld + rr) * 4;
+    // everything here is workgroup-uniform; say so (readfirstlane), or a descriptor the compiler cannot prove uniform costs a waterfall loop around every load
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int nrec = __builtin_amdgcn_readfirstlane((int)max(0L, min(bytes, 0xffffffffL)));   // r0 >= R: zero range
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
+  }
+  static __device__ __forceinline__ int lane_offset(int ld) {
+    const int t = threadIdx.x;
+    if (KC) return ((t / LPR) * ld + (t % LPR) * 8) * 4;
+    return ((t >> 6) * KPT * ld + 2 * (t & 63)) * 4;
+  }
+  static __device__ __forceinline__ void fetch(float (&v)[NREG], __amdgpu_buffer_rsrc_t rsrc, int voff, int ld, int krel_) {
+    const int krel = __builtin_amdgcn_readfirstlane(krel_);   // uniform (see descriptor()): the scalar-offset operand must not become a waterfall loop
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int soff = (i * RPP * ld + krel) * 4;
+        const gemm_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0), y = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + 16, 0);
+        v[8 * i + 0] = __uint_as_float(x.x); v[8 * i + 1] = __uint_as_float(x.y); v[8 * i + 2] = __uint_as_float(x.z); v[8 * i + 3] = __uint_as_float(x.w);
+        v[8 * i + 4] = __uint_as_float(y.x); v[8 * i + 5] = __uint_as_float(y.y); v[8 * i + 6] = __uint_as_float(y.z); v[8 * i + 7] = __uint_as_float(y.w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const sp_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (i + krel) * ld * 4, 0);
+        v[2 * i] = __uint_as_float(x.x); v[2 * i + 1] = __uint_as_float(x.y);
+      }
+    }
+  }
+  // registers -> the three planes.  KC: krem = kend - (first k of the k-tile): quads of k past it are zeroed (the range check only sees the row end)
+  template <bool CHEAP = false>
+  static __device__ __forceinline__ void stash(char* __restrict__ tile, const float (&v)[NREG], int krem) {
+    const int t = threadIdx.x;
+    if (KC) {
+      const int kq = (t % LPR) * 8;
+      const bool z0 = kq >= krem, z1 = kq + 4 >= krem;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        unsigned h[4], m[4], l[4];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? z0 : z1) ? 0.f : v[8 * i + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sp_split2<CHEAP>(x[2 * e], x[2 * e + 1], h[e], m[e], l[e]);
+        char* q = tile + (t / LPR + i * RPP) * PITCH + kq * 2;
+        *reinterpret_cast<gemm_u32x4*>(q) = gemm_u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<gemm_u32x4*>(q + PLANE) = gemm_u32x4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<gemm_u32x4*>(q + 2 * PLANE) = gemm_u32x4{l[0], l[1], l[2], l[3]};
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
+#pragma unroll
+        for (int i = 0; i < KPT / 2; ++i) sp_split2<CHEAP>(v[4 * i + c], v[4 * i + 2 + c], h[i], m[i], l[i]);
+        char* q = tile + (2 * (t & 63) + c) * PITCH + (t >> 6) * KPT * 2;
+        if (KPT == 4) {
+          *reinterpret_cast<sp_u32x2*>(q) = sp_u32x2{h[0], h[1]};
+          *reinterpret_cast<sp_u32x2*>(q + PLANE) = sp_u32x2{m[0], m[1]};
+          *reinterpret_cast<sp_u32x2*>(q + 2 * PLANE) = sp_u32x2{l[0], l[1]};
+        } else {
+          *reinterpret_cast<gemm_u32x4*>(q) = gemm_u32x4{h[0], h[1], h[KPT / 2 - 2], h[KPT / 2 - 1]};
+          *reinterpret_cast<gemm_u32x4*>(q + PLANE) = gemm_u32x4{m[0], m[1], m[KPT / 2 - 2], m[KPT / 2 - 1]};
+          *reinterpret_cast<gemm_u32x4*>(q + 2 * PLANE) = gemm_u32x4{l[0], l[1], l[KPT / 2 - 2], l[KPT / 2 - 1]};
+        }
+      }
+    }
+  }
+  // MFMA operand of plane pl, 32-row sub-tile at `base`, k16 step kk: lane (lr, lk) -> k = kk + 8 lk + {0..7}
+  static __device__ __forceinline__ sp_bf8 frag(const char* __restrict__ tile, int pl, int base, int kk, int lr, int lk) {
+    return *reinterpret_cast<const sp_bf8*>(tile + pl * PLANE + (base + lr) * PITCH + kk * 2 + lk * 16);
+  }
+};
+
+extern __shared__ __attribute__((aligned(16))) char sp_lds[];
+
+struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-tile) step of a workgroup; tile >= ntiles: past the end (kbeg == kend == 0)
+
+// Software pipeline, prefetch distance TWO: a k16 step is 24 MFMAs = 768 cycles of the matrix pipe, less than one trip to L2 / HBM, so the loads of
+// step s+2 are issued at the top of step s (two register sets), the registers of step s+1 are split and written to the other LDS buffer during
+// step s, and step s's MFMAs read the buffer filled during step s-1.  Everything is branch-free up to the per-tile epilogue: past the last step the
+// descriptors have zero range (the loads return zeros, the stash writes zeros nobody reads).
+// ABL (lab only): 1 = no split arithmetic (the three planes get the truncated value), 2 = no global loads inside the loop, 4 = no ds_reads inside the loop
+template <bool A_KC, bool B_KC, int EPI, int BK, int WPE = 2, int TERMS = 6, int ABL = 0>
+__global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
+  constexpr int BM = 128, BN = 128, NT = 256, NWN = 2, TM = 2, TN = 2;
+  using SA = SplitStage<A_KC, BM, BK, NT>;
+  using SB = SplitStage<B_KC, BN, BK, NT>;
+  constexpr int BUF = SA::BYTES + SB::BYTES;
+  constexpr int NLOADS = (A_KC ? 2 * SA::NP : SA::KPT) + (B_KC ? 2 * SB::NP : SB::KPT);   // load instructions of one step's fetch
+  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
+  char* lds = sp_lds;
+
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int per_split = ntn * ntm;
+  const int nsplit = EPI == EPI_PARTIAL ? (p.K + p.k_per_split - 1) / p.k_per_split : 1;
+  const int ntiles = per_split * nsplit;
+  if ((int)blockIdx.x >= ntiles) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int wrow0 = wm * (TM * 32), wcol0 = wn * (TN * 32);
+  const int lr = lane & 31, lk = lane >> 5;
+  const int voff_a = SA::lane_offset(p.lda), voff_b = SB::lane_offset(p.ldb);
+
+  auto first_step = [&](int tile) {
+    SpStep s;
+    s.tile = tile;
+    if (tile >= ntiles) { s.split = 0; s.m0 = 0; s.n0 = 0; s.kbeg = 0; s.kend = 0; s.k0 = 0; return s; }
+    s.split = tile / per_split;
+    const int rem = tile - s.split * per_split;
+    s.m0 = (rem / ntn) * BM; s.n0 = (rem % ntn) * BN;
+    s.kbeg = EPI == EPI_PARTIAL ? s.split * p.k_per_split : 0;
+    s.kend = EPI == EPI_PARTIAL ? min(p.K, s.kbeg + p.k_per_split) : p.K;
+    s.k0 = s.kbeg;
+    return s;
+  };
+  auto advance = [&](const SpStep& s) {
+    if (s.k0 + BK < s.kend) { SpStep n = s; n.k0 += BK; return n; }
+    return first_step(s.tile >= ntiles ? s.tile : s.tile + (int)gridDim.x);
+  };
+  __amdgpu_buffer_rsrc_t da, db;
+  auto descriptors = [&](const SpStep& s) {   // of the step's tile; zero range past the end
+    const bool v = s.tile < ntiles;
+    da = SA::descriptor(p.A, p.lda, v ? s.m0 : p.M, p.M, s.kbeg, s.kend);
+    db = SB::descriptor(p.B, p.ldb, v ? s.n0 : p.N, p.N, s.kbeg, s.kend);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // bias gradient of the weight-gradient contraction (EPI_PARTIAL, A = gy [rows][M]): column sums of A over the rows < brows, taken from the f32
+  // registers on their way into LDS (wavefront w holds KPT of the step's 16 rows, lane l the columns 2l, 2l+1); the four wavefronts' sums meet in LDS
+  // at the end of the tile, fixed order.  bnext: a tile's first step is staged while the previous tile is still being finished.
+  constexpr bool BIAS = EPI == EPI_PARTIAL && !A_KC;
+  const bool bias_on = BIAS && p.bpart != nullptr;
+  float bsum[2] = {0.f, 0.f}, bnext[2] = {0.f, 0.f};
+  float* lds_b = reinterpret_cast<float*>(lds + 2 * BUF);   // [4][128], only allocated for EPI_PARTIAL
+  auto colsum = [&](const float (&v)[SA::NREG], const SpStep& s, float (&o)[2]) {
+    o[0] = 0.f; o[1] = 0.f;
+    if (BIAS) {
+      const int kb = s.k0 + wave * SA::KPT;
+#pragma unroll
+      for (int i = 0; i < SA::KPT; ++i)
+        if (kb + i < p.brows) { o[0] += v[(2 * i) % SA::NREG]; o[1] += v[(2 * i + 1) % SA::NREG]; }
+    }
+  };
+
+  SpStep cur = first_step(blockIdx.x), n1 = advance(cur), n2 = advance(n1);
+  float ra[2][SA::NREG], rb[2][SB::NREG];
+  descriptors(cur);
+  SA::fetch(ra[0], da, voff_a, p.lda, 0);
+  SB::fetch(rb[0], db, voff_b, p.ldb, 0);
+  if (n1.k0 == n1.kbeg) descriptors(n1);
+  SA::fetch(ra[1], da, voff_a, p.lda, n1.k0 - n1.kbeg);
+  SB::fetch(rb[1], db, voff_b, p.ldb, n1.k0 - n1.kbeg);
+  SA::stash(lds, ra[0], cur.kend - cur.k0);
+  SB::stash(lds + SA::BYTES, rb[0], cur.kend - cur.k0);
+  if (bias_on && cur.n0 == 0) colsum(ra[0], cur, bsum);
+  __syncthreads();
+  do {   // two steps per trip and ONE exit test: an exit between the halves would be a control-flow edge from the first half to the loop header, along which
+         // the compiler must assume the first half's loads pending and guards every reuse of their registers with vmcnt(0)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {   // u = parity of the step: LDS buffer u holds it, register set u^1 the next one, register set u receives the one after
+      const char* As = lds + u * BUF;
+      const char* Bs = As + SA::BYTES;
+      const bool last_k = cur.tile < ntiles && cur.k0 + BK >= cur.kend;   // (a trailing odd step past the end runs on zeros and stores nothing)
+      const long tile_off = (long)cur.m0 * p.ldc + cur.n0;
+      const bool full = cur.m0 + BM <= p.M && cur.n0 + BN <= p.N;
+      // epilogue inputs of this tile FIRST (older than the prefetch below: the wait before the stores leaves the prefetch in flight)
+      float bias_v[TN];
+      f32x16 aux[AUX ? TM : 1][AUX ? TN : 1];
+      if (last_k) {
+        if (EPI != EPI_PARTIAL) {
+          const __amdgpu_buffer_rsrc_t dbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bias_v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(dbias, (cur.n0 + wcol0 + j * 32 + lr) * 4, 0, 0));
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bias_v[j] = 0.f;
+        }
+        if (AUX) {
+          const __amdgpu_buffer_rsrc_t daux = gemm_aux_descriptor(EPI == EPI_ACC ? p.C : p.resid, tile_off, (long)(p.M - 1) * p.ldc + p.N);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) gemm_load_aux(aux[AUX ? i : 0][AUX ? j : 0], daux, p.ldc, wrow0 + i * 32 + 4 * lk, wcol0 + j * 32 + lr);
+        }
+      }
+      descriptors(n2);   // every step (scalar work): a conditional update would be a block merge with loads pending, which costs a vmcnt(0)
+      if (!(ABL & 2)) {
+        SA::fetch(ra[u], da, voff_a, p.lda, n2.k0 - n2.kbeg);
+        SB::fetch(rb[u], db, voff_b, p.ldb, n2.k0 - n2.kbeg);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        sp_bf8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          if (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { fa[pl][i][e] = (__bf16)(float)(lane + pl + i + e); fb[pl][i][e] = (__bf16)(float)(lane - pl - i - e); }
+            continue;
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[pl][i] = SA::frag(As, pl, wrow0 + 32 * i, kk, lr, lk);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[pl][j] = SB::frag(Bs, pl, wcol0 + 32 * j, kk, lr, lk);
+        }
+        constexpr int PA[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, PB[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};   // small terms first
+#pragma unroll
+        for (int tt = 9 - TERMS; tt < 9; ++tt)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[tt]][i], fb[PB[tt]][j], acc[i][j], 0, 0, 0);
+      }
+      {
+        char* An = lds + (u ^ 1) * BUF;
+        SA::template stash<(ABL & 1) != 0>(An, ra[u ^ 1], n1.kend - n1.k0);
+        SB::template stash<(ABL & 1) != 0>(An + SA::BYTES, rb[u ^ 1], n1.kend - n1.k0);
+        if (bias_on && n1.n0 == 0) {
+          float t2[2];
+          colsum(ra[u ^ 1], n1, t2);
+          if (n1.k0 == n1.kbeg) { bnext[0] = t2[0]; bnext[1] = t2[1]; }
+          else { bsum[0] += t2[0]; bsum[1] += t2[1]; }
+        }
+      }
+      if (last_k && bias_on) {
+        if (cur.n0 == 0) { lds_b[wave * 128 + 2 * lane] = bsum[0]; lds_b[wave * 128 + 2 * lane + 1] = bsum[1]; }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (cur.n0 == 0 && t < BM && cur.m0 + t < p.M)
+          p.bpart[(long)cur.split * p.M + cur.m0 + t] = (lds_b[t] + lds_b[128 + t]) + (lds_b[256 + t] + lds_b[384 + t]);
+        bsum[0] = bnext[0]; bsum[1] = bnext[1];
+      }
+      if (last_k) {
+        // bias / aux were requested before this step's prefetch: wait for everything but the NLOADS youngest loads
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (NLOADS & 15) | ((NLOADS >> 4) << 14));
+        float* tbase = p.C + tile_off + (EPI == EPI_PARTIAL ? (long)cur.split * p.part_stride : 0L);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int rl = wrow0 + i * 32 + 4 * lk, cl = wcol0 + j * 32 + lr;
+            if (full) gemm_store_acc<EPI, true>(acc[i][j], aux[AUX ? i : 0][AUX ? j : 0], p, tbase, rl, cl, BM, BN, bias_v[j], tile_off);
+            else gemm_store_acc<EPI, false>(acc[i][j], aux[AUX ? i : 0][AUX ? j : 0], p, tbase, rl, cl, p.M - cur.m0, p.N - cur.n0, bias_v[j], tile_off);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
+      cur = n1; n1 = n2; n2 = advance(n2);
+      __syncthreads();
+    }
+  } while (cur.tile < ntiles);
+}

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "gemm_tile.h"
+#include "gemm_split.h"
 
 extern "C" {
 int nq_linear_forward(const float* A, const float* W, const float* bias, float* C, float* C_silu, int32_t M, int32_t N, int32_t K, void* stream);
@@ -20,16 +21,18 @@ int nq_linear_input_grad(const float* G, const float* W, float* C, int32_t M, in
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
 const char* nq_last_error();
+void nq_set_gemm_variant(int32_t v);
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
 
-__global__ void k_fill(float* p, long n, uint32_t seed, float scale) {
+__global__ void k_fill(float* p, long n, uint32_t seed, float scale, int positive = 0) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t x = (uint32_t)i * 2654435761u + seed;
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  p[i] = scale * ((float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f);
+  const float u = (float)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  p[i] = scale * (positive ? fabsf(u) : u);
 }
 // reference on a row sample: C[m][n] = sum_k a(m,k) b(k,n) in double
 __global__ void k_ref(const float* A, const float* B, double* C, int M, int N, int K, long lda, long ldb, int a_kc, int b_kc, const int* rows, int nrows) {
@@ -86,10 +89,25 @@ static void launch2(hipStream_t st, GemmArgs p, int splits, int wg_per_cu) {   /
   hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, BM, BN, BK, NWM, NWN, WPE, ABL>), grid, dim3(NWM * NWN * 64), 0, st, p);
 }
 
+template <bool A_KC, bool B_KC, int EPI, int BK, int WPE, int TERMS, int ABL = 0>
+static void launch3(hipStream_t st, GemmArgs p, int splits, int wg_per_cu) {
+  using SA = SplitStage<A_KC, 128, BK, 256>;
+  using SB = SplitStage<B_KC, 128, BK, 256>;
+  constexpr int lds = 2 * (SA::BYTES + SB::BYTES);
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute((const void*)k_gemm3<A_KC, B_KC, EPI, BK, WPE, TERMS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  int ntiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * splits;
+  dim3 grid(std::min(ntiles, wg_per_cu * 256), 1, 1);
+  hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, BK, WPE, TERMS, ABL>), grid, dim3(256), lds, st, p);
+}
+
 struct Variant { std::string name; std::function<void()> run; bool check; };
 
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  const bool pos = argc > 1 && !strcmp(argv[1], "pos");   // one-signed operands: every product positive (shows a biased accumulation)
+  const bool abl = argc > 1 && !strcmp(argv[1], "abl");
+  const bool split_only = abl || pos || (argc > 1 && !strcmp(argv[1], "split"));
   hipStream_t st; CK(hipStreamCreate(&st));
   {   // matrix-pipe ceiling: 256 CUs x (1, 2, 4) workgroups of 4 waves, 4 independent accumulators, ~0.2 s of sustained MFMA issue in total
     float* sink; CK(hipMalloc(&sink, 1024 * 256 * 4 * sizeof(float)));
@@ -120,6 +138,8 @@ int main(int argc, char** argv) {
       {"nt", "qh pair", 27552, 8320, 128}, {"nt", "qh edge", 27000, 5376, 32}, {"nt", "4096^3", 4096, 4096, 4096},
   };
   if (quick) shapes.resize(2);
+  if (pos) shapes = {{"nt", "eq 896", 20000, 896, 896}, {"nn", "painn U", 256728, 256, 128}, {"tn", "painn U", 256, 128, 513456}, {"nt", "4096^3", 4096, 4096, 4096}};
+  if (abl) shapes = {{"nt", "painn U", 256728, 256, 128}, {"nt", "eq 896", 20000, 896, 896}, {"nt", "4096^3", 4096, 4096, 4096}};
   for (const Shape& s : shapes) {
     const bool nt = !strcmp(s.kind, "nt"), nn = !strcmp(s.kind, "nn"), tn = !strcmp(s.kind, "tn");
     const int M = s.M, N = s.N, K = s.K;
@@ -129,8 +149,8 @@ int main(int argc, char** argv) {
     const long lda = a_kc ? K : M, ldb = b_kc ? K : N;
     float *A, *B, *C, *bias, *part = nullptr, *scr = nullptr;
     CK(hipMalloc(&A, a_elems * 4)); CK(hipMalloc(&B, b_elems * 4)); CK(hipMalloc(&C, c_elems * 4)); CK(hipMalloc(&bias, N * 4));
-    hipLaunchKernelGGL(k_fill, dim3((a_elems + 255) / 256), dim3(256), 0, st, A, a_elems, 1u, 1.0f);
-    hipLaunchKernelGGL(k_fill, dim3((b_elems + 255) / 256), dim3(256), 0, st, B, b_elems, 2u, tn ? 1.0f : 0.1f);
+    hipLaunchKernelGGL(k_fill, dim3((a_elems + 255) / 256), dim3(256), 0, st, A, a_elems, 1u, 1.0f, (int)pos);
+    hipLaunchKernelGGL(k_fill, dim3((b_elems + 255) / 256), dim3(256), 0, st, B, b_elems, 2u, tn ? 1.0f : 0.1f, (int)pos);
     hipLaunchKernelGGL(k_fill, dim3((N + 255) / 256), dim3(256), 0, st, bias, (long)N, 3u, 1.0f);
     // split count for tn, as the library chooses it: ~768 workgroups, >= 128 rows per split
     int splits = 1, kper = K;
@@ -161,11 +181,27 @@ int main(int argc, char** argv) {
     auto reduce = [&]() { if (tn) hipLaunchKernelGGL(k_reduce, dim3((c_elems + 63) / 64), dim3(64), 0, st, part, splits, c_elems, c_elems, C); };
 
     std::vector<Variant> vs;
+    if (nt) vs.push_back({"lib exact-f32 engine", [&]() { nq_set_gemm_variant(1 | 32); nq_linear_forward(A, B, nullptr, C, nullptr, M, N, K, st); nq_set_gemm_variant(1); }, true});
+    if (nn) vs.push_back({"lib exact-f32 engine", [&]() { nq_set_gemm_variant(1 | 32); nq_linear_input_grad(A, B, C, M, K, N, 0, st); nq_set_gemm_variant(1); }, true});
+    if (tn) vs.push_back({"lib exact-f32 engine", [&]() { nq_set_gemm_variant(1 | 32); nq_linear_weight_grad(A, B, C, K, M, N, scr, st); nq_set_gemm_variant(1); }, true});
     if (nt) vs.push_back({"lib", [&]() { nq_linear_forward(A, B, nullptr, C, nullptr, M, N, K, st); }, true});
     if (nn) vs.push_back({"lib", [&]() { nq_linear_input_grad(A, B, C, M, K, N, 0, st); }, true});   // (G[M,Nout=K], W[Nout=K, Kin=N]) -> C[M, Kin=N]
     if (tn) vs.push_back({"lib", [&]() { nq_linear_weight_grad(A, B, C, K, M, N, scr, st); }, true});
 #define V(name, AKC, BKC, EPI, BM, BN, BK, WM, WN, ABL, chk, PC) vs.push_back({name, [&]() { launch2<AKC, BKC, EPI, BM, BN, BK, WM, WN, ((PC) ? (PC) : 2) * WM * WN / 4, ABL>(st, p, splits, PC); reduce(); }, chk})
+#define S(name, AKC, BKC, EPI, BK, WPE, TERMS, PC) vs.push_back({name, [&]() { launch3<AKC, BKC, EPI, BK, WPE, TERMS>(st, p, splits, PC); reduce(); }, true})
     if (nt) {
+      S("split6 bk16 p2", true, true, EPI_STORE, 16, 2, 6, 2);
+      S("split3 bk16 p2", true, true, EPI_STORE, 16, 2, 3, 2);
+#define SA_(name, ABL) vs.push_back({name, [&]() { launch3<true, true, EPI_STORE, 16, 2, 6, ABL>(st, p, splits, 2); }, false})
+      if (abl) { SA_("  abl1 no split arith", 1); SA_("  abl2 no loads", 2); SA_("  abl3 no split, no loads", 3); SA_("  abl4 no ds_read", 4); SA_("  abl7 mfma+ds_write+barrier only", 7); }
+    }
+    if (nn) {
+      S("split6 bk16 p2", true, false, EPI_STORE, 16, 2, 6, 2);
+    }
+    if (tn) {
+      S("split6 bk16 p2", false, false, EPI_PARTIAL, 16, 2, 6, 2);
+    }
+    if (nt && !split_only) {
       V("128x128x32 w4x2 p2", true, true, EPI_STORE, 128, 128, 32, 4, 2, 0, true, 2);
       V("128x128x32 w2x2 p2", true, true, EPI_STORE, 128, 128, 32, 2, 2, 0, true, 2);
       V("128x64x32 w2x2 p4", true, true, EPI_STORE, 128, 64, 32, 2, 2, 0, true, 4);
@@ -176,13 +212,13 @@ int main(int argc, char** argv) {
       V("  abl nostore 128x128x32 w4x2 p2", true, true, EPI_STORE, 128, 128, 32, 4, 2, 1, false, 2);
       V("  abl neither 128x128x32 w4x2 p2", true, true, EPI_STORE, 128, 128, 32, 4, 2, 3, false, 2);
     }
-    if (nn) {
+    if (nn && !split_only) {
       V("128x128x32 w4x2 p2", true, false, EPI_STORE, 128, 128, 32, 4, 2, 0, true, 2);
       V("128x64x32 w2x2 p4", true, false, EPI_STORE, 128, 64, 32, 2, 2, 0, true, 4);
       V("64x64x32 w2x2 p4", true, false, EPI_STORE, 64, 64, 32, 2, 2, 0, true, 4);
       V("  abl neither 128x128x32 w4x2 p2", true, false, EPI_STORE, 128, 128, 32, 4, 2, 3, false, 2);
     }
-    if (tn) {
+    if (tn && !split_only) {
       V("128x128x32 w4x2 p2", false, false, EPI_PARTIAL, 128, 128, 32, 4, 2, 0, true, 2);
       V("128x128x32 w2x2 p2", false, false, EPI_PARTIAL, 128, 128, 32, 2, 2, 0, true, 2);
       V("128x64x32 w2x2 p4", false, false, EPI_PARTIAL, 128, 64, 32, 2, 2, 0, true, 4);
