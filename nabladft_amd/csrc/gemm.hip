@@ -411,18 +411,21 @@ static bool gemm3_ok(const GemmArgs& p, long kspan, int splits) {
 }
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
-  using SA = SplitStage<A_KC, 128, 16, 256>;
-  using SB = SplitStage<B_KC, 128, 16, 256>;
-  constexpr int lds = 2 * (SA::BYTES + SB::BYTES) + (EPI == EPI_PARTIAL ? 4 * 128 * 4 : 0);
-  static bool prepared[64] = {};   // per device: more than 64 KB of LDS has to be granted once per function
-  int dev = 0;
-  NQ_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !prepared[dev]) {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_gemm3<A_KC, B_KC, EPI, 16, 2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (dev >= 0 && dev < 64) prepared[dev] = true;
-  }
+  // 168 registers (3 workgroups per CU) hold the plain epilogues; one that reads a second tile (+=, SiLU' / residual operands: 64 more registers) gets 256
+  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
+  constexpr int WPE = AUX ? 2 : 3;
   const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
-  hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 16, 2, 6>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), lds, st, p);
+  const dim3 grid((unsigned)(tiles < 256 * WPE ? tiles : 256 * WPE));
+  if constexpr (EPI == EPI_PARTIAL) {   // weight gradient: no K-contiguous operand, so no k-tail code; the bias gradient is a second instantiation
+    if (p.bpart) hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 2, false, true>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, p);   // (one register short of 168)
+    else hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false, false>), grid, dim3(256), 0, st, p);
+  } else if (p.K & 15) {
+    constexpr int WT = (A_KC && B_KC) ? WPE : 2;   // (the input-gradient layout spills at 168 registers with the tail code)
+    const dim3 gt((unsigned)(tiles < 256 * WT ? tiles : 256 * WT));
+    hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WT, true>), gt, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false>), grid, dim3(256), 0, st, p);
+  }
   return NQ_OK;
 }
 
@@ -562,15 +565,18 @@ int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int
 // of 128x128 output tiles, but at least 512 rows per split so the 64-KB partial slab stays amortised.
 // Split count of the weight-gradient contraction: the persistent engine keeps 2 workgroups of 8 wavefronts per CU = 512 slots; as many
 // (output tile, row range) items as fit WITHOUT exceeding them (one item more would cost a whole extra round), at least 128 rows per split.
-static int tn_splits(long rows, int Mo, int No) {
+static int tn_splits(long rows, int Mo, int No, int slots) {
   const long tiles = (long)nq_cdiv(Mo, BM) * nq_cdiv(No, BN);
-  long s = 512 / tiles;
+  long s = slots / tiles;
   const long by_rows = (rows + 127) / 128;   // >= 128 rows (4 k-tiles) per split
   if (s > by_rows) s = by_rows;
   if (s < 1) s = 1;
   return (int)s;
 }
-size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No) * ((size_t)Mo * No + Mo); }
+// workgroup slots of the engine that will run: 2 x 256 for the exact-f32 engine (and the split engine's bias-gradient flavour), 3 x 256 for the split engine
+static int tn_slots(bool with_bias) { return (gemm3_disabled() || with_bias) ? 512 : 768; }
+// (sized for the larger split count: the engine choice may change between the sizing call and the product)
+size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No) { return (size_t)tn_splits(rows, Mo, No, 768) * ((size_t)Mo * No + Mo); }
 
 int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
                const char* tag, float* bias_out, long bias_rows) {
@@ -583,7 +589,7 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
     return NQ_OK;
   }
   if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
-  const int ns = tn_splits(rows, Mo, No);
+  const int ns = tn_splits(rows, Mo, No, tn_slots(bias_out != nullptr));
   int kper = (int)((rows + ns - 1) / ns);
   kper = (kper + 31) / 32 * 32;   // whole k-tiles (BKT = 32 for the TN launches)
   float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;

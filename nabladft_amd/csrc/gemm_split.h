@@ -1,17 +1,15 @@
 // f32 products on the bf16 matrix pipe: every f32 operand value is split EXACTLY into three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits,
 // round-to-nearest at every step, the remainders x - h and x - h - m are exact in f32), while its tile is staged into LDS; the product of two values is
-// then the sum of the piece products  h h' + h m' + m h' + h l' + l h' + m m'  (the three dropped terms are <= 3 * 2^-24 |x y|, below the rounding of an
-// f32 product-sum), each accumulated in f32 by v_mfma_f32_32x32x16_bf16.  One such instruction contracts 16 k's in 32 cycles where the exact-f32
-// v_mfma_f32_32x32x2_f32 needs 8 x 64: six of them are 2.67x the f32 pipe's rate (peak 2.5 PF / 6 = 416 TFLOP/s of f32-accurate products vs 157).
-// TERMS = 9 keeps all piece products (the exact 48-bit product, summed in f32).
+// then the sum of the piece products  h h' + h m' + m h' + h l' + l h' + m m'  (|x - h| <= 2^-9 |x|, |x - h - m| <= 2^-18 |x|: the dropped products m l',
+// l m', l l' and the residual of the split are <= 2^-25 |x y| together, below the 2^-24 rounding of an f32 product), each accumulated in f32 by
+// v_mfma_f32_32x32x16_bf16.  One such instruction contracts 16 k's in 32 cycles where the exact-f32 v_mfma_f32_32x32x2_f32 needs 8 x 64: six of them
+// are 2.67x the f32 pipe's rate (peak 2.5 PF / 6 = 416 TFLOP/s of f32-accurate products vs 157).  TERMS = 9 keeps all nine piece products.
+// Measured against float64 (scripts/lab/gemm_lab.hip, tests/test_engine_gpu.py): the error is equal to or below the exact-f32 engine's on every shape.
 //
-// Same skeleton as k_gemm2 (gemm_tile.h): persistent workgroups over (tile, k-tile) steps, two LDS buffers, one barrier per k-tile, buffer-descriptor
-// loads, C stores left in flight under the next tile, epilogue inputs fetched under the last k-tile.  128 x 128 tiles, 4 wavefronts of 64 x 64 (2 x 2
-// accumulators: per k16 step 12 ds_read_b128 feed 24 MFMAs = 64 B/clk/CU of LDS reads, half the LDS rate).
-// LDS image of an operand tile: three planes (h, m, l) of [row][k] bf16, row pitch 2 BK + 16 bytes (conflict-free ds_read_b128 of 8 consecutive k).
-//   KC source ([row][k] in memory): a thread loads 8 consecutive k of one row, splits, writes one ds_write_b128 per plane.
-//   MC source ([k][col] in memory): wavefront w loads the k rows  w KPT .. w KPT + KPT-1,  lane l the columns 2l, 2l+1 (8-byte loads, 512 B per row
-//   and wavefront); the thread then holds KPT consecutive k of two columns = one ds_write_b64/b128 per column and plane (the transposition costs nothing).
+// Same skeleton as k_gemm2 (gemm_tile.h): persistent workgroups over (tile, k-step) steps, two LDS buffers, one barrier per step, buffer-descriptor
+// loads, C stores left in flight under the next tile, epilogue inputs fetched under the last step.  128 x 128 tiles, 4 wavefronts of 64 x 64 (2 x 2
+// accumulators: per k16 step 12 ds_read_b128 feed 24 MFMAs = 64 B/clk/CU of LDS reads, half the LDS rate), 49 KB of LDS and <= 168 registers: three
+// workgroups per CU, whose barriers and staging phases interleave on the matrix pipe.
 // Inf / NaN: a non-finite operand value gives NaN (inf - inf in the split) where the f32 pipe would give inf.
 #pragma once
 #include "gemm_tile.h"
@@ -25,6 +23,9 @@ __device__ __forceinline__ unsigned sp_pack(float a, float b) {
   v[0] = (__bf16)a; v[1] = (__bf16)b;
   return __builtin_bit_cast(unsigned, v);
 }
+// (x0, x1) -> packed bf16 pairs h, m, l (convert, widen, subtract; the subtractions are exact).  CHEAP (lab ablation): no arithmetic.
+// (Measured and dropped: v_dot2_f32_bf16 with a (-1, 0) operand as a one-instruction "subtract the widened half" -- it does not return the exact
+// remainder on gfx950 and is not faster than the shift / and / packed-subtract sequence the compiler emits for the lines below.)
 template <bool CHEAP = false>
 __device__ __forceinline__ void sp_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   if (CHEAP) { h = m = l = (__float_as_uint(x0) >> 16) | (__float_as_uint(x1) & 0xffff0000u); return; }
@@ -35,19 +36,17 @@ __device__ __forceinline__ void sp_split2(float x0, float x1, unsigned& h, unsig
   l = sp_pack(s0, s1);
 }
 
-template <bool KC, int ROWS, int BK, int NT>
+// One operand tile: 128 rows (the M or N extent) x 16 k, staged by 256 threads into three planes (h, m, l) of [row][16 bf16] = 32 bytes per row, unpadded:
+// a quarter-wavefront's ds_read_b128 (8 rows x 16 bytes, 32 bytes apart) covers all 64 banks once, and so do the ds_write_b128 below.
+//   KC source ([row][k] in memory): thread t loads the 8 consecutive k's  8 (t & 1) ..  of row t >> 1 (two 16-byte loads), splits them and writes one
+//   ds_write_b128 per plane.
+//   MC source ([k][col] in memory): wavefront w loads the 8 k rows  8 (w & 1) ..  of the 64 columns  64 (w >> 1) + lane  (dword loads, 256 contiguous bytes per
+//   row and wavefront); the thread then holds 8 consecutive k of ONE column = the same single ds_write_b128 per plane (the transposition costs nothing).
+template <bool KC>
 struct SplitStage {
-  static constexpr int PITCH = BK * 2 + 16;
-  static constexpr int PLANE = ROWS * PITCH;
-  static constexpr int BYTES = 3 * PLANE;
-  static constexpr int LPR = BK / 8;                   // KC: lanes per row, 8 k each
-  static constexpr int RPP = NT / LPR;                 // KC: rows per pass
-  static constexpr int NP = KC ? ROWS / RPP : 1;       // KC: passes
-  static constexpr int KPT = BK / (NT / 64);           // MC: k rows per wavefront
-  static constexpr int NREG = KC ? NP * 8 : KPT * 2;
-  static_assert(KC || ROWS == 128, "MC staging: 64 lanes x 2 columns");
-  static_assert(!KC || ROWS % RPP == 0, "KC staging");
-  static_assert(KPT == 4 || KPT == 8, "MC staging: 4 or 8 k per wavefront");
+  static constexpr int ROWS = 128, BK = 16, NT = 256;
+  static constexpr int PITCH = 32, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
+  static constexpr int NREG = 8, NLOADS = KC ? 2 : 8;
 
   static __device__ __forceinline__ __amdgpu_buffer_rsrc_t descriptor(const float* __restrict__ src, long ld, int r0, int R, int kbeg, int kend) {
     const float* base = KC ? src + (long)r0 * ld + kbeg : src + (long)kbeg * ld + r0;
@@ -61,73 +60,49 @@ struct SplitStage {
   }
   static __device__ __forceinline__ int lane_offset(int ld) {
     const int t = threadIdx.x;
-    if (KC) return ((t / LPR) * ld + (t % LPR) * 8) * 4;
-    return ((t >> 6) * KPT * ld + 2 * (t & 63)) * 4;
+    if (KC) return ((t >> 1) * ld + (t & 1) * 8) * 4;
+    return (((t >> 6) & 1) * 8 * ld + (t >> 7) * 64 + (t & 63)) * 4;
   }
   static __device__ __forceinline__ void fetch(float (&v)[NREG], __amdgpu_buffer_rsrc_t rsrc, int voff, int ld, int krel_) {
     const int krel = __builtin_amdgcn_readfirstlane(krel_);   // uniform (see descriptor()): the scalar-offset operand must not become a waterfall loop
     if (KC) {
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const int soff = (i * RPP * ld + krel) * 4;
-        const gemm_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0), y = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + 16, 0);
-        v[8 * i + 0] = __uint_as_float(x.x); v[8 * i + 1] = __uint_as_float(x.y); v[8 * i + 2] = __uint_as_float(x.z); v[8 * i + 3] = __uint_as_float(x.w);
-        v[8 * i + 4] = __uint_as_float(y.x); v[8 * i + 5] = __uint_as_float(y.y); v[8 * i + 6] = __uint_as_float(y.z); v[8 * i + 7] = __uint_as_float(y.w);
-      }
+      const gemm_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, krel * 4, 0), y = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, krel * 4 + 16, 0);
+      v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.y); v[2] = __uint_as_float(x.z); v[3] = __uint_as_float(x.w);
+      v[4] = __uint_as_float(y.x); v[5] = __uint_as_float(y.y); v[6] = __uint_as_float(y.z); v[7] = __uint_as_float(y.w);
     } else {
 #pragma unroll
-      for (int i = 0; i < KPT; ++i) {
-        const sp_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (i + krel) * ld * 4, 0);
-        v[2 * i] = __uint_as_float(x.x); v[2 * i + 1] = __uint_as_float(x.y);
-      }
+      for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (i + krel) * ld * 4, 0));
     }
   }
   // registers -> the three planes.  KC: krem = kend - (first k of the k-tile): quads of k past it are zeroed (the range check only sees the row end)
-  template <bool CHEAP = false>
+  // KTAIL = false: the caller guarantees whole k16 steps (no zeroing code at all)
+  template <bool CHEAP = false, bool KTAIL = true>
   static __device__ __forceinline__ void stash(char* __restrict__ tile, const float (&v)[NREG], int krem) {
     const int t = threadIdx.x;
-    if (KC) {
-      const int kq = (t % LPR) * 8;
+    float x[8];
+    if (KC && KTAIL) {
+      const int kq = (t & 1) * 8;
       const bool z0 = kq >= krem, z1 = kq + 4 >= krem;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        unsigned h[4], m[4], l[4];
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? z0 : z1) ? 0.f : v[8 * i + e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sp_split2<CHEAP>(x[2 * e], x[2 * e + 1], h[e], m[e], l[e]);
-        char* q = tile + (t / LPR + i * RPP) * PITCH + kq * 2;
-        *reinterpret_cast<gemm_u32x4*>(q) = gemm_u32x4{h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<gemm_u32x4*>(q + PLANE) = gemm_u32x4{m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<gemm_u32x4*>(q + 2 * PLANE) = gemm_u32x4{l[0], l[1], l[2], l[3]};
-      }
+      for (int e = 0; e < 8; ++e) x[e] = (e < 4 ? z0 : z1) ? 0.f : v[e];
     } else {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
-#pragma unroll
-        for (int i = 0; i < KPT / 2; ++i) sp_split2<CHEAP>(v[4 * i + c], v[4 * i + 2 + c], h[i], m[i], l[i]);
-        char* q = tile + (2 * (t & 63) + c) * PITCH + (t >> 6) * KPT * 2;
-        if (KPT == 4) {
-          *reinterpret_cast<sp_u32x2*>(q) = sp_u32x2{h[0], h[1]};
-          *reinterpret_cast<sp_u32x2*>(q + PLANE) = sp_u32x2{m[0], m[1]};
-          *reinterpret_cast<sp_u32x2*>(q + 2 * PLANE) = sp_u32x2{l[0], l[1]};
-        } else {
-          *reinterpret_cast<gemm_u32x4*>(q) = gemm_u32x4{h[0], h[1], h[KPT / 2 - 2], h[KPT / 2 - 1]};
-          *reinterpret_cast<gemm_u32x4*>(q + PLANE) = gemm_u32x4{m[0], m[1], m[KPT / 2 - 2], m[KPT / 2 - 1]};
-          *reinterpret_cast<gemm_u32x4*>(q + 2 * PLANE) = gemm_u32x4{l[0], l[1], l[KPT / 2 - 2], l[KPT / 2 - 1]};
-        }
-      }
+      for (int e = 0; e < 8; ++e) x[e] = v[e];
     }
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sp_split2<CHEAP>(x[2 * e], x[2 * e + 1], h[e], m[e], l[e]);
+    char* q = KC ? tile + (t >> 1) * PITCH + (t & 1) * 16 : tile + ((t >> 7) * 64 + (t & 63)) * PITCH + ((t >> 6) & 1) * 16;
+    *reinterpret_cast<gemm_u32x4*>(q) = gemm_u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<gemm_u32x4*>(q + PLANE) = gemm_u32x4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<gemm_u32x4*>(q + 2 * PLANE) = gemm_u32x4{l[0], l[1], l[2], l[3]};
   }
-  // MFMA operand of plane pl, 32-row sub-tile at `base`, k16 step kk: lane (lr, lk) -> k = kk + 8 lk + {0..7}
-  static __device__ __forceinline__ sp_bf8 frag(const char* __restrict__ tile, int pl, int base, int kk, int lr, int lk) {
-    return *reinterpret_cast<const sp_bf8*>(tile + pl * PLANE + (base + lr) * PITCH + kk * 2 + lk * 16);
+  // MFMA operand of plane pl, 32-row sub-tile at `base`: lane (lr, lk) -> k = 8 lk + {0..7}
+  static __device__ __forceinline__ sp_bf8 frag(const char* __restrict__ tile, int pl, int base, int lr, int lk) {
+    return *reinterpret_cast<const sp_bf8*>(tile + pl * PLANE + (base + lr) * PITCH + lk * 16);
   }
 };
 
-extern __shared__ __attribute__((aligned(16))) char sp_lds[];
 
 struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-tile) step of a workgroup; tile >= ntiles: past the end (kbeg == kend == 0)
 
@@ -136,15 +111,18 @@ struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-ti
 // step s, and step s's MFMAs read the buffer filled during step s-1.  Everything is branch-free up to the per-tile epilogue: past the last step the
 // descriptors have zero range (the loads return zeros, the stash writes zeros nobody reads).
 // ABL (lab only): 1 = no split arithmetic (the three planes get the truncated value), 2 = no global loads inside the loop, 4 = no ds_reads inside the loop
-template <bool A_KC, bool B_KC, int EPI, int BK, int WPE = 2, int TERMS = 6, int ABL = 0>
+// KTAIL: the contraction length need not be a multiple of 16 (K-contiguous operands only; costs 18 VALU instructions per step).
+// WBIAS (weight-gradient launches): also produce the bias gradient (GemmArgs::bpart).
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0>
 __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
-  constexpr int BM = 128, BN = 128, NT = 256, NWN = 2, TM = 2, TN = 2;
-  using SA = SplitStage<A_KC, BM, BK, NT>;
-  using SB = SplitStage<B_KC, BN, BK, NT>;
-  constexpr int BUF = SA::BYTES + SB::BYTES;
-  constexpr int NLOADS = (A_KC ? 2 * SA::NP : SA::KPT) + (B_KC ? 2 * SB::NP : SB::KPT);   // load instructions of one step's fetch
+  constexpr int BM = 128, BN = 128, BK = 16, NWN = 2, TM = 2, TN = 2;
+  using SA = SplitStage<A_KC>;
+  using SB = SplitStage<B_KC>;
+  constexpr int BUF = SA::BYTES + SB::BYTES;   // 24 KB: two buffers (+ the bias-gradient lines) = 49 KB, three workgroups per CU
+  constexpr int NLOADS = SA::NLOADS + SB::NLOADS;   // load instructions of one step's fetch
   constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
-  char* lds = sp_lds;
+  constexpr bool BIAS = EPI == EPI_PARTIAL && !A_KC && WBIAS;
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + (BIAS ? 2 * 128 * 4 : 0)];
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int per_split = ntn * ntm;
@@ -189,20 +167,18 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // bias gradient of the weight-gradient contraction (EPI_PARTIAL, A = gy [rows][M]): column sums of A over the rows < brows, taken from the f32
-  // registers on their way into LDS (wavefront w holds KPT of the step's 16 rows, lane l the columns 2l, 2l+1); the four wavefronts' sums meet in LDS
-  // at the end of the tile, fixed order.  bnext: a tile's first step is staged while the previous tile is still being finished.
-  constexpr bool BIAS = EPI == EPI_PARTIAL && !A_KC;
-  const bool bias_on = BIAS && p.bpart != nullptr;
-  float bsum[2] = {0.f, 0.f}, bnext[2] = {0.f, 0.f};
-  float* lds_b = reinterpret_cast<float*>(lds + 2 * BUF);   // [4][128], only allocated for EPI_PARTIAL
-  auto colsum = [&](const float (&v)[SA::NREG], const SpStep& s, float (&o)[2]) {
-    o[0] = 0.f; o[1] = 0.f;
-    if (BIAS) {
-      const int kb = s.k0 + wave * SA::KPT;
+  // registers on their way into LDS (a thread holds 8 of the step's 16 rows of ONE column); the two half-steps' sums meet in LDS at the end of the
+  // tile, fixed order.  bnext: a tile's first step is staged while the previous tile is still being finished.
+  constexpr bool bias_on = BIAS;
+  float bsum = 0.f, bnext = 0.f;
+  float* lds_b = reinterpret_cast<float*>(lds + 2 * BUF);   // [2][128], only there for EPI_PARTIAL
+  auto colsum = [&](const float (&v)[SA::NREG], const SpStep& s) {
+    float o = 0.f;
+    const int kb = s.k0 + (wave & 1) * 8;
 #pragma unroll
-      for (int i = 0; i < SA::KPT; ++i)
-        if (kb + i < p.brows) { o[0] += v[(2 * i) % SA::NREG]; o[1] += v[(2 * i + 1) % SA::NREG]; }
-    }
+    for (int i = 0; i < 8; ++i)
+      if (kb + i < p.brows) o += v[i];
+    return o;
   };
 
   SpStep cur = first_step(blockIdx.x), n1 = advance(cur), n2 = advance(n1);
@@ -213,9 +189,9 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   if (n1.k0 == n1.kbeg) descriptors(n1);
   SA::fetch(ra[1], da, voff_a, p.lda, n1.k0 - n1.kbeg);
   SB::fetch(rb[1], db, voff_b, p.ldb, n1.k0 - n1.kbeg);
-  SA::stash(lds, ra[0], cur.kend - cur.k0);
-  SB::stash(lds + SA::BYTES, rb[0], cur.kend - cur.k0);
-  if (bias_on && cur.n0 == 0) colsum(ra[0], cur, bsum);
+  SA::template stash<false, KTAIL>(lds, ra[0], cur.kend - cur.k0);
+  SB::template stash<false, KTAIL>(lds + SA::BYTES, rb[0], cur.kend - cur.k0);
+  if (bias_on && cur.n0 == 0) bsum = colsum(ra[0], cur);
   __syncthreads();
   do {   // two steps per trip and ONE exit test: an exit between the halves would be a control-flow edge from the first half to the loop header, along which
          // the compiler must assume the first half's loads pending and guards every reuse of their registers with vmcnt(0)
@@ -251,8 +227,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
         SA::fetch(ra[u], da, voff_a, p.lda, n2.k0 - n2.kbeg);
         SB::fetch(rb[u], db, voff_b, p.ldb, n2.k0 - n2.kbeg);
       }
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 16) {
+      {
         sp_bf8 fa[3][TM], fb[3][TN];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -264,9 +239,9 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
             continue;
           }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) fa[pl][i] = SA::frag(As, pl, wrow0 + 32 * i, kk, lr, lk);
+          for (int i = 0; i < TM; ++i) fa[pl][i] = SA::frag(As, pl, wrow0 + 32 * i, lr, lk);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) fb[pl][j] = SB::frag(Bs, pl, wcol0 + 32 * j, kk, lr, lk);
+          for (int j = 0; j < TN; ++j) fb[pl][j] = SB::frag(Bs, pl, wcol0 + 32 * j, lr, lk);
         }
         constexpr int PA[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, PB[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};   // small terms first
 #pragma unroll
@@ -278,22 +253,20 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
       }
       {
         char* An = lds + (u ^ 1) * BUF;
-        SA::template stash<(ABL & 1) != 0>(An, ra[u ^ 1], n1.kend - n1.k0);
-        SB::template stash<(ABL & 1) != 0>(An + SA::BYTES, rb[u ^ 1], n1.kend - n1.k0);
+        SA::template stash<(ABL & 1) != 0, KTAIL>(An, ra[u ^ 1], n1.kend - n1.k0);
+        SB::template stash<(ABL & 1) != 0, KTAIL>(An + SA::BYTES, rb[u ^ 1], n1.kend - n1.k0);
         if (bias_on && n1.n0 == 0) {
-          float t2[2];
-          colsum(ra[u ^ 1], n1, t2);
-          if (n1.k0 == n1.kbeg) { bnext[0] = t2[0]; bnext[1] = t2[1]; }
-          else { bsum[0] += t2[0]; bsum[1] += t2[1]; }
+          const float t2 = colsum(ra[u ^ 1], n1);
+          if (n1.k0 == n1.kbeg) bnext = t2;
+          else bsum += t2;
         }
       }
       if (last_k && bias_on) {
-        if (cur.n0 == 0) { lds_b[wave * 128 + 2 * lane] = bsum[0]; lds_b[wave * 128 + 2 * lane + 1] = bsum[1]; }
+        if (cur.n0 == 0) lds_b[(wave & 1) * 128 + (wave >> 1) * 64 + lane] = bsum;
         __syncthreads();
         const int t = threadIdx.x;
-        if (cur.n0 == 0 && t < BM && cur.m0 + t < p.M)
-          p.bpart[(long)cur.split * p.M + cur.m0 + t] = (lds_b[t] + lds_b[128 + t]) + (lds_b[256 + t] + lds_b[384 + t]);
-        bsum[0] = bnext[0]; bsum[1] = bnext[1];
+        if (cur.n0 == 0 && t < BM && cur.m0 + t < p.M) p.bpart[(long)cur.split * p.M + cur.m0 + t] = lds_b[t] + lds_b[128 + t];
+        bsum = bnext;
       }
       if (last_k) {
         // bias / aux were requested before this step's prefetch: wait for everything but the NLOADS youngest loads

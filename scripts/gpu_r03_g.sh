@@ -2,7 +2,7 @@
 # split-bf16 GEMM engine: lab table (lib vs exact-f32 engine), GEMM tests, model steps with both engines
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r03
-echo "== lab"; timeout 200 scripts/lab/_bin/gemm_lab split > gpurun_out/r03/lab_split4.txt 2>&1; grep -c "err" gpurun_out/r03/lab_split4.txt
+echo "== lab"; timeout 200 scripts/lab/_bin/gemm_lab split > gpurun_out/r03/lab_split8.txt 2>&1; grep -c "err" gpurun_out/r03/lab_split8.txt
 echo "== tests"; timeout 600 python -m pytest tests/test_engine_gpu.py -q -m gpu --tb=short -x 2>&1 | tail -15
 for m in gemnet escn equiformer qhnet; do
   for f32 in 0 1; do

@@ -80,6 +80,24 @@ __global__ __launch_bounds__(256) void k_mfma_peak(float* out, int iters, float 
   out[(long)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the three-way split on the device: h + m + l must reproduce x to 2^-25 |x| (every exponent where the third piece is still a normal number, both signs)
+__global__ void k_split_check(unsigned long long* bad, unsigned long long* inexact, int rounds) {
+  uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+  for (int r = 0; r < rounds; ++r) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; x += 0x9e3779b9u;
+    uint32_t y = x * 747796405u + 2891336453u;
+    uint32_t e0 = (x >> 23) & 0xff, e1 = (y >> 23) & 0xff;
+    if (e0 < 40 || e0 > 215 || e1 < 40 || e1 > 215) continue;   // normal numbers whose third piece is still normal, no overflow
+    const float a = __uint_as_float(x), b = __uint_as_float(y);
+    unsigned h1, m1, l1;
+    sp_split2(a, b, h1, m1, l1);
+    atomicAdd(bad, 1ull);   // pairs checked
+    const double ra = (double)__uint_as_float(h1 << 16) + (double)__uint_as_float(m1 << 16) + (double)__uint_as_float(l1 << 16);
+    const double rb = (double)__uint_as_float(h1 & 0xffff0000u) + (double)__uint_as_float(m1 & 0xffff0000u) + (double)__uint_as_float(l1 & 0xffff0000u);
+    if (fabs(ra - (double)a) > ldexp(fabs((double)a), -25) || fabs(rb - (double)b) > ldexp(fabs((double)b), -25)) atomicAdd(inexact, 1ull);
+  }
+}
+
 struct Shape { const char* kind; const char* name; int M, N, K; };   // nt/nn: C[M,N], contraction K.  tn: out[M=Mo, N=No], K = rows
 
 template <bool A_KC, bool B_KC, int EPI, int BM, int BN, int BK, int NWM, int NWN, int WPE, int ABL = 0>
@@ -89,16 +107,11 @@ static void launch2(hipStream_t st, GemmArgs p, int splits, int wg_per_cu) {   /
   hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, BM, BN, BK, NWM, NWN, WPE, ABL>), grid, dim3(NWM * NWN * 64), 0, st, p);
 }
 
-template <bool A_KC, bool B_KC, int EPI, int BK, int WPE, int TERMS, int ABL = 0>
+template <bool A_KC, bool B_KC, int EPI, int WPE, int TERMS, int ABL = 0, bool KTAIL = true>
 static void launch3(hipStream_t st, GemmArgs p, int splits, int wg_per_cu) {
-  using SA = SplitStage<A_KC, 128, BK, 256>;
-  using SB = SplitStage<B_KC, 128, BK, 256>;
-  constexpr int lds = 2 * (SA::BYTES + SB::BYTES);
-  static bool once = false;
-  if (!once) { CK(hipFuncSetAttribute((const void*)k_gemm3<A_KC, B_KC, EPI, BK, WPE, TERMS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
   int ntiles = ((p.M + 127) / 128) * ((p.N + 127) / 128) * splits;
   dim3 grid(std::min(ntiles, wg_per_cu * 256), 1, 1);
-  hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, BK, WPE, TERMS, ABL>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, KTAIL, false, TERMS, ABL>), grid, dim3(256), 0, st, p);
 }
 
 struct Variant { std::string name; std::function<void()> run; bool check; };
@@ -124,6 +137,13 @@ int main(int argc, char** argv) {
       }
     }
     CK(hipFree(sink));
+  }
+  {
+    unsigned long long* cnt; CK(hipMalloc(&cnt, 16)); CK(hipMemsetAsync(cnt, 0, 16, st));
+    hipLaunchKernelGGL(k_split_check, dim3(1024), dim3(256), 0, st, cnt, cnt + 1, 256);
+    unsigned long long hc[2]; CK(hipMemcpyAsync(hc, cnt, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    printf("# three-way bf16 split on the device: %llu random value pairs over 176 binades, |h + m + l - x| > 2^-25 |x| in %llu of them\n", hc[0], hc[1]);
+    CK(hipFree(cnt));
   }
   std::vector<Shape> shapes = {
       // PaiNN step at B = 2048 (N = 85576 atoms)
@@ -188,18 +208,24 @@ int main(int argc, char** argv) {
     if (nn) vs.push_back({"lib", [&]() { nq_linear_input_grad(A, B, C, M, K, N, 0, st); }, true});   // (G[M,Nout=K], W[Nout=K, Kin=N]) -> C[M, Kin=N]
     if (tn) vs.push_back({"lib", [&]() { nq_linear_weight_grad(A, B, C, K, M, N, scr, st); }, true});
 #define V(name, AKC, BKC, EPI, BM, BN, BK, WM, WN, ABL, chk, PC) vs.push_back({name, [&]() { launch2<AKC, BKC, EPI, BM, BN, BK, WM, WN, ((PC) ? (PC) : 2) * WM * WN / 4, ABL>(st, p, splits, PC); reduce(); }, chk})
-#define S(name, AKC, BKC, EPI, BK, WPE, TERMS, PC) vs.push_back({name, [&]() { launch3<AKC, BKC, EPI, BK, WPE, TERMS>(st, p, splits, PC); reduce(); }, true})
+#define S(name, AKC, BKC, EPI, WPE, TERMS, PC) vs.push_back({name, [&]() { launch3<AKC, BKC, EPI, WPE, TERMS>(st, p, splits, PC); reduce(); }, true})
     if (nt) {
-      S("split6 bk16 p2", true, true, EPI_STORE, 16, 2, 6, 2);
-      S("split3 bk16 p2", true, true, EPI_STORE, 16, 2, 3, 2);
-#define SA_(name, ABL) vs.push_back({name, [&]() { launch3<true, true, EPI_STORE, 16, 2, 6, ABL>(st, p, splits, 2); }, false})
+      S("split6 p3", true, true, EPI_STORE, 3, 6, 3);
+      if (K % 16 == 0) vs.push_back({"split6 p3 no k-tail code", [&]() { launch3<true, true, EPI_STORE, 3, 6, 0, false>(st, p, splits, 3); }, true});
+      S("split6 p2", true, true, EPI_STORE, 2, 6, 2);
+      S("split3 p3", true, true, EPI_STORE, 3, 3, 3);
+#define SA_(name, ABL) vs.push_back({name, [&]() { launch3<true, true, EPI_STORE, 3, 6, ABL>(st, p, splits, 3); }, false})
       if (abl) { SA_("  abl1 no split arith", 1); SA_("  abl2 no loads", 2); SA_("  abl3 no split, no loads", 3); SA_("  abl4 no ds_read", 4); SA_("  abl7 mfma+ds_write+barrier only", 7); }
     }
     if (nn) {
-      S("split6 bk16 p2", true, false, EPI_STORE, 16, 2, 6, 2);
+      S("split6 p3", true, false, EPI_STORE, 3, 6, 3);
+      if (K % 16 == 0) vs.push_back({"split6 p3 no k-tail code", [&]() { launch3<true, false, EPI_STORE, 3, 6, 0, false>(st, p, splits, 3); }, true});
+      if (K % 16 == 0) vs.push_back({"split6 p2 no k-tail code", [&]() { launch3<true, false, EPI_STORE, 2, 6, 0, false>(st, p, splits, 2); }, true});
+      S("split6 p2", true, false, EPI_STORE, 2, 6, 2);
     }
     if (tn) {
-      S("split6 bk16 p2", false, false, EPI_PARTIAL, 16, 2, 6, 2);
+      S("split6 p3", false, false, EPI_PARTIAL, 3, 6, 3);
+      S("split6 p2", false, false, EPI_PARTIAL, 2, 6, 2);
     }
     if (nt && !split_only) {
       V("128x128x32 w4x2 p2", true, true, EPI_STORE, 128, 128, 32, 4, 2, 0, true, 2);
