@@ -4,7 +4,11 @@ of a 90-atom molecule (one molecule = one graph):
   * energies and forces of a molecule do not depend on what else is in the batch (90-atom rows stress the per-atom LDS tables and the host-split row tiles);
   * the gradient of a loss that is a sum over molecules equals the sum of the per-molecule gradients (every backward kernel, same stress);
   * everything is finite and the neighbour caps really bind on the large molecules.
-Tolerance: 2e-5 of the largest magnitude (float32 sums in a different association: batch rows change the split of the weight-gradient contractions)."""
+Tolerance: 2e-5 of the largest magnitude (float32 sums in a different association: batch rows change the split of the weight-gradient contractions) on the
+exact-f32 GEMM engine, whose rows do not depend on the batch.  With the split-bf16 engine (default for large products) the whole batch and the single
+molecules run on DIFFERENT engines, i.e. every intermediate differs in its last f32 bit, and autograd forces of a random-weight model amplify that: the
+yardstick there is what a pure f32 reordering does to the same outputs (the exact engine against the generic exact-f32 kernels, which sum over k in another
+order), measured in the test, times two."""
 import os
 import sys
 
@@ -44,6 +48,30 @@ def _mix(dev, sizes_fixed=(10, 90), n_random=3, seed=11):
 
 
 def _check(net, dev, weight_seed=0, tol=2e-5, grad_tol=5e-5):
+    """Strict on the exact-f32 engine; on the default engines held to twice the measured f32 reordering sensitivity (never below the strict tolerance)."""
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    whole, _, _ = _mix(dev)
+    try:
+        lib.nq_set_gemm_variant(1 | 32)
+        out = _check_engine(net, dev, weight_seed, tol, grad_tol)
+        Ex, Fx = [t.detach().clone() for t in net(whole)[:2]]
+        lib.nq_set_gemm_variant(1 | 16)
+        Eg, Fg = [t.detach() for t in net(whole)[:2]]
+    finally:
+        lib.nq_set_gemm_variant(1)
+    reorder = max(float((Ex - Eg).abs().max()) / float(Ex.abs().max()), float((Fx - Fg).abs().max()) / float(Fx.abs().max()))
+    try:
+        _check_engine(net, dev, weight_seed, max(tol, 2.0 * reorder), max(grad_tol, 2.0 * reorder))
+    finally:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "mixed_sizes_report.txt"), "a") as f:
+            f.write(f"{type(net).__name__}: f32 reordering sensitivity of E / F on the 10-90 atom mix {reorder:.3e} (exact engine vs generic exact kernels)\n")
+    return out
+
+
+def _check_engine(net, dev, weight_seed, tol, grad_tol):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     whole, singles, sizes = _mix(dev)
     assert min(sizes) == 10 and max(sizes) == 90
     g = torch.Generator().manual_seed(weight_seed)
@@ -71,6 +99,8 @@ def _check(net, dev, weight_seed=0, tol=2e-5, grad_tol=5e-5):
             if gk is not None:
                 Gsum[k] = gk if Gsum[k] is None else Gsum[k] + gk
         off += n
+    with open(os.path.join(ROOT, "gpurun_out", "mixed_sizes_report.txt"), "a") as f:
+        f.write(f"{type(net).__name__}: whole batch vs single molecules: E {worst_e:.3e}  F {worst_f:.3e}  (tolerance {tol:.3e})\n")
     assert worst_e < tol and worst_f < tol, (worst_e, worst_f)
     num = den = 0.0
     for a, b in zip(G, Gsum):
