@@ -27,6 +27,8 @@ import torch.distributed as dist  # noqa: E402
 F, L, R, CUTOFF, KNBR = 128, 6, 100, 5.0, 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+SPLIT_TERMS = 6                # csrc/gemm_split.h: bf16 piece products per f32 product -> 2500 / 6 = 416.7 TFLOP/s of f32-accurate products
 
 
 def make_batches(seed, n_batches, B, device):
@@ -144,22 +146,34 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
 _MSG_FLOP_PER_EDGE_CHANNEL = {"msgf_fwd": 81 + 16, "msgf_tan": 162 + 39, "msgf_rev_force": 162 + 39, "msgf_rev_dual": 162 + 103 + 27, "gwr_sorted": 3 * 26}
 
 
-def step_bounds(kernels, n_atoms, E, batch, ms_per_step, prof=None, steps=1):
-    """Step-level roofs of the PaiNN training step: the fp32 arithmetic the step executes (GEMM flops from the role tags of every GEMM launch of the step +
-    the message-path kernels' VALU flops) against the 157.3 TFLOP/s fp32 peak (matrix cores and VALU have the SAME fp32 peak on gfx950), and SURVEY 8(d)'s
-    17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger of the two times is the roof that binds."""
+def gemm_engine_name():
+    return "exact-f32" if os.environ.get("NQ_GEMM_F32", "0") not in ("", "0") else "split-bf16"
+
+
+def step_bounds(kernels, n_atoms, E, batch, ms_per_step, prof=None, steps=1, engine=None):
+    """Step-level roofs of the PaiNN training step: the arithmetic the step executes (GEMM flops recorded by every dense launcher + the message-path kernels'
+    VALU flops) against the pipes it runs on, and SURVEY 8(d)'s 17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger time binds.
+    Pipes: message path = f32 VALU (157.3 TFLOP/s; the exact-f32 MFMA has the same peak).  Dense products: the exact-f32 engine = 157.3; the split-bf16
+    engine (default for the large launches: every f32 value split exactly into three bf16 pieces, six piece products per product, f32 accumulation) =
+    2500 / 6 = 416.7 TFLOP/s of f32-accurate products.  Both roofs are reported; `binding_roof` uses the engine that ran."""
+    engine = engine or gemm_engine_name()
     if prof is not None:      # exact: every dense launcher records its 2 M N K with the event pair (nq_profile_read2)
         gemm = sum(v[2] for v in prof.values()) / steps
     else:
         gemm = sum(gemm_flops(k, n_atoms, E, n) * n for k, _, n in kernels if k.startswith("gemm"))
     msg = sum(_MSG_FLOP_PER_EDGE_CHANNEL[k] * float(E) * F * n for k, _, n in kernels if k in _MSG_FLOP_PER_EDGE_CHANNEL)
     t_fp32 = (gemm + msg) / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
+    t_split = (gemm / (MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS * 1e12) + msg / (MFMA_F32_PEAK_TFLOPS * 1e12)) * 1e3
+    t_arith = t_fp32 if engine == "exact-f32" else t_split
     t_hbm = 17.8e6 * batch / (HBM_PEAK_GBS * 1e9) * 1e3
-    bind = "fp32" if t_fp32 >= t_hbm else "hbm"
-    return {"flops_per_step": gemm + msg, "gemm_flops_per_step": gemm, "message_valu_flops_per_step": msg, "fp32_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
-            "fp32_bound_ms": t_fp32, "hbm_bound_ms": t_hbm, "binding_roof": bind, "achieved_TFLOPs": (gemm + msg) / (ms_per_step * 1e-3) / 1e12,
-            "frac_of_fp32_roof": t_fp32 / ms_per_step, "frac_of_hbm_roof": t_hbm / ms_per_step, "frac_of_binding_roof": max(t_fp32, t_hbm) / ms_per_step,
-            "note": "exact-fp32 arithmetic makes the step FLOP-bound: the HBM fraction cannot exceed hbm_bound_ms / fp32_bound_ms"}
+    bind = "arithmetic" if t_arith >= t_hbm else "hbm"
+    return {"flops_per_step": gemm + msg, "gemm_flops_per_step": gemm, "message_valu_flops_per_step": msg, "gemm_engine": engine,
+            "fp32_peak_TFLOPs": MFMA_F32_PEAK_TFLOPS, "split_bf16_peak_TFLOPs_of_f32_products": MFMA_BF16_PEAK_TFLOPS / SPLIT_TERMS,
+            "fp32_bound_ms": t_fp32, "split_engine_bound_ms": t_split, "hbm_bound_ms": t_hbm, "binding_roof": bind,
+            "achieved_TFLOPs": (gemm + msg) / (ms_per_step * 1e-3) / 1e12,
+            "frac_of_fp32_roof": t_fp32 / ms_per_step, "frac_of_split_engine_roof": t_split / ms_per_step, "frac_of_hbm_roof": t_hbm / ms_per_step,
+            "frac_of_binding_roof": max(t_arith, t_hbm) / ms_per_step,
+            "note": "the step is arithmetic-bound: the HBM fraction cannot exceed hbm_bound_ms / (arithmetic bound)"}
 
 
 def _graph_replay(which):
@@ -503,6 +517,26 @@ def main():
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
         roofline["step"] = step_bounds(kernels, n_atoms, E, args.batch, 1e3 * dt / args.steps, prof, args.steps)
 
+    gemm_engine = {"engine": gemm_engine_name(),
+                   "what": "dense products of >= 192 tiles of 128x128: every f32 operand value is split exactly into three bf16 pieces (x = h + m + l) and the product "
+                           "is the sum of six piece products on v_mfma_f32_32x32x16_bf16 with f32 accumulation (csrc/gemm_split.h; error vs float64 measured <= the "
+                           "exact-f32 MFMA engine's on every shape, profiles/r03_gemm_lab_split_bf16_engine.txt); smaller products and NQ_GEMM_F32=1: "
+                           "v_mfma_f32_32x32x2_f32 (csrc/gemm_tile.h)"}
+    if rank == 0 and world == 1 and not args.no_roofline and gemm_engine["engine"] == "split-bf16":
+        # the same steps with every product on the exact-f32 matrix instruction, for the record
+        _lib.load().nq_set_gemm_variant((args.gemm_variant if args.gemm_variant is not None else 1) | 32)
+        for i in range(2):
+            step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_x = step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - t0
+        _lib.load().nq_set_gemm_variant(args.gemm_variant if args.gemm_variant is not None else 1)
+        gemm_engine["exact_f32_engine"] = {"value": args.batch * args.steps / dtx, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dtx / args.steps,
+                                           "final_loss": float(loss_x)}
+
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk(args.model)
@@ -657,6 +691,7 @@ def main():
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
                        "parallelism": f"dp{world}"},
             "final_loss": float(loss),
+            "gemm_engine": gemm_engine,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "mae_vs_cpu_reference": parity,

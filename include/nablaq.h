@@ -529,7 +529,15 @@ int nq_profile_read(char* names_host, int32_t name_stride, double* total_ms_host
  * class's TFLOP/s is flops / time without re-deriving shapes from names (every other launcher records 0).  ABI 11. */
 int nq_profile_read2(char* names_host, int32_t name_stride, double* total_ms_host, int64_t* counts_host, double* flops_host, int32_t cap);
 
-/* Tuning hook (process-global): GEMM kernel variant, bit0 = 8 wavefronts per 128x128 tile, bit1 = register prefetch. */
+/* Engine / tuning switch of the dense products (process-global; default 1):
+ *   bits 0-1  generic round-1 kernel flavour (bit0 = 8 wavefronts per 128x128 tile, bit1 = register prefetch),
+ *   bit 3 (8)   never the small-problem kernel,  bit 4 (16)  only the generic kernels (no k_gemm2 / k_gemm3),
+ *   bit 5 (32)  exact-f32 MFMA only: every product on v_mfma_f32_32x32x2_f32.  Without it (the default) launches of >= 192 tiles of 128x128 run on the
+ *               split-bf16 engine (csrc/gemm_split.h): each f32 operand value is split EXACTLY into three bf16 pieces and a product is the sum of six
+ *               piece products on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- f32-accurate (error vs float64 measured <= the exact engine's),
+ *               1.3-1.7x faster, but a row's bits then depend on which engine the launch size selects, and non-finite operands give NaN where the
+ *               exact engine would give inf.  The environment variable NQ_GEMM_F32=1 (read once) has the same effect as bit 5.
+ * The weight-gradient scratch size does not depend on the switch. */
 void nq_set_gemm_variant(int32_t variant);
 
 /* ---- building blocks exported for unit tests ----------------------------------------------- */
