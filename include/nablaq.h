@@ -537,6 +537,7 @@ int nq_profile_read2(char* names_host, int32_t name_stride, double* total_ms_hos
  *               piece products on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- f32-accurate (error vs float64 measured <= the exact engine's),
  *               1.3-1.7x faster, but a row's bits then depend on which engine the launch size selects, and non-finite operands give NaN where the
  *               exact engine would give inf.  The environment variable NQ_GEMM_F32=1 (read once) has the same effect as bit 5.
+ *   bit 6 (64)  the split-bf16 engine for EVERY launch it can run, whatever the size (tests: the golden vectors with all products on it).
  * The weight-gradient scratch size does not depend on the switch. */
 void nq_set_gemm_variant(int32_t variant);
 
