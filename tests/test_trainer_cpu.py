@@ -91,3 +91,30 @@ def test_ema_follows_torch_ema_semantics():
     ema2.load_state_dict(sd)
     assert ema2.decay == 0.9 and ema2.num_updates == 1 and torch.equal(ema2.shadow_params[1], ema.shadow_params[1])
     ema2.restore()
+
+
+def test_flat_parameters_put_every_matrix_on_a_16_byte_boundary():
+    """The tile engines of the dense products read 16 bytes at a time: a weight that starts off a 16-byte boundary falls back to the generic kernels.  Odd-sized
+    tensors in front (QHNet's 50-element radial parameters) must therefore not shift the matrices behind them; values, gradients and the optimiser view stay
+    intact, the padding stays zero, and runs of small vectors stay contiguous (block_of)."""
+    import torch
+    from nabladft_amd.trainer import FlatParameters
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in [(50,), (8, 16), (3,), (5,), (32, 7), (1,), (128,), (128,), (17, 4)]]
+    want = [p.detach().clone() for p in ps]
+    flat = FlatParameters(ps)
+    for p, w in zip(ps, want):
+        assert torch.equal(p.detach(), w)
+        if p.numel() >= 16:
+            assert p.data.storage_offset() % 4 == 0 and p.grad.storage_offset() == p.data.storage_offset()
+    used = torch.zeros(flat.flat.numel(), dtype=torch.bool)
+    for p in ps:
+        o = flat.offset[id(p)]
+        assert not used[o:o + p.numel()].any()
+        used[o:o + p.numel()] = True
+    assert float(flat.flat.data[~used].abs().sum()) == 0.0 and flat.flat.numel() - int(used.sum()) <= 3 * len(ps)
+    assert flat.block_of([ps[6], ps[7]]) == (flat.offset[id(ps[6])], 256)            # two [128] vectors side by side
+    sum((p * p).sum() for p in ps).backward()
+    for p, w in zip(ps, want):
+        assert torch.allclose(p.grad, 2 * w)
+    flat.validate()
