@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 12
+#define NQ_ABI_VERSION 13
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -548,6 +548,9 @@ int nq_linear_forward(const float* A, const float* W, const float* bias, float* 
 /* C[M,N] = A W^T and C_act = alpha * resid (nullable) + beta * silu(C): Dense + ScaledSiLU (+ residual) of gemnet_oc/layers/base_layers.py:11-97 in one pass. */
 int nq_linear_forward_act(const float* A, const float* W, float* C, float* C_act, const float* resid, float alpha, float beta, int32_t M, int32_t N,
                           int32_t K, void* stream);
+/* C[M,N] = alpha * aux + A[M,K] W[N,K]^T  (aux [M,N], not aliasing C): the second product of a two-term sum in the epilogue of the GEMM -- the +-m pairs of
+ * the SO(2) convolutions (escn.py:858-877 `x_r[:, 0] - x_i[:, 1]`, `x_r[:, 1] + x_i[:, 0]`; equiformer_v2 so2_ops.py:53-61) without a separate pass.  ABI 13. */
+int nq_linear_forward_res(const float* A, const float* W, const float* aux, float alpha, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* bf16 MFMA variants (fp32 operands in HBM rounded to bf16 on the way into LDS, fp32 accumulation; BASELINE.json configs[2] names bf16 for GemNet-OC):
  * nq_bf16_pack: W [N][K] fp32 -> Wb [N][K], WbT [K][N] (bf16, round to nearest even).  nq_linear_forward_bf16: as nq_linear_forward_act with W = Wb (C_act
  * nullable -> plain store); K % 32 == 0.  nq_linear_input_grad_bf16: C[M,K] (+)= G[M,N] W[N,K] with W given as WbT; N % 32 == 0. */

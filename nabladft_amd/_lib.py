@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -137,6 +137,7 @@ SYMBOLS = {
     "nq_gn_lincomb": (C.c_int, [_P, _P, _F, _F, _I64, _P, _P]),
     "nq_gn_ssilu_backward": (C.c_int, [_P, _P, _F, _I64, _P, _P]),
     "nq_linear_forward_act": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _I32, _I32, _I32, _P]),
+    "nq_linear_forward_res": (C.c_int, [_P, _P, _P, _F, _P, _I32, _I32, _I32, _P]),
     "nq_bf16_pack": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "nq_linear_forward_bf16": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _I32, _I32, _I32, _P]),
     "nq_linear_input_grad_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),

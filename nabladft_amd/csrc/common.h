@@ -184,6 +184,7 @@ int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const floa
                int ldw, int ldc, const char* tag = nullptr);
 int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc, int accumulate,
                const char* tag = nullptr);
+int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, const float* aux, float ea, int M, int N, int K);
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
 int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
                const char* tag = nullptr, float* bias_out = nullptr, long bias_rows = 0);

@@ -690,6 +690,11 @@ int nq_linear_forward_act(const float* A, const float* Wt, float* C, float* C_ac
   if (!A || !Wt || !C || !C_act) return nq_fail(NQ_ERR_ARG, "null argument");
   return nq_gemm_nt_act((hipStream_t)stream, A, Wt, C, C_act, resid, alpha, beta, M, N, K);
 }
+int nq_linear_forward_res(const float* A, const float* Wt, const float* aux, float alpha, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (!A || !Wt || !C || !aux) return nq_fail(NQ_ERR_ARG, "null argument");
+  if (aux == C) return nq_fail(NQ_ERR_ARG, "nq_linear_forward_res: aux must not alias C");
+  return nq_gemm_nt_res((hipStream_t)stream, A, Wt, C, aux, alpha, M, N, K);
+}
 int nq_linear_input_grad(const float* G, const float* Wt, float* C, int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream) {
   return nq_gemm_nn((hipStream_t)stream, G, Wt, C, M, N, K, N, K, K, accumulate);
 }

@@ -493,6 +493,28 @@ int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, flo
   return NQ_OK;
 }
 
+// C[M, N] = ea * aux + A W^T   (aux [M, N], must not alias C): the second product of a two-term sum (the +-m pairs of the SO(2) convolutions:
+// out_p = x_p W_r^T - x_m W_i^T is a plain product into t followed by this one with aux = t, ea = -1 -- no separate linear-combination pass)
+int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, const float* aux, float ea, int M, int N, int K) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:[n=%d,k=%d]", N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * N * K);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{A, W, C, nullptr, nullptr, M, N, K, K, K, N, 0, 0, nullptr, 0};
+  p.resid = aux; p.ea = ea; p.eb = 0.f;
+  if (gemm3_ok<true, true>(p, K, 1)) {
+    NQ_TRY((launch_gemm3<true, true, EPI_RES>(st, p, 1)));
+  } else if (gemm2_ok<true, true>(p, K)) {
+    launch_gemm2<true, true, EPI_RES>(st, p, 1);
+  } else if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
+    hipLaunchKernelGGL((k_gemm_small<true, EPI_RES>), dim3(nq_cdiv(M, SM), nq_cdiv(N, SM), 1), dim3(256), 0, st, p);
+  } else {
+    launch_gemm<true, true, EPI_RES>(st, dim3(nq_cdiv(M, BM), nq_cdiv(N, BN), 1), p);
+  }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
 // C[M, Kin] (+)= G[M, Nout] * W[Nout, Kin]
 int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc,
                int accumulate, const char* tag) {

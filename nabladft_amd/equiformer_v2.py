@@ -26,7 +26,7 @@ from . import _lib
 from .escn import (CoefficientOrder, GaussianSmearing, _BlocksInFn, _BlocksOutFn, _S2ActBlocksFn, s2_activation_fusable, _EmbeddingFn, _RotateBackFn, _RotateFn, _RowFn, _silu, eSCN, j_matrices,
                    s2_grids)
 from . import gemnet_oc as _gemnet
-from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _new, _st, lin
+from .gemnet_oc import _DenseFn, _MulFn, _SO2PairFn, _SegSumFn, _new, _st, fused_pairs_available, lin
 from .phisnet import _SphLinearFn
 from .qhnet import _LinearBiasFn, _f32
 
@@ -383,6 +383,8 @@ class SO2_m_Convolution(nn.Module):
         """x_p / x_m [E, n]: the +m / -m coefficients -> the two parts of the result (so2_ops.py:53-61)."""
         half = self.fc.out_features // 2
         Wr, Wi = self.fc.weight.narrow(0, 0, half), self.fc.weight.narrow(0, half, half)
+        if fused_pairs_available():      # four launches, the sums in the GEMM epilogues (forward and adjoint)
+            return _SO2PairFn.apply(x_p, x_m, Wr, Wi)
         out_p = lin(_DenseFn.apply(x_p, Wr, False), _DenseFn.apply(x_m, Wi, False), 1.0, -1.0)          # x_r[:, 0] - x_i[:, 1]
         out_m = lin(_DenseFn.apply(x_m, Wr, False), _DenseFn.apply(x_p, Wi, False), 1.0, 1.0)           # x_r[:, 1] + x_i[:, 0]
         return out_p, out_m

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib, cg
 from . import gemnet_oc as _gemnet
-from .gemnet_oc import _DenseFn, _MulFn, _SegSumFn, _gather_raw, _new, _segsum_raw, _st, lin
+from .gemnet_oc import _DenseFn, _MulFn, _SO2GatedPairFn, _SegSumFn, _gather_raw, _new, _segsum_raw, _st, fused_pairs_available, lin
 from .qhnet import _ActFn, _LinearBiasFn, _MatmulFn, _f32
 
 
@@ -432,6 +432,8 @@ class SO2Conv(torch.nn.Module):
         H = self.hidden_channels
         g = self.fc1_dist(x_edge, act=True)
         g_r, g_i = g[:, :H].contiguous(), g[:, H:].contiguous()
+        if fused_pairs_available():      # one autograd node: the two output sums and the two input-gradient sums are formed in GEMM epilogues
+            return _SO2GatedPairFn.apply(x_re, x_im, g_r, g_i, self.fc1_r.weight, self.fc1_i.weight, self.fc2_r.weight, self.fc2_i.weight)
         r0 = self.fc2_r(_MulFn.apply(self.fc1_r(x_re), g_r))
         r1 = self.fc2_r(_MulFn.apply(self.fc1_r(x_im), g_r))
         i0 = self.fc2_i(_MulFn.apply(self.fc1_i(x_re), g_i))

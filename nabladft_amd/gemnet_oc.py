@@ -299,6 +299,88 @@ class _DenseFn(torch.autograd.Function):
         return gx, gW, None
 
 
+def _fwd_f32(x, W, aux=None, alpha=0.0):
+    """x W^T, or alpha * aux + x W^T in the epilogue of the same launch (f32-accurate engines only)."""
+    M, K = x.shape
+    N = W.shape[0]
+    out = _new(M, N, like=x)
+    if M > 0 and aux is None:
+        _lib.check(_lib.load().nq_linear_forward(_lib.ptr(x), _lib.ptr(W), None, _lib.ptr(out), None, M, N, K, _st()))
+    elif M > 0:
+        _lib.check(_lib.load().nq_linear_forward_res(_lib.ptr(x), _lib.ptr(W), _lib.ptr(aux), float(alpha), _lib.ptr(out), M, N, K, _st()))
+    if GEMM_FLOPS[0] is not None:
+        GEMM_FLOPS[0] += 2.0 * M * N * K
+    if GEMM_BYTES[0] is not None:
+        GEMM_BYTES[0] += 4.0 * M * K + (4.0 if aux is None else 8.0) * M * N + 4.0 * N * K
+    return out
+
+
+def fused_pairs_available():
+    """The two-term products below exist for the f32-accurate engines; the bf16 mode keeps the composed form (its operands are packed per launch)."""
+    return _PRECISION[0] != "bf16"
+
+
+class _SO2PairFn(torch.autograd.Function):
+    """The +-m pair of an SO(2) convolution whose two inputs share the weights (equiformer_v2 so2_ops.py:53-61):
+        out_p = x_p W_r^T - x_m W_i^T,   out_m = x_m W_r^T + x_p W_i^T
+    as four launches (the second product of each sum takes the first one in its epilogue) instead of four products and two linear combinations; the
+    adjoint likewise sums its two contributions per input inside the input-gradient products (no autograd accumulation passes)."""
+
+    @staticmethod
+    def forward(ctx, xp, xm, Wr, Wi):
+        xp, xm, Wr, Wi = _f32(xp), _f32(xm), _f32(Wr), _f32(Wi)
+        out_p = _fwd_f32(xp, Wr, _fwd_f32(xm, Wi), -1.0)
+        out_m = _fwd_f32(xm, Wr, _fwd_f32(xp, Wi), 1.0)
+        ctx.save_for_backward(xp, xm, Wr, Wi)
+        return out_p, out_m
+
+    @staticmethod
+    def backward(ctx, gp, gm):
+        xp, xm, Wr, Wi = ctx.saved_tensors
+        gp, gm = _f32(gp), _f32(gm)
+        need = ctx.needs_input_grad
+        dxp = _dgrad_epi(gp, Wr, _dgrad(gm, Wi), 1.0, 0.0, 2) if need[0] else None          # g_p W_r + g_m W_i
+        dxm = _dgrad_epi(gm, Wr, _dgrad(gp, Wi), -1.0, 0.0, 2) if need[1] else None         # g_m W_r - g_p W_i
+        dWr = _wgrad(gp, xp).add_(_wgrad(gm, xm)) if need[2] else None
+        dWi = _wgrad(gm, xp).sub_(_wgrad(gp, xm)) if need[3] else None
+        return dxp, dxm, dWr, dWi
+
+
+class _SO2GatedPairFn(torch.autograd.Function):
+    """eSCN's SO(2) convolution of one m > 0 (escn.py:858-877) with everything between its inputs and outputs in one autograd node:
+        a_r{0,1} = (x_{re,im} W1r^T) * g_r,  a_i{0,1} = (x_{re,im} W1i^T) * g_i,
+        out_p = a_r0 W2r^T - a_i1 W2i^T,     out_m = a_r1 W2r^T + a_i0 W2i^T.
+    Both output sums and, in the adjoint, both input-gradient sums are formed in GEMM epilogues (alpha * aux + product); the composed form spent two
+    linear combinations forward and one scaled copy plus two gradient accumulations of [E, n] tensors backward on them."""
+
+    @staticmethod
+    def forward(ctx, x_re, x_im, g_r, g_i, W1r, W1i, W2r, W2i):
+        x_re, x_im, g_r, g_i, W1r, W1i, W2r, W2i = (_f32(t) for t in (x_re, x_im, g_r, g_i, W1r, W1i, W2r, W2i))
+        p = [_fwd_f32(x_re, W1r), _fwd_f32(x_im, W1r), _fwd_f32(x_re, W1i), _fwd_f32(x_im, W1i)]             # r0, r1, i0, i1
+        a = [_mul_raw(p[0], g_r), _mul_raw(p[1], g_r), _mul_raw(p[2], g_i), _mul_raw(p[3], g_i)]
+        out_p = _fwd_f32(a[0], W2r, _fwd_f32(a[3], W2i), -1.0)
+        out_m = _fwd_f32(a[1], W2r, _fwd_f32(a[2], W2i), 1.0)
+        ctx.save_for_backward(x_re, x_im, g_r, g_i, W1r, W1i, W2r, W2i, *p, *a)
+        return out_p, out_m
+
+    @staticmethod
+    def backward(ctx, gp, gm):
+        x_re, x_im, g_r, g_i, W1r, W1i, W2r, W2i, p_r0, p_r1, p_i0, p_i1, a_r0, a_r1, a_i0, a_i1 = ctx.saved_tensors
+        gp, gm = _f32(gp), _f32(gm)
+        need = ctx.needs_input_grad
+        da_r0, da_r1, da_i0, da_i1n = _dgrad(gp, W2r), _dgrad(gm, W2r), _dgrad(gm, W2i), _dgrad(gp, W2i)      # da_i1 = -da_i1n
+        dW2r = _wgrad(gp, a_r0).add_(_wgrad(gm, a_r1)) if need[6] else None
+        dW2i = _wgrad(gm, a_i0).sub_(_wgrad(gp, a_i1)) if need[7] else None
+        dp_r0, dp_r1, dp_i0, dp_i1n = _mul_raw(da_r0, g_r), _mul_raw(da_r1, g_r), _mul_raw(da_i0, g_i), _mul_raw(da_i1n, g_i)
+        dg_r = _lin_raw(_mul_raw(da_r0, p_r0), _mul_raw(da_r1, p_r1), 1.0, 1.0) if need[2] else None
+        dg_i = _lin_raw(_mul_raw(da_i0, p_i0), _mul_raw(da_i1n, p_i1), 1.0, -1.0) if need[3] else None
+        dx_re = _dgrad_epi(dp_r0, W1r, _dgrad(dp_i0, W1i), 1.0, 0.0, 2) if need[0] else None                    # dp_r0 W1r + dp_i0 W1i
+        dx_im = _dgrad_epi(dp_r1, W1r, _dgrad(dp_i1n, W1i), -1.0, 0.0, 2) if need[1] else None                  # dp_r1 W1r - dp_i1n W1i
+        dW1r = _wgrad(dp_r0, x_re).add_(_wgrad(dp_r1, x_im)) if need[4] else None
+        dW1i = _wgrad(dp_i0, x_re).sub_(_wgrad(dp_i1n, x_im)) if need[5] else None
+        return dx_re, dx_im, dg_r, dg_i, dW1r, dW1i, dW2r, dW2i
+
+
 class _ResidualFn(torch.autograd.Function):
     """ResidualLayer (layers/base_layers.py:74-97) with two activated Dense layers: out = (x + ssilu(ssilu(x W1^T) W2^T)) / sqrt(2) -- two GEMM launches
     forward (activation and residual in the epilogues), two elementwise + four GEMM launches backward."""
