@@ -150,6 +150,26 @@ def gemm_engine_name():
     return "exact-f32" if os.environ.get("NQ_GEMM_F32", "0") not in ("", "0") else "split-bf16"
 
 
+def gemm_accuracy_probe(dev, restore_variant=1):
+    """max |C - C64| / max |C64| of the forward product [40000 x 128] x [128 x 256]^T (626 tiles: split engine by default) on both engines, C64 = torch float64."""
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 40000, 256, 128
+    A, W = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    ref = A.double() @ W.double().T
+    out = {"shape": [M, N, K]}
+    try:
+        for name, var in (("split_bf16_engine", 1), ("exact_f32_engine", 1 | 32)):
+            lib.nq_set_gemm_variant(var)
+            Cd = torch.empty(M, N, device=dev)
+            _lib.check(lib.nq_linear_forward(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(Cd), None, M, N, K, _lib.stream_ptr()))
+            out[name] = float((Cd.double() - ref).abs().max() / ref.abs().max())
+    finally:
+        lib.nq_set_gemm_variant(restore_variant)
+    return out
+
+
 def step_bounds(kernels, n_atoms, E, batch, ms_per_step, prof=None, steps=1, engine=None):
     """Step-level roofs of the PaiNN training step: the arithmetic the step executes (GEMM flops recorded by every dense launcher + the message-path kernels'
     VALU flops) against the pipes it runs on, and SURVEY 8(d)'s 17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger time binds.
@@ -522,6 +542,11 @@ def main():
                            "is the sum of six piece products on v_mfma_f32_32x32x16_bf16 with f32 accumulation (csrc/gemm_split.h; error vs float64 measured <= the "
                            "exact-f32 MFMA engine's on every shape, profiles/r03_gemm_lab_split_bf16_engine.txt); smaller products and NQ_GEMM_F32=1: "
                            "v_mfma_f32_32x32x2_f32 (csrc/gemm_tile.h)"}
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:    # both engines against float64 on one forward product of this step's shape class, in every record (never worth losing the record over)
+            gemm_engine["max_error_vs_float64_rel_to_largest_entry"] = gemm_accuracy_probe(dev, args.gemm_variant if args.gemm_variant is not None else 1)
+        except Exception as e:
+            gemm_engine["max_error_vs_float64_rel_to_largest_entry"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_roofline and gemm_engine["engine"] == "split-bf16":
         # the same steps with every product on the exact-f32 matrix instruction, for the record
         _lib.load().nq_set_gemm_variant((args.gemm_variant if args.gemm_variant is not None else 1) | 32)
