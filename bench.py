@@ -92,20 +92,35 @@ _SN = {"sn_filter1": lambda N, E: E / 2 * (F * 4 + 128.0), "sn_filter1_tan": lam
        "sn_pair_rev_dual": lambda N, E: E * F * 4.0 + 4 * N * F * 4.0}
 
 
+def _kernel_in_build(name):
+    """True if the kernel's identifier (e.g. 'k_msgf_rev' of 'k_msgf_rev<true, 2>') is a symbol of the libnablaq.so this run loaded."""
+    ident = name.split("<")[0].strip().encode()
+    so = os.path.join(ROOT, "nabladft_amd", "libnablaq.so")
+    try:
+        with open(so, "rb") as fh:
+            return ident in fh.read()
+    except OSError:
+        return False
+
+
 def pmc_traffic_bytes(kernel_prefix, batch):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/r0N_pmc_traffic.json; FETCH_SIZE doubled per the
-    gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported), only if it was taken at this batch size."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)
+    """(HBM bytes per launch, source) from the newest committed PMC summary (profiles/r0N_pmc_traffic.json; FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as reported).  Refused (None, reason) if the file was taken at another batch size,
+    if it does not hold this kernel, or if the kernel it names is not in the library this run loaded (a stale file of an earlier build)."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
-        return None
+        return None, "no PMC summary committed"
     with open(path) as fh:
         rec = json.load(fh)
+    tag = os.path.basename(path)
     if rec.get("batch") != batch:
-        return None
+        return None, f"{tag} was taken at batch {rec.get('batch')}"
     for name, v in rec.get("kernels", {}).items():
         if name.startswith(kernel_prefix):
-            return 1024.0 * (2.0 * v.get("fetch_kb_per_launch", 0.0) + v.get("write_kb_per_launch", 0.0))
-    return None
+            if not _kernel_in_build(name):
+                return None, f"{tag} names {name}, which is not in this build"
+            return 1024.0 * (2.0 * v.get("fetch_kb_per_launch", 0.0) + v.get("write_kb_per_launch", 0.0)), f"profiles/{tag} (rocprofv3 --pmc, separate passes; FETCH x2 per the gfx950 note)"
+    return None, f"{tag} does not hold {kernel_prefix}"
 
 
 def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
@@ -116,9 +131,9 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
         prefix, mult = _MSG[dom]
         nbytes = mult * (8.0 * n_atoms * F * 4 + 24.0 * E)
         ach = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic = pmc_traffic_bytes(prefix, batch)
+        traffic, tsrc = pmc_traffic_bytes(prefix, batch)
         return {"kernel": f"{prefix}, {F // 64}>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,   # measured HBM bytes per second of the launch
+                "traffic": traffic, "traffic_source": tsrc, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,   # measured HBM bytes per second of the launch
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
     if dom.startswith("gemm"):
         flops = gemm_flops(dom, n_atoms, E, launches)
@@ -134,7 +149,7 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
         flops = 2.0 * 26 * E * 3 * F          # 26 FMAs per (edge, column)
         ach = flops / (avg_ms * 1e-3) / 1e12
         return {"kernel": "k_gwr_sorted", "bound": "hbm", "achieved": (2.0 * E * 3 * F * 4) / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": (2.0 * E * 3 * F * 4) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_gwr_sorted", batch),
+                "unit": "GB/s", "frac": (2.0 * E * 3 * F * 4) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("k_gwr_sorted", batch)[0],
                 "valu_tflops": ach, "avg_launch_ms": avg_ms, "launches_per_step": launches}
     return {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "avg_launch_ms": avg_ms, "launches_per_step": launches}
@@ -241,7 +256,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
         cpu = BG.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": dtype_string(), "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
@@ -249,7 +264,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "reference_batch_size_8": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
                "reference_batch_size_8_prepared_eager_vs_graph_replay": _graph_replay("gemnet") if world == 1 and not args.no_roofline else None,
                "batch_64": big if bf is not None else None}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -287,14 +302,14 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
         cpu = BE.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": dtype_string(), "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "edges": rec["edges"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
                "parity": rec.get("parity"), "bf16_mode": bf,
                f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
                f"reference_batch_size_{ref_batch}_prepared_eager_vs_graph_replay": _graph_replay(which) if world == 1 and not args.no_roofline else None}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -322,16 +337,89 @@ def bench_qhnet(args, rank, world, local_dev, dev):
         cpu = BQ.cpu_baseline() if world == 1 and not args.no_cpu_baseline else None
         out = {"metric": "conformer-steps/sec (fwd+bwd) + MAE(H) vs CPU reference", "value": mol * world * args.steps / dt, "unit": "conformer-steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": dtype_string(), "data": "synthetic",
                "config": {"workload": rec.pop("workload") + f"; {mol} conformers/GPU/step", "conformers_per_gpu": mol, "atoms_per_step_per_gpu": rec["atoms"],
                           "ordered_pairs": rec["ordered_pairs"], "edges_within_cutoff": rec["edges_within_cutoff"], "parallelism": f"dp{world}"},
                "final_loss": rec["final_loss"], "roofline": rec.get("roofline"), "cpu_baseline": cpu, "kernel_ms_per_step": rec.get("kernel_ms_per_step"), "gemm_classes_TFLOPs": rec.get("gemm_classes_TFLOPs"),
                "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
                "reference_batch_size_2_prepared_eager_vs_graph_replay": _graph_replay("qhnet") if world == 1 and not args.no_roofline else None}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+COMPACT_LIMIT = 4000     # bytes: the driver parses the LAST stdout line; round 3's 23-KB line was not parsed
+DTYPE_SPLIT = ("f32 (dense products >= 192 tiles: f32 values split exactly into 3 bf16 pieces, 6 MFMA piece products, f32 accumulate; "
+               "non-finite operands give NaN where plain f32 gives inf)")
+
+
+def dtype_string():
+    return "f32" if os.environ.get("NQ_GEMM_F32", "0") not in ("", "0") else DTYPE_SPLIT
+
+
+def _short(x, n=160):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def _num(x):
+    return float(f"{x:.6g}") if isinstance(x, float) else x
+
+
+def _pick(d, keys):
+    return None if d is None else {k: _num(_short(d[k])) for k in keys if k in d and d[k] is not None}
+
+
+def compact_record(full, full_path=None):
+    """The one line the driver parses: the contract fields + roofline + cpu_baseline + accuracy, < COMPACT_LIMIT bytes.  Everything else
+    (other models' legs, kernel tables, engine probes) stays in the full record (gpurun_out/bench_full.json, copied to profiles/)."""
+    rec = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                          "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = _short(cfg.get("workload", ""), 300)
+    rec["config"] = {k: _num(v) for k, v in cfg.items()}
+    if full.get("final_loss") is not None:
+        rec["final_loss"] = _num(full["final_loss"])
+    rf = full.get("roofline")
+    if rf is not None:
+        r = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                       "launches_per_step", "device_ms_per_step_all_kernels"))
+        r.setdefault("traffic", None)
+        if rf.get("step") is not None:
+            r["step"] = _pick(rf["step"], ("flops_per_step", "gemm_flops_per_step", "message_valu_flops_per_step", "gemm_engine", "fp32_bound_ms",
+                                           "split_engine_bound_ms", "hbm_bound_ms", "binding_roof", "achieved_TFLOPs", "frac_of_binding_roof", "frac_of_hbm_roof"))
+        rec["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        rec["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "host_cpus", "kind", "sample"))
+    if full.get("mae_vs_cpu_reference") is not None:
+        rec["mae_vs_cpu_reference"] = {k: _num(v) for k, v in full["mae_vs_cpu_reference"].items()}
+    for extra in ("reference_batch_size_32", "reference_batch_size_8", "reference_batch_size_2"):
+        if full.get(extra) is not None:
+            rec[extra] = _pick(full[extra], ("value", "unit", "ms_per_step"))
+    if full.get("kernel_ms_per_step"):
+        rec["kernel_ms_per_step"] = dict(list(full["kernel_ms_per_step"].items())[:6])
+    if full_path:
+        rec["full_record"] = full_path
+    for drop in ("kernel_ms_per_step", "reference_batch_size_32", "reference_batch_size_8", "reference_batch_size_2", "mae_vs_cpu_reference"):
+        if len(json.dumps(rec)) <= COMPACT_LIMIT:
+            break
+        rec.pop(drop, None)
+    assert len(json.dumps(rec)) <= COMPACT_LIMIT, len(json.dumps(rec))
+    return rec
+
+
+def emit(full):
+    """Full record -> gpurun_out/bench_full.json; compact record -> the last stdout line."""
+    path = os.path.join("gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, path), "w") as fh:
+            json.dump(full, fh)
+    except OSError:
+        path = None
+    sys.stdout.flush()
+    print(json.dumps(compact_record(full, path)), flush=True)
 
 
 WORKLOADS = {
@@ -461,6 +549,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="conformers per GPU per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--full", action="store_true", help="also run the side legs (other engine, sibling config, host feed, inference, QHNet / GemNet-OC / eSCN / "
+                                                        "EquiformerV2 / PhiSNet records) into gpurun_out/bench_full.json; the stdout line stays the compact record")
     ap.add_argument("--model", choices=sorted(WORKLOADS), default="painn-oc",
                     help="painn-oc: in-tree PaiNN (parity pinned by reference golden vectors); painn-spk: config/painn.yaml (schnetpack PaiNN, unpinned)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="tuning: nq_set_gemm_variant (bit0 8 waves, bit1 prefetch)")
@@ -497,6 +587,7 @@ def main():
     for i in range(args.warmup):
         step(batches[i % len(batches)])
     sync()
+    snap = (step._eng.flat().clone(), step.m.clone(), step.v.clone(), step.t) if args.full and world == 1 else None   # for the engine comparison leg
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[i % len(batches)])
@@ -542,32 +633,39 @@ def main():
                            "is the sum of six piece products on v_mfma_f32_32x32x16_bf16 with f32 accumulation (csrc/gemm_split.h; error vs float64 measured <= the "
                            "exact-f32 MFMA engine's on every shape, profiles/r03_gemm_lab_split_bf16_engine.txt); smaller products and NQ_GEMM_F32=1: "
                            "v_mfma_f32_32x32x2_f32 (csrc/gemm_tile.h)"}
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.full:
         try:    # both engines against float64 on one forward product of this step's shape class, in every record (never worth losing the record over)
             gemm_engine["max_error_vs_float64_rel_to_largest_entry"] = gemm_accuracy_probe(dev, args.gemm_variant if args.gemm_variant is not None else 1)
         except Exception as e:
             gemm_engine["max_error_vs_float64_rel_to_largest_entry"] = {"error": repr(e)[:200]}
-    if rank == 0 and world == 1 and not args.no_roofline and gemm_engine["engine"] == "split-bf16":
-        # the same steps with every product on the exact-f32 matrix instruction, for the record
-        _lib.load().nq_set_gemm_variant((args.gemm_variant if args.gemm_variant is not None else 1) | 32)
+    if rank == 0 and world == 1 and not args.no_roofline and args.full and gemm_engine["engine"] == "split-bf16":
+        # the same steps from the same parameters / optimiser state / batches with every product on the exact-f32 matrix instruction
+        var = args.gemm_variant if args.gemm_variant is not None else 1
+        end_state = (step._eng.flat().clone(), step.m.clone(), step.v.clone(), step.t)
+        _lib.load().nq_set_gemm_variant(var | 32)
         for i in range(2):
             step(batches[i % len(batches)])
+        with torch.no_grad():
+            step._eng.flat().copy_(snap[0]); step.m.copy_(snap[1]); step.v.copy_(snap[2]); step.t = snap[3]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             loss_x = step(batches[i % len(batches)])
         torch.cuda.synchronize()
         dtx = time.perf_counter() - t0
-        _lib.load().nq_set_gemm_variant(args.gemm_variant if args.gemm_variant is not None else 1)
+        _lib.load().nq_set_gemm_variant(var)
         gemm_engine["exact_f32_engine"] = {"value": args.batch * args.steps / dtx, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dtx / args.steps,
-                                           "final_loss": float(loss_x)}
+                                           "final_loss": float(loss_x), "final_loss_default_engine": float(loss),
+                                           "what": "same initial parameters, optimiser state and batches as the timed region"}
+        with torch.no_grad():
+            step._eng.flat().copy_(end_state[0]); step.m.copy_(end_state[1]); step.v.copy_(end_state[2]); step.t = end_state[3]
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk(args.model)
 
     host_feed = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.full:
         # PCIe-inclusive rate: the same steps fed from a pinned host arena through the overlapped loader (nabladft_amd/data.py);
         # reported next to `value`, never as `value` (inputs of the timed region above are HBM-resident)
         from nabladft_amd import data as nqdata
@@ -593,7 +691,7 @@ def main():
                      "what": "same step, batches collated from a pinned host arena and copied on a side stream (PCIe-inclusive)"}
 
     inference = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.full:
         # serving / geometry-optimisation mode (optimization/calculator.py:124-130 -> model(batch)): energies + forces only, no second-order sweep
         try:
             model.eval()
@@ -614,7 +712,7 @@ def main():
             model.train()
 
     other, kind2 = None, None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline and args.full:
         # the sibling PaiNN configuration through the same kernels (reported, not `value`)
         kind2 = "painn-spk" if args.model == "painn-oc" else "painn-oc"
         if args.model == "schnet-spk":
@@ -664,7 +762,7 @@ def main():
             other["cpu_baseline"], other["mae_vs_cpu_reference"] = cpu2, par2
 
     hamiltonian = None
-    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+    if rank == 0 and world == 1 and not args.no_roofline and args.full and args.model == "painn-oc":
         # BASELINE.json configs[3] (QHNet, config/qhnet.yaml) in the same record: a short run at the reference's batch size (2) and at 16
         try:
             del step2, model2
@@ -681,7 +779,7 @@ def main():
                        "cpu_baseline": None if args.no_cpu_baseline else BQ.cpu_baseline(seconds_budget=20.0)}
 
     gemnet = None
-    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+    if rank == 0 and world == 1 and not args.no_roofline and args.full and args.model == "painn-oc":
         # BASELINE.json configs[2] (GemNet-OC, config/model/gemnet-oc.yaml, fp32) in the same record
         torch.cuda.empty_cache()
         import bench_gemnet as BG
@@ -693,7 +791,7 @@ def main():
                   "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
     escn = equiformer = None
-    if rank == 0 and world == 1 and not args.no_roofline and args.model == "painn-oc":
+    if rank == 0 and world == 1 and not args.no_roofline and args.full and args.model == "painn-oc":
         # BASELINE.json configs[4] (eSCN, config/model/escn-oc.yaml, fp32) in the same record
         torch.cuda.empty_cache()
         import bench_escn as BE
@@ -711,7 +809,7 @@ def main():
         out = {
             "metric": "conformer-steps/sec (fwd+bwd) + MAE(E,F) vs CPU reference", "value": value, "unit": "conformer-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype_string(), "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.model]}; synthetic ~42-atom drug-like conformers, {args.batch} conformers/GPU/step",
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
                        "parallelism": f"dp{world}"},
@@ -731,7 +829,7 @@ def main():
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},
         }
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

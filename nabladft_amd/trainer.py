@@ -307,19 +307,24 @@ class OverlappedAllReduce:
         import torch.distributed as dist
         self.flat, self.group, self.dist = flat, group, dist
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.buckets = []                                   # [lo, hi, n_params]
+        self.buckets = []                                   # [lo, hi, n_params]: ranges of the FLAT buffer (alignment padding included)
         self._bucket_of = {}
-        lo = o = 0
-        count = 0
-        for p in flat.params:
-            o += p.numel()
+        # FlatParameters pads tensors of >= 16 elements to 16-byte boundaries: a bucket's range comes from the real offsets, never from a running
+        # sum of numel().  A bucket = a run of consecutive parameters; it starts where the previous one ended (so the padding in front of its first
+        # parameter travels with it) and the last bucket ends at the end of the buffer.
+        total = flat.flat.numel()
+        lo, count = 0, 0
+        for i, p in enumerate(flat.params):
+            assert flat.offset[id(p)] >= lo, "FlatParameters.params is not in buffer order"
+            end = flat.offset[id(p)] + p.numel()
             count += 1
             self._bucket_of[id(p)] = len(self.buckets)
-            if (o - lo) * 4 >= bucket_bytes:
-                self.buckets.append([lo, o, count])
-                lo, count = o, 0
-        if count:
-            self.buckets.append([lo, o, count])
+            if (end - lo) * 4 >= bucket_bytes and i + 1 < len(flat.params):
+                self.buckets.append([lo, end, count])
+                lo, count = end, 0
+        if count or not self.buckets:
+            self.buckets.append([lo, total, count])
+        self.check_tiling()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -329,6 +334,17 @@ class OverlappedAllReduce:
         if self.world > 1:
             for p in flat.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def check_tiling(self):
+        """The buckets tile [0, flat.numel()) exactly and every parameter's slice lies inside its own bucket."""
+        assert self.buckets[0][0] == 0 and self.buckets[-1][1] == self.flat.flat.numel(), (self.buckets[0], self.buckets[-1], self.flat.flat.numel())
+        for a, b in zip(self.buckets, self.buckets[1:]):
+            assert a[1] == b[0] and a[0] < a[1], (a, b)
+        for p in self.flat.params:
+            lo, hi, _ = self.buckets[self._bucket_of[id(p)]]
+            o = self.flat.offset[id(p)]
+            assert lo <= o and o + p.numel() <= hi, (o, p.numel(), lo, hi)
+        assert sum(b[2] for b in self.buckets) == len(self.flat.params)
 
     def _hook(self, p):
         b = self._bucket_of[id(p)]

@@ -123,11 +123,51 @@ def test_bench_never_calls_a_training_step_on_one_rank_only():
 
 
 # ---- bucketed all-reduce overlapped with backward (trainer.OverlappedAllReduce), world 2 and 3 over gloo ------------------------------------------------
+class _OddNet(torch.nn.Module):
+    """Parameter sizes chosen against FlatParameters' 16-byte alignment: an odd-sized tensor first (50 floats, as QHNet's radial parameters), unused
+    parameters in the MIDDLE (their bucket must still be reduced: zeros), and the LAST parameters receive non-zero gradients -- with ranges taken from
+    a running sum of numel() (the round-3 bug) the tail of the buffer was scaled by 1/world without being reduced and buckets cut through parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.randn(50) * 0.1 + 1.0)
+        self.l1 = torch.nn.Linear(7, 50)
+        self.unused = torch.nn.Linear(3, 3)
+        self.l2 = torch.nn.Linear(50, 19)
+        self.odd = torch.nn.Parameter(torch.randn(17))
+        self.l3 = torch.nn.Linear(19, 1)
+        self.tail = torch.nn.Parameter(torch.randn(21))
+
+    def forward(self, x):
+        h = torch.nn.functional.silu(self.l1(x) * self.scale)
+        h = torch.nn.functional.silu(self.l2(h))
+        return self.l3(h) * self.odd[:16].sum() + (self.tail * self.tail).sum()
+
+
 def _mlp(seed):
     torch.manual_seed(seed)
-    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.SiLU(), torch.nn.Linear(33, 19), torch.nn.SiLU(), torch.nn.Linear(19, 1))
-    unused = torch.nn.Linear(3, 3)                          # parameters that never receive a gradient: their bucket must still be reduced (zeros)
-    return net, unused
+    return _OddNet()
+
+
+def test_overlapped_buckets_tile_the_padded_flat_buffer():
+    from nabladft_amd.trainer import FlatParameters, OverlappedAllReduce
+    sizes = [(50,), (8, 16), (3,), (5,), (32, 7), (1,), (128,), (17, 4)]             # ADVICE r3: summed numel 607, padded buffer 612 floats
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in sizes]
+    flat = FlatParameters(ps)
+    assert flat.flat.numel() > sum(p.numel() for p in ps)                               # padding is present
+    for bb in (1, 64, 600, 1 << 20):
+        ov = OverlappedAllReduce(flat, bucket_bytes=bb)
+        ov.check_tiling()
+        assert ov.buckets[0][0] == 0 and ov.buckets[-1][1] == flat.flat.numel()
+        for p in ps:
+            lo, hi, _ = ov.buckets[ov._bucket_of[id(p)]]
+            assert lo <= flat.offset[id(p)] and flat.offset[id(p)] + p.numel() <= hi
+    net = _mlp(0)
+    flat = FlatParameters(list(net.parameters()))
+    assert flat.flat.numel() > sum(p.numel() for p in net.parameters())
+    ov = OverlappedAllReduce(flat, bucket_bytes=600)
+    ov.check_tiling()
+    assert len(ov.buckets) >= 3
 
 
 def _overlap_worker(rank, world, port, out_dir):
@@ -135,12 +175,12 @@ def _overlap_worker(rank, world, port, out_dir):
     torch.set_num_threads(1)
     nqdist.init_from_env(backend="gloo")
     from nabladft_amd.trainer import FlatParameters, OverlappedAllReduce
-    net, unused = _mlp(0)
-    flat = FlatParameters(list(net.parameters()) + list(unused.parameters()))
-    ov = OverlappedAllReduce(flat, bucket_bytes=600)        # several buckets over ~1.6 k parameters
-    assert len(ov.buckets) >= 3
-    net2, unused2 = _mlp(0)                                 # the same model without hooks: local gradient -> one flat all-reduce
-    flat2 = FlatParameters(list(net2.parameters()) + list(unused2.parameters()))
+    net = _mlp(0)
+    flat = FlatParameters(list(net.parameters()))
+    ov = OverlappedAllReduce(flat, bucket_bytes=600)        # several buckets over ~1.5 k parameters, padded layout
+    assert len(ov.buckets) >= 3 and flat.flat.numel() > sum(p.numel() for p in net.parameters())
+    net2 = _mlp(0)                                          # the same model without hooks: local gradient -> one flat all-reduce
+    flat2 = FlatParameters(list(net2.parameters()))
     g = torch.Generator().manual_seed(10 + rank)
     outs = []
     for step in range(2):                                   # two steps: the counters re-arm
@@ -172,3 +212,4 @@ def test_overlapped_bucketed_allreduce_equals_one_flat_allreduce(tmp_path):
                     assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())      # ring order differs with the chunking: last-bit differences
                 assert torch.equal(got, res[0][step][0])    # every rank holds the same mean
             assert float(res[0][step][0].abs().max()) > 0
+            assert float(res[0][step][0][-20:].abs().min()) > 0      # the last parameters (l3.weight, l3.bias) have non-zero gradients and were reduced
