@@ -31,6 +31,25 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_m
 SPLIT_TERMS = 6                # csrc/gemm_split.h: bf16 piece products per f32 product -> 2500 / 6 = 416.7 TFLOP/s of f32-accurate products
 
 
+def nqdist_mod():
+    from nabladft_amd import dist as nqdist
+    return nqdist
+
+
+def collective_name():
+    nq = nqdist_mod()
+    if not nq.active():
+        return "none (1 rank)"
+    if nq.native_comm(create=False) is not None:
+        return "rccl via the C ABI (nq_allreduce)"
+    return {"nccl": "rccl via torch.distributed (backend nccl)"}.get(dist.get_backend(), dist.get_backend())
+
+
+def dist_on():
+    """A process group exists and its collectives run: world > 1, or the forced 1-rank group of the single-GPU RCCL test (NQ_DIST_FORCE=1)."""
+    return nqdist_mod().active()
+
+
 def make_batches(seed, n_batches, B, device):
     """n_batches distinct batches of B conformers: 64 generated molecules per batch seed, replicated with
     independent random rotations and 0.02 A jitter (keeps the generator's statistics, costs O(64) python)."""
@@ -230,14 +249,14 @@ def bench_gemnet(args, rank, world, local_dev, dev):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     mol = args.batch if args.batch != 2048 else 16
     rec = BG.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
     t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     bf = b8 = big = None
@@ -265,9 +284,7 @@ def bench_gemnet(args, rank, world, local_dev, dev):
                "reference_batch_size_8_prepared_eager_vs_graph_replay": _graph_replay("gemnet") if world == 1 and not args.no_roofline else None,
                "batch_64": big if bf is not None else None}
         emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(local_dev)
 
 
 def bench_escn(args, rank, world, local_dev, dev, which="escn"):
@@ -281,14 +298,14 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     mol = args.batch if args.batch != 2048 else 16
     rec = BE.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
     t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     b8 = BE.run(ref_batch, args.steps, args.warmup, kernels=False, device=dev) if world == 1 and not args.no_roofline and mol != ref_batch else None
@@ -310,9 +327,7 @@ def bench_escn(args, rank, world, local_dev, dev, which="escn"):
                f"reference_batch_size_{ref_batch}": None if b8 is None else {k: b8[k] for k in ("value", "unit", "ms_per_step", "atoms")},
                f"reference_batch_size_{ref_batch}_prepared_eager_vs_graph_replay": _graph_replay(which) if world == 1 and not args.no_roofline else None}
         emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(local_dev)
 
 
 def bench_qhnet(args, rank, world, local_dev, dev):
@@ -322,14 +337,14 @@ def bench_qhnet(args, rank, world, local_dev, dev):
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     mol = args.batch if args.batch != 2048 else 16
     rec = BQ.run(mol, args.steps, args.warmup, kernels=not args.no_roofline and rank == 0 and world == 1, device=dev, world=world, rank=rank, sync=sync)
     t = torch.tensor([rec.pop("_dt")], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     if rank == 0:
@@ -344,9 +359,7 @@ def bench_qhnet(args, rank, world, local_dev, dev):
                "gemm_tflops": rec.get("gemm_tflops"), "reference_batch_size_2": None if small is None else {k: small[k] for k in ("value", "unit", "ms_per_step", "atoms", "ordered_pairs")},
                "reference_batch_size_2_prepared_eager_vs_graph_replay": _graph_replay("qhnet") if world == 1 and not args.no_roofline else None}
         emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(local_dev)
 
 
 COMPACT_LIMIT = 4000     # bytes: the driver parses the LAST stdout line; round 3's 23-KB line was not parsed
@@ -418,8 +431,38 @@ def emit(full):
             json.dump(full, fh)
     except OSError:
         path = None
+    global _LINE
+    _LINE = json.dumps(compact_record(full, path))
+
+
+_LINE = None
+
+
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def finish(local_dev):
+    """Print the record as the LAST line of the job's stdout.  librccl printf()s a line ("Librccl path : ...") into the C stdio buffer of every rank, which
+    a piped stdout only flushes at process exit -- after Python's prints (seen on the GPU box: the record was the second-to-last line).  So: every rank
+    flushes its C buffers, the ranks meet at a barrier, the group is torn down, buffers are flushed again, the other ranks exit, and rank 0 prints last."""
+    multi = False
+    if dist_on():
+        multi = dist.get_world_size() > 1
+        _flush_c_stdio()
+        dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
+        nqdist_mod().drop_native_comm()
+        dist.destroy_process_group()
     sys.stdout.flush()
-    print(json.dumps(compact_record(full, path)), flush=True)
+    _flush_c_stdio()
+    if _LINE is not None:
+        if multi:
+            time.sleep(1.5)          # the other ranks are exiting (their exit flushes anything a library buffered after the barrier)
+        print(_LINE, flush=True)
 
 
 WORKLOADS = {
@@ -580,7 +623,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on():
             dist.barrier(device_ids=[local_dev]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
@@ -594,7 +637,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     total_conf = args.batch * world * args.steps
@@ -812,7 +855,7 @@ def main():
             "dtype": dtype_string(), "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.model]}; synthetic ~42-atom drug-like conformers, {args.batch} conformers/GPU/step",
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "collective": collective_name()},
             "final_loss": float(loss),
             "gemm_engine": gemm_engine,
             "roofline": roofline,
@@ -830,9 +873,7 @@ def main():
             "kernel_ms_per_step": {k: round(ms, 4) for k, ms, _ in (kernels or [])[:8]},
         }
         emit(out)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(local_dev)
 
 
 if __name__ == "__main__":

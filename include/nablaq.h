@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 13
+#define NQ_ABI_VERSION 14
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -576,6 +576,22 @@ size_t nq_column_sum_scratch_floats(int64_t rows, int32_t cols);
 int nq_column_sum(const float* A, int64_t rows, int32_t cols, int64_t lda, float* out, float* scratch, void* stream);
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
+
+/* ---- Data-parallel gradient exchange over RCCL (round 4; SURVEY 8(b) `nq_allreduce`) -------------------------------------------------------
+ * Replaces: Lightning DDPStrategy's gradient all-reduce (nablaDFT/utils/pipelines.py:65-68, `strategy: ddp` of the config yaml files).  One process
+ * per GPU; the only thing ever exchanged is the flat fp32 gradient buffer (one conformer = one graph: no data-path collective).  librccl.so is bound with
+ * dlopen at the first call (no link-time dependency; nq_rccl_available() = 0 and NQ_ERR_ARG from the other entry points if it cannot be loaded).
+ * Job set-up: rank 0 calls nq_rccl_unique_id (128 bytes) and hands the bytes to every rank through any side channel (nabladft_amd/dist.py uses the
+ * torch.distributed store); every rank calls nq_rccl_comm_create with its HIP device current.  The collectives are enqueued on `stream` (ordered after the
+ * kernels that wrote `buf`, before the optimiser kernel; no host synchronisation).  nq_allreduce: buf <- sum over ranks (in place, fp32);
+ * nq_allreduce_mean: sum, then * 1/world on the same stream; nq_rccl_broadcast: buf of `root` -> all (initial parameters). */
+int nq_rccl_available(void);
+int nq_rccl_unique_id(void* id128);
+int nq_rccl_comm_create(const void* id128, int32_t world, int32_t rank, void** comm);
+int nq_rccl_comm_destroy(void* comm);
+int nq_allreduce(float* buf, size_t n, void* comm, void* stream);
+int nq_allreduce_mean(float* buf, size_t n, void* comm, void* stream);
+int nq_rccl_broadcast(float* buf, size_t n, int32_t root, void* comm, void* stream);
 
 #ifdef __cplusplus
 }

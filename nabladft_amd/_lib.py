@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -182,6 +182,13 @@ SYMBOLS = {
     "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "nq_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32]),
     "nq_linear_weight_grad": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_rccl_available": (C.c_int, []),
+    "nq_rccl_unique_id": (C.c_int, [_P]),
+    "nq_rccl_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "nq_rccl_comm_destroy": (C.c_int, [_P]),
+    "nq_allreduce": (C.c_int, [_P, _SZ, _P, _P]),
+    "nq_allreduce_mean": (C.c_int, [_P, _SZ, _P, _P]),
+    "nq_rccl_broadcast": (C.c_int, [_P, _SZ, _I32, _P, _P]),
 }
 
 _lib = None

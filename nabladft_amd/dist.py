@@ -8,12 +8,18 @@ import torch
 import torch.distributed as dist
 
 
+def forced() -> bool:
+    """NQ_DIST_FORCE=1: initialise the process group and run every collective even in a 1-rank job -- the whole RCCL path of a step (group
+    creation, stream-ordered all-reduce, barriers) then executes on a single GPU (tests/test_dist_gpu.py; a 1-GPU box cannot host a second rank)."""
+    return os.environ.get("NQ_DIST_FORCE", "0") not in ("", "0")
+
+
 def init_from_env(backend: str = None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* if a launcher set them. Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only (RCCL)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -22,6 +28,8 @@ def init_from_env(backend: str = None):
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("NQ_RCCL_NATIVE", "0") not in ("", "0") and dist.is_initialized() and torch.cuda.is_available():
+        native_comm()
     return rank, world, local
 
 
@@ -29,19 +37,116 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def active(group=None) -> bool:
+    """Do the collectives of a step have to run?  A process group exists and it has more than one rank (or NQ_DIST_FORCE=1)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced())
+
+
+# ---- RCCL through the C ABI (include/nablaq.h: nq_rccl_*, nq_allreduce) ------------------------------------------------------------------------
+class NativeComm:
+    """An RCCL communicator created and driven through libnablaq's C ABI (SURVEY 8(b) ``nq_allreduce(buf, n, comm, stream)``): rank 0 makes the
+    128-byte unique id, the ranks receive it through the torch.distributed store (any backend), every rank joins with its current HIP device.  The
+    collectives run on torch's CURRENT stream (the step's stream), so they need no event plumbing.  Opt-in: ``NQ_RCCL_NATIVE=1`` (default: the same
+    collectives through torch.distributed's "nccl" backend, which is the same librccl)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        if not lib.nq_rccl_available():
+            raise RuntimeError("librccl.so cannot be loaded: " + lib.nq_last_error().decode(errors="replace"))
+        self.world = world_size(group)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.nq_rccl_unique_id(ident))
+        if self.world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        self._comm = C.c_void_p()
+        _lib.check(lib.nq_rccl_comm_create(ident, self.world, self.rank, C.byref(self._comm)))
+        self._lib, self._libmod = lib, _lib
+
+    def allreduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._libmod.check(self._lib.nq_allreduce(self._libmod.ptr(t), t.numel(), self._comm, self._libmod.stream_ptr()))
+        return t
+
+    def allreduce_mean_(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._libmod.check(self._lib.nq_allreduce_mean(self._libmod.ptr(t), t.numel(), self._comm, self._libmod.stream_ptr()))
+        return t
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._libmod.check(self._lib.nq_rccl_broadcast(self._libmod.ptr(t), t.numel(), src, self._comm, self._libmod.stream_ptr()))
+        return t
+
+    def destroy(self):
+        if self._comm:
+            self._libmod.check(self._lib.nq_rccl_comm_destroy(self._comm))
+            self._comm = None
+
+
+_native = None
+
+
+def native_comm(create: bool = True):
+    """The process-wide NativeComm of the default group (created on first use when ``create``)."""
+    global _native
+    if _native is None and create:
+        _native = NativeComm()
+    return _native
+
+
+def drop_native_comm():
+    global _native
+    if _native is not None:
+        _native.destroy()
+        _native = None
+
+
+def _use_native(t, group):
+    return _native is not None and group is None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks on the current stream (slices of the flat gradient in the overlapped reverse sweep)."""
+    if active(group):
+        if _use_native(t, group):
+            return _native.allreduce_sum_(t)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place mean over ranks of ONE contiguous buffer (a single collective per step; PaiNN: 5.4 MB)."""
-    w = world_size(group)
-    if w > 1:
+    if active(group):
+        if _use_native(flat, group):
+            return _native.allreduce_mean_(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.mul_(1.0 / w)
+        w = world_size(group)
+        if w > 1:
+            flat.mul_(1.0 / w)
     return flat
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
-    if world_size(group) > 1:
+    if active(group):
+        if _use_native(flat, group):
+            return _native.broadcast_(flat, src)
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+def barrier(device=None, group=None):
+    """dist.barrier with the device pinned for the nccl backend (an unpinned nccl barrier guesses the device from the rank)."""
+    if active(group):
+        if dist.get_backend(group) == "nccl" and device is not None:
+            dist.barrier(group=group, device_ids=[device])
+        else:
+            dist.barrier(group=group)
 
 
 # ---- per-conformer cost proxies (one molecule = one graph; the cost of a step is the sum over its conformers) ------------------------------------

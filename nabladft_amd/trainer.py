@@ -157,7 +157,7 @@ class FusedTrainStep:
     overlap = True      # set False to fall back to one all-reduce of the whole flat gradient after the backward
 
     def _overlap_ready(self, lib, bwd_fn):
-        if not self.overlap or nqdist.world_size(self.group) <= 1 or bwd_fn is not lib.nq_painn_backward:
+        if not self.overlap or not nqdist.active(self.group) or bwd_fn is not lib.nq_painn_backward:
             return False
         if self._ov is None:
             L = int(self._eng.cfg.num_layers)
@@ -183,7 +183,7 @@ class FusedTrainStep:
 
         def reduce(off, cnt):
             if cnt > 0:
-                torch.distributed.all_reduce(g[off:off + cnt], op=torch.distributed.ReduceOp.SUM, group=self.group)
+                nqdist.allreduce_sum_(g[off:off + cnt], self.group)
 
         with torch.cuda.stream(ov.side):
             for i in range(ov.L):
@@ -307,6 +307,7 @@ class OverlappedAllReduce:
         import torch.distributed as dist
         self.flat, self.group, self.dist = flat, group, dist
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.on = nqdist.active(group)                      # world > 1, or a forced 1-rank group (NQ_DIST_FORCE=1: the single-GPU RCCL test)
         self.buckets = []                                   # [lo, hi, n_params]: ranges of the FLAT buffer (alignment padding included)
         self._bucket_of = {}
         # FlatParameters pads tensors of >= 16 elements to 16-byte boundaries: a bucket's range comes from the real offsets, never from a running
@@ -331,7 +332,7 @@ class OverlappedAllReduce:
         self._cuda = flat.flat.is_cuda
         self._comm = torch.cuda.Stream(device=flat.flat.device) if self._cuda else None
         self._handles = []
-        if self.world > 1:
+        if self.on:
             for p in flat.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
@@ -369,14 +370,15 @@ class OverlappedAllReduce:
 
     def finish(self):
         """After backward: every bucket reduced, the flat gradient holds the mean over ranks; counters re-armed for the next step."""
-        if self.world > 1:
+        if self.on:
             for b in range(len(self.buckets)):              # parameters without a gradient this step never fire their hook
                 self._launch(b)
             for w in self._works:
                 w.wait()
             if self._cuda:
                 torch.cuda.current_stream().wait_stream(self._comm)
-            self.flat.flat.grad.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat.flat.grad.mul_(1.0 / self.world)
         self._works = []
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)

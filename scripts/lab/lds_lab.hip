@@ -18,8 +18,8 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k_lds(float* out, int iters, const int* k0s) {
   extern __shared__ float lds[];
   float* wrt = lds;                       // [ROWS + 13][COLS]
-  float* acc = lds + (ROWS + 13) * COLS;  // [ROWS + 13][COLS]
-  for (int i = threadIdx.x; i < 2 * (ROWS + 13) * COLS; i += blockDim.x) lds[i] = (i < (ROWS + 13) * COLS) ? 1e-3f * (i % 97) : 0.f;
+  float* acc = lds + ROWS * COLS;  // [ROWS + 13][COLS]
+  for (int i = threadIdx.x; i < 2 * ROWS * COLS; i += blockDim.x) lds[i] = (i < ROWS * COLS) ? 1e-3f * (i % 97) : 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g0 = 1.0f + lane * 1e-3f, g1 = 0.5f, g2 = 0.25f, s = 0.f;
@@ -51,13 +51,13 @@ __global__ __launch_bounds__(1024) void k_lds(float* out, int iters, const int* 
   }
   __syncthreads();
   float tot = s;
-  for (int i = threadIdx.x; i < (ROWS + 13) * COLS; i += blockDim.x) tot += acc[i];
+  for (int i = threadIdx.x; i < ROWS * COLS; i += blockDim.x) tot += acc[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = tot;
 }
 
 template <int MODE>
 void run(const char* name, int waves, int iters, float* out, const int* k0s) {
-  const size_t lds = 2 * (ROWS + 13) * COLS * sizeof(float);
+  const size_t lds = 2 * ROWS * COLS * sizeof(float);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

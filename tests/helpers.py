@@ -29,6 +29,40 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / denom)
 
 
+def elem_err(a, b, floor=None):
+    """Element-wise relative error max_i |a_i - b_i| / max(|b_i|, floor), fp64; floor = rms(b) unless given: an element is measured against its own
+    magnitude, but never against less than the typical magnitude of the array (a force component that happens to be ~0 is not held to 1e-5 of itself)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    if floor is None:
+        floor = float(np.sqrt((b * b).mean()))
+    return float((np.abs(a - b) / np.maximum(np.abs(b), max(floor, 1e-30))).max())
+
+
+def _report(line):
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_report.txt"), "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+
+
+def assert_close(name, got, ref, tol=1e-5, elem_tol=None):
+    """Both measures against a reference array: array-level max|a-b| / max|b| < tol AND element-wise |a_i-b_i| <= elem_tol * max(|b_i|, rms(b))
+    (elem_tol defaults to tol).  Appends both numbers to gpurun_out/parity_report.txt."""
+    elem_tol = tol if elem_tol is None else elem_tol
+    e_arr, e_el = rel_err(got, ref), elem_err(got, ref)
+    ok = e_arr < tol and e_el <= elem_tol
+    _report(f"{name:60s} array-level {e_arr:.3e} (< {tol:.1e})  element-wise {e_el:.3e} (<= {elem_tol:.1e})  {'ok' if ok else 'ABOVE'}")
+    if os.environ.get("NQ_PARITY_REPORT_ONLY") != "1":
+        assert ok, (name, e_arr, tol, e_el, elem_tol)
+    return e_arr, e_el
+
+
 def check_grads(fx, grads, tol, label=""):
     """grads: name -> array. Compares against full ('grad:') or sampled ('gidx:/gval:') golden grads."""
     worst = (0.0, None)
@@ -58,17 +92,18 @@ PARITY_FLOOR = 1e-5          # BASELINE.json north_star: "within 1e-5 rel fp32"
 def assert_parity(name, got, ref64, ref32=None, floor=PARITY_FLOOR, factor=1.5):
     """err_hip = |got - ref64|max / |ref64|max must be <= max(floor, factor * err_ref) where err_ref is the same measure of the REFERENCE's own float32
     run (ref32) against its float64 run: a float32 pipeline cannot be asked to sit closer to the float64 answer than the reference's float32 pipeline
-    does.  Every call appends "name err_hip err_ref bound" to gpurun_out/parity_report.txt (kept as evidence under profiles/)."""
+    does.  The same holds element-wise (elem_err).  Every call appends both measures to gpurun_out/parity_report.txt (kept as evidence under profiles/)."""
     err = rel_err(got, ref64)
     own = rel_err(ref32, ref64) if ref32 is not None else 0.0
     bound = max(floor, factor * own)
-    try:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(root, "gpurun_out", "parity_report.txt"), "a") as fh:
-            fh.write(f"{name:60s} err_hip {err:.3e}  err_ref_fp32 {own:.3e}  bound {bound:.3e}  {'ok' if err <= bound else 'ABOVE'}\n")
-    except OSError:
-        pass
+    # element-wise: every element against max(|ref_i|, rms(ref)), same yardstick (the reference's own float32 error in the same measure)
+    err_el = elem_err(got, ref64)
+    own_el = elem_err(ref32, ref64) if ref32 is not None else 0.0
+    bound_el = max(floor, factor * own_el)
+    ok = err <= bound and err_el <= bound_el
+    _report(f"{name:60s} err_hip {err:.3e}  err_ref_fp32 {own:.3e}  bound {bound:.3e}  | element-wise err_hip {err_el:.3e}  err_ref_fp32 {own_el:.3e}  "
+            f"bound {bound_el:.3e}  {'ok' if ok else 'ABOVE'}")
     if os.environ.get("NQ_PARITY_REPORT_ONLY") != "1":
         assert err <= bound, (name, err, own, bound)
+        assert err_el <= bound_el, (name, "element-wise", err_el, own_el, bound_el)
     return err, own

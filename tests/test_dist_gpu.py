@@ -145,6 +145,7 @@ def test_bench_eight_rank_rehearsal(model, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE JSON line
+    assert r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # ... as the LAST line of the job's stdout, compact (the driver parses it)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["steps"] == 1 and rec["scaling"] == "weak" and rec["unit"] == "conformer-steps/s" and rec["value"] > 0
     assert rec["config"]["parallelism"] == "dp8"

@@ -13,7 +13,7 @@ import torch
 
 from oracle import painn_ref as R
 from oracle.painn_sweeps import Sweeps, loss_and_seeds
-from tests.helpers import GOLDEN, check_grads, load_case, rel_err
+from tests.helpers import assert_close, GOLDEN, check_grads, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -377,6 +377,8 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
     with open(os.path.join(OUT, f"trace_{name_tag}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     assert e_err < 1e-5 and f_err < 1e-5, lines[-2]
+    assert_close(f"painn golden {name} E", energy.detach().cpu().numpy(), fx["energy"], 1e-5)        # array-level and element-wise (|a-b| <= 1e-5 max(|b|, rms b))
+    assert_close(f"painn golden {name} F", forces.detach().cpu().numpy(), fx["forces"], 1e-5)
     assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
     assert rel_err(model.workspace_view("x_msg", 0).cpu().numpy(), fx["x_msg0"].reshape(-1)) < 1e-5
     Lm = cfg.num_layers

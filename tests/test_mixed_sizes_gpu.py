@@ -8,7 +8,7 @@ Tolerance: 2e-5 of the largest magnitude (float32 sums in a different associatio
 exact-f32 GEMM engine, whose rows do not depend on the batch.  With the split-bf16 engine (default for large products) the whole batch and the single
 molecules run on DIFFERENT engines, i.e. every intermediate differs in its last f32 bit, and autograd forces of a random-weight model amplify that: the
 yardstick there is what a pure f32 reordering does to the same outputs (the exact engine against the generic exact-f32 kernels, which sum over k in another
-order), measured in the test, times two."""
+order); it is measured and reported, but the bounds are fixed per model (VERDICT r3 item 8 ii)."""
 import os
 import sys
 
@@ -47,10 +47,15 @@ def _mix(dev, sizes_fixed=(10, 90), n_random=3, seed=11):
     return mk(list(range(n_mol))), [mk([i]) for i in range(n_mol)], torch.bincount(batch).tolist()
 
 
-def _check(net, dev, weight_seed=0, tol=2e-5, grad_tol=5e-5):
-    """Strict on the exact-f32 engine; on the default engines held to twice the measured f32 reordering sensitivity (never below the strict tolerance)."""
+def _check(net, dev, weight_seed=0, tol=2e-5, grad_tol=5e-5, default_tol=None, default_grad_tol=None):
+    """Strict (`tol`) on the exact-f32 engine, whose rows do not depend on the batch.  On the default engines the whole batch and the single molecules run on
+    DIFFERENT engines (split-bf16 above 192 tiles, exact f32 below), so every intermediate differs in its last f32 bit: the bound there is FIXED per model
+    (`default_tol`, stated at the call site with the measurement behind it) -- not derived from anything measured inside the test.  The f32 reordering
+    sensitivity (exact engine vs the generic exact-f32 kernels, which sum over k in another order) is still measured and written to the report."""
     from nabladft_amd import _lib
     lib = _lib.load()
+    default_tol = tol if default_tol is None else default_tol
+    default_grad_tol = grad_tol if default_grad_tol is None else default_grad_tol
     whole, _, _ = _mix(dev)
     try:
         lib.nq_set_gemm_variant(1 | 32)
@@ -62,11 +67,12 @@ def _check(net, dev, weight_seed=0, tol=2e-5, grad_tol=5e-5):
         lib.nq_set_gemm_variant(1)
     reorder = max(float((Ex - Eg).abs().max()) / float(Ex.abs().max()), float((Fx - Fg).abs().max()) / float(Fx.abs().max()))
     try:
-        _check_engine(net, dev, weight_seed, max(tol, 2.0 * reorder), max(grad_tol, 2.0 * reorder))
+        _check_engine(net, dev, weight_seed, default_tol, default_grad_tol)
     finally:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "mixed_sizes_report.txt"), "a") as f:
-            f.write(f"{type(net).__name__}: f32 reordering sensitivity of E / F on the 10-90 atom mix {reorder:.3e} (exact engine vs generic exact kernels)\n")
+            f.write(f"{type(net).__name__}: f32 reordering sensitivity of E / F on the 10-90 atom mix {reorder:.3e} (exact engine vs generic exact kernels; reported, "
+                    f"not used as a bound); fixed bound on the default engines {default_tol:.1e}\n")
     return out
 
 
@@ -120,7 +126,10 @@ def test_escn_yaml_configuration_on_10_to_90_atoms():
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
     net = eSCN(**FULL).to(dev)
-    whole, sizes = _check(net, dev)
+    # eSCN's force head sums a nearly constant scalar field times the unit vectors of 128 sphere points (escn.py:437-457): with random initial weights the sum
+    # cancels to ~1e-3 of its terms, so forces amplify last-bit differences: two pure-f32 summation orders of the SAME engine differ by 4.3e-5 of max|F| on this
+    # mix, whole batch vs single molecules across the two engines by 4.0e-5 (profiles/r03_final2_mixed_sizes_report.txt).  Fixed bound: 1e-4 (E: 2e-5 holds).
+    whole, sizes = _check(net, dev, default_tol=1e-4, default_grad_tol=1e-4)
     G = net.build_graph(whole)
     deg = torch.maximum(torch.bincount(G.dst.cpu(), minlength=sum(sizes)), torch.bincount(G.src.cpu(), minlength=sum(sizes)))
     assert int(deg.max()) >= FULL["max_neighbors"]                     # the cap of 40 binds on the 90-atom molecule ...

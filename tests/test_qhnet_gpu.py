@@ -38,6 +38,9 @@ def load_case(name, dev):
     return g, cfg, net, Batch(g["pos"], g["z"], g["sizes"], dev)
 
 
+from tests.helpers import assert_parity  # noqa: E402
+
+
 def rel(a, ref):
     ref = torch.as_tensor(ref, dtype=torch.float64)
     a = torch.as_tensor(a).detach().cpu().double()
@@ -82,6 +85,7 @@ def test_small_forward_layer_by_layer():
         ref = g["inter64_" + k]
         errs[k] = rel(v, ref) if k.endswith("blocks") else rel(v, from_e3nn(ref, c))
     errs["H"] = rel(H, g["H64"])
+    assert_parity("qhnet_small H", H.cpu().numpy(), g["H64"], g["H32"])          # array-level and element-wise, yardstick = the reference's own fp32 run
     print("qhnet small, rel. error vs the reference in fp64:", {k: f"{v:.1e}" for k, v in errs.items()})
     print("reference fp32 vs fp64: H", rel(g["H32"], g["H64"]))
     assert max(errs.values()) < TOL, errs
@@ -156,6 +160,7 @@ def test_full_configuration():
     assert torch.equal(batch.edge_index.cpu(), torch.tensor(g["edge_index"])) and torch.equal(batch.full_edge_index.cpu(), torch.tensor(g["full_edge_index"]))
     errs = {k: (rel(v, g[k]) if k.endswith("blocks") else rel(v, from_e3nn(g[k], 128))) for k, v in inter.items()}
     errs["H"] = rel(H, g["H64"])
+    assert_parity("qhnet_full H", H.detach().cpu().numpy(), g["H64"], g["H32"])
     print("qhnet full, rel. error vs the reference in fp64:", {k: f"{v:.1e}" for k, v in errs.items()}, "| reference fp32:", rel(g["H32"], g["H64"]))
     assert max(errs.values()) < TOL, errs
     assert abs(float(loss) - float(g["loss64"])) / float(g["loss64"]) < 1e-6
