@@ -282,12 +282,20 @@ int nq_qh_expansion_backward(const float* x, const float* weights, const float* 
 /* out [P][(order+1)^2]: real spherical harmonics Y_0..Y_order (order <= 4) of unit vectors [P][3], PhiSNet convention
  * (phisnet/nn/spherical_harmonics/spherical_harmonics.py:10-25: no 1/sqrt(4 pi), Condon-Shortley, m = -l..l). */
 int nq_sph_harm(const float* unit_vectors, int64_t P, int32_t order, float* out, void* stream);
+/* Adjoint of nq_sph_harm w.r.t. the vectors: gu[P][3] = sum_c grad_out[P][c] dY_c/d(x,y,z), the closed forms differentiated as polynomials of a free vector
+ * (what autograd does with phisnet/nn/spherical_harmonics/spherical_harmonics_any_order.py before the chain rule through u = r/|r|): the angular half of
+ * PhiSNet's forces = -dE/dR (phisnet/nn/neural_network.py:737, :981-984). */
+int nq_sph_harm_backward(const float* unit_vectors, const float* grad_out, int64_t P, int32_t order, float* gu, void* stream);
 /* out [P][K] = cutoff_function(r) * exp(logc_k + n_k x + v_k log(1 - e^x)), x = -alpha r  (ExponentialBernsteinRadialBasisFunctions.forward,
  * phisnet/nn/modules/exponential_bernstein_radial_basis_functions.py:36-41 == qhnet/layers.py:115-120); alpha = softplus(_alpha). */
 int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n, const float* v, float* out,
                      void* stream);
 int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P, int32_t K, float alpha, float cutoff, const float* logc, const float* n,
                                 const float* v, float* galpha_rows, void* stream);
+
+/* gr[p] = sum_k grad_out[p][k] d rbf[p][k] / d r (cutoff function included): the radial half of PhiSNet's forces; alpha from a device scalar. */
+int nq_bernstein_rbf_grad_r_dev(const float* r, const float* grad_out, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc,
+                                const float* n, const float* v, float* gr, void* stream);
 
 /* The same two calls with alpha = softplus(_alpha) read from a DEVICE scalar: no host read of the learnable parameter, so a whole training step can be
  * captured into a HIP graph (trainer.GraphedStep). */

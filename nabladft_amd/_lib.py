@@ -94,6 +94,8 @@ SYMBOLS = {
     "nq_so3_mix_partial_blocks": (C.c_int64, [_I64, _I32]),
     "nq_so3_mix_backward_shared": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "nq_sph_harm": (C.c_int, [_P, _I64, _I32, _P, _P]),
+    "nq_sph_harm_backward": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "nq_bernstein_rbf_grad_r_dev": (C.c_int, [_P, _P, _I64, _I32, _P, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf_grad_alpha": (C.c_int, [_P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P]),
     "nq_bernstein_rbf_dev": (C.c_int, [_P, _I64, _I32, _P, _F, _P, _P, _P, _P, _P]),

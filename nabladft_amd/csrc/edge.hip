@@ -864,8 +864,15 @@ __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restri
 // wavefront therefore keeps GWR_DEPTH edges in flight (5 VGPRs each: CH floats of gphi and gpsi per lane plus the edge's 32-float
 // window record spread over the lanes, broadcast with v_readlane when it is consumed); with one edge in flight the kernel ran at
 // edges x latency / waves (1.29 ms per launch at 1.6 M edges), i.e. 3.1 TB/s.
+#ifndef GWR_WAVES
 #define GWR_WAVES 4
+#endif
+#ifndef GWR_DEPTH
 #define GWR_DEPTH 6
+#endif
+#ifndef GWR_CHUNKS
+#define GWR_CHUNKS 1360
+#endif
 template <int CH>
 __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
                                                                const int* __restrict__ order, int E, int F, int F3, int R, int chunk_len,
@@ -1186,7 +1193,7 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
 // ---- k0-sorted edge order + register-resident rbf_proj weight gradient ---------------------------------------------
 static int gwr_nbins(int R) { return R - (R < FWIN ? R : FWIN) + 1; }
 static int gwr_chunks(int E) {   // ~4096 wavefronts (16 per CU) over 3 column slices
-  int chunk_len = nq_cdiv(E, 1360);
+  int chunk_len = nq_cdiv(E, GWR_CHUNKS);
   if (chunk_len < 64) chunk_len = 64;
   return nq_cdiv(E, chunk_len);
 }

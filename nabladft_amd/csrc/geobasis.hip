@@ -39,8 +39,74 @@ __global__ void k_sph_harm(const float* __restrict__ u, long P, int L, float* __
   o[21] = d * xz * t7z2m3; o[22] = e * t7z2m1 * x2my2; o[23] = f * xz * x2m3y2; o[24] = g * (x4 - 6.0f * x2y2 + y4);
 }
 
+// gu[p] = sum_c g[p][c] dY_c/d(x, y, z): the closed forms above differentiated as polynomials of free (x, y, z) -- what autograd does with the reference's
+// expressions (spherical_harmonics_any_order.py) before the chain rule through u = r / |r| (phisnet forces, neural_network.py:981-984)
+__global__ void k_sph_harm_bwd(const float* __restrict__ u, const float* __restrict__ gy, long P, int L, float* __restrict__ gu) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int nc = (L + 1) * (L + 1);
+  const float* g = gy + p * nc;
+  const float x = u[3 * p], y = u[3 * p + 1], z = u[3 * p + 2];
+  float gx = 0.f, gyv = 0.f, gz = 0.f;
+  if (L >= 1) {
+    const float s3 = 1.7320508075688772f;
+    gyv += s3 * g[1]; gz += s3 * g[2]; gx += s3 * g[3];
+  }
+  const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, yz = y * z, xz = x * z;
+  if (L >= 2) {
+    const float s15 = 3.872983346207417f, s5o2 = 1.118033988749895f, s15o2 = 1.9364916731037085f;
+    gx += s15 * y * g[4];  gyv += s15 * x * g[4];                       // s15 xy
+    gyv += s15 * z * g[5]; gz += s15 * y * g[5];                        // s15 yz
+    gz += s5o2 * 6.0f * z * g[6];                                       // s5o2 (3 z^2 - 1)
+    gx += s15 * z * g[7];  gz += s15 * x * g[7];                        // s15 xz
+    gx += s15o2 * 2.0f * x * g[8]; gyv -= s15o2 * 2.0f * y * g[8];      // s15o2 (x^2 - y^2)
+  }
+  if (L >= 3) {
+    const float s70o4 = 2.091650066335189f, s105 = 10.246950765959598f, s42o4 = 1.620185174601965f, s7o2 = 1.3228756555322954f, s105o2 = 5.123475382979799f;
+    const float t5z2m1 = 5.0f * z2 - 1.0f;
+    // o9 = s70o4 y (3 x^2 - y^2)
+    gx += s70o4 * 6.0f * xy * g[9];  gyv += s70o4 * (3.0f * x2 - 3.0f * y2) * g[9];
+    // o10 = s105 x y z
+    gx += s105 * yz * g[10]; gyv += s105 * xz * g[10]; gz += s105 * xy * g[10];
+    // o11 = s42o4 y (5 z^2 - 1)
+    gyv += s42o4 * t5z2m1 * g[11]; gz += s42o4 * 10.0f * yz * g[11];
+    // o12 = s7o2 z (5 z^2 - 3)
+    gz += s7o2 * (15.0f * z2 - 3.0f) * g[12];
+    // o13 = s42o4 x (5 z^2 - 1)
+    gx += s42o4 * t5z2m1 * g[13]; gz += s42o4 * 10.0f * xz * g[13];
+    // o14 = s105o2 z (x^2 - y^2)
+    gx += s105o2 * 2.0f * xz * g[14]; gyv -= s105o2 * 2.0f * yz * g[14]; gz += s105o2 * (x2 - y2) * g[14];
+    // o15 = s70o4 x (x^2 - 3 y^2)
+    gx += s70o4 * (3.0f * x2 - 3.0f * y2) * g[15]; gyv -= s70o4 * 6.0f * xy * g[15];
+  }
+  if (L >= 4) {
+    const float a = 8.874119674649425f, b = 18.824850597016705f, c = 3.3541019662496847f, d = 2.3717082451262845f, e = 1.6770509831248424f,
+                f = 6.274950199005566f, gg = 2.2185299186623562f;
+    const float x2my2 = x2 - y2, t7z2m1 = 7.0f * z2 - 1.0f, t7z2m3 = 7.0f * z2 - 3.0f, x2m3y2 = x2 - 3.0f * y2;
+    // o16 = a xy (x^2 - y^2)
+    gx += a * (3.0f * x2 * y - y2 * y) * g[16]; gyv += a * (x2 * x - 3.0f * x * y2) * g[16];
+    // o17 = b yz (x^2 - y^2 / 3)
+    gx += b * 2.0f * x * yz * g[17]; gyv += b * z * (x2 - y2) * g[17]; gz += b * y * (x2 - y2 / 3.0f) * g[17];
+    // o18 = c xy (7 z^2 - 1)
+    gx += c * y * t7z2m1 * g[18]; gyv += c * x * t7z2m1 * g[18]; gz += c * 14.0f * xy * z * g[18];
+    // o19 = d yz (7 z^2 - 3)
+    gyv += d * z * t7z2m3 * g[19]; gz += d * y * (21.0f * z2 - 3.0f) * g[19];
+    // o20 = (105 z^4 - 90 z^2 + 9) / 8
+    gz += 0.125f * (420.0f * z2 * z - 180.0f * z) * g[20];
+    // o21 = d xz (7 z^2 - 3)
+    gx += d * z * t7z2m3 * g[21]; gz += d * x * (21.0f * z2 - 3.0f) * g[21];
+    // o22 = e (7 z^2 - 1)(x^2 - y^2)
+    gx += e * t7z2m1 * 2.0f * x * g[22]; gyv -= e * t7z2m1 * 2.0f * y * g[22]; gz += e * 14.0f * z * x2my2 * g[22];
+    // o23 = f xz (x^2 - 3 y^2)
+    gx += f * z * (3.0f * x2 - 3.0f * y2) * g[23]; gyv -= f * 6.0f * xz * y * g[23]; gz += f * x * x2m3y2 * g[23];
+    // o24 = gg (x^4 - 6 x^2 y^2 + y^4)
+    gx += gg * (4.0f * x2 * x - 12.0f * x * y2) * g[24]; gyv += gg * (4.0f * y2 * y - 12.0f * x2 * y) * g[24];
+  }
+  gu[3 * p] = gx; gu[3 * p + 1] = gyv; gu[3 * p + 2] = gz;
+}
+
 // rbf[p][k] and (optionally) the integrand of d/d alpha:  drbf/dalpha = rbf * (-r) * (n_k - v_k e^x / (1 - e^x))
-template <bool GRAD>
+template <int GRAD>   // 0: values; 1: sum_k g dRBF/dalpha per row; 2: sum_k g dRBF/dr per row
 __global__ void k_bernstein_rbf(const float* __restrict__ r, long P, int K, float alpha_host, float cutoff, const float* __restrict__ logc,
                                 const float* __restrict__ nk, const float* __restrict__ vk, float* __restrict__ out,
                                 const float* __restrict__ gout, float* __restrict__ galpha_rows, const float* __restrict__ alpha_dev) {
@@ -67,9 +133,12 @@ __global__ void k_bernstein_rbf(const float* __restrict__ r, long P, int K, floa
       const float om = -expm1f(x);                 // 1 - e^x
       const float ratio = (1.0f - om) / om;        // e^x / (1 - e^x)
       const float lg = logf(om);
+      const float c2mr2 = (cutoff - rr) * (cutoff + rr);
+      const float dlogfc = -2.0f * rr * cutoff * cutoff / (c2mr2 * c2mr2);      // d/dr of -r^2 / (c^2 - r^2)
       for (int k = 0; k < K; ++k) {
         const float val = fc * expf(logc[k] + nk[k] * x + vk[k] * lg);
-        acc = fmaf(gout[p * K + k] * val, -rr * (nk[k] - vk[k] * ratio), acc);
+        const float dx = nk[k] - vk[k] * ratio;                                  // d/dx of the exponent
+        acc = fmaf(gout[p * K + k] * val, GRAD == 1 ? -rr * dx : dlogfc - alpha * dx, acc);
       }
     }
     galpha_rows[p] = acc;
@@ -92,7 +161,7 @@ int nq_bernstein_rbf(const float* r, int64_t P, int32_t K, float alpha, float cu
   if (!r || !logc || !n || !v || !out || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf");
-  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<0>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
                                 out, nullptr, nullptr, nullptr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
@@ -104,7 +173,7 @@ int nq_bernstein_rbf_dev(const float* r, int64_t P, int32_t K, const float* alph
   if (!r || !alpha_dev || !logc || !n || !v || !out || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf");
-  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<false>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<0>), dim3((unsigned)((P * K + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
                                 out, nullptr, nullptr, alpha_dev);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
@@ -114,8 +183,30 @@ int nq_bernstein_rbf_grad_alpha_dev(const float* r, const float* grad_out, int64
   if (!r || !grad_out || !alpha_dev || !logc || !n || !v || !galpha_rows || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf_grad");
-  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<1>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
                                 nullptr, grad_out, galpha_rows, alpha_dev);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* gr[p] = sum_k grad_out[p][k] * d rbf[p][k] / d r (smooth cutoff included): the radial half of -dE/dR (phisnet/nn/neural_network.py:981-984) */
+int nq_bernstein_rbf_grad_r_dev(const float* r, const float* grad_out, int64_t P, int32_t K, const float* alpha_dev, float cutoff, const float* logc,
+                                const float* n, const float* v, float* gr, void* stream) {
+  if (!r || !grad_out || !alpha_dev || !logc || !n || !v || !gr || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "bernstein_rbf_grad_r");
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<2>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, 0.f, cutoff, logc, n, v,
+                                nullptr, grad_out, gr, alpha_dev);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+/* gu [P][3] = sum_c grad_out[P][(order+1)^2] dY_c / d(x, y, z) (the harmonics as polynomials of a free vector; the caller chains through u = r / |r|) */
+int nq_sph_harm_backward(const float* unit_vectors, const float* grad_out, int64_t P, int32_t order, float* gu, void* stream) {
+  if (!unit_vectors || !grad_out || !gu || order < 0 || order > 4 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument (orders 0..4)");
+  hipStream_t st = (hipStream_t)stream;
+  NQ_PROF(st, "sph_harm_bwd");
+  if (P > 0) hipLaunchKernelGGL(k_sph_harm_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, unit_vectors, grad_out, (long)P, order, gu);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -126,7 +217,7 @@ int nq_bernstein_rbf_grad_alpha(const float* r, const float* grad_out, int64_t P
   if (!r || !grad_out || !logc || !n || !v || !galpha_rows || K <= 0 || P < 0) return nq_fail(NQ_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   NQ_PROF(st, "bernstein_rbf_grad");
-  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<true>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
+  if (P > 0) hipLaunchKernelGGL((k_bernstein_rbf<1>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, r, (long)P, K, alpha, cutoff, logc, n, v,
                                 nullptr, grad_out, galpha_rows, nullptr);
   NQ_LAUNCH_CHECK();
   return NQ_OK;

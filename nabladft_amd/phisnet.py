@@ -510,7 +510,9 @@ class NeuralNetwork(nn.Module):
       * ``pindex``: {molecule size: (idx_pi, idx_pj)} (the reference loads ``modules/pindex_dict.npy``, missing from its tree); default = the
         inferred table ``inferred_pair_of_pairs`` -- UNVERIFIED;
       * matrices are returned packed (``*_packed``, differentiable) and dense ([1, Norb, Norb], detached copy as in the reference's layout);
-      * forces (``calculate_forces``) and the non-Bernstein radial bases are not built (raise); ``predict_energy`` (EnergyLayer) is."""
+      * forces (``predict_energy`` + ``calculate_forces``, neural_network.py:737, :981-984): ``-dE/dR`` through the adjoints of the geometry bases
+        (nq_sph_harm_backward, nq_bernstein_rbf_grad_r_dev), FIRST ORDER only -- set ``create_graph = False`` (inference / evaluation; the reference's
+        default True keeps the second-order graph for a force loss, which the HIP ops do not provide: raises).  exp-bernstein basis only."""
 
     def __init__(self, max_orbitals=None, order=None, num_features=None, num_basis_functions=None, num_modules=None, num_residual_pre_x=None,
                  num_residual_post_x=None, num_residual_pre_vi=None, num_residual_pre_vj=None, num_residual_post_v=None, num_residual_output=None,
@@ -528,6 +530,7 @@ class NeuralNetwork(nn.Module):
             raise ValueError(f"basis function type: {basis_functions} is not supported")
         self.calculate_full_hamiltonian = self.calculate_core_hamiltonian = self.calculate_overlap_matrix = True
         self.calculate_energy = self.predict_energy = self.calculate_forces = False
+        self.create_graph = True                       # neural_network.py:93; forces need False here (first-order adjoints only)
         self.max_orbitals, self.order, self.num_features, self.num_basis_functions = max_orbitals, order, num_features, num_basis_functions
         self.num_modules, self.cutoff, self.activation, self.Zmax = num_modules, cutoff, activation, Zmax
         order_max = max(l for orbs in max_orbitals for _, l in orbs)
@@ -630,6 +633,9 @@ class NeuralNetwork(nn.Module):
                                plan=self._assembler.plan(Z[0], ptr, idx_i, idx_j), sizes=sizes, checked=False)
 
     def forward(self, atoms_batch):
+        if self.predict_energy and self.calculate_forces and not torch.is_grad_enabled():
+            with torch.enable_grad():                   # forces are a derivative: the graph is needed even under torch.no_grad()
+                return self.forward(atoms_batch)
         R = atoms_batch["positions"]
         R = R.view(1, -1, 3)
         _require_gpu(R)
@@ -640,6 +646,12 @@ class NeuralNetwork(nn.Module):
         self.idx_i, self.idx_j, self.idx_pi, self.idx_pj = prep.idx_i, prep.idx_j, prep.idx_pi, prep.idx_pj
         ptr, idx_i, idx_j, pidx, ppidx = prep.ptr, prep.idx_i, prep.idx_j, prep.pidx, prep.ppidx
         N, P = Z.shape[1], idx_i.numel()
+        want_forces = bool(self.predict_energy and self.calculate_forces)
+        if want_forces:
+            if self.create_graph:
+                raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: forces with create_graph=True (a force LOSS: second-order derivatives) are not "
+                                          "built; set net.create_graph = False for inference / evaluation forces")
+            R = R.detach().clone().requires_grad_(True)          # neural_network.py:737 (R.requires_grad = True), without touching the caller's tensor
         rij = R[0].index_select(0, idx_j) - R[0].index_select(0, idx_i)
         dij = rij.norm(dim=-1, keepdim=True)
         uij = rij / dij
@@ -689,8 +701,6 @@ class NeuralNetwork(nn.Module):
         for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):
             if k + "_packed" in results:
                 results[k] = asm.to_dense(plan, results[k + "_packed"].detach()).unsqueeze(0)
-        if self.calculate_forces:
-            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: forces (-dE/dR through the geometry bases) are not built")
         norb, eye = plan.m_total, None
         for k in ("full_hamiltonian", "core_hamiltonian", "overlap_matrix"):                # a disabled matrix is the identity (:935-966)
             if k not in results:
@@ -701,7 +711,11 @@ class NeuralNetwork(nn.Module):
             results["energy"] = self.energy_predictor(fii, fij, sizes, [n * (n - 1) for n in sizes])
         else:
             results["energy"] = torch.zeros(1, 1, device=R.device, dtype=R.dtype)
-        results["forces"] = torch.zeros_like(R)
+        if want_forces:                                            # neural_network.py:981-984
+            with torch.enable_grad():
+                results["forces"] = -torch.autograd.grad(torch.sum(results["energy"]), R, create_graph=False, retain_graph=True)[0]
+        else:
+            results["forces"] = torch.zeros_like(R)
         results["orbital_energies"] = torch.zeros(1, norb, device=R.device, dtype=R.dtype)
         results["orbital_coefficients"] = torch.zeros(1, norb, norb, device=R.device, dtype=R.dtype)
         results["plan"] = plan

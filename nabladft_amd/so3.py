@@ -304,17 +304,45 @@ class SelfMixing(nn.Module):
 
 
 # ---- geometry bases (radial part of a13) --------------------------------------------------------------------
+class _SphHarmFn(torch.autograd.Function):
+    """Y_0..Y_L of (unit) vectors with the adjoint w.r.t. the vectors (nq_sph_harm_backward): the harmonics are differentiated as polynomials of a free
+    vector, as autograd does with the reference's closed forms; first order only (forces at inference, create_graph=False)."""
+
+    @staticmethod
+    def forward(ctx, u2, L):
+        lib = _lib.load()
+        out = torch.empty(u2.shape[0], (L + 1) ** 2, device=u2.device, dtype=torch.float32)
+        _lib.check(lib.nq_sph_harm(_lib.ptr(u2), u2.shape[0], L, _lib.ptr(out), _lib.stream_ptr()))
+        ctx.save_for_backward(u2)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        (u2,) = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        gu = torch.empty_like(u2)
+        _lib.check(lib.nq_sph_harm_backward(_lib.ptr(u2), _lib.ptr(g), u2.shape[0], ctx.L, _lib.ptr(gu), _lib.stream_ptr()))
+        return gu, None
+
+
 def spherical_harmonics(L: int, u: torch.Tensor) -> List[torch.Tensor]:
     """List over l = 0..L of [..., 2l+1]: same call and conventions as phisnet/nn/spherical_harmonics/spherical_harmonics.py:28-64
-    (unit vectors in, no 1/sqrt(4 pi), Condon-Shortley phase, m = -l..l).  L <= 4 on the GPU path."""
+    (unit vectors in, no 1/sqrt(4 pi), Condon-Shortley phase, m = -l..l).  L <= 4 on the GPU path.  Differentiable w.r.t. ``u`` (first order) when
+    ``u`` requires a gradient (PhiSNet forces)."""
     _require_gpu(u)
     if L > cg.LMAX:
         raise NotImplementedError(f"nabladft_amd.so3.spherical_harmonics: orders up to {cg.LMAX} are built")
-    lib = _lib.load()
     lead = u.shape[:-1]
-    u2 = u.detach().to(torch.float32).reshape(-1, 3).contiguous()
-    out = torch.empty(u2.shape[0], (L + 1) ** 2, device=u.device, dtype=torch.float32)
-    _lib.check(lib.nq_sph_harm(_lib.ptr(u2), u2.shape[0], L, _lib.ptr(out), _lib.stream_ptr()))
+    if torch.is_grad_enabled() and u.requires_grad:
+        out = _SphHarmFn.apply(u.to(torch.float32).reshape(-1, 3).contiguous(), L)
+    else:
+        lib = _lib.load()
+        u2 = u.detach().to(torch.float32).reshape(-1, 3).contiguous()
+        out = torch.empty(u2.shape[0], (L + 1) ** 2, device=u.device, dtype=torch.float32)
+        _lib.check(lib.nq_sph_harm(_lib.ptr(u2), u2.shape[0], L, _lib.ptr(out), _lib.stream_ptr()))
     return [out[:, l * l:(l + 1) * (l + 1)].reshape(*lead, 2 * l + 1) for l in range(L + 1)]
 
 
@@ -345,13 +373,19 @@ class _BernsteinFn(torch.autograd.Function):
         _lib.check(lib.nq_bernstein_rbf_grad_alpha_dev(_lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, _lib.ptr(alpha), cutoff, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v),
                                                        _lib.ptr(rows), _lib.stream_ptr()))
         g_raw = rows.double().sum() * torch.sigmoid(raw_alpha.detach().double())       # d softplus
-        return None, g_raw.to(raw_alpha.dtype).reshape(raw_alpha.shape), None
+        gr = None
+        if ctx.needs_input_grad[0]:                                                    # distances differentiated: forces = -dE/dR (first order only)
+            gr = torch.empty(r2.shape[0], device=r2.device, dtype=torch.float32)
+            _lib.check(lib.nq_bernstein_rbf_grad_r_dev(_lib.ptr(r2), _lib.ptr(g2), r2.shape[0], K, _lib.ptr(alpha), cutoff, _lib.ptr(logc), _lib.ptr(n), _lib.ptr(v),
+                                                       _lib.ptr(gr), _lib.stream_ptr()))
+            gr = gr.view(ctx.meta[2])
+        return gr, g_raw.to(raw_alpha.dtype).reshape(raw_alpha.shape), None
 
 
 class ExponentialBernsteinRadialBasisFunctions(nn.Module):
     """Same constructor, buffers (cutoff, logc, n, v) and parameter (_alpha) as the reference classes of that name
     (phisnet/nn/modules/exponential_bernstein_radial_basis_functions.py:13-41, qhnet/layers.py:92-120).  forward(r [..., 1]) -> [..., K].
-    Gradient: w.r.t. ``_alpha`` only (distances are inputs of the Hamiltonian models, not differentiated)."""
+    Gradient: w.r.t. ``_alpha``, and (first order) w.r.t. the distances when they require a gradient (PhiSNet forces)."""
 
     def __init__(self, num_basis_functions, cutoff, ini_alpha=0.5, dtype=torch.float32):
         super().__init__()
@@ -410,6 +444,8 @@ class _RadialFn(torch.autograd.Function):
     def backward(ctx, g):
         kind, alpha, cutoff, width, K = ctx.meta
         r2, raw_alpha, *t = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("d(radial basis)/dr (forces) is built for the exponential Bernstein basis only (basis_functions='exp-bernstein')")
         if kind not in (2, 3):
             return None, torch.zeros_like(raw_alpha), None            # "_alpha" of the Gaussian basis "doesn't do anything"
         lib = _lib.load()

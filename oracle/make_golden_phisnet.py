@@ -66,7 +66,7 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix", "--network"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix", "--network", "--forces"} & set(sys.argv)):
     main()
 
 
@@ -266,7 +266,7 @@ if __name__ == "__main__" and "--matrix" in sys.argv:
     matrix_assembly()
 
 
-def network():
+def _network_setup():
     """The REAL NeuralNetwork end to end (embedding -> modules -> pair features -> irreps -> matrices) on a small batch.  CAVEAT, also in
     DESIGN.md: the reference reads its pair-of-pairs table from modules/pindex_dict.npy, which its tree does not contain; the load is answered
     here with the inferred table (nabladft_amd.phisnet.inferred_pair_of_pairs), so this fixture pins everything except that table's content."""
@@ -307,6 +307,12 @@ def network():
     pos = np.concatenate([rng.normal(0, 1.1, size=(s, 3)) + 0.0 for s in sizes]).astype(np.float32)
     batch = dict(positions=torch.tensor(pos).view(1, -1, 3), atomic_numbers=torch.tensor(zs), orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs],
                  molecule_size=torch.tensor(sizes))
+    return m, batch, hp, rng, zs, pos, sizes
+
+
+def network():
+    """Fixture phisnet_network.npz: matrices, energy and all parameter gradients of the REAL NeuralNetwork (see _network_setup)."""
+    m, batch, hp, rng, zs, pos, sizes = _network_setup()
     m.predict_energy = True
     import copy
     m64 = copy.deepcopy(m).double()             # the same network evaluated in float64: the truth both fp32 evaluations are measured against
@@ -339,5 +345,27 @@ def network():
     print("phisnet_network.npz:", len(fx), "arrays; Norb", fx["full_hamiltonian"].shape, "params", sum(p.numel() for p in m.parameters()))
 
 
+def forces():
+    """Fixture phisnet_forces.npz: the REAL NeuralNetwork with predict_energy = calculate_forces = True (neural_network.py:92-93, :737, :981-984:
+    forces = -autograd.grad(sum(energy), R)), create_graph = False (inference: no second-order graph), evaluated in float32 and in float64."""
+    import copy
+    m, batch, hp, rng, zs, pos, sizes = _network_setup()
+    m.predict_energy = m.calculate_forces = True
+    m.create_graph = False
+    m64 = copy.deepcopy(m).double()
+    out = m(dict(batch, positions=batch["positions"].clone()))
+    out64 = m64(dict(batch, positions=batch["positions"].double()))
+    fx = dict(z=zs, positions=pos, sizes=np.array(sizes), hp=np.array([hp["order"], hp["num_features"], hp["num_basis_functions"], hp["num_modules"]]),
+              cutoff=np.float64(hp["cutoff"]), energy=out["energy"].detach().numpy(), forces=out["forces"].detach().numpy()[0])
+    fx["f64:energy"], fx["f64:forces"] = out64["energy"].detach().numpy(), out64["forces"].detach().numpy()[0]
+    for n, p in m.named_parameters():
+        fx["p:" + n] = p.detach().numpy()
+    assert np.abs(fx["forces"]).max() > 0
+    np.savez_compressed(os.path.join(OUT, "phisnet_forces.npz"), **fx)
+    print("phisnet_forces.npz: |F|max", np.abs(fx["forces"]).max(), "fp32 vs fp64", np.abs(fx["forces"] - fx["f64:forces"]).max() / np.abs(fx["f64:forces"]).max())
+
+
 if __name__ == "__main__" and "--network" in sys.argv:
     network()
+if __name__ == "__main__" and "--forces" in sys.argv:
+    forces()

@@ -255,3 +255,46 @@ def test_graphed_training_step_equals_eager_steps():
     assert np.allclose(l_eager, l_graph, rtol=1e-6), (l_eager, l_graph)
     assert float((p_eager - p_graph).abs().max()) < 1e-6
     assert len(set(l_graph)) == 3                      # the replays really saw the new positions
+
+
+def test_forces_match_reference():
+    """predict_energy + calculate_forces (neural_network.py:92-93, :737, :981-984): forces = -dE/dR through the adjoints of the spherical harmonics and the
+    radial basis, against the REAL NeuralNetwork.forward with create_graph = False (oracle/make_golden_phisnet.py --forces; float64 run = truth, the
+    reference's float32 run = yardstick).  create_graph = True (force loss, second order) is not built and must say so."""
+    from tests.helpers import assert_parity
+    fx = np.load(os.path.join(GOLDEN, "phisnet_network.npz"))
+    ff = np.load(os.path.join(GOLDEN, "phisnet_forces.npz"))
+    m, shells = _network_from_fixture(fx)
+    for n, p in m.named_parameters():
+        assert np.array_equal(ff["p:" + n], fx["p:" + n]), n                           # both fixtures are the same network
+    assert np.array_equal(ff["positions"], fx["positions"]) and np.array_equal(ff["z"], fx["z"])
+    zs = fx["z"]
+    pos = torch.tensor(fx["positions"]).view(1, -1, 3).cuda()
+    batch = dict(positions=pos, atomic_numbers=torch.tensor(zs).cuda(), orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs],
+                 molecule_size=torch.tensor(fx["sizes"]))
+    m.predict_energy = m.calculate_forces = True
+    with pytest.raises(NotImplementedError):
+        m(batch)                                                                        # default create_graph = True (the reference's default): second order
+    m.create_graph = False
+    out = m(batch)
+    assert not pos.requires_grad                                                        # the caller's tensor is left alone
+    assert out["forces"].shape == (1, len(zs), 3)
+    assert_parity("phisnet forces E", out["energy"].detach().cpu().numpy(), ff["f64:energy"], ff["energy"])
+    assert_parity("phisnet forces F", out["forces"][0].detach().cpu().numpy(), ff["f64:forces"], ff["forces"])
+    with torch.no_grad():                                                               # inference under no_grad still differentiates internally
+        out2 = m(batch)
+    assert torch.equal(out2["forces"], out["forces"])
+    # the matrices are still differentiable after the force evaluation (retain_graph)
+    out["full_hamiltonian_packed"].sum().backward()
+    # forces of a molecule do not depend on the other molecules of the batch, and a rigid translation leaves them unchanged
+    sizes = fx["sizes"].tolist()
+    sel = np.arange(sizes[0])
+    b1 = dict(positions=(torch.tensor(fx["positions"][sel]) + 0.37).view(1, -1, 3).cuda(), atomic_numbers=torch.tensor(zs[sel]).cuda(),
+              orbitals=[tuple((int(a), l) for l in shells[int(a)]) for a in zs[sel]], molecule_size=torch.tensor([sizes[0]]))
+    f1 = m(b1)["forces"][0]
+    assert rel_err(f1.detach().cpu().numpy(), out["forces"][0][: sizes[0]].detach().cpu().numpy()) < 2e-5
+    # net force on each molecule vanishes (translation invariance of E)
+    o = 0
+    for n in sizes:
+        assert float(out["forces"][0][o:o + n].sum(0).abs().max()) < 1e-5 * float(out["forces"].abs().max()) * n
+        o += n
