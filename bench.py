@@ -833,6 +833,16 @@ def main():
                   "batch16_bf16_gemms": {k: g16b.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "final_loss", "roofline", "gemm_bf16_ms_per_step")},
                   "cpu_baseline": None if args.no_cpu_baseline else BG.cpu_baseline(seconds_budget=15.0)}
 
+    phisnet = None
+    if rank == 0 and world == 1 and not args.no_roofline and args.full and args.model == "painn-oc":
+        # PhiSNet (rows a21-a24; north_star "QHNet/PhiSNet SO(3) tensor-product convolutions") at the nablaDFT configuration, 2 molecules per step, in the same record
+        torch.cuda.empty_cache()
+        import bench_phisnet as BP
+        try:
+            phisnet = {"eager": BP.run(2, 42, 10, 3, kernels=True, forces=True), "graph_replay": BP.run(2, 42, 10, 3, graph=True)}
+        except Exception as e:                      # a failed capture must not cost the record its other legs
+            phisnet = {"error": repr(e)[:300]}
+
     escn = equiformer = None
     if rank == 0 and world == 1 and not args.no_roofline and args.full and args.model == "painn-oc":
         # BASELINE.json configs[4] (eSCN, config/model/escn-oc.yaml, fp32) in the same record
@@ -863,6 +873,7 @@ def main():
             "mae_vs_cpu_reference": parity,
             "sibling_config": other,
             "hamiltonian": hamiltonian,
+            "phisnet": phisnet,
             "gemnet_oc": gemnet,
             "escn": escn,
             "equiformer_v2": equiformer,

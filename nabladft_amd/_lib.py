@@ -246,3 +246,17 @@ def profile_read(cap=4096, stride=64):
         nm = names.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode()
         out[nm] = (tot[i], cnt[i], fl[i])
     return out
+
+
+def geometry_key(data):
+    """What a prepared batch (net.prepare(data)) is tied to: the identity AND the in-place version of the position tensor plus the atom count.  A forward with
+    ``data.prepared`` compares it, so positions updated in place (MD, geometry optimisation, refreshed inputs of a captured step) or another batch of the
+    same size cannot silently reuse a stale neighbour list / frames / Wigner rows."""
+    pos = data.pos
+    return (int(pos.data_ptr()), int(pos._version), tuple(pos.shape), int(data.z.data_ptr()) if getattr(data, "z", None) is not None and hasattr(data.z, "data_ptr") else 0)
+
+
+def check_prepared(prep, data):
+    key = getattr(prep, "geometry_key", None)
+    if key is not None and key != geometry_key(data):
+        raise ValueError("data.prepared was built for another geometry (positions changed in place, or another batch): call net.prepare(data) again")

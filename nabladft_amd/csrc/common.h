@@ -177,7 +177,9 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
                         int* row_ptr, int* lowptr, int* E_host, hipStream_t st);
 int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st);
 
-int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode);
+int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode,
+                   const char* tag = nullptr);
+int nq_gemm_nt_dsilu(hipStream_t st, const float* A, const float* W, float* C, float* C2, const float* aux, int M, int N, int K, const char* tag = nullptr);
 int nq_gemm_nt_act(hipStream_t, const float* A, const float* W, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
                    const char* tag = nullptr);
 int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K, int lda,

@@ -375,8 +375,8 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
     NQ_TRY(nq_upd_rev(st, u, 1, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, 3 * F, F, F, 0, "V2"));
-    NQ_TRY(nq_silu_rev(st, ws + y.ZQ, nullptr, ws + W.GQ, nullptr, (long)NF, false));
+    // G_Q = (G_Y V2) * silu'(Z_Q): the activation's adjoint in the epilogue of the input-gradient product (no separate k_silu_rev pass)
+    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2"));
     NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
@@ -392,8 +392,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
       NQ_TRY(nq_msg_rev(st, m, false));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, 3 * F, F, F, 0, "W2"));
-    NQ_TRY(nq_silu_rev(st, ws + y.Z1, nullptr, ws + W.GH, nullptr, (long)NF, false));
+    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2"));
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1, "W1"));
   }
   NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
@@ -503,8 +502,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     float* TZ1 = ws + y.Z1 + NF; float* TH = ws + y.Hh + NF; float* TXH = ws + y.XH + 3 * NF;
-    NQ_TRY(nq_gemm_nt(st, ws + W.X[l] + NF, params + mp.W1, TZ1, nullptr, nullptr, N, F, F, F, F, F, "W1"));
-    NQ_TRY(nq_silu_tan(st, ws + y.Z1, TZ1, TH, (long)NF));
+    // tangent pre-activation and tangent activation TH = TZ1 * silu'(Z1) in one pass
+    NQ_TRY(nq_gemm_nt_dsilu(st, ws + W.X[l] + NF, params + mp.W1, TZ1, TH, ws + y.Z1, N, F, F, "W1"));
     NQ_TRY(nq_gemm_nt(st, TH, params + mp.W2, TXH, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "W2"));
     MsgArgs m{};
     m.g = g; m.F = F; m.X = ws + W.X[l]; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
@@ -525,8 +524,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF; u.TX1 = ws + W.X[l + 1] + NF; u.TV1 = ws + W.V[l + 1] + 3 * NF;
     NQ_TRY(nq_upd_a(st, u, true));
     float* TZQ = ws + y.ZQ + NF; float* TQ = ws + y.Q + NF;
-    NQ_TRY(nq_gemm_nt(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, nullptr, nullptr, N, F, 2 * F, 2 * F, 2 * F, F, "V1"));
-    NQ_TRY(nq_silu_tan(st, ws + y.ZQ, TZQ, TQ, (long)NF));
+    NQ_TRY(nq_gemm_nt_dsilu(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, TQ, ws + y.ZQ, N, F, 2 * F, "V1"));
     NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
     NQ_TRY(nq_upd_b(st, u, true));
   }

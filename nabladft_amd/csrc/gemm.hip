@@ -208,6 +208,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
         else Cout[off] = v;
         if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
         if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);
+        if (EPI == EPI_DSILU2) p.C2[off] = v * nq_dsilu_fast(p.resid[off]);
       }
     }
 }
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256) void k_gemm_small(GemmArgs p) {
     else p.C[off] = v;
     if (EPI == EPI_SILU) p.C2[off] = nq_silu(v);
     if (EPI == EPI_SILU_RES) p.C2[off] = p.resid ? p.ea * p.resid[off] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);
+    if (EPI == EPI_DSILU2) p.C2[off] = v * nq_dsilu_fast(p.resid[off]);
   }
 }
 // fewer than one 128x128 tile per CU -> the small-tile kernel
@@ -412,7 +414,7 @@ static bool gemm3_ok(const GemmArgs& p, long kspan, int splits) {
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
   // 168 registers (3 workgroups per CU) hold the plain epilogues; one that reads a second tile (+=, SiLU' / residual operands: 64 more registers) gets 256
-  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
+  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES || EPI == EPI_DSILU2;
   constexpr int WPE = AUX ? 2 : 3;
   const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
   const dim3 grid((unsigned)(tiles < 256 * WPE ? tiles : 256 * WPE));
@@ -493,6 +495,28 @@ int nq_gemm_nt_act(hipStream_t st, const float* A, const float* W, float* C, flo
   return NQ_OK;
 }
 
+// C[M, N] = A W^T (no bias) and C2 = C * silu'(aux): the tangent of a Linear + SiLU layer in one pass (aux = the primal pre-activation Z, C = the tangent
+// pre-activation, C2 = the tangent of the activation); leading dimensions = the matrix widths
+int nq_gemm_nt_dsilu(hipStream_t st, const float* A, const float* W, float* C, float* C2, const float* aux, int M, int N, int K, const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nt:%s[n=%d,k=%d]", tag ? tag : "", N, K); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * N * K);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{A, W, C, nullptr, C2, M, N, K, K, K, N, 0, 0, nullptr, 0};
+  p.resid = aux; p.ea = 0.f; p.eb = 1.f;
+  if (gemm3_ok<true, true>(p, K, 1)) {
+    NQ_TRY((launch_gemm3<true, true, EPI_DSILU2>(st, p, 1)));
+  } else if (gemm2_ok<true, true>(p, K)) {
+    launch_gemm2<true, true, EPI_DSILU2>(st, p, 1);
+  } else if (gemm_is_small(M, N) && !(g_gemm_variant & 8)) {
+    hipLaunchKernelGGL((k_gemm_small<true, EPI_DSILU2>), dim3(nq_cdiv(M, SM), nq_cdiv(N, SM), 1), dim3(256), 0, st, p);
+  } else {
+    launch_gemm<true, true, EPI_DSILU2>(st, dim3(nq_cdiv(M, BM), nq_cdiv(N, BN), 1), p);
+  }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
 // C[M, N] = ea * aux + A W^T   (aux [M, N], must not alias C): the second product of a two-term sum (the +-m pairs of the SO(2) convolutions:
 // out_p = x_p W_r^T - x_m W_i^T is a plain product into t followed by this one with aux = t, ea = -1 -- no separate linear-combination pass)
 int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, const float* aux, float ea, int M, int N, int K) {
@@ -550,8 +574,8 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 }
 
 // C[M, Kin] = epilogue(G[M, Nout] * W[Nout, Kin]): mode 1: eb * v * silu'(aux), mode 2: ea * aux + v   (aux [M, Kin])
-int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode) {
-  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:[n=%d,k=%d]", Kin, Nout); else nm__[0] = 0;
+int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode, const char* tag) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
@@ -611,12 +635,23 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
     return NQ_OK;
   }
   if (rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn: too many rows");
-  const int ns = tn_splits(rows, Mo, No, tn_slots(bias_out != nullptr));
-  int kper = (int)((rows + ns - 1) / ns);
-  kper = (kper + 31) / 32 * 32;   // whole k-tiles (BKT = 32 for the TN launches)
-  float* bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
-  GemmArgs p{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
-  const int nse = nq_cdiv(rows, kper);   // splits that actually hold rows (<= ns); only their slabs are reduced
+  // The split count belongs to the engine that RUNS: sized for the split engine's 3 x 256 workgroup slots first; if that launch turns out not to be
+  // eligible for it (operand alignment, M / N not multiples of 4, too few tiles) the count is taken again for the 2 x 256 slots of the exact / generic
+  // engines (they used to inherit a split count tuned for the other engine).
+  int ns = 0, kper = 0, nse = 0;
+  float* bpart = nullptr;
+  GemmArgs p{};
+  auto plan = [&](int slots) {
+    ns = tn_splits(rows, Mo, No, slots);
+    kper = (int)((rows + ns - 1) / ns);
+    kper = (kper + 31) / 32 * 32;   // whole k-tiles (BKT = 32 for the TN launches)
+    bpart = bias_out ? scratch + (size_t)ns * Mo * No : nullptr;
+    p = GemmArgs{GY, X, scratch, nullptr, nullptr, Mo, No, (int)rows, ldg, ldx, No, kper, (long)Mo * No, bpart, (int)bias_rows};
+    nse = nq_cdiv(rows, kper);      // splits that actually hold rows (<= ns); only their slabs are reduced
+  };
+  const int slots0 = tn_slots(bias_out != nullptr);
+  plan(slots0);
+  if (slots0 != 512 && !gemm3_ok<false, false>(p, kper, nse)) plan(512);
   if (gemm3_ok<false, false>(p, kper, nse)) NQ_TRY((launch_gemm3<false, false, EPI_PARTIAL>(st, p, nse)));
   else if (gemm2_ok<false, false>(p, kper)) launch_gemm2<false, false, EPI_PARTIAL>(st, p, nse);
   else launch_gemm<false, false, EPI_PARTIAL>(st, dim3(nq_cdiv(Mo, BM), nq_cdiv(No, BN), nse), p);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   using SB = SplitStage<B_KC>;
   constexpr int BUF = SA::BYTES + SB::BYTES;   // 24 KB: two buffers (+ the bias-gradient lines) = 49 KB, three workgroups per CU
   constexpr int NLOADS = SA::NLOADS + SB::NLOADS;   // load instructions of one step's fetch
-  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
+  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES || EPI == EPI_DSILU2;
   constexpr bool BIAS = EPI == EPI_PARTIAL && !A_KC && WBIAS;
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF + (BIAS ? 2 * 128 * 4 : 0)];
 

@@ -15,7 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4, EPI_DSILU = 5, EPI_RES = 6 };   // 4: C = v, C2 = ea * resid + eb * silu(v)
+enum { EPI_STORE = 0, EPI_SILU = 1, EPI_ACC = 2, EPI_PARTIAL = 3, EPI_SILU_RES = 4, EPI_DSILU = 5, EPI_RES = 6, EPI_DSILU2 = 7 };   // 4: C = v, C2 = ea * resid + eb * silu(v); 7: C = v, C2 = v * silu'(aux)
 
 struct GemmArgs {
   const float* A; const float* B; float* C; const float* bias; float* C2;
@@ -130,9 +130,10 @@ __device__ __forceinline__ void gemm_store_acc(const f32x16& a, const f32x16& x,
     else if (EPI == EPI_DSILU) *cptr = p.eb * v * nq_dsilu_fast(x[r]);   // 5: C = eb * v * silu'(aux)   (adjoint of the activation of the layer below)
     else if (EPI == EPI_RES) *cptr = p.ea * x[r] + v;                    // 6: C = ea * aux + v          (skip connection of the adjoint)
     else *cptr = v;
-    if (EPI == EPI_SILU || EPI == EPI_SILU_RES) {
+    if (EPI == EPI_SILU || EPI == EPI_SILU_RES || EPI == EPI_DSILU2) {
       float* c2 = reinterpret_cast<float*>(reinterpret_cast<char*>(p.C2 + tile_off) + rc * row_bytes + boff);
       if (EPI == EPI_SILU) *c2 = nq_silu(v);
+      else if (EPI == EPI_DSILU2) *c2 = v * nq_dsilu_fast(x[r]);   // 7: C = v, C2 = v * silu'(aux): tangent of a Linear + SiLU layer (aux = the primal pre-activation)
       else *c2 = p.resid ? p.ea * x[r] + p.eb * nq_silu_fast(v) : p.eb * nq_silu_fast(v);   // 4: C = v, C2 = ea * resid + eb * silu(v)   (resid nullable)
     }
   }
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPE) void k_gemm2(GemmArgs p) {
   using SA = GemmStage<A_KC, BM, BK, NT>;
   using SB = GemmStage<B_KC, BN, BK, NT>;
   constexpr int BUF = SA::FLOATS + SB::FLOATS;
-  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES;
+  constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES || EPI == EPI_DSILU2;
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;

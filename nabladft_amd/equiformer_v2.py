@@ -772,6 +772,8 @@ class EquiformerV2_OC20(nn.Module):
             G = self.build_graph(data, edge_rot_mat)
         elif G.N != int(data.pos.shape[0]):
             raise ValueError("data.prepared belongs to another batch")
+        else:
+            _lib.check_prepared(G, data)
         K = self._constants(data.pos.device)
         Cc, nf = self.sphere_channels, K.order.n_full
         emb = _EmbeddingFn.apply(self.sphere_embedding.weight, G.z, [G.z_inverse])                     # the l = 0 coefficient (equiformer_v2_oc20.py:517-530)

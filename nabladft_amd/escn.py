@@ -595,7 +595,9 @@ class eSCN(torch.nn.Module):
     def prepare(self, data, edge_rot_mat=None):
         """Graph, frames, Wigner rows and index lists of a batch (all host reads of the step happen here).  ``data.prepared = net.prepare(data)`` makes
         ``forward(data)`` free of host synchronisation: a training step on that batch can be captured into a HIP graph (trainer.GraphedStep)."""
-        return self.build_graph(data, edge_rot_mat)
+        G = self.build_graph(data, edge_rot_mat)
+        G.geometry_key = _lib.geometry_key(data)        # checked by forward: a prepared batch is tied to its geometry
+        return G
 
     def build_graph(self, data, edge_rot_mat=None):
         """radius graph + frames + Wigner rows (escn.py:313-325)."""
@@ -656,6 +658,8 @@ class eSCN(torch.nn.Module):
             G = self.build_graph(data, edge_rot_mat)
         elif G.N != int(data.pos.shape[0]):
             raise ValueError("data.prepared belongs to another batch")
+        else:
+            _lib.check_prepared(G, data)
         K = self._constants(data.pos.device)
         Cc, nf = self.sphere_channels, K.order.n_full
         emb = _EmbeddingFn.apply(self.sphere_embedding.weight, G.z, [G.z_inverse])                                   # [N, C] -> the l = 0 coefficient (escn.py:333-341)

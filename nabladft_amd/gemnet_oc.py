@@ -1212,6 +1212,7 @@ class GemNetOC(torch.nn.Module):
         G = self.get_graphs_and_indices(data)
         with torch.no_grad():
             self.atom_emb(G)                            # runs the range check once (sets G.z_checked)
+        G.geometry_key = _lib.geometry_key(data)        # checked by forward: a prepared batch is tied to its geometry
         return G
 
     def forward(self, data, return_intermediates: bool = False):
@@ -1223,6 +1224,8 @@ class GemNetOC(torch.nn.Module):
             G = self.get_graphs_and_indices(data)
         elif G.N != int(data.pos.shape[0]):
             raise ValueError("data.prepared belongs to another batch")
+        else:
+            _lib.check_prepared(G, data)
         B = self.get_bases(G)
         NS = self.num_spherical
         h = self.atom_emb(G)

@@ -22,6 +22,7 @@ second assignment (layers.py:440); Expansion.weights is an unused parameter (lay
 of the node features as even irreps (qhnet.py:56-58).
 """
 import ctypes as C
+import copy
 import math
 from typing import Dict, List, Optional
 
@@ -725,6 +726,7 @@ class QHNet(nn.Module):
         g.ptr = data.ptr.to(data.pos.device)
         g.transpose = transpose_index(g.ptr)
         g.n_atoms = int(data.pos.shape[0])
+        g.geometry_key = _lib.geometry_key(data)        # checked by forward: the edge sets depend on the positions
         return g
 
     def forward(self, data, keep_blocks=False, packed=False):
@@ -734,6 +736,9 @@ class QHNet(nn.Module):
             g = self.prepare(data)
         elif g.n_atoms != int(data.pos.shape[0]):
             raise ValueError("data.prepared belongs to another batch")
+        else:
+            _lib.check_prepared(g, data)
+        g = copy.copy(g)                                # per-call view: the autograd-tracked edge features below never land on the cached prepare() result
         self._features(g)
         z = data.z.squeeze().long()
         node_attr = self.node_embedding(z)

@@ -37,6 +37,13 @@ def synthetic_batch(molecules, atoms, seed=0):
     return dict(z=z, positions=np.concatenate(pos), sizes=np.array(sizes), orbitals=[tuple((int(a), l) for l in SHELLS[int(a)]) for a in z])
 
 
+def run(molecules=2, atoms=42, steps=20, warmup=3, kernels=False, graph=False, per_tensor_optimizer=False, forces=False):
+    """One record (dict) of the PhiSNet training step; ``forces`` adds the inference call with predict_energy + calculate_forces (first-order adjoints)."""
+    from types import SimpleNamespace
+    return _run(SimpleNamespace(molecules=molecules, atoms=atoms, steps=steps, warmup=warmup, kernels=kernels, graph=graph,
+                                per_tensor_optimizer=per_tensor_optimizer, forces=forces))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--molecules", type=int, default=2)
@@ -46,7 +53,11 @@ def main():
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event table (nq profile hooks)")
     ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph (trainer.GraphedStep) and replay it")
     ap.add_argument("--per-tensor-optimizer", action="store_true", help="torch Adam over the 2.4 k parameter tensors instead of the flat buffer")
-    a = ap.parse_args()
+    ap.add_argument("--forces", action="store_true", help="also time the energy + forces inference call (predict_energy, calculate_forces, create_graph=False)")
+    print(json.dumps(_run(ap.parse_args())))
+
+
+def _run(a):
     import torch
     from nabladft_amd import _lib
     from nabladft_amd.phisnet import NeuralNetwork
@@ -115,7 +126,26 @@ def main():
         _lib.profile_enable(False)
         out["device_ms_per_step_nq_kernels"] = sum(v[0] for v in prof.values()) / a.steps
         out["kernel_ms_per_step"] = {k: [round(v[0] / a.steps, 4), int(v[1] // a.steps)] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
-    print(json.dumps(out))
+        dense = {k: v for k, v in prof.items() if v[2] > 0}
+        if dense:   # the dense classes record their 2 M N K: TFLOP/s per class and the roofline entry of the largest one
+            k, v = max(dense.items(), key=lambda kv: kv[1][0])
+            ach = v[2] / (v[0] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                               "avg_launch_ms": v[0] / max(v[1], 1), "launches_per_step": int(v[1] // a.steps),
+                               "note": "largest dense launcher class of the step by device time; exact-f32 MFMA peak (these launches are below the split engine's 192-tile threshold)"}
+    if getattr(a, "forces", False):
+        m.predict_energy = m.calculate_forces = True
+        m.create_graph = False
+        for _ in range(2):
+            m(batch)
+        torch.cuda.synchronize()
+        t0 = __import__("time").perf_counter()
+        for _ in range(a.steps):
+            m(batch)
+        torch.cuda.synchronize()
+        out["energy_forces_inference_ms"] = 1e3 * (__import__("time").perf_counter() - t0) / a.steps
+        m.predict_energy = m.calculate_forces = False
+    return out
 
 
 if __name__ == "__main__":

@@ -140,7 +140,7 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
            "load_balance": {"cost_model": "qhnet", "this_run_predicted_spread": getattr(batches[0], "cost_spread", 0.0),
                             "predicted_spread_8_ranks_10_to_90_atoms_by_conformers_per_rank": nqdist.spread_table("qhnet")}, "atoms": N,
            "edges_within_cutoff": E, "ordered_pairs": P, "orbitals": int(net.last_plan.m_total), "parameters": net.get_number_of_parameters(),
-           "_dt": dt, "final_loss": float(loss), "dtype": "f32", "data": "synthetic", "parity": "pinned to the reference QHNet classes; e3nn arithmetic restated (unpinned)"}
+           "_dt": dt, "final_loss": float(loss.detach()), "dtype": "f32", "data": "synthetic", "parity": "pinned to the reference QHNet classes; e3nn arithmetic restated (unpinned)"}
     if kernels:
         _lib.profile_enable(True)
         for i in range(steps):

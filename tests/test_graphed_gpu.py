@@ -59,6 +59,31 @@ def test_prepared_batch_of_another_size_is_refused():
         net(b)
 
 
+def test_prepared_batch_is_tied_to_its_geometry():
+    """positions updated in place (MD, geometry optimisation, refreshed graph inputs) or another batch of the SAME size must not reuse a stale
+    neighbour list / frames / Wigner rows: prepare() records (data_ptr, in-place version, shape) of the positions and forward compares it."""
+    import bench_escn as BE
+    import bench_qhnet as BQ
+    dev = torch.device("cuda:0")
+    for mod in (BE, BQ):
+        net = mod.build(dev)
+        a = mod.synthetic_batch(2, 100, dev)
+        a.prepared = net.prepare(a)
+        with torch.no_grad():
+            net(a)                                          # unchanged geometry: accepted, twice
+            net(a)
+            a.pos.add_(0.01)                                # in place: same tensor, new version
+            with pytest.raises(ValueError):
+                net(a)
+            a.prepared = net.prepare(a)                     # prepared again: accepted
+            net(a)
+            b = mod.synthetic_batch(2, 100, dev)            # same sizes, other tensor
+            b.prepared = a.prepared
+            with pytest.raises(ValueError):
+                net(b)
+        assert not any(torch.is_tensor(v) and v.requires_grad for v in vars(a.prepared).values())      # nothing autograd-tracked is cached on it
+
+
 def test_qhnet_prepared_forward_is_free_of_host_synchronisation():
     """Capturing a region fails on any host read inside it: the forward on a prepared batch captures, replays, and equals the eager forward."""
     import bench_qhnet as BQ
