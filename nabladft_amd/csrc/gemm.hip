@@ -431,6 +431,77 @@ static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
   return NQ_OK;
 }
 
+// ---- split-K for long contractions with few output tiles (round 4) -----------------------------------------------------------------------------------
+// QHNet's generator adjoints are [rows x 5376] x [5376 x 32] and [rows x 8320] x [8320 x 128] at 17-28 k rows: 136-215 output tiles of 128 x 128, each a
+// 1.4-4.3 MB serial stream of the long operand -- one tile per CU at best, 2.2-2.5 TB/s.  With the contraction cut into S ranges (S x tiles workgroups,
+// partial slabs in a per-stream scratch of the library, fixed-order reduction that also applies bias / accumulation) the same bytes are streamed by the whole chip.
+#include <map>
+#include <mutex>
+static int splitk_count(int M, int N, int K) {
+  const long tiles = (long)nq_cdiv(M, 128) * nq_cdiv(N, 128);
+  if (K < 2048 || (K & 31) || tiles >= 256 || (g_gemm_variant & 128)) return 1;      // bit 7: never split (A/B switch)
+  long s = 768 / tiles;
+  if (s > K / 512) s = K / 512;          // >= 512 k per range
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
+}
+struct SplitkScratch { float* ptr = nullptr; size_t floats = 0; };
+static std::mutex g_splitk_mu;
+static std::map<std::pair<int, hipStream_t>, SplitkScratch> g_splitk;
+// grow-only buffer per (device, stream): a launch on stream s may only reuse what earlier launches of the SAME stream wrote (stream order protects it)
+static float* splitk_scratch(hipStream_t st, size_t floats) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_splitk_mu);
+  SplitkScratch& b = g_splitk[{dev, st}];
+  if (b.floats < floats) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture: plain launch instead
+    if (b.ptr) { (void)hipStreamSynchronize(st); (void)hipFree(b.ptr); b.ptr = nullptr; b.floats = 0; }
+    const size_t want = floats + floats / 4;
+    if (hipMalloc(reinterpret_cast<void**>(&b.ptr), want * sizeof(float)) != hipSuccess) { b.ptr = nullptr; (void)hipGetLastError(); return nullptr; }
+    b.floats = want;
+  }
+  return b.ptr;
+}
+// out[i] = (acc ? out[i] : 0) + bias[col] + sum_s part[s * stride + i]   (fixed order)
+__global__ void k_reduce_splitk(const float* __restrict__ part, int nsplit, long stride, long count, int N, const float* __restrict__ bias, int accumulate,
+                                float* __restrict__ out) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= count) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nsplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long)k * stride + i4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (bias) { const int c = (int)(i4 % N); s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3]; }
+  float4* o = reinterpret_cast<float4*>(out + i4);
+  if (accumulate) { const float4 v = *o; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  *o = s;
+}
+// returns true if the product was issued as a split-K launch (C contiguous, N % 4 == 0)
+template <bool A_KC, bool B_KC>
+static bool try_splitk(hipStream_t st, GemmArgs p, const float* bias, int accumulate, int& rc) {
+  rc = NQ_OK;
+  if (p.ldc != p.N || (p.N & 3) || (reinterpret_cast<uintptr_t>(p.C) & 15)) return false;
+  const int S = splitk_count(p.M, p.N, p.K);
+  if (S < 2) return false;
+  int kper = nq_cdiv(p.K, S);
+  kper = (kper + 31) / 32 * 32;
+  const int nse = nq_cdiv(p.K, kper);
+  if (nse < 2) return false;
+  const long cnt = (long)p.M * p.N;
+  float* scratch = splitk_scratch(st, (size_t)nse * cnt);
+  if (!scratch) return false;
+  float* out = p.C;
+  p.C = scratch; p.bias = nullptr; p.C2 = nullptr; p.k_per_split = kper; p.part_stride = cnt; p.bpart = nullptr; p.brows = 0;
+  if (gemm3_ok<A_KC, B_KC>(p, kper, nse)) { rc = launch_gemm3<A_KC, B_KC, EPI_PARTIAL>(st, p, nse); if (rc != NQ_OK) return true; }
+  else if (gemm2_ok<A_KC, B_KC>(p, kper)) launch_gemm2<A_KC, B_KC, EPI_PARTIAL>(st, p, nse);
+  else return false;
+  hipLaunchKernelGGL(k_reduce_splitk, dim3((unsigned)nq_cdiv(cnt / 4, 256)), dim3(256), 0, st, scratch, nse, cnt, cnt, p.N, bias, accumulate, out);
+  return true;
+}
+
 // ---- host launchers ------------------------------------------------------------------------
 int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K,
                int lda, int ldw, int ldc, const char* tag) {
@@ -439,6 +510,10 @@ int nq_gemm_nt(hipStream_t st, const float* A, const float* W, float* C, const f
   NQ_PROF_FLOPS(2.0 * M * N * K);
   if (M <= 0) return NQ_OK;
   GemmArgs p{A, W, C, bias, C2_silu, M, N, K, lda, ldw, ldc, 0, 0, nullptr, 0};
+  if (!C2_silu) {
+    int rc;
+    if (try_splitk<true, true>(st, p, bias, 0, rc)) { NQ_TRY(rc); NQ_LAUNCH_CHECK(); return NQ_OK; }
+  }
   if (gemm3_ok<true, true>(p, K, 1)) {
     if (C2_silu) NQ_TRY((launch_gemm3<true, true, EPI_SILU>(st, p, 1)));
     else NQ_TRY((launch_gemm3<true, true, EPI_STORE>(st, p, 1)));
@@ -547,6 +622,10 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
   NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
+  {
+    int rc;
+    if (try_splitk<true, false>(st, p, nullptr, accumulate, rc)) { NQ_TRY(rc); NQ_LAUNCH_CHECK(); return NQ_OK; }
+  }
   if (gemm3_ok<true, false>(p, Nout, 1)) {
     if (accumulate) NQ_TRY((launch_gemm3<true, false, EPI_ACC>(st, p, 1)));
     else NQ_TRY((launch_gemm3<true, false, EPI_STORE>(st, p, 1)));

@@ -80,10 +80,12 @@ def test_library_is_loaded_native():
 
 @pytest.mark.parametrize("M,N,K", [(300, 384, 100), (1000, 128, 128), (257, 64, 128), (129, 384, 20), (4096, 256, 128), (77, 128, 256),
                                    (500, 1, 64), (501, 2, 64), (333, 64, 64), (1000, 3, 128),
-                                   (40000, 256, 128), (33100, 128, 100), (16500, 384, 128)])      # >= 256 tiles of 128x128: the large-tile kernels
+                                   (40000, 256, 128), (33100, 128, 100), (16500, 384, 128),       # >= 256 tiles of 128x128: the large-tile kernels
+                                   (5000, 32, 5376), (3000, 8320, 128), (17000, 128, 2048)])       # long contractions, few tiles: split-K forward / input gradient
 def test_gemm_forward_and_grads(M, N, K):
     from nabladft_amd import _lib
     lib, dev = _lib.load(), _dev()
+    tol = 2e-6 if max(K, N) <= 512 else 6e-6          # f32 accumulation error grows with the contraction length (5376 / 8320 terms here)
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) * 0.1
@@ -94,23 +96,23 @@ def test_gemm_forward_and_grads(M, N, K):
     st = _lib.stream_ptr()
     _lib.check(lib.nq_linear_forward(_lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(Cd), _lib.ptr(Sd), M, N, K, st))
     ref = (A.double() @ W.double().T + b.double())
-    assert rel_err(Cd.cpu().numpy(), ref.numpy()) < 2e-6
-    assert rel_err(Sd.cpu().numpy(), torch.nn.functional.silu(ref).numpy()) < 2e-6
+    assert rel_err(Cd.cpu().numpy(), ref.numpy()) < tol
+    assert rel_err(Sd.cpu().numpy(), torch.nn.functional.silu(ref).numpy()) < tol
     # transpose-detecting: asymmetric operands above; no-bias / no-silu variant
     _lib.check(lib.nq_linear_forward(_lib.ptr(Ad), _lib.ptr(Wd), None, _lib.ptr(Cd), None, M, N, K, st))
-    assert rel_err(Cd.cpu().numpy(), (A.double() @ W.double().T).numpy()) < 2e-6
+    assert rel_err(Cd.cpu().numpy(), (A.double() @ W.double().T).numpy()) < tol
     # input gradient, with and without accumulation
     Xd = torch.full((M, K), 0.5, device=dev)
     _lib.check(lib.nq_linear_input_grad(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(Xd), M, N, K, 1, st))
     refx = G.double() @ W.double() + 0.5
-    assert rel_err(Xd.cpu().numpy(), refx.numpy()) < 2e-6
+    assert rel_err(Xd.cpu().numpy(), refx.numpy()) < tol
     _lib.check(lib.nq_linear_input_grad(_lib.ptr(Gd), _lib.ptr(Wd), _lib.ptr(Xd), M, N, K, 0, st))
-    assert rel_err(Xd.cpu().numpy(), (G.double() @ W.double()).numpy()) < 2e-6
+    assert rel_err(Xd.cpu().numpy(), (G.double() @ W.double()).numpy()) < tol
     # weight gradient (split-K over rows)
     scr = torch.empty(lib.nq_weight_grad_scratch_floats(M, N, K), device=dev)
     gW = torch.empty(N, K, device=dev)
     _lib.check(lib.nq_linear_weight_grad(_lib.ptr(Gd), _lib.ptr(Ad), _lib.ptr(gW), M, N, K, _lib.ptr(scr), st))
-    assert rel_err(gW.cpu().numpy(), (G.double().T @ A.double()).numpy()) < 3e-6
+    assert rel_err(gW.cpu().numpy(), (G.double().T @ A.double()).numpy()) < 1.5 * tol
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (130, 68, 36), (70000, 256, 128), (5000, 512, 256), (257, 3, 64)])
