@@ -586,6 +586,9 @@ size_t nq_column_sum_scratch_floats(int64_t rows, int32_t cols);
 int nq_column_sum(const float* A, int64_t rows, int32_t cols, int64_t lda, float* out, float* scratch, void* stream);
 size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K);
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
+/* The same launch also produces the bias gradient gb[N] = column sums of G (taken from the operand registers on their way into LDS: no separate pass over G;
+ * torch.nn.Linear backward); same scratch size. */
+int nq_linear_weight_grad_bias(const float* G, const float* X, float* gW, float* gb, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream);
 
 /* ---- Data-parallel gradient exchange over RCCL (round 4; SURVEY 8(b) `nq_allreduce`) -------------------------------------------------------
  * Replaces: Lightning DDPStrategy's gradient all-reduce (nablaDFT/utils/pipelines.py:65-68, `strategy: ddp` of the config yaml files).  One process

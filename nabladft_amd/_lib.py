@@ -184,6 +184,7 @@ SYMBOLS = {
     "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "nq_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32]),
     "nq_linear_weight_grad": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_linear_weight_grad_bias": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_rccl_available": (C.c_int, []),
     "nq_rccl_unique_id": (C.c_int, [_P]),
     "nq_rccl_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

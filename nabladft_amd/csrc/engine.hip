@@ -710,5 +710,9 @@ size_t nq_weight_grad_scratch_floats(int64_t rows, int32_t N, int32_t K) { retur
 int nq_linear_weight_grad(const float* G, const float* X, float* gW, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream) {
   return nq_gemm_tn((hipStream_t)stream, G, X, gW, rows, N, K, N, K, scratch);
 }
+int nq_linear_weight_grad_bias(const float* G, const float* X, float* gW, float* gb, int64_t rows, int32_t N, int32_t K, float* scratch, void* stream) {
+  if (!gb) return nq_fail(NQ_ERR_ARG, "null bias gradient");
+  return nq_gemm_tn((hipStream_t)stream, G, X, gW, rows, N, K, N, K, scratch, nullptr, gb, rows);
+}
 
 }  // extern "C"

@@ -169,11 +169,10 @@ class _LinearBiasFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         _lib.check(lib.nq_linear_input_grad(_lib.ptr(g), _lib.ptr(W), _lib.ptr(gx), M, N, K, 0, _lib.stream_ptr()))
         gW = torch.empty_like(W)
-        scr = torch.empty(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, device=x.device, dtype=torch.float32)
-        _lib.check(lib.nq_linear_weight_grad(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
         gb = torch.empty(N, device=g.device, dtype=torch.float32)
-        cs = torch.empty(int(lib.nq_column_sum_scratch_floats(M, N)) + 64, device=g.device, dtype=torch.float32)
-        _lib.check(lib.nq_column_sum(_lib.ptr(g), M, N, N, _lib.ptr(gb), _lib.ptr(cs), _lib.stream_ptr()))      # bias gradient: fixed-order column sums
+        scr = torch.empty(int(lib.nq_weight_grad_scratch_floats(M, N, K)) + 64, device=x.device, dtype=torch.float32)
+        # weight and bias gradient in one launch: the column sums of g are taken from the operand registers of the contraction (fixed order)
+        _lib.check(lib.nq_linear_weight_grad_bias(_lib.ptr(g), _lib.ptr(x), _lib.ptr(gW), _lib.ptr(gb), M, N, K, _lib.ptr(scr), _lib.stream_ptr()))
         return gx, gW, gb, None
 
 

@@ -111,6 +111,10 @@ def _run(a):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
+    prof = None
+    if a.kernels:                       # read the per-kernel table of exactly the timed steps (the wall-clock loop below must not add to it)
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
     n_params = sum(p.numel() for p in params)
     P = int(sum(s * (s - 1) for s in b["sizes"]))
     wall0 = __import__("time").perf_counter()
@@ -122,8 +126,6 @@ def _run(a):
            "ms_per_step": ms, "molecules": a.molecules, "atoms": int(len(b["z"])), "ordered_pairs": P, "orbitals": int(sum(2 * l + 1 for o in b["orbitals"] for _, l in o)),
            "parameters": n_params, "final_loss": float(loss), "config": {k: v for k, v in HP.items()}, "data": "synthetic", "dtype": "f32"}
     if a.kernels:
-        prof = _lib.profile_read()
-        _lib.profile_enable(False)
         out["device_ms_per_step_nq_kernels"] = sum(v[0] for v in prof.values()) / a.steps
         out["kernel_ms_per_step"] = {k: [round(v[0] / a.steps, 4), int(v[1] // a.steps)] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]}
         dense = {k: v for k, v in prof.items() if v[2] > 0}
