@@ -204,6 +204,43 @@ def gemm_accuracy_probe(dev, restore_variant=1):
     return out
 
 
+# Compulsory HBM traffic of the node-level kernels of the PaiNN step, in units of one [N][F] fp32 array per launch (what the kernel must read + write once;
+# csrc/node.hip).  "single" = forward / force-adjoint / tangent flavour, "dual" = the (primal, tangent) flavour of the dual reverse sweep.
+_NODE_NF = {"upd_a": 6 + 1 + 1 + 2, "upd_b": 1 + 3 + 1 + 3 + 3 + 4, "silu_rev": 2 * (2 + 2) + 2, "silu_tan": 3}
+
+
+def kernel_table(kernels, prof, steps, n_atoms, E):
+    """Every launcher class of the step against BOTH roofs where a byte / flop count is defined: message kernels and node kernels by their compulsory HBM bytes,
+    dense products by 2MNK (recorded by the launchers) and by the bytes of their row operands (A read once, C written once; weights are L2-resident)."""
+    NF = n_atoms * F * 4.0
+    rows = []
+    for name, ms, n in kernels:
+        r = {"name": name, "ms_per_step": round(ms, 4), "launches_per_step": int(n)}
+        sec = ms * 1e-3
+        if name in _MSG:
+            b = _MSG[name][1] * (8.0 * n_atoms * F * 4 + 24.0 * E) * n
+            r.update(bound="hbm", GBps=b / sec / 1e9, frac=b / sec / 1e9 / HBM_PEAK_GBS)
+        elif name == "gwr_sorted":
+            b = (2.0 * (E / 2) * 3 * F * 4 + 128.0 * E / 2) * n          # one g_phi and one g_psi row per pair + the window record
+            r.update(bound="hbm", GBps=b / sec / 1e9, frac=b / sec / 1e9 / HBM_PEAK_GBS)
+        elif name == "upd_rev":
+            b = (22 + 44 + 11 + 22) * NF * (n / 4.0)                     # rev1 + rev2, dual and single flavours (DESIGN 5): 4 launches per layer
+            r.update(bound="hbm", GBps=b / sec / 1e9, frac=b / sec / 1e9 / HBM_PEAK_GBS)
+        elif name in _NODE_NF:
+            b = _NODE_NF[name] * NF * n * (1.5 if name in ("upd_a", "upd_b") else 1.0)   # forward (1x) + tangent (2x operands) flavours averaged
+            r.update(bound="hbm", GBps=b / sec / 1e9, frac=b / sec / 1e9 / HBM_PEAK_GBS)
+        elif name.startswith("gemm") and prof is not None and name in prof and prof[name][2] > 0:
+            fl = prof[name][2] / steps
+            dims = [int(x) for x in name.split("[")[1].rstrip("]").replace("n=", "").replace("k=", "").replace("x", ",").split(",")]
+            d0, d1 = dims[0], dims[1]
+            mrows = fl / (2.0 * d0 * d1)                                  # rows streamed per step by this class
+            b = 4.0 * mrows * (d0 + d1)
+            r.update(bound="mfma/hbm", TFLOPs=fl / sec / 1e12, frac_mfma_f32=fl / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, GBps=b / sec / 1e9,
+                     frac_hbm=b / sec / 1e9 / HBM_PEAK_GBS)
+        rows.append({k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in r.items()})
+    return rows
+
+
 def step_bounds(kernels, n_atoms, E, batch, ms_per_step, prof=None, steps=1, engine=None):
     """Step-level roofs of the PaiNN training step: the arithmetic the step executes (GEMM flops recorded by every dense launcher + the message-path kernels'
     VALU flops) against the pipes it runs on, and SURVEY 8(d)'s 17.8 MB / conformer-step of compulsory HBM traffic against 8 TB/s.  The larger time binds.
@@ -670,6 +707,7 @@ def main():
         roofline = roofline_record(dom, avg_ms, dom_launches, n_atoms, E, args.batch)
         roofline["device_ms_per_step_all_kernels"] = tot / args.steps
         roofline["step"] = step_bounds(kernels, n_atoms, E, args.batch, 1e3 * dt / args.steps, prof, args.steps)
+        roofline["kernel_table"] = kernel_table(kernels, prof, args.steps, n_atoms, E)      # full record only (compact_record keeps the dominant kernel)
 
     gemm_engine = {"engine": gemm_engine_name(),
                    "what": "dense products of >= 192 tiles of 128x128: every f32 operand value is split exactly into three bf16 pieces (x = h + m + l) and the product "

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
     __syncthreads();
     if (EPI == EPI_PARTIAL && !A_KC) {
       // bias gradient for free: column sums of the A tile (= gy rows) that is already in LDS, primal rows only
-      if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM) {
+      if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM && (RM != 3 || zc == 0)) {   // RM 3: the scalar rows (component 0) carry the bias
         const int kmax = min(BKT, p.brows - k0);
         for (int kk = 0; kk < kmax; ++kk) bsum += As[kk * LDA_S + threadIdx.x];
       }
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(NW * 64) GEMM_OCC void k_gemm(GemmArgs p) {
   }
 
   if (EPI == EPI_PARTIAL && !A_KC) {
-    if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M)
-      p.bpart[(long)blockIdx.z * p.M + m0 + threadIdx.x] = bsum;
+    if (p.bpart && blockIdx.y == 0 && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M && (RM != 3 || zc == 0))
+      p.bpart[(long)blockIdx.z * p.M + m0 + threadIdx.x] = bsum;   // RM 3: component 0 owns the first rm_s values of blockIdx.z
   }
   // epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* Cout = p.C;
@@ -846,7 +846,8 @@ int nq_sph_linear_input_grad(const float* gy, const float* const* W_host, float*
 
 size_t nq_sph_weight_grad_scratch_floats(int64_t rows, int32_t order, int32_t Fin, int32_t Fout) {
   const size_t ncomp = (size_t)(order + 1) * (order + 1);
-  const size_t part = ncomp * sph_tn_splits(rows, (int)ncomp) * (size_t)Fout * Fin, cs = nq_colsum_scratch_floats(rows, Fout);
+  const size_t sps = sph_tn_splits(rows, (int)ncomp);
+  const size_t part = ncomp * sps * (size_t)Fout * Fin + sps * (size_t)Fout, cs = nq_colsum_scratch_floats(rows, Fout);   // + the bias partials of the scalar rows
   return part > cs ? part : cs;
 }
 
@@ -871,6 +872,8 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
     p.A = gy; p.B = x; p.C = scratch; p.M = Fout; p.N = Fin; p.K = (int)rows * (2 * order + 1); p.lda = Fout; p.ldb = Fin; p.ldc = Fin;
     p.k_per_split = kper; p.part_stride = (long)Fout * Fin;
     p.rm_rows = (int)rows; p.rm_ncomp = ncomp; p.rm_s = sps;
+    float* bpart = scratch + (size_t)ncomp * sps * Fout * Fin;
+    if (gbias0) { p.bpart = bpart; p.brows = (int)rows; }      // bias gradient = column sums of the scalar rows of gy, taken from the staged A tiles of component 0
     dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ncomp * sps);
     hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 3>), grid, dim3(512), 0, st, p);
     NQ_LAUNCH_CHECK();
@@ -882,7 +885,11 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
   }
   if (gbias0) {
     if (rows == 0) NQ_HIP(hipMemsetAsync(gbias0, 0, sizeof(float) * Fout, st));
-    else NQ_TRY(nq_colsum(st, gy, rows, Fout, ncomp * Fout, gbias0, scratch));   // scalar rows: packed row r * ncomp
+    else {   // fixed-order sum of the per-split partials written by the contraction above (no separate pass over gy)
+      const int sps = sph_tn_splits(rows, ncomp);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Fout, 64)), dim3(64), 0, st, scratch + (size_t)ncomp * sps * Fout * Fin, sps, (long)Fout, (long)Fout, gbias0);
+      NQ_LAUNCH_CHECK();
+    }
   }
   return NQ_OK;
 }
