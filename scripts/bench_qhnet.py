@@ -65,9 +65,9 @@ def gemm_flops_per_step(net, N, E, P):
 
 
 def pmc_traffic_bytes(kernel_prefix, molecules):
-    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r02_pmc_traffic_qhnet.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/r0N_pmc_traffic_qhnet.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), only if it was taken at this batch size."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_qhnet.json") for r in (3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic_qhnet.json") for r in (9, 8, 7, 6, 5, 4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None
     with open(path) as fh:
