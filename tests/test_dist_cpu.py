@@ -213,3 +213,42 @@ def test_overlapped_bucketed_allreduce_equals_one_flat_allreduce(tmp_path):
                 assert torch.equal(got, res[0][step][0])    # every rank holds the same mean
             assert float(res[0][step][0].abs().max()) > 0
             assert float(res[0][step][0][-20:].abs().min()) > 0      # the last parameters (l3.weight, l3.bias) have non-zero gradients and were reduced
+
+
+# ---- forced 1-rank group (NQ_DIST_FORCE=1): the switch the single-GPU RCCL tests rely on, exercised here over gloo -------------------------------------
+def _forced_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", NQ_DIST_FORCE="1")
+    torch.set_num_threads(1)
+    assert not nqdist.active()
+    r, w, _ = nqdist.init_from_env(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and nqdist.forced() and nqdist.active()      # a 1-rank group exists and its collectives run
+    from nabladft_amd.trainer import FlatParameters, OverlappedAllReduce
+    net = _mlp(0)
+    flat = FlatParameters(list(net.parameters()))
+    ov = OverlappedAllReduce(flat, bucket_bytes=600)
+    assert ov.on and ov.world == 1 and len(ov._handles) == len(flat.params)                      # hooks registered although world == 1
+    x = torch.randn(16, 7, generator=torch.Generator().manual_seed(3))
+    flat.zero_grad()
+    net(x).pow(2).mean().backward()
+    got = ov.finish().clone()
+    assert all(ov._launched[b] is False for b in range(len(ov.buckets)))                         # re-armed
+    net2 = _mlp(0)
+    flat2 = FlatParameters(list(net2.parameters()))
+    flat2.zero_grad()
+    net2(x).pow(2).mean().backward()
+    ref = flat2.flat.grad.clone()
+    t = ref.clone()
+    nqdist.allreduce_mean_(t)                                                                     # runs the collective: sum over one rank, no scaling
+    nqdist.allreduce_sum_(t)
+    nqdist.broadcast_(t, 0)
+    nqdist.barrier()
+    torch.save((got, ref, t), os.path.join(out_dir, "forced.pt"))
+    dist.destroy_process_group()
+    os.environ.pop("NQ_DIST_FORCE")
+    assert not nqdist.active()
+
+
+def test_forced_one_rank_group_runs_every_collective(tmp_path):
+    mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got, ref, t = torch.load(tmp_path / "forced.pt")
+    assert torch.equal(got, ref) and torch.equal(t, ref) and float(ref.abs().max()) > 0
