@@ -206,7 +206,7 @@ def gemm_accuracy_probe(dev, restore_variant=1):
 
 # Compulsory HBM traffic of the node-level kernels of the PaiNN step, in units of one [N][F] fp32 array per launch (what the kernel must read + write once;
 # csrc/node.hip).  "single" = forward / force-adjoint / tangent flavour, "dual" = the (primal, tangent) flavour of the dual reverse sweep.
-_NODE_NF = {"upd_a": 6 + 1 + 1 + 2, "upd_b": 1 + 3 + 1 + 3 + 3 + 4, "silu_rev": 2 * (2 + 2) + 2, "silu_tan": 3}
+_NODE_NF = {"upd_a": 6 + 1 + 1 + 2, "upd_b": 1 + 3 + 1 + 3 + 3 + 4, "silu_rev": 4 + 2, "silu_tan": 3}   # silu_rev: the dual flavour (Z, TZ, G, GT in; G, GT out); the single flavours live in GEMM epilogues
 
 
 def kernel_table(kernels, prof, steps, n_atoms, E):
@@ -673,6 +673,7 @@ def main():
         loss = step(batches[i % len(batches)])
     sync()
     dt = time.perf_counter() - t0
+    final_loss = float(loss)          # NOW: `loss` is the step's device-side loss buffer, which every later step (roofline pass, side legs) overwrites
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -736,7 +737,7 @@ def main():
         dtx = time.perf_counter() - t0
         _lib.load().nq_set_gemm_variant(var)
         gemm_engine["exact_f32_engine"] = {"value": args.batch * args.steps / dtx, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dtx / args.steps,
-                                           "final_loss": float(loss_x), "final_loss_default_engine": float(loss),
+                                           "final_loss": float(loss_x), "final_loss_default_engine": final_loss,
                                            "what": "same initial parameters, optimiser state and batches as the timed region"}
         with torch.no_grad():
             step._eng.flat().copy_(end_state[0]); step.m.copy_(end_state[1]); step.v.copy_(end_state[2]); step.t = end_state[3]
@@ -904,7 +905,7 @@ def main():
             "config": {"workload": f"{WORKLOADS[args.model]}; synthetic ~42-atom drug-like conformers, {args.batch} conformers/GPU/step",
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
                        "parallelism": f"dp{world}", "collective": collective_name()},
-            "final_loss": float(loss),
+            "final_loss": final_loss,
             "gemm_engine": gemm_engine,
             "roofline": roofline,
             "cpu_baseline": cpu,

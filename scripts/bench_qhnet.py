@@ -187,7 +187,7 @@ def run(molecules=2, steps=10, warmup=3, kernels=True, device=None, seed=1, worl
     return out
 
 
-def cpu_baseline(seconds_budget=30.0, atoms=None, conformers=2):
+def cpu_baseline(seconds_budget=30.0, atoms=None, conformers=1):   # (this oracle needs ~6 s per conformer-step on the GPU box's host: one conformer keeps >= 3 timed steps inside the budget)
     """oracle/qhnet_ref.py (pure torch CPU, fp32) forward + loss + backward on ONE synthetic conformer of the same generator."""
     import torch
     from nabladft_amd.synth import gen_conformers
