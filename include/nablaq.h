@@ -546,6 +546,8 @@ int nq_profile_read2(char* names_host, int32_t name_stride, double* total_ms_hos
  *               1.3-1.7x faster, but a row's bits then depend on which engine the launch size selects, and non-finite operands give NaN where the
  *               exact engine would give inf.  The environment variable NQ_GEMM_F32=1 (read once) has the same effect as bit 5.
  *   bit 6 (64)  the split-bf16 engine for EVERY launch it can run, whatever the size (tests: the golden vectors with all products on it).
+ *   bit 8 (256) spherical linears on the row-mapped generic kernel (default since round 4: one plain strided product per packed component as ONE batched
+ *               launch of the tile engines, grid.y = component).
  *   bit 7 (128) never split the contraction of a forward / input-gradient product (default: contractions of >= 2048 with fewer than 256 output tiles of
  *               128x128 are cut into up to 16 ranges, partial slabs in a library-owned per-stream scratch, fixed-order reduction; round 4).
  * The weight-gradient scratch size does not depend on the switch. */

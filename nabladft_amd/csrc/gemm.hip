@@ -13,6 +13,7 @@
 // 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).  Both operands are staged in LDS k-major
 // ([BK][BM+pad]) so that the MFMA operand fetch (lane l: row l&31, k = l>>5) is a conflict-free
 // ds_read_b32 of 32 consecutive floats per half-wave.
+#include <algorithm>
 #include "gemm_tile.h"   // round 3: the persistent, double-buffered tile engine k_gemm2 (every launch whose operands are 16-byte friendly)
 #include "gemm_split.h"  // round 3: the same skeleton on the bf16 matrix pipe, every f32 value split exactly into three bf16 pieces (large launches)
 
@@ -431,6 +432,32 @@ static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
   return NQ_OK;
 }
 
+// ---- batched launches (round 4): nbatch independent products that differ by operand offsets only (GemmArgs::nbatch, bsA / bsB / bsC, Bz), grid.y = batch.
+// The spherical linears of QHNet / PhiSNet / EquiformerV2 act on packed irreps tensors [rows][ncomp][F]; for ONE packed component the rows form a plain
+// strided matrix (leading dimension ncomp * F), so the whole layer is ncomp plain products = one batched launch of the tile engines instead of the
+// row-mapped launch of the generic round-1 kernel (32-48 TFLOP/s).
+template <bool A_KC, bool B_KC, int EPI>
+static bool launch_batched(hipStream_t st, const GemmArgs& p, int splits, long kspan) {
+  if (g_gemm_variant & 256) return false;                                   // bit 8: keep the row-mapped generic launches (A/B switch)
+  if (!gemm2_ok<A_KC, B_KC>(p, kspan) || p.nbatch < 1) return false;
+  if ((p.bsA & 3) || (p.bsB & 3) || (p.bsC & 3) || (p.ldc & 3) || (reinterpret_cast<uintptr_t>(p.C) & 15)) return false;
+  if (p.bz) for (int L = 0; L < 7; ++L) if (p.Bz[L] && (reinterpret_cast<uintptr_t>(p.Bz[L]) & 15)) return false;
+  const long t128 = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits, t64 = (long)nq_cdiv(p.M, 64) * nq_cdiv(p.N, 64) * splits;
+  const bool use3 = !gemm3_disabled() && !p.bpart && EPI != EPI_PARTIAL && ((g_gemm_variant & 64) || t128 * p.nbatch >= 192) && !(p.K & 15);
+  if (use3) {
+    const long cap = 256 * 3;
+    const unsigned gx = (unsigned)std::min<long>(t128, std::max<long>(1, (cap + p.nbatch - 1) / p.nbatch));
+    hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 3, false, false, 6, 0, true>), dim3(gx, p.nbatch), dim3(256), 0, st, p);
+  } else if (gemm2_small_tiles(p.M * p.nbatch, p.N, splits)) {
+    const unsigned gx = (unsigned)std::min<long>(t64, std::max<long>(1, (1024 + p.nbatch - 1) / p.nbatch));
+    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 64, 64, 32, 2, 2, 4, 0, true>), dim3(gx, p.nbatch), dim3(256), 0, st, p);
+  } else {
+    const unsigned gx = (unsigned)std::min<long>(t128, std::max<long>(1, (512 + p.nbatch - 1) / p.nbatch));
+    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 128, 128, 32, 4, 2, 4, 0, true>), dim3(gx, p.nbatch), dim3(512), 0, st, p);
+  }
+  return true;
+}
+
 // ---- split-K for long contractions with few output tiles (round 4) -----------------------------------------------------------------------------------
 // QHNet's generator adjoints are [rows x 5376] x [5376 x 32] and [rows x 8320] x [8320 x 128] at 17-28 k rows: 136-215 output tiles of 128 x 128, each a
 // 1.4-4.3 MB serial stream of the long operand -- one tile per CU at best, 2.2-2.5 TB/s.  With the contraction cut into S ranges (S x tiles workgroups,
@@ -817,6 +844,11 @@ int nq_sph_linear_forward(const float* x, const float* const* W_host, const floa
   p.rm_rows = (int)rows; p.rm_ncomp = ncomp;
   for (int L = 0; L <= order; ++L) { if (!W_host[L]) return nq_fail(NQ_ERR_ARG, "null weight"); p.Bz[L] = W_host[L]; }
   p.B = p.Bz[0];
+  {   // one plain strided product per packed component on the tile engines (rows x Fin, leading dimension ncomp * Fin)
+    GemmArgs b = p;
+    b.M = (int)rows; b.lda = ncomp * Fin; b.ldc = ncomp * Fout; b.nbatch = ncomp; b.bz = 1; b.bsA = Fin; b.bsB = 0; b.bsC = Fout;
+    if (launch_batched<true, true, EPI_STORE>(st, b, 1, Fin)) { NQ_LAUNCH_CHECK(); return NQ_OK; }
+  }
   dim3 grid(nq_cdiv(p.M, BM), nq_cdiv(Fout, BN), order + 1);
   hipLaunchKernelGGL((k_gemm<true, true, EPI_STORE, 8, true, 32, 1>), grid, dim3(512), 0, st, p);
   NQ_LAUNCH_CHECK();
@@ -838,6 +870,11 @@ int nq_sph_linear_input_grad(const float* gy, const float* const* W_host, float*
   p.rm_rows = (int)rows; p.rm_ncomp = ncomp;
   for (int L = 0; L <= order; ++L) { if (!W_host[L]) return nq_fail(NQ_ERR_ARG, "null weight"); p.Bz[L] = W_host[L]; }
   p.B = p.Bz[0];
+  {
+    GemmArgs b = p;
+    b.M = (int)rows; b.lda = ncomp * Fout; b.ldc = ncomp * Fin; b.nbatch = ncomp; b.bz = 1; b.bsA = Fout; b.bsB = 0; b.bsC = Fin;
+    if (launch_batched<true, false, EPI_STORE>(st, b, 1, Fout)) { NQ_LAUNCH_CHECK(); return NQ_OK; }
+  }
   dim3 grid(nq_cdiv(p.M, BM), nq_cdiv(Fin, BN), order + 1);
   hipLaunchKernelGGL((k_gemm<true, false, EPI_STORE, 8, true, 16, 1>), grid, dim3(512), 0, st, p);
   NQ_LAUNCH_CHECK();
@@ -874,8 +911,16 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
     p.rm_rows = (int)rows; p.rm_ncomp = ncomp; p.rm_s = sps;
     float* bpart = scratch + (size_t)ncomp * sps * Fout * Fin;
     if (gbias0) { p.bpart = bpart; p.brows = (int)rows; }      // bias gradient = column sums of the scalar rows of gy, taken from the staged A tiles of component 0
-    dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ncomp * sps);
-    hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 3>), grid, dim3(512), 0, st, p);
+    bool done = false;
+    if (nq_cdiv(rows, kper) == sps) {   // every split holds rows: the slab layout [component][split] is the same for both kernels
+      GemmArgs b = p;                   // per packed component: gW partial[split] = gy_c[rows, Fout]^T x_c[rows, Fin] over the split's rows
+      b.K = (int)rows; b.lda = ncomp * Fout; b.ldb = ncomp * Fin; b.nbatch = ncomp; b.bz = 0; b.bsA = Fout; b.bsB = Fin; b.bsC = (long)sps * Fout * Fin;
+      done = launch_batched<false, false, EPI_PARTIAL>(st, b, sps, kper);
+    }
+    if (!done) {
+      dim3 grid(nq_cdiv(Fout, BM), nq_cdiv(Fin, BN), ncomp * sps);
+      hipLaunchKernelGGL((k_gemm<false, false, EPI_PARTIAL, 8, true, 32, 3>), grid, dim3(512), 0, st, p);
+    }
     NQ_LAUNCH_CHECK();
     SphOut outs{};
     for (int L = 0; L <= order; ++L) outs.out[L] = gW_host[L];

@@ -113,8 +113,9 @@ struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-ti
 // ABL (lab only): 1 = no split arithmetic (the three planes get the truncated value), 2 = no global loads inside the loop, 4 = no ds_reads inside the loop
 // KTAIL: the contraction length need not be a multiple of 16 (K-contiguous operands only; costs 18 VALU instructions per step).
 // WBIAS (weight-gradient launches): also produce the bias gradient (GemmArgs::bpart).
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0>
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false>
 __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
+  if (BATCH) gemm_apply_batch(p);
   constexpr int BM = 128, BN = 128, BK = 16, NWN = 2, TM = 2, TN = 2;
   using SA = SplitStage<A_KC>;
   using SB = SplitStage<B_KC>;

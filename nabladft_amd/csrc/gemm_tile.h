@@ -30,7 +30,20 @@ struct GemmArgs {
   int rm_s;                               // RM == 3 (weight gradients of all orders): splits per component; blockIdx.z = component * rm_s + split
   const float* Bz[7];                     // RM == 1 (forward / input gradient of all orders, blockIdx.z = L): per-order weights
   const float* resid; float ea, eb;       // EPI_SILU_RES (resid nullable, same leading dimension as C)
+  // batched launches of the tile engines (round 4: the spherical linears as one plain strided product per packed component): blockIdx.y = z shifts the
+  // operands, A += z * bsA, C += z * bsC, B = Bz[order of component z] (bz) or B + z * bsB; bias and bias-gradient partials belong to z = 0 only
+  int nbatch, bz; long bsA, bsB, bsC;
 };
+__device__ __forceinline__ void gemm_apply_batch(GemmArgs& p) {
+  const int z = blockIdx.y;
+  const int L = z >= 36 ? 6 : z >= 25 ? 5 : z >= 16 ? 4 : z >= 9 ? 3 : z >= 4 ? 2 : z >= 1 ? 1 : 0;
+  // (static indices only: a dynamically indexed member would move the whole argument block to scratch memory)
+  const float* bz = L == 0 ? p.Bz[0] : L == 1 ? p.Bz[1] : L == 2 ? p.Bz[2] : L == 3 ? p.Bz[3] : L == 4 ? p.Bz[4] : L == 5 ? p.Bz[5] : p.Bz[6];
+  p.A += (long)z * p.bsA;
+  p.B = p.bz ? bz : p.B + (long)z * p.bsB;
+  p.C += (long)z * p.bsC;
+  if (z > 0) { p.bias = nullptr; p.bpart = nullptr; }
+}
 
 typedef unsigned int gemm_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -149,8 +162,9 @@ __device__ __forceinline__ void gemm_store_acc(const f32x16& a, const f32x16& x,
 // tile's last k-tile, so nothing in the store sequence waits on memory.
 // WPE: wavefronts per SIMD the register allocation must leave room for (workgroups per CU * NWM * NWN / 4).
 // ABL (lab only): 1 = no C stores, 2 = no global loads after the first k-tile, 3 = both.
-template <bool A_KC, bool B_KC, int EPI, int BM, int BN, int BK, int NWM, int NWN, int WPE = 2, int ABL = 0>
+template <bool A_KC, bool B_KC, int EPI, int BM, int BN, int BK, int NWM, int NWN, int WPE = 2, int ABL = 0, bool BATCH = false>
 __global__ __launch_bounds__(NWM * NWN * 64, WPE) void k_gemm2(GemmArgs p) {
+  if (BATCH) gemm_apply_batch(p);
   constexpr int NT = NWM * NWN * 64, TM = BM / NWM / 32, TN = BN / NWN / 32;
   static_assert(TM >= 1 && TN >= 1 && BK % 8 == 0, "bad tile");
   using SA = GemmStage<A_KC, BM, BK, NT>;
