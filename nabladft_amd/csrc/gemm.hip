@@ -393,7 +393,9 @@ template <bool A_KC, bool B_KC, int EPI>
 static void launch_gemm2(hipStream_t st, const GemmArgs& p, int splits) {
   if (gemm2_small_tiles(p.M, p.N, splits)) {
     const long tiles = (long)nq_cdiv(p.M, 64) * nq_cdiv(p.N, 64) * splits;
-    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 64, 64, 32, 2, 2, 4>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, p);
+    // (the two-output tangent epilogue needs 3 workgroups per CU worth of registers: at 4 it spilled 124 bytes per lane)
+    constexpr int WPE64 = EPI == EPI_DSILU2 ? 3 : 4;
+    hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 64, 64, 32, 2, 2, WPE64>), dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(256), 0, st, p);
   } else {
     const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
     hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 128, 128, 32, 4, 2, 4>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(512), 0, st, p);
