@@ -16,8 +16,12 @@
 
 #define QH_NCOMP 25
 #define QH_NPATHS 65
-#ifndef QH_WCH
-#define QH_WCH 8
+// Paths per prefetched weight chunk and register budget, per kernel flavour (round 4, scripts/bench_qh_tp.py at 27.5 k rows, profiles/r04_qh_tp_variants.txt):
+//   uuu forward 4 (0.81 -> 0.67 ms), uvu forward 8, uuu reverse 8 at TWO wavefronts per SIMD (21 spilled registers, 1.94 -> 1.62 ms), uvu reverse 16 (0.77 -> 0.68 ms)
+#ifdef QH_WCH
+#define QH_WCH_OF(UVU, BWD) (QH_WCH)
+#else
+#define QH_WCH_OF(UVU, BWD) ((UVU) ? ((BWD) ? 16 : 8) : ((BWD) ? 8 : 4))
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -101,8 +105,11 @@ struct QhTpArgs {
   long R; int C, n1, np_rt;
 };
 
+#ifndef QH_BWD_WPE
+#define QH_BWD_WPE 2   // wavefronts per SIMD the reverse kernels are compiled for (register budget 512 / QH_BWD_WPE): 2 since round 4 (see QH_WCH_OF)
+#endif
 template <int SET, bool UVU, bool BWD, int VAR>
-__global__ __launch_bounds__(256, (BWD || VAR == 0) ? 1 : (VAR == 1 ? 4 : 3)) void k_qh_tp(QhTpArgs a) {
+__global__ __launch_bounds__(256, (BWD || VAR == 0) ? QH_BWD_WPE : (VAR == 1 ? 4 : 3)) void k_qh_tp(QhTpArgs a) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.R * a.C) return;
   const long r = idx / a.C;
@@ -126,14 +133,15 @@ __global__ __launch_bounds__(256, (BWD || VAR == 0) ? 1 : (VAR == 1 ? 4 : 3)) vo
   float* g1r = BWD ? a.gw1 + r * NP * C + u : nullptr;
   float* g2r = (BWD && a.w2) ? a.gw2 + r * NP * C + u : nullptr;
 
-  // VAR 0: each path loads its own weights; VAR 1 / 2: weights fetched in chunks of QH_WCH paths, double buffered (the loads of chunk k+1 are
+  // VAR 0: each path loads its own weights; VAR 1 / 2: weights fetched in chunks of WCHK paths, double buffered (the loads of chunk k+1 are
   // issued before the arithmetic of chunk k), with (1) / without (2) scheduling barriers.  The runtime test on np_rt is always true: it keeps one
   // basic block per path -- as one block the reverse kernel spills 4 kB per lane.
   constexpr bool CHUNK = VAR != 0, BAR = VAR == 1;
-  float wq1[2][QH_WCH], wq2[2][QH_WCH];
+  constexpr int WCHK = QH_WCH_OF(UVU, BWD);
+  float wq1[2][WCHK], wq2[2][WCHK];
   if constexpr (CHUNK) {
 #pragma unroll
-    for (int i = 0; i < QH_WCH; ++i) {
+    for (int i = 0; i < WCHK; ++i) {
       wq1[0][i] = i < NP ? w1r[(long)i * C] : 0.f;
       wq2[0][i] = (w2r && i < NP) ? w2r[(long)i * C] : 1.f;
     }
@@ -143,11 +151,11 @@ __global__ __launch_bounds__(256, (BWD || VAR == 0) ? 1 : (VAR == 1 ? 4 : 3)) vo
     constexpr int slot = qh_path_slot(SET, pid);                        \
     if (slot < a.np_rt) {                                               \
     constexpr long ci = slot;                                           \
-    constexpr int cb = (slot / QH_WCH) % 2, ck = slot % QH_WCH;         \
+    constexpr int cb = (slot / WCHK) % 2, ck = slot % WCHK;               \
     if constexpr (CHUNK && ck == 0) {                                   \
-      _Pragma("unroll") for (int i = 0; i < QH_WCH; ++i) {              \
+      _Pragma("unroll") for (int i = 0; i < WCHK; ++i) {                \
         constexpr int nb = 1 - cb;                                      \
-        const int sl = slot + QH_WCH + i;                               \
+        const int sl = slot + WCHK + i;                                 \
         wq1[nb][i] = sl < NP ? w1r[(long)sl * C] : 0.f;                 \
         wq2[nb][i] = (w2r && sl < NP) ? w2r[(long)sl * C] : 1.f;        \
       }                                                                 \
