@@ -524,8 +524,30 @@ class NeuralNetwork(nn.Module):
         from . import cg as _cg
         from .hamiltonian import IrrepsAssembler, compute_matrix_irreps
         from .so3 import RADIAL_BASES
-        if load_from is not None:
-            raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: construct with hyper-parameters and load_state_dict the checkpoint")
+        saved_state = None
+        if load_from is not None:   # neural_network.py:97-140: hyper-parameters come from the file ('args' namespace of the training script, or the flat dict `save` writes)
+            from argparse import Namespace
+            saved_state = torch.load(load_from, map_location="cpu", weights_only=False)
+            try:
+                args = saved_state["args"]
+            except KeyError:
+                args = Namespace(**saved_state)
+            if isinstance(args, dict):
+                args = Namespace(**args)
+            max_orbitals = args.max_orbitals if max_orbitals is None else max_orbitals
+            order, num_features, num_basis_functions, num_modules = args.order, args.num_features, args.num_basis_functions, args.num_modules
+            num_residual_pre_x, num_residual_post_x = args.num_residual_pre_x, args.num_residual_post_x
+            num_residual_pre_vi, num_residual_pre_vj, num_residual_post_v = args.num_residual_pre_vi, args.num_residual_pre_vj, args.num_residual_post_v
+            num_residual_output, num_residual_pc, num_residual_pn = args.num_residual_output, args.num_residual_pc, args.num_residual_pn
+            num_residual_ii, num_residual_ij = args.num_residual_ii, args.num_residual_ij
+            num_residual_full_ii, num_residual_full_ij = args.num_residual_full_ii, args.num_residual_full_ij
+            num_residual_core_ii, num_residual_core_ij, num_residual_over_ij = args.num_residual_core_ii, args.num_residual_core_ij, args.num_residual_over_ij
+            basis_functions, cutoff, activation = args.basis_functions, args.cutoff, args.activation
+        self._hp = dict(num_residual_pre_x=num_residual_pre_x, num_residual_post_x=num_residual_post_x, num_residual_pre_vi=num_residual_pre_vi,
+                        num_residual_pre_vj=num_residual_pre_vj, num_residual_post_v=num_residual_post_v, num_residual_output=num_residual_output,
+                        num_residual_pc=num_residual_pc, num_residual_pn=num_residual_pn, num_residual_ii=num_residual_ii, num_residual_ij=num_residual_ij,
+                        num_residual_full_ii=num_residual_full_ii, num_residual_full_ij=num_residual_full_ij, num_residual_core_ii=num_residual_core_ii,
+                        num_residual_core_ij=num_residual_core_ij, num_residual_over_ij=num_residual_over_ij, basis_functions=basis_functions)
         if basis_functions not in ("exp-gaussian", "exp-bernstein", "gaussian", "bernstein"):         # the four choices of neural_network.py:210-221
             raise ValueError(f"basis function type: {basis_functions} is not supported")
         self.calculate_full_hamiltonian = self.calculate_core_hamiltonian = self.calculate_overlap_matrix = True
@@ -586,6 +608,23 @@ class NeuralNetwork(nn.Module):
         for orbs in max_orbitals:
             a2o.setdefault(int(orbs[0][0]), tuple((int(zz), int(l)) for zz, l in orbs))
         self._assembler = IrrepsAssembler(a2o, self.irreps_ii, self.irreps_ij, cgp)
+        if saved_state is not None:
+            # neural_network.py:445-449: non-strict load; the reference constructs its EnergyLayer AFTER this load (:453), so the energy predictor keeps its fresh
+            # initialisation there -- reproduced by leaving its keys out
+            try:
+                sd = saved_state["model_state_dict"]
+            except KeyError:
+                sd = saved_state["state_dict"]
+            self.load_state_dict({k: v for k, v in sd.items() if not k.startswith("energy_predictor.")}, strict=False)
+
+    def save(self, PATH):
+        """The model and all hyper-parameters in the flat layout of neural_network.py:470-503 (a file `load_from` accepts, here and in the reference)."""
+        torch.save(dict(state_dict=self.state_dict(), max_orbitals=self.max_orbitals, order=self.order, num_features=self.num_features,
+                        num_basis_functions=self.num_basis_functions, num_modules=self.num_modules, cutoff=self.cutoff, activation=self.activation, Zmax=self.Zmax,
+                        num_energy_features=self.num_energy_features, **self._hp), PATH)
+
+    def get_number_of_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
     # ---- helpers ------------------------------------------------------------------------------------------------------------------------
     def fill_idx(self, molecule_size, device):

@@ -66,7 +66,7 @@ def main():
     print("phisnet_mixing.npz:", len(fx), "arrays")
 
 
-if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix", "--network", "--forces"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--bases", "--blocks", "--matrix", "--network", "--forces", "--checkpoint"} & set(sys.argv)):
     main()
 
 
@@ -365,7 +365,23 @@ def forces():
     print("phisnet_forces.npz: |F|max", np.abs(fx["forces"]).max(), "fp32 vs fp64", np.abs(fx["forces"] - fx["f64:forces"]).max() / np.abs(fx["f64:forces"]).max())
 
 
+def checkpoint():
+    """Fixture phisnet_checkpoint.pt: the file the REAL NeuralNetwork.save (neural_network.py:470-503) writes for the network of _network_setup -- what
+    `load_from` reads.  The Clebsch-Gordan buffers of the reference module (fp64 tables up to L = 10, constants of the code, tens of MB) are dropped from the
+    saved state_dict to keep the fixture small; everything else is the reference's own output (tensors, tuples, numbers, strings: no code objects)."""
+    m, batch, hp, rng, zs, pos, sizes = _network_setup()
+    path = os.path.join(OUT, "phisnet_checkpoint.pt")
+    m.save(path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    n0 = len(ck["state_dict"])
+    ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if "clebsch_gordan" not in k}
+    torch.save(ck, path)
+    print("phisnet_checkpoint.pt:", n0, "->", len(ck["state_dict"]), "state entries;", os.path.getsize(path) // 1024, "kB; keys", sorted(k for k in ck if k != "state_dict"))
+
+
 if __name__ == "__main__" and "--network" in sys.argv:
     network()
+if __name__ == "__main__" and "--checkpoint" in sys.argv:
+    checkpoint()
 if __name__ == "__main__" and "--forces" in sys.argv:
     forces()
