@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 14
+#define NQ_ABI_VERSION 15
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -63,7 +63,9 @@ typedef struct nq_painn_cfg {
 
 /* Neighbour list in engine layout (CSR by target atom, sources ascending; symmetric). */
 typedef struct nq_graph {
-  int32_t N, B, E, reserved;
+  int32_t N, B, E;
+  int32_t max_mol_atoms;    /* largest molecule of the batch (the value passed to nq_graph_count); 0 = unknown: the per-molecule LDS kernels
+                             * (rbf_proj gradient with node rows staged per molecule, csrc/molpair.hip) are then replaced by the row-gather path */
   const int32_t* mol_ptr;   /* [B+1] first atom of each molecule */
   const int32_t* row_ptr;   /* [N+1] */
   const int32_t* col;       /* [E] source atom of the in-edge at this slot */

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -28,7 +28,7 @@ class SchnetCfg(C.Structure):
 
 
 class Graph(C.Structure):
-    _fields_ = [("N", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("N", C.c_int32), ("B", C.c_int32), ("E", C.c_int32), ("max_mol_atoms", C.c_int32),
                 ("mol_ptr", C.c_void_p), ("row_ptr", C.c_void_p), ("col", C.c_void_p), ("dst", C.c_void_p),
                 ("rev", C.c_void_p), ("geom", C.c_void_p), ("z", C.c_void_p), ("atom_mol", C.c_void_p), ("lowptr", C.c_void_p)]
 

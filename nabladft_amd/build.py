@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnablaq.so")
-SOURCES = ["graph.hip", "gemm.hip", "gemm_bf16.hip", "edge.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "qhnet.hip", "gemnet_graph.hip", "gemnet.hip", "escn.hip", "equiformer.hip", "geobasis.hip", "rccl.hip", "engine.hip"]
+SOURCES = ["graph.hip", "gemm.hip", "gemm_bf16.hip", "edge.hip", "molpair.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "qhnet.hip", "gemnet_graph.hip", "gemnet.hip", "escn.hip", "equiformer.hip", "geobasis.hip", "rccl.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 

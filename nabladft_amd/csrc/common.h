@@ -210,7 +210,17 @@ size_t nq_gwr_scratch_floats(int E, int F, int R, int parts = 3);
 int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
                   float* scratch, int parts = 3);
 int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
-int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual);
+int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual, bool pair_rows = true);   // pair_rows = false: the dual flavour neither writes gphi / gpsi nor GBR (molpair.hip computes the rbf_proj gradient)
+// rbf_proj gradient with the molecule's node rows staged in LDS (molpair.hip): no gphi / gpsi arrays
+bool nq_molgw_supported(int F, int R, int max_mol_atoms);
+size_t nq_molgw_sched_ints(int E, int B);
+size_t nq_molgw_rec_floats(int E);
+size_t nq_molgw_part_floats(int F, int B);
+int nq_molgw_schedule(hipStream_t, const NqGraphView&, const int* dst, const float* RW, int R, int* sched_ints, float* recs);
+int nq_molgw_geometry(hipStream_t, const NqGraphView&, const float* TD, const float* TR, const int* sched_ints, float* recs);
+int nq_gwr_mol(hipStream_t, const NqGraphView&, int F, int R, int max_mol_atoms, const float* XH, const float* V, const float* TXH, const float* TV,
+               const float* GX, const float* GV, const float* GTX, const float* GTV, const int* sched_ints, const float* recs, float* part, float* gWr,
+               float* gbr);
 int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);
 int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* pos_dot, float* TD, float* TR);
 int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);

@@ -263,9 +263,14 @@ __global__ void k_msg_rev(MsgRevArgs q) {
 #define NQ_TAN2_THREADS 768     // tangent, 2 channels/lane: 148 VGPRs (1024 threads: 26 spilled, 7.3 ms vs 3.35 ms per step)
 #endif
 // workgroup size per kernel flavour and channels-per-lane (register budget: 1024 thr -> 128 VGPRs, 768 -> 168, 512 -> 256)
-// kind: 0 forward, 1 tangent, 2 force adjoint, 3 dual reverse.  Workgroup size = VGPR budget (one workgroup per CU: LDS holds WrT)
+#ifndef NQ_DUALNG2_THREADS
+#define NQ_DUALNG2_THREADS 768  // dual reverse without the pair rows, 2 channels/lane: 165 VGPRs, no spill
+#endif
+// kind: 0 forward, 1 tangent, 2 force adjoint, 3 dual reverse, 4 dual reverse without pair rows.  Workgroup size = VGPR budget (one workgroup per CU: LDS holds WrT)
 __host__ __device__ constexpr int fused_threads(int kind, int ch) {
-  return ch >= 4 ? 512 : (ch == 2 ? (kind == 3 ? NQ_DUAL2_THREADS : (kind == 1 ? NQ_TAN2_THREADS : 1024)) : (kind == 3 ? 768 : 1024));
+  return ch >= 4 ? 512
+                 : (ch == 2 ? (kind == 3 ? NQ_DUAL2_THREADS : (kind == 4 ? NQ_DUALNG2_THREADS : (kind == 1 ? NQ_TAN2_THREADS : 1024)))
+                            : (kind >= 3 ? 768 : 1024));
 }
 #define FUSED_THREADS_DUAL 1024  // window records live in SGPRs (scalar loads), so the dual reverse also fits 16 waves per CU
 
@@ -362,7 +367,7 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
   const float* wk = wrt + k0 * F3 + fb;
 #pragma unroll
   for (int t = 0; t < FWIN; ++t) {  // always 13 taps: LDS rows >= R and window taps >= R are zero
-    const V wa = O::load(wk + t * F3), wb = O::load(wk + t * F3 + F), wc = O::load(wk + t * F3 + 2 * F);
+    const V wa = lds_tap<CH>(wk + t * F3), wb = lds_tap<CH>(wk + t * F3 + F), wc = lds_tap<CH>(wk + t * F3 + 2 * F);
     const V r = O::splat(w.rr[t]);
     va = O::fma(wa, r, va); vb = O::fma(wb, r, vb); vc = O::fma(wc, r, vc);
     if (PSI) {
@@ -588,12 +593,14 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
 #ifndef NQ_DUAL_KX_EARLY
 #define NQ_DUAL_KX_EARLY 1      // neighbour primal / tangent rows requested at the start of the step (1) or after the filter evaluation (0)
 #endif
-template <bool DUAL, int CH>
-__global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
+// GW (dual only): this kernel also produces the pair rows gphi / gpsi and the per-atom bias sums for the rbf_proj gradient (rounds 1-4, still the path
+// for molecules that do not fit the LDS of molpair.hip); GW = false: the gradient is recomputed from node rows by k_gwr_mol, nothing is stored per pair.
+template <bool DUAL, int CH, bool GW>
+__device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterArgs& fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   FUSED_ROWS(DUAL ? 3 : 2) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
-    const int nlow = DUAL ? __builtin_amdgcn_readfirstlane(q.g.lowptr[n + 1]) - __builtin_amdgcn_readfirstlane(q.g.lowptr[n]) : 0;
+    const int nlow = (DUAL && GW) ? __builtin_amdgcn_readfirstlane(q.g.lowptr[n + 1]) - __builtin_amdgcn_readfirstlane(q.g.lowptr[n]) : 0;
     const long o3 = (long)n * F3 + fb;
     float xa[CH], xb[CH], xc[CH], v0[CH], v1[CH], v2[CH], txa[CH], txb[CH], txc[CH], tv0[CH], tv1[CH], tv2[CH];
     ldv<CH>(xa, q.XH + o3); ldv<CH>(xb, q.XH + o3 + F); ldv<CH>(xc, q.XH + o3 + 2 * F);
@@ -603,9 +610,11 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
       ldv<CH>(txa, q.TXH + o3); ldv<CH>(txb, q.TXH + o3 + F); ldv<CH>(txc, q.TXH + o3 + 2 * F);
       ldv<CH>(tv0, q.TV + o3); ldv<CH>(tv1, q.TV + o3 + F); ldv<CH>(tv2, q.TV + o3 + 2 * F);
 #if NQ_DUAL_NA_RESIDENT
+      if (GW) {
       ldv<CH>(nA0, q.GV + o3); ldv<CH>(nA1, q.GV + o3 + F); ldv<CH>(nA2, q.GV + o3 + 2 * F);
       ldv<CH>(nT0, q.GTV + o3); ldv<CH>(nT1, q.GTV + o3 + F); ldv<CH>(nT2, q.GTV + o3 + 2 * F);
       ldv<CH>(ngma, q.GX + (long)n * F + fb); ldv<CH>(ngtma, q.GTX + (long)n * F + fb);
+      }
 #endif
     } else {
 #pragma unroll
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
     }
     for (int c0 = beg; c0 < end; c0 += 64) {
       const int cnt = min(64, end - c0);
-      const int nlo = DUAL ? max(0, min(cnt, nlow - (c0 - beg))) : 0;   // lower edges of this chunk come first
+      const int nlo = (DUAL && GW) ? max(0, min(cnt, nlow - (c0 - beg))) : 0;   // lower edges of this chunk come first
       RowRegs row;
       load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
       RevOps<DUAL, CH> opA, opB;   // ping-pong operands; scalar window loads are issued after the filter's LDS reads (see k_msgf_fwd)
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded
         load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
         float kxa[CH], kxb[CH], kxc[CH], kv0[CH], kv1[CH], kv2[CH], ktxa[CH], ktxb[CH], ktxc[CH], ktv0[CH], ktv1[CH], ktv2[CH];
-        if (DUAL && LOW && NQ_DUAL_KX_EARLY) {
+        if (DUAL && GW && LOW && NQ_DUAL_KX_EARLY) {
           const long k3 = (long)ABL_K(j) * F3 + fb;
           ldv<CH>(kxa, q.XH + k3); ldv<CH>(kxb, q.XH + k3 + F); ldv<CH>(kxc, q.XH + k3 + 2 * F);
           ldv<CH>(kv0, q.V + k3); ldv<CH>(kv1, q.V + k3 + F); ldv<CH>(kv2, q.V + k3 + 2 * F);
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
         const float beta = win.rr[14], dbeta = win.dd[14];
         __builtin_amdgcn_sched_barrier(0);
         load_win<true>(win, RW, ABL_SP(c0 + jn));
-        if (DUAL && LOW && !NQ_DUAL_KX_EARLY) {   // primal / tangent rows of the neighbour: issued here, consumed after the main block of the step
+        if (DUAL && GW && LOW && !NQ_DUAL_KX_EARLY) {   // primal / tangent rows of the neighbour: issued here, consumed after the main block of the step
           const long k3 = (long)ABL_K(j) * F3 + fb;
           ldv<CH>(kxa, q.XH + k3); ldv<CH>(kxb, q.XH + k3 + F); ldv<CH>(kxc, q.XH + k3 + 2 * F);
           ldv<CH>(kv0, q.V + k3); ldv<CH>(kv1, q.V + k3 + F); ldv<CH>(kv2, q.V + k3 + 2 * F);
@@ -683,18 +692,20 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
             gtv0[c] += T0 * mb; gtv1[c] += T1 * mb; gtv2[c] += T2 * mb;
             gxa[c] += gma * pa[c] + gtma * tpa; gxb[c] += gmb * pb[c] + gtmb * tpb; gxc[c] += gmc * pc[c] + gtmc * tpc;
             gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c];
-            ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
-            ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
-            sba[c] += ga[c] * beta + ha[c] * dbeta;
-            sbb[c] += gb[c] * beta + hb[c] * dbeta;
-            sbc[c] += gc[c] * beta + hc[c] * dbeta;
+            if (GW) {
+              ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
+              ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
+              sba[c] += ga[c] * beta + ha[c] * dbeta;
+              sbb[c] += gb[c] * beta + hb[c] * dbeta;
+              sbc[c] += gc[c] * beta + hc[c] * dbeta;
+            }
           } else {
             gxa[c] += gma * pa[c]; gxb[c] += gmb * pb[c]; gxc[c] += gmc * pc[c];
             gd += gma * xa[c] * qa[c] + gmb * xb[c] * qb[c] + gmc * xc[c] * qc[c];
             e0 += A0 * mc; e1 += A1 * mc; e2 += A2 * mc;
           }
         }
-        if (DUAL && LOW && NQ_ABLATE != 1) {
+        if (DUAL && GW && LOW && NQ_ABLATE != 1) {
           // direction k -> n: roles swapped, unit vector and its tangent negated, t_d unchanged.  The adjoint rows of n are the same
           // addresses for every edge of the row (L1 hits): loaded only now, so that they do not occupy registers during the block above
 #if !NQ_DUAL_NA_RESIDENT
@@ -776,7 +787,7 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
     stv<CH>(q.GV_out + o3, g0); stv<CH>(q.GV_out + o3 + F, g1); stv<CH>(q.GV_out + o3 + 2 * F, g2);
     if (DUAL) {
       stv<CH>(q.GTXH + o3, gtxa); stv<CH>(q.GTXH + o3 + F, gtxb); stv<CH>(q.GTXH + o3 + 2 * F, gtxc);
-      stv<CH>(q.GBR + o3, sba); stv<CH>(q.GBR + o3 + F, sbb); stv<CH>(q.GBR + o3 + 2 * F, sbc);
+      if (GW) { stv<CH>(q.GBR + o3, sba); stv<CH>(q.GBR + o3 + F, sbb); stv<CH>(q.GBR + o3 + 2 * F, sbc); }
       ldv<CH>(g0, q.GTV + o3); ldv<CH>(g1, q.GTV + o3 + F); ldv<CH>(g2, q.GTV + o3 + 2 * F);
 #pragma unroll
       for (int c = 0; c < CH; ++c) { g0[c] += gtv0[c]; g1[c] += gtv1[c]; g2[c] += gtv2[c]; }
@@ -785,6 +796,15 @@ __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(Ms
   }
 }
 
+
+template <bool DUAL, int CH>
+__global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
+  msgf_rev_body<DUAL, CH, DUAL>(q, fa, RW);
+}
+template <bool DUAL, int CH>   // DUAL is always true here (same template shape as k_msgf_rev for the dispatch macros)
+__global__ __launch_bounds__(fused_threads(4, CH)) void k_msgf_rev_nopair(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
+  msgf_rev_body<true, CH, false>(q, fa, RW);
+}
 
 // =============================================================================================
 // Gradient of rbf_proj.weight with the windowed filter, register-resident and deterministic.
@@ -1178,13 +1198,15 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
   return NQ_OK;
 }
 
-int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool dual) {
-  NQ_PROF(st, dual ? "msgf_rev_dual" : "msgf_rev_force");
+int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool dual, bool pair_rows) {
+  NQ_PROF(st, dual ? (pair_rows ? "msgf_rev_dual" : "msgf_rev_dual_ng") : "msgf_rev_force");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
+  const int kind = dual ? (pair_rows ? 3 : 4) : 2;
   const int ch = fused_ch(dual ? 3 : 2, q.F);
-  const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(dual ? 3 : 2, ch));
-  if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
+  const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(kind, ch));
+  if (dual && !pair_rows) FUSED_DISPATCH(k_msgf_rev_nopair, true, q);
+  else if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
   else FUSED_DISPATCH(k_msgf_rev, false, q);
   NQ_LAUNCH_CHECK();
   return NQ_OK;

@@ -90,7 +90,7 @@ struct WsLayout {
   size_t X[65], V[65];
   WsLayer lay[64];
   size_t RHO2, RW, ORDER, ZO, e_atom, te_atom, TD, TR, pos_dot, ge, gte;
-  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GBR, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, ROWCTR, scratch;
+  size_t GX, GVa, GVb, GY, GQ, GCAT, GU, GXH, GH, GBR, GPHI2, GEDGE, GZO, TMPW, GRHO, BCON, ROWCTR, SCHED, GWREC, GWPART, scratch;
   size_t scratch_floats, total_floats;
   bool fused;   // radial filter evaluated inside the message kernels (WrT resident in LDS); PHI/PSI not materialised
 };
@@ -129,6 +129,9 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
   W->GRHO = take(c->rbf_type ? 2 * E * R : 0); W->BCON = take(c->rbf_type ? E * R : 0);   // learnable bases: adjoints of rho / drho, per-edge contributions
   W->ROWCTR = take(4 * L * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]
+  W->SCHED = take(W->fused ? nq_molgw_sched_ints((int)E, (int)B) : 0);      // int32: per-molecule pair lists of the molecule-per-workgroup rbf_proj gradient (molpair.hip)
+  W->GWREC = take(W->fused ? nq_molgw_rec_floats((int)E) : 0);               // its per-pair records: expanded matrix-core A operands (per step) + packed geometry (per backward sweep)
+  W->GWPART = take(W->fused ? nq_molgw_part_floats((int)F, (int)B) : 0);   // its per-workgroup partial rows
   // scratch for split-K partials / column sums / embedding partials: max over all uses
   size_t s = 0;
   auto mx = [&](size_t v) { if (v > s) s = v; };
@@ -143,6 +146,13 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->scratch = take(s);
   W->total_floats = o;
   (void)B;
+}
+
+// rbf_proj gradient from node rows staged per molecule in LDS (molpair.hip) instead of gphi / gpsi pair rows through HBM: needs the fused filter and a
+// batch whose largest molecule fits the LDS of one workgroup (nq_graph::max_mol_atoms, 0 = unknown); NQ_NO_MOLGW=1 forces the pair-row path.
+static bool use_molgw(const nq_painn_cfg* c, const nq_graph* g, const WsLayout& W) {
+  const char* off = getenv("NQ_NO_MOLGW");
+  return W.fused && !(off && off[0] == '1') && nq_molgw_supported(c->hidden_channels, c->num_rbf, g->max_mol_atoms);
 }
 
 static NqGraphView view_of(const nq_graph* g) {
@@ -278,6 +288,14 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'order' exists only with the fused filter");
     base = W.ORDER; rows = e; w = 1; dual = false;
   }
+  else if (!strcmp(name, "pair_sched")) {                                     // int32 payload: {slot, off << 26 | n << 13 | k} per pair (molpair.hip)
+    if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched' exists only with the fused filter");
+    base = W.SCHED; rows = e; w = 1; dual = false;
+  }
+  else if (!strcmp(name, "pair_sched_meta")) {                                // int32: sched_ptr [B][13], hist [128], wlo [13]
+    if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched_meta' exists only with the fused filter");
+    base = W.SCHED + ((e + 1) & ~(size_t)1); rows = nq_molgw_sched_ints((int)e, B) - ((e + 1) & ~(size_t)1); w = 1; dual = false;
+  }
   else if (!strcmp(name, "rw")) {
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'rw' exists only with the fused filter");
     base = W.RW; rows = e; w = 32; dual = false;
@@ -321,7 +339,8 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     FilterArgs fa0;
     nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
-    NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col));   // lower slots only
+    if (use_molgw(cfg, graph, W)) NQ_TRY(nq_molgw_schedule(st, g, graph->dst, ws + W.RW, R, reinterpret_cast<int*>(ws + W.SCHED), ws + W.GWREC));
+    else NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col));   // lower slots only
   } else {
     NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho, cfg->rbf_type, params + P.basis));
   }
@@ -557,6 +576,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (seed_vec) NQ_HIP(hipMemcpyAsync(gv_cur, seed_vec, 3 * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
+  const bool molgw = use_molgw(cfg, graph, W);
+  if (molgw) NQ_TRY(nq_molgw_geometry(st, g, ws + W.TD, ws + W.TR, reinterpret_cast<const int*>(ws + W.SCHED), ws + W.GWREC));
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     UpdRevArgs u{};
@@ -594,17 +615,22 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       fa.row_ctr = row_ctr(3, l);
-      NQ_TRY(nq_msgf_rev(st, m, fa, true));
+      NQ_TRY(nq_msgf_rev(st, m, fa, true, !molgw));
+      // rbf_proj weight and bias gradient from the same node rows, staged per molecule in LDS (main stream: it reads the adjoints this layer's input-gradient
+      // products overwrite next; the fork below orders the side stream and the layer event behind it)
+      if (molgw)
+        NQ_TRY(nq_gwr_mol(st, g, F, R, graph->max_mol_atoms, m.XH, m.V, m.TXH, m.TV, m.GX, m.GV, m.GTX, m.GTV, reinterpret_cast<const int*>(ws + W.SCHED),
+                          ws + W.GWREC, ws + W.GWPART, gp + mp.Wr, gp + mp.br));
     } else {
       NQ_TRY(nq_msg_rev(st, m, true));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
     sd = ss.fork();
-    if (W.fused) NQ_TRY(nq_gwr_sorted(sd, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr));   // one row per pair
-    else NQ_TRY(nq_gemm_tn(sd, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
+    if (W.fused && !molgw) NQ_TRY(nq_gwr_sorted(sd, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr));   // one row per pair
+    else if (!W.fused) NQ_TRY(nq_gemm_tn(sd, gphi, ws + W.RHO2, gp + mp.Wr, 2L * E, 3 * F, R, 3 * F, R, scr, "Wr"));
     if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
       NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));
-    NQ_TRY(nq_colsum(sd, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
+    if (!molgw) NQ_TRY(nq_colsum(sd, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
     NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); ss.read_by_side(SB_GXH);
     ss.before_main_writes(SB_GH);

@@ -62,6 +62,22 @@ __device__ __forceinline__ void load_win(WinRegs<PSI>& w, const float* __restric
   }
 }
 
+// LDS filter taps, never paired: the compiler merges two ds_read_b64 of one base address into ds_read2(st64)_b64, which the LDS serves at half the
+// bytes per clock (measured on MI355X, profiles/r05_valu_lds_issue_rates_lab.txt: paired 261 B/ns per CU, single ds_read_b64 348, ds_read_b128 474;
+// the 13-tap x 3-part filter of one edge: 66.5 ns paired vs 46.4 ns single at 16 wavefronts per CU).  A volatile access through an LDS-address-space
+// pointer stays a single ds_read_b64 and keeps the compiler's own lgkmcnt accounting.
+#ifndef NQ_LDS_SINGLE_READS
+#define NQ_LDS_SINGLE_READS 1
+#endif
+template <int CH>
+__device__ __forceinline__ typename VecOf<CH>::T lds_tap(const float* p) {
+  typedef typename VecOf<CH>::T V;
+#if NQ_LDS_SINGLE_READS
+  if constexpr (CH == 2) return *(__attribute__((address_space(3))) const volatile V*)(p);
+#endif
+  return *reinterpret_cast<const V*>(p);
+}
+
 // CH-wide vector arithmetic: every FMA pair becomes one v_pk_fma_f32
 template <int CH> struct VOps {
   typedef typename VecOf<CH>::T V;

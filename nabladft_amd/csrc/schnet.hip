@@ -83,7 +83,7 @@ __device__ __forceinline__ void sn_filter1(const WinRegs<PSI>& w, const float* w
   const float* wk = wt + k0 * F + fb;
 #pragma unroll
   for (int t = 0; t < FWIN; ++t) {
-    const typename O::V wv = O::load(wk + t * F);
+    const typename O::V wv = lds_tap<CH>(wk + t * F);
     vz = O::fma(wv, O::splat(w.rr[t]), vz);
     if (PSI) vp = O::fma(wv, O::splat(w.dd[t]), vp);
   }

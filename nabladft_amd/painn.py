@@ -85,7 +85,7 @@ def build_neighbor_list(pos: torch.Tensor, batch: torch.Tensor, z: Optional[torc
     nl.t = dict(pos=pos32, mol_ptr=mol_ptr, row_ptr=row_ptr, lowptr=lowptr, col=col, dst=dst, rev=rev, geom=geom, slot2canon=s2c,
                 atom_mol=atom_mol, z=z32, deg=deg)
     g = _lib.Graph()
-    g.N, g.B, g.E = N, B, E
+    g.N, g.B, g.E, g.max_mol_atoms = N, B, E, max_n
     g.mol_ptr, g.row_ptr, g.col, g.dst = mol_ptr.data_ptr(), row_ptr.data_ptr(), col.data_ptr(), dst.data_ptr()
     g.rev, g.geom, g.atom_mol = rev.data_ptr(), geom.data_ptr(), atom_mol.data_ptr()
     g.z = z32.data_ptr() if z32 is not None else None

@@ -298,7 +298,9 @@ def _trace_report(name, model, sw, s2c, tag, lines):
             e = rel_err(got, ref)
             worst = max(worst, e)
             lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
-    else:
+    elif os.environ.get("NQ_NO_MOLGW") != "1" and tag == "fwd":
+        _check_pair_schedule(model)
+    elif os.environ.get("NQ_NO_MOLGW") == "1":
         # k0-sorted order of the LOWER CSR slots (col < dst: one gphi / gpsi row per pair): every lower slot once, keys non-decreasing, stable
         nl = model._last_nl
         lower = torch.nonzero(nl.t["col"].cpu() < nl.t["dst"].cpu()).view(-1)
@@ -333,15 +335,59 @@ def _trace_report(name, model, sw, s2c, tag, lines):
     return worst
 
 
-@pytest.mark.parametrize("fused", ["fused", "materialised"])
+def _check_pair_schedule(model):
+    """Pair lists of the molecule-per-workgroup rbf_proj gradient (csrc/molpair.hip): every lower CSR slot (col < dst) exactly once, inside its molecule's
+    segment; entries sorted by window start k0, slot-ascending among equal k0; the wavefront segments tile the molecule's list, every pair sits inside
+    the accumulator rows of its wavefront (0 <= k0 - wlo[w] < 19 = the stored row offset) and no segment is longer than ceil(pairs / wavefronts) unless the next
+    wavefront's rows cannot hold the surplus; the local atom indices are the slot's (dst, col) relative to the molecule's first atom."""
+    nl = model._last_nl
+    col, dst = nl.t["col"].cpu().long(), nl.t["dst"].cpu().long()
+    lowptr, mol_ptr = nl.t["lowptr"].cpu().long(), nl.t["mol_ptr"].cpu().long()
+    lower = torch.nonzero(col < dst).view(-1)
+    assert lower.numel() * 2 == nl.E
+    sched = model.workspace_view("pair_sched").cpu().view(torch.int32)[:nl.E].view(-1, 2).long()
+    meta = model.workspace_view("pair_sched_meta").cpu().view(torch.int32).long()
+    NW, WMAX = (meta.numel() - 144) // (nl.B + 1) - 1, 19   # wavefronts per workgroup of k_gwr_mol (meta = sched_ptr [B][NW+1], hist [128], wlo [NW+1], 16 spare)
+    assert NW in (8, 12, 16)
+    sp = meta[:nl.B * (NW + 1)].view(nl.B, NW + 1)
+    hist, wlo = meta[nl.B * (NW + 1):][:128], meta[nl.B * (NW + 1) + 128:][:NW + 1]
+    k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
+    assert torch.equal(torch.bincount(k0s[lower], minlength=128)[:128], hist)
+    assert bool((wlo[1:NW] >= wlo[:NW - 1]).all()) and bool((wlo[1:NW] <= wlo[:NW - 1] + WMAX).all())
+    assert int(wlo[0]) <= int(k0s[lower].min()) and int(wlo[NW - 1]) + WMAX > int(k0s[lower].max())
+    slot, word = sched[:, 0], sched[:, 1] & 0xFFFFFFFF
+    assert torch.equal(torch.sort(slot).values, lower)
+    off, nloc, kloc = word >> 26, (word >> 13) & 0x1FFF, word & 0x1FFF
+    for m in range(nl.B):
+        pb, pe = int(lowptr[mol_ptr[m]]), int(lowptr[mol_ptr[m + 1]])
+        assert int(sp[m, 0]) == 0 and int(sp[m, NW]) == pe - pb and bool((sp[m, 1:] >= sp[m, :-1]).all())
+        sl, k = slot[pb:pe], k0s[slot[pb:pe]]
+        assert bool((dst[sl] >= mol_ptr[m]).all()) and bool((dst[sl] < mol_ptr[m + 1]).all())
+        assert bool((k[1:] >= k[:-1]).all()) and bool((sl[1:][k[1:] == k[:-1]] > sl[:-1][k[1:] == k[:-1]]).all())
+        assert torch.equal(nloc[pb:pe], dst[sl] - mol_ptr[m]) and torch.equal(kloc[pb:pe], col[sl] - mol_ptr[m])
+        target = -(-(pe - pb) // NW)
+        for w in range(NW):
+            seg = slice(pb + int(sp[m, w]), pb + int(sp[m, w + 1]))
+            assert torch.equal(off[seg], k0s[slot[seg]] - wlo[w]) and bool((off[seg] >= 0).all()) and bool((off[seg] < WMAX).all())
+            n_seg = int(sp[m, w + 1] - sp[m, w])
+            if n_seg > target and w < NW - 1:   # surplus only when forced: those pairs lie below the next wavefront's first row
+                assert bool((k0s[slot[seg]][target:] < wlo[w + 1]).all())
+
+
+@pytest.mark.parametrize("fused", ["fused", "fused_pair_rows", "materialised"])
 @pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz", "painn_small_expenv.npz"])
 def test_engine_matches_reference_golden(name, fused, monkeypatch):
-    """fused: radial filter evaluated inside the message kernels (WrT in LDS, 13-Gaussian window);
+    """fused: radial filter evaluated inside the message kernels (WrT in LDS, 13-Gaussian window), rbf_proj gradient from node rows staged per molecule in
+    LDS (csrc/molpair.hip); fused_pair_rows: the same with the gphi / gpsi pair rows through HBM (path of molecules that do not fit the LDS);
     materialised: fallback path (phi/psi through the GEMM) used when WrT does not fit the LDS."""
     if fused == "materialised":
         monkeypatch.setenv("NQ_NO_FUSED_FILTER", "1")
     else:
         monkeypatch.delenv("NQ_NO_FUSED_FILTER", raising=False)
+    if fused == "fused_pair_rows":
+        monkeypatch.setenv("NQ_NO_MOLGW", "1")
+    else:
+        monkeypatch.delenv("NQ_NO_MOLGW", raising=False)
     name_tag = f"{name}.{fused}"
     dev = _dev()
     fx, cfg, params = load_case(name)
