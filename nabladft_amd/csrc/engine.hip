@@ -152,7 +152,11 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
 // batch whose largest molecule fits the LDS of one workgroup (nq_graph::max_mol_atoms, 0 = unknown); NQ_NO_MOLGW=1 forces the pair-row path.
 static bool use_molgw(const nq_painn_cfg* c, const nq_graph* g, const WsLayout& W) {
   const char* off = getenv("NQ_NO_MOLGW");
-  return W.fused && !(off && off[0] == '1') && nq_molgw_supported(c->hidden_channels, c->num_rbf, g->max_mol_atoms);
+  if (!W.fused || (off && off[0] == '1') || !nq_molgw_supported(c->hidden_channels, c->num_rbf, g->max_mol_atoms)) return false;
+  // small batches (the reference's 32 conformers): the schedule kernels and the two launches per layer are pure latency there (measured 3.99 vs 3.72 ms per
+  // step at 32 conformers), the pair rows are a few MB; NQ_MOLGW=1 forces the per-molecule path at any size (tests)
+  const char* on = getenv("NQ_MOLGW");
+  return (on && on[0] == '1') || g->N >= 4096;
 }
 
 static NqGraphView view_of(const nq_graph* g) {

@@ -386,8 +386,10 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
         monkeypatch.delenv("NQ_NO_FUSED_FILTER", raising=False)
     if fused == "fused_pair_rows":
         monkeypatch.setenv("NQ_NO_MOLGW", "1")
+        monkeypatch.delenv("NQ_MOLGW", raising=False)
     else:
         monkeypatch.delenv("NQ_NO_MOLGW", raising=False)
+        monkeypatch.setenv("NQ_MOLGW", "1")   # the golden batches are small: force the per-molecule path (default from 4096 atoms per step)
     name_tag = f"{name}.{fused}"
     dev = _dev()
     fx, cfg, params = load_case(name)

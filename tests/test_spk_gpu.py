@@ -22,8 +22,15 @@ def _potential(scfg):
         postprocessors=[spk.AddOffsets("energy", add_mean=True)])
 
 
+@pytest.mark.parametrize("gw", ["pair_rows", "per_molecule"])
 @pytest.mark.parametrize("F,L,R,cutoff,n_mol,size", [(64, 2, 20, 4.0, 5, (3, 14)), (128, 6, 100, 5.0, 6, (8, 30)), (256, 1, 50, 5.0, 3, (5, 20))])
-def test_spk_potential_matches_restatement(F, L, R, cutoff, n_mol, size):
+def test_spk_potential_matches_restatement(F, L, R, cutoff, n_mol, size, gw, monkeypatch):
+    """gw: filter-network weight gradient from gphi / gpsi pair rows (small batches) or from node rows staged per molecule in LDS (csrc/molpair.hip, default
+    from 4096 atoms per step; forced here).  schnetpack mode exercises the cosine-cutoff bias multiplier (beta, beta') of the window record."""
+    if gw == "per_molecule":
+        monkeypatch.setenv("NQ_MOLGW", "1")
+    else:
+        monkeypatch.delenv("NQ_MOLGW", raising=False)
     from oracle import painn_ref as PR
     from oracle import spk_painn_ref as S
     scfg = S.SpkPaiNNConfig(n_atom_basis=F, n_interactions=L, n_rbf=R, cutoff=cutoff, max_z=20)
