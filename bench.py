@@ -45,6 +45,28 @@ def collective_name():
     return {"nccl": "rccl via torch.distributed (backend nccl)"}.get(dist.get_backend(), dist.get_backend())
 
 
+def collective_record(step=None):
+    """What the gradient collective of this job is and how many ranks the collective library ITSELF sees (ncclCommCount of the native communicator, or the
+    world size torch.distributed built its RCCL communicator with), so that the driver can check the rank count independently of --gpus."""
+    nq = nqdist_mod()
+    if not nq.active():
+        return {"backend": "none", "ranks_seen": 1, "path": "none", "name": collective_name(), "allreduce_exposed_ms": None}
+    native = nq.native_comm(create=False) is not None
+    backend = dist.get_backend()
+    exposed = step.allreduce_exposed_ms() if step is not None and hasattr(step, "allreduce_exposed_ms") else None
+    return {"backend": "rccl" if (native or backend == "nccl") else backend, "ranks_seen": int(nq.ranks_seen()), "path": "native" if native else "torch",
+            "name": collective_name(), "allreduce_exposed_ms": exposed}
+
+
+def check_ranks(expected):
+    """Abort (exit code != 0) when the collective library does not see the number of ranks this job was launched for."""
+    nq = nqdist_mod()
+    seen = nq.ranks_seen() if nq.active() else 1
+    if seen != expected:
+        print(f"bench.py: the collective library sees {seen} ranks but --gpus is {expected}", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
 def dist_on():
     """A process group exists and its collectives run: world > 1, or the forced 1-rank group of the single-GPU RCCL test (NQ_DIST_FORCE=1)."""
     return nqdist_mod().active()
@@ -99,7 +121,7 @@ def gemm_flops(name, N, E, launches):
 
 # HIP-event launcher class -> rocprofv3 kernel name (for the PMC traffic file) and sweep multiplicity
 _MSG = {"msgf_fwd": ("k_msgf_fwd<false", 1), "msgf_tan": ("k_msgf_fwd<true", 2), "msgf_rev_force": ("k_msgf_rev<false", 1),
-        "msgf_rev_dual": ("k_msgf_rev<true", 2)}
+        "msgf_rev_dual": ("k_msgf_rev<true", 2), "msgf_rev_dual_ng": ("k_msgf_rev_nopair<true", 2)}
 
 
 # SchNet streaming kernels: bytes that must cross HBM once per launch (edge arrays [E][F] fp32, 128-B window records, node rows [N][F])
@@ -142,7 +164,34 @@ def pmc_traffic_bytes(kernel_prefix, batch):
     return None, f"{tag} does not hold {kernel_prefix}"
 
 
+def rocprof_avg_launch_us(kernel_prefix):
+    """Average launch duration (us) of the kernel in the newest committed rocprofv3 --kernel-trace --stats summary of the PaiNN bench (profiles/r0N_rocprofv3_kernel_stats_painn_b2048.csv),
+    or None: lets the record show the HIP-event figure next to the profiler's."""
+    import csv
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_rocprofv3_kernel_stats_painn_b2048.csv") for r in (9, 8, 7, 6, 5)) if os.path.exists(q)), None)
+    if path is None or kernel_prefix is None:
+        return None, None
+    ident = kernel_prefix.split(",")[0].split(" ")[0]
+    try:
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                name = (row.get("Name") or row.get("KernelName") or "").replace("void ", "")
+                if name.startswith(ident):
+                    avg = row.get("AverageNs") or row.get("Average")
+                    return (float(avg) / 1e3 if avg else None), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        pass
+    return None, os.path.relpath(path, ROOT)
+
+
 def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
+    rec = _roofline_record(dom, avg_ms, launches, n_atoms, E, batch)
+    us, src = rocprof_avg_launch_us(rec.get("kernel"))
+    rec["rocprof_avg_launch_us"], rec["rocprof_source"] = us, src
+    return rec
+
+
+def _roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
     """Roofline entry of the dominant launcher class.  Message kernels are HBM-bound: algorithmic bytes per launch =
     SURVEY 8(d)'s message share of one layer, (8*N*F*4 + 24*E) bytes, x2 for the sweeps that carry (primal, tangent) pairs.
     GEMM classes are bound by the fp32 matrix cores: flop per launch from the role tag."""
@@ -164,6 +213,18 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
         ach = nbytes / (avg_ms * 1e-3) / 1e9
         return {"kernel": "k_" + dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
+    if dom == "gwr_mol":
+        # rbf_proj gradient, molecule per workgroup (csrc/molpair.hip): reads the 20 node rows of the layer once (12 primal / tangent + 8 adjoint: 20 N F floats)
+        # and the per-pair records (64-float matrix-core A operand + 8-float geometry record per pair and 32-channel slice)
+        nbytes = 20.0 * n_atoms * F * 4 + (E / 2.0) * (64 + 8) * 4 * (F // 32)
+        ach = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic, tsrc = pmc_traffic_bytes("k_gwr_mol", batch)
+        return {"kernel": "k_gwr_mol (+ k_gwr_mol_reduce)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": tsrc, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                "matrix_core_flops_per_launch": 2.0 * 32 * 32 * 2 * 3 * (E / 2.0) * (F // 32),
+                "note": "compute-bound on the SIMD shared by VALU and the f32 matrix-core path (profiles/r05_mfma_valu_overlap_lab.txt: the two do not overlap): "
+                        "per pair and 32-channel slice ~52 VALU instructions + 3 v_mfma_f32_32x32x2_f32"}
     if dom == "gwr_sorted":
         flops = 2.0 * 26 * E * 3 * F          # 26 FMAs per (edge, column)
         ach = flops / (avg_ms * 1e-3) / 1e12
@@ -177,7 +238,8 @@ def roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
 # fp32 operations per (directed edge, channel) of the message-path kernels, counted from csrc/edge.hip (FMA = 2): the 13-tap filter is 39 FMA + 3 mul
 # (phi) or 78 FMA + 6 mul (phi and psi); then the per-edge message arithmetic of each flavour; the dual reverse runs its second direction on half of the edges;
 # k_gwr_sorted: 26 FMA per (pair, column) = 13 per directed edge and column, three column parts.
-_MSG_FLOP_PER_EDGE_CHANNEL = {"msgf_fwd": 81 + 16, "msgf_tan": 162 + 39, "msgf_rev_force": 162 + 39, "msgf_rev_dual": 162 + 103 + 27, "gwr_sorted": 3 * 26}
+_MSG_FLOP_PER_EDGE_CHANNEL = {"msgf_fwd": 81 + 16, "msgf_tan": 162 + 39, "msgf_rev_force": 162 + 39, "msgf_rev_dual": 162 + 103 + 27, "gwr_sorted": 3 * 26,
+                              "msgf_rev_dual_ng": 162 + 76, "gwr_mol": 27 + 3 * 26}   # without pair rows the dual flavour loses the second direction; k_gwr_mol recomputes gphi / gpsi (~54 flop per directed edge and channel) and contracts 26 FMA per (pair, column)
 
 
 def gemm_engine_name():
@@ -433,7 +495,7 @@ def compact_record(full, full_path=None):
     rf = full.get("roofline")
     if rf is not None:
         r = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms",
-                       "launches_per_step", "device_ms_per_step_all_kernels"))
+                       "rocprof_avg_launch_us", "rocprof_source", "launches_per_step", "device_ms_per_step_all_kernels"))
         r.setdefault("traffic", None)
         if rf.get("step") is not None:
             r["step"] = _pick(rf["step"], ("flops_per_step", "gemm_flops_per_step", "message_valu_flops_per_step", "gemm_engine", "fp32_bound_ms",
@@ -447,11 +509,17 @@ def compact_record(full, full_path=None):
     for extra in ("reference_batch_size_32", "reference_batch_size_8", "reference_batch_size_2"):
         if full.get(extra) is not None:
             rec[extra] = _pick(full[extra], ("value", "unit", "ms_per_step"))
+    if full.get("sibling_config") is not None:      # BASELINE.json configs[1] as literally written (config/painn.yaml: schnetpack PaiNN), one number
+        sc = full["sibling_config"]
+        rec["sibling_config"] = {"workload": _short(sc.get("workload", ""), 60), "value": _num(sc.get("value")), "ms_per_step": _num(sc.get("ms_per_step")),
+                                 "parity": "unpinned" if "unpinned" in str(sc.get("parity", "")) else "pinned"}
+    if full.get("sustained") is not None:
+        rec["sustained"] = _pick(full["sustained"], ("value", "unit", "steps", "seconds"))
     if full.get("kernel_ms_per_step"):
         rec["kernel_ms_per_step"] = dict(list(full["kernel_ms_per_step"].items())[:6])
     if full_path:
         rec["full_record"] = full_path
-    for drop in ("kernel_ms_per_step", "reference_batch_size_32", "reference_batch_size_8", "reference_batch_size_2", "mae_vs_cpu_reference"):
+    for drop in ("kernel_ms_per_step", "sustained", "reference_batch_size_32", "reference_batch_size_8", "reference_batch_size_2", "mae_vs_cpu_reference"):
         if len(json.dumps(rec)) <= COMPACT_LIMIT:
             break
         rec.pop(drop, None)
@@ -588,18 +656,29 @@ def cpu_baseline(seconds_budget=25.0):
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     ei, _, _ = Rf.build_graph(pos, batch, cfg.cutoff, cfg.max_neighbors)
+    # the same work as the GPU step: forward, forces, loss, double backward, gradient clipping and AdamW (torch's own optimiser on the flat CPU gradient)
+    names_o = [k for k, _ in Rf.param_shapes(cfg)]
+    flat_p = torch.nn.Parameter(torch.cat([params[k].reshape(-1) for k in names_o]).clone())
+    opt = torch.optim.AdamW([flat_p], lr=5e-4, weight_decay=0.01)
+
+    def cpu_step():
+        _, _, _, g = Rf.train_step(params, cfg, pos, z, batch, y, ft)
+        flat_p.grad = torch.cat([g[k].reshape(-1) for k in names_o])
+        torch.nn.utils.clip_grad_norm_([flat_p], 5.0)
+        opt.step()
+
     t0 = time.perf_counter()
-    Rf.train_step(params, cfg, pos, z, batch, y, ft)          # warm-up (includes graph build inside)
+    cpu_step()          # warm-up (includes graph build inside)
     warm = time.perf_counter() - t0
     times = []
     while sum(times) + warm < seconds_budget and len(times) < 5:
         t0 = time.perf_counter()
-        Rf.train_step(params, cfg, pos, z, batch, y, ft)
+        cpu_step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times)) if times else warm
     out = {"value": 32.0 / med, "unit": "conformer-steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
            "sample": f"B=32 synthetic conformers ({pos.shape[0]} atoms, {ei.shape[1]} edges), PaiNN-OC config, "
-                     f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 without optimizer step"}
+                     f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 incl. gradient clipping + AdamW (the same work as the GPU step)"}
     # accuracy half of the metric: the HIP path vs this CPU reference on the identical inputs and weights
     import nabladft_amd as nq
     e_ref, f_ref, loss_ref, g_ref = Rf.train_step(params, cfg, pos, z, batch, y, ft, ei)
@@ -627,6 +706,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2048, help="conformers per GPU per step (weak scaling)")
+    ap.add_argument("--sustain", type=float, default=8.0, help="seconds of extra (untimed) steps after the timed region: keeps the GPU visibly busy for coarse samplers; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full", action="store_true", help="also run the side legs (other engine, sibling config, host feed, inference, QHNet / GemNet-OC / eSCN / "
@@ -640,6 +720,7 @@ def main():
     from nabladft_amd import _lib, dist as nqdist
     rank, world, local = nqdist.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    check_ranks(args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     local_dev = local % torch.cuda.device_count()   # (>1 rank per device only in the 1-GPU plumbing test, NQ_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_dev)
@@ -673,6 +754,7 @@ def main():
         loss = step(batches[i % len(batches)])
     sync()
     dt = time.perf_counter() - t0
+    collective = collective_record(step)   # incl. the exposed all-reduce time of the last timed step
     final_loss = float(loss)          # NOW: `loss` is the step's device-side loss buffer, which every later step (roofline pass, side legs) overwrites
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist_on():
@@ -681,6 +763,20 @@ def main():
     total_conf = args.batch * world * args.steps
     value = total_conf / dt
     n_edges = model._last_nl.E
+
+    sustained = None
+    if world == 1 and not args.no_roofline and args.sustain > 0:
+        # the same steps for a few seconds of wall time (untimed by the contract, reported next to `value`): long enough for a coarse GPU-busy sampler to see the
+        # run, and a second throughput figure over ~100 steps
+        n_s, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.sustain:
+            for i in range(10):
+                step(batches[(n_s + i) % len(batches)])
+            n_s += 10
+            torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        sustained = {"value": args.batch * n_s / dts, "unit": "conformer-steps/s", "steps": n_s, "seconds": dts,
+                     "what": "the timed region's step repeated for --sustain seconds (synchronised every 10 steps)"}
 
     roofline, kernels = None, None
     if not args.no_roofline:
@@ -794,8 +890,8 @@ def main():
             model.train()
 
     other, kind2 = None, None
-    if rank == 0 and world == 1 and not args.no_roofline and args.full:
-        # the sibling PaiNN configuration through the same kernels (reported, not `value`)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # the sibling PaiNN configuration through the same kernels (reported, not `value`): the timing leg always, its kernel table / CPU leg with --full
         kind2 = "painn-spk" if args.model == "painn-oc" else "painn-oc"
         if args.model == "schnet-spk":
             kind2 = None
@@ -828,18 +924,20 @@ def main():
         other = {"workload": WORKLOADS[kind2], "value": args.batch * args.steps / dt2, "unit": "conformer-steps/s", "ms_per_step": 1e3 * dt2 / args.steps,
                  "parity": "pinned (reference golden vectors)" if kind2 == "painn-oc" else "unpinned (schnetpack is not in the reference tree; restatement oracle/spk_painn_ref.py)"}
         # its own roofline record (same instrumented pass as the headline workload) and accuracy against its CPU restatement
-        _lib.profile_enable(True)
-        for i in range(args.steps):
-            step2(batches[i % len(batches)])
-        torch.cuda.synchronize()
-        prof2 = _lib.profile_read()
-        _lib.profile_enable(False)
-        k2 = sorted(((k, v[0] / args.steps, v[1] // args.steps) for k, v in prof2.items()), key=lambda x: -x[1])
+        k2 = []
+        if args.full:
+            _lib.profile_enable(True)
+            for i in range(args.steps):
+                step2(batches[i % len(batches)])
+            torch.cuda.synchronize()
+            prof2 = _lib.profile_read()
+            _lib.profile_enable(False)
+            k2 = sorted(((k, v[0] / args.steps, v[1] // args.steps) for k, v in prof2.items()), key=lambda x: -x[1])
         if k2:
             d2, ms2, n2 = k2[0]
             other["roofline"] = roofline_record(d2, ms2 / max(n2, 1), n2, n_atoms, model2._last_nl.E if hasattr(model2, "_last_nl") else n_edges, args.batch)
             other["kernel_ms_per_step"] = {k: round(ms, 4) for k, ms, _ in k2[:6]}
-        if not args.no_cpu_baseline and kind2 != "painn-oc":
+        if args.full and not args.no_cpu_baseline and kind2 != "painn-oc":
             cpu2, par2 = cpu_baseline_spk(kind2, seconds_budget=8.0)
             other["cpu_baseline"], other["mae_vs_cpu_reference"] = cpu2, par2
 
@@ -904,7 +1002,7 @@ def main():
             "dtype": dtype_string(), "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.model]}; synthetic ~42-atom drug-like conformers, {args.batch} conformers/GPU/step",
                        "conformers_per_gpu": args.batch, "atoms_per_step_per_gpu": n_atoms, "edges_last_step": n_edges,
-                       "parallelism": f"dp{world}", "collective": collective_name()},
+                       "parallelism": f"dp{world}", "collective": collective},
             "final_loss": final_loss,
             "gemm_engine": gemm_engine,
             "roofline": roofline,
@@ -917,6 +1015,7 @@ def main():
             "escn": escn,
             "equiformer_v2": equiformer,
             "reference_batch_size_32": small,
+            "sustained": sustained,
             "host_feed": host_feed, "inference": inference,
             # end-to-end fraction of the HBM roofline under SURVEY.md 8(d)'s contract figure (17.8 MB / conformer-step)
             "e2e_algorithmic_GBps_per_gpu": 17.8e6 * value / world / 1e9,

@@ -554,6 +554,13 @@ int nq_profile_read2(char* names_host, int32_t name_stride, double* total_ms_hos
  *               128x128 are cut into up to 16 ranges, partial slabs in a library-owned per-stream scratch, fixed-order reduction; round 4).
  * The weight-gradient scratch size does not depend on the switch. */
 void nq_set_gemm_variant(int32_t variant);
+/* The split-K scratch (bit 7 above) is one grow-only device buffer per (device, stream), owned by the library.  A buffer that was handed out while its stream
+ * was capturing is never freed or moved afterwards (the captured graph replays into the raw pointer): when a later eager call needs more, the old buffer is
+ * retired and a new one allocated; inside a capture nothing is allocated (a too small buffer means the plain, unsplit launch).  nq_gemm_splitk_release frees
+ * every buffer of the current device, retired ones included -- call it only when no graph that used them will be replayed again.  nq_gemm_splitk_state is the
+ * test hook: current pointer, size in floats, captured flag and number of retired buffers of one stream. */
+void nq_gemm_splitk_release(void);
+int nq_gemm_splitk_state(void* stream, uint64_t* ptr, uint64_t* floats, int32_t* captured, int32_t* retired);
 
 /* ---- building blocks exported for unit tests ----------------------------------------------- */
 /* C[M,N] = A[M,K] W[N,K]^T (+bias[N]); if C_silu != NULL also writes silu(C). */
@@ -606,6 +613,7 @@ int nq_rccl_available(void);
 int nq_rccl_unique_id(void* id128);
 int nq_rccl_comm_create(const void* id128, int32_t world, int32_t rank, void** comm);
 int nq_rccl_comm_destroy(void* comm);
+int nq_rccl_comm_count(void* comm, int32_t* count);   /* ncclCommCount: the ranks RCCL itself sees (bench.py reports it as config.collective.ranks_seen) */
 int nq_allreduce(float* buf, size_t n, void* comm, void* stream);
 int nq_allreduce_mean(float* buf, size_t n, void* comm, void* stream);
 int nq_rccl_broadcast(float* buf, size_t n, int32_t root, void* comm, void* stream);

@@ -180,6 +180,8 @@ SYMBOLS = {
     "nq_profile_read": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
     "nq_profile_read2": (C.c_int, [C.c_char_p, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _I32]),
     "nq_set_gemm_variant": (None, [_I32]),
+    "nq_gemm_splitk_release": (None, []),
+    "nq_gemm_splitk_state": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "nq_linear_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "nq_linear_input_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "nq_weight_grad_scratch_floats": (_SZ, [_I64, _I32, _I32]),
@@ -189,6 +191,7 @@ SYMBOLS = {
     "nq_rccl_unique_id": (C.c_int, [_P]),
     "nq_rccl_comm_create": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
     "nq_rccl_comm_destroy": (C.c_int, [_P]),
+    "nq_rccl_comm_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "nq_allreduce": (C.c_int, [_P, _SZ, _P, _P]),
     "nq_allreduce_mean": (C.c_int, [_P, _SZ, _P, _P]),
     "nq_rccl_broadcast": (C.c_int, [_P, _SZ, _I32, _P, _P]),

@@ -466,6 +466,7 @@ static bool launch_batched(hipStream_t st, const GemmArgs& p, int splits, long k
 // partial slabs in a per-stream scratch of the library, fixed-order reduction that also applies bias / accumulation) the same bytes are streamed by the whole chip.
 #include <map>
 #include <mutex>
+#include <vector>
 static int splitk_count(int M, int N, int K) {
   const long tiles = (long)nq_cdiv(M, 128) * nq_cdiv(N, 128);
   if (K < 2048 || (K & 31) || tiles >= 256 || (g_gemm_variant & 128)) return 1;      // bit 7: never split (A/B switch)
@@ -474,24 +475,62 @@ static int splitk_count(int M, int N, int K) {
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int)s;
 }
-struct SplitkScratch { float* ptr = nullptr; size_t floats = 0; };
+struct SplitkScratch {
+  float* ptr = nullptr; size_t floats = 0;
+  bool captured = false;       // handed out while its stream was capturing: a HIP graph holds this pointer, it must outlive the library's own use
+  size_t failed = 0;           // smallest request hipMalloc has refused: not retried on every call
+  std::vector<float*> retired; // buffers replaced after a capture used them: kept for the graphs that replay into them (nq_gemm_splitk_release frees them)
+};
 static std::mutex g_splitk_mu;
 static std::map<std::pair<int, hipStream_t>, SplitkScratch> g_splitk;
-// grow-only buffer per (device, stream): a launch on stream s may only reuse what earlier launches of the SAME stream wrote (stream order protects it)
+// Grow-only buffer per (device, stream): a launch on stream s may only reuse what earlier launches of the SAME stream wrote (stream order protects it).
+// Lifetime rule: a buffer a capture has seen is never freed or moved (a captured graph replays into the raw pointer); when a later eager call needs more, the old
+// buffer is retired, not freed.  No allocation happens inside a capture (too small -> the caller issues the plain launch).
 static float* splitk_scratch(hipStream_t st, size_t floats) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(g_splitk_mu);
   SplitkScratch& b = g_splitk[{dev, st}];
-  if (b.floats < floats) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation inside a capture: plain launch instead
-    if (b.ptr) { (void)hipStreamSynchronize(st); (void)hipFree(b.ptr); b.ptr = nullptr; b.floats = 0; }
-    const size_t want = floats + floats / 4;
-    if (hipMalloc(reinterpret_cast<void**>(&b.ptr), want * sizeof(float)) != hipSuccess) { b.ptr = nullptr; (void)hipGetLastError(); return nullptr; }
-    b.floats = want;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (b.floats >= floats) { if (capturing) b.captured = true; return b.ptr; }
+  if (capturing) return nullptr;
+  if (b.failed && floats >= b.failed) return nullptr;
+  const size_t want = floats + floats / 4;
+  float* fresh = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); b.failed = floats; return b.floats >= floats ? b.ptr : nullptr; }
+  if (b.ptr) {
+    if (b.captured) b.retired.push_back(b.ptr);
+    else { (void)hipStreamSynchronize(st); (void)hipFree(b.ptr); }
   }
+  b.ptr = fresh; b.floats = want; b.captured = false;
   return b.ptr;
+}
+// frees every split-K buffer of the calling thread's device, retired ones included: only when no captured graph that used them will be replayed again
+extern "C" void nq_gemm_splitk_release(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lock(g_splitk_mu);
+  for (auto it = g_splitk.begin(); it != g_splitk.end();) {
+    if (it->first.first != dev) { ++it; continue; }
+    if (it->second.ptr) (void)hipFree(it->second.ptr);
+    for (float* r : it->second.retired) (void)hipFree(r);
+    it = g_splitk.erase(it);
+  }
+}
+// test hook: {current pointer, floats, captured flag, retired count} of the (device, stream) buffer
+extern "C" int nq_gemm_splitk_state(void* stream, uint64_t* ptr, uint64_t* floats, int32_t* captured, int32_t* retired) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NQ_ERR_HIP;
+  std::lock_guard<std::mutex> lock(g_splitk_mu);
+  auto it = g_splitk.find({dev, (hipStream_t)stream});
+  const bool have = it != g_splitk.end();
+  if (ptr) *ptr = have ? (uint64_t)(uintptr_t)it->second.ptr : 0;
+  if (floats) *floats = have ? it->second.floats : 0;
+  if (captured) *captured = have && it->second.captured;
+  if (retired) *retired = have ? (int32_t)it->second.retired.size() : 0;
+  return NQ_OK;
 }
 // out[i] = (acc ? out[i] : 0) + bias[col] + sum_s part[s * stride + i]   (fixed order)
 __global__ void k_reduce_splitk(const float* __restrict__ part, int nsplit, long stride, long count, int N, const float* __restrict__ bias, int accumulate,

@@ -92,6 +92,16 @@ int nq_rccl_comm_destroy(void* comm) {
   return NQ_OK;
 }
 
+// number of ranks in the communicator as RCCL reports it (ncclCommCount)
+int nq_rccl_comm_count(void* comm, int32_t* count) {
+  NQ_TRY(need_api());
+  if (!comm || !count) return nq_fail(NQ_ERR_ARG, "null communicator or output");
+  int world = 0;
+  NQ_RCCL(g_api.CommCount(reinterpret_cast<ncclComm_t>(comm), &world));
+  *count = world;
+  return NQ_OK;
+}
+
 // buf <- sum over ranks of buf (fp32, in place), enqueued on `stream`
 int nq_allreduce(float* buf, size_t n, void* comm, void* stream) {
   NQ_TRY(need_api());

@@ -83,6 +83,13 @@ class NativeComm:
         self._libmod.check(self._lib.nq_rccl_broadcast(self._libmod.ptr(t), t.numel(), src, self._comm, self._libmod.stream_ptr()))
         return t
 
+    def ranks_seen(self) -> int:
+        """ncclCommCount of this communicator: the number of ranks RCCL itself sees (not what the launcher claims)."""
+        import ctypes as C
+        n = C.c_int32(0)
+        self._libmod.check(self._lib.nq_rccl_comm_count(self._comm, C.byref(n)))
+        return int(n.value)
+
     def destroy(self):
         if self._comm:
             self._libmod.check(self._lib.nq_rccl_comm_destroy(self._comm))
@@ -96,7 +103,9 @@ def native_comm(create: bool = True):
     """The process-wide NativeComm of the default group (created on first use when ``create``)."""
     global _native
     if _native is None and create:
+        import atexit
         _native = NativeComm()
+        atexit.register(drop_native_comm)   # the communicator is destroyed with the process even when the group is torn down outside bench.py
     return _native
 
 
@@ -105,6 +114,14 @@ def drop_native_comm():
     if _native is not None:
         _native.destroy()
         _native = None
+
+
+def ranks_seen(group=None) -> int:
+    """Ranks the collective library of this job sees: ncclCommCount of the native communicator when it exists, else torch.distributed's world size
+    (its "nccl" backend creates the RCCL communicator lazily with exactly that count), 1 without a process group."""
+    if _native is not None and group is None:
+        return _native.ranks_seen()
+    return world_size(group)
 
 
 def _use_native(t, group):

@@ -533,6 +533,21 @@ class _Graph:
     pass
 
 
+class _SphereSumFn(torch.autograd.Function):
+    """out = a @ w with float64 accumulation (w: constant quadrature directions [P, 3])."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(w)
+        return (a.double() @ w.double()).to(a.dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return (g.double() @ w.double().t()).to(g.dtype), None
+
+
 class eSCN(torch.nn.Module):
     """escn/escn.py:36-490 (constructor arguments :63-84)."""
 
@@ -674,7 +689,10 @@ class eSCN(torch.nn.Module):
         mean = torch.full((P, 1), 1.0 / P, device=x.device)
         node_energy = _MatmulFn.apply(self.energy_block(x_pt).view(G.N, P), mean)                     # [N, 1]
         energy = _SegSumFn.apply(node_energy, G.mol_ptr, G.atom_mol, G.B).squeeze(1) * 0.001          # escn.py:411-414
-        forces = _MatmulFn.apply(self.force_block(x_pt).view(G.N, P), (self.sphere_points / P).contiguous())
+        # Force head (escn.py:437-457): a nearly constant scalar field times the unit vectors of the 128 sphere points -- the sum cancels to ~1e-3 of its terms,
+        # so this ONE reduction is carried in float64 (a [N,128] x [128,3] product: no cost); the f32 sum's own rounding was the largest contribution to the
+        # 4e-5 whole-batch vs single-molecule force difference of round 4
+        forces = _SphereSumFn.apply(self.force_block(x_pt).view(G.N, P), (self.sphere_points / P).contiguous())
         if return_layers:
             return energy, forces, layers, G
         return energy, forces

@@ -12,6 +12,8 @@ deterministic, unlike ``index_add`` on a GPU).  torch is used for autograd plumb
 """
 from typing import List
 
+import os
+
 import torch
 from torch import nn
 
@@ -527,7 +529,13 @@ class NeuralNetwork(nn.Module):
         saved_state = None
         if load_from is not None:   # neural_network.py:97-140: hyper-parameters come from the file ('args' namespace of the training script, or the flat dict `save` writes)
             from argparse import Namespace
-            saved_state = torch.load(load_from, map_location="cpu", weights_only=False)
+            # tensors + the training script's argparse.Namespace only: no arbitrary pickle execution for a checkpoint path a user passes
+            # (NQ_UNSAFE_LOAD=1 restores the full unpickler for files that carry other Python objects)
+            if os.environ.get("NQ_UNSAFE_LOAD") == "1":
+                saved_state = torch.load(load_from, map_location="cpu", weights_only=False)
+            else:
+                with torch.serialization.safe_globals([Namespace]):
+                    saved_state = torch.load(load_from, map_location="cpu", weights_only=True)
             try:
                 args = saved_state["args"]
             except KeyError:
@@ -686,6 +694,7 @@ class NeuralNetwork(nn.Module):
         ptr, idx_i, idx_j, pidx, ppidx = prep.ptr, prep.idx_i, prep.idx_j, prep.pidx, prep.ppidx
         N, P = Z.shape[1], idx_i.numel()
         want_forces = bool(self.predict_energy and self.calculate_forces)
+        grad_was_enabled = torch.is_grad_enabled()
         if want_forces:
             if self.create_graph:
                 raise NotImplementedError("nabladft_amd.phisnet.NeuralNetwork: forces with create_graph=True (a force LOSS: second-order derivatives) are not "
@@ -752,7 +761,7 @@ class NeuralNetwork(nn.Module):
             results["energy"] = torch.zeros(1, 1, device=R.device, dtype=R.dtype)
         if want_forces:                                            # neural_network.py:981-984
             with torch.enable_grad():
-                results["forces"] = -torch.autograd.grad(torch.sum(results["energy"]), R, create_graph=False, retain_graph=True)[0]
+                results["forces"] = -torch.autograd.grad(torch.sum(results["energy"]), R, create_graph=False, retain_graph=grad_was_enabled)[0]   # keep the graph only for a caller who will backpropagate through the other outputs
         else:
             results["forces"] = torch.zeros_like(R)
         results["orbital_energies"] = torch.zeros(1, norb, device=R.device, dtype=R.dtype)

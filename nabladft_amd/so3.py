@@ -364,6 +364,7 @@ class _BernsteinFn(torch.autograd.Function):
         return out.view(*r.shape[:-1], K) if r.shape[-1] == 1 else out.view(*r.shape, K)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # a second-order request through the radial path raises instead of returning wrong gradients
     def backward(ctx, g):
         lib = _lib.load()
         r2, raw_alpha, alpha, logc, n, v = ctx.saved_tensors

@@ -139,7 +139,9 @@ class FusedTrainStep:
         else:
             _lib.check(bwd_fn(cfg, _lib.ptr(flat), _lib.ptr(eng.offsets), C.byref(nl.c), _lib.ptr(ws), ws_bytes, _lib.ptr(gE), _lib.ptr(gF),
                               _lib.ptr(self.grad), st))
+            self._mark_exposed(0)
             nqdist.allreduce_mean_(self.grad, self.group)
+            self._mark_exposed(1)
         if update:
             self.t += 1
             _lib.check(lib.nq_adamw_step(_lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.m), _lib.ptr(self.v), flat.numel(),
@@ -195,8 +197,28 @@ class FusedTrainStep:
                 reduce(r[4 * l + 2], r[4 * l + 3])
             ov.side.wait_event(ov.done)
             reduce(r[4 * ov.L + 2], r[4 * ov.L + 3])
+        self._mark_exposed(0)
         main.wait_stream(ov.side)
+        self._mark_exposed(1)
         g.mul_(1.0 / w)
+
+    # ---- exposed all-reduce time: what the step's stream spends waiting for (or running) the gradient collective ---------------------------------------
+    _exposed = None
+
+    def _mark_exposed(self, which):
+        if not nqdist.active(self.group) or not self.grad.is_cuda:
+            return
+        if self._exposed is None:
+            self._exposed = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self._exposed[which].record(torch.cuda.current_stream())
+
+    def allreduce_exposed_ms(self):
+        """GPU time of the LAST step between the end of the reverse sweep on the step's stream and the point where the reduced gradient is available to it:
+        the wait for the side-stream all-reduces (overlapped path) or the whole collective (single all-reduce).  None without a process group."""
+        if self._exposed is None:
+            return None
+        torch.cuda.synchronize()
+        return float(self._exposed[0].elapsed_time(self._exposed[1]))
 
 
 
@@ -364,7 +386,11 @@ class OverlappedAllReduce:
             ready.record(torch.cuda.current_stream())       # the accumulations into this slice are on the stream autograd runs this node on
             self._comm.wait_event(ready)
             with torch.cuda.stream(self._comm):
-                self._works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.group is None and nqdist.native_comm(create=False) is not None:
+                    nqdist.allreduce_sum_(view)   # NQ_RCCL_NATIVE=1: the SAME communicator as FusedTrainStep / allreduce_mean_ (two communicators issuing collectives from
+                                                  # different streams in one step is the classic cross-rank ordering hazard); stream-ordered, no work handle
+                else:
+                    self._works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -2,6 +2,9 @@
 sharding).  Each rank computes the ORACLE's gradient on its shard; the all-reduced mean must equal the mean of the
 two single-process results -- the data-parallel semantics of the reference (Lightning DDP, utils/pipelines.py:65-68)."""
 import os
+import sys
+
+import pytest
 import socket
 
 import numpy as np
@@ -252,3 +255,38 @@ def test_forced_one_rank_group_runs_every_collective(tmp_path):
     mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     got, ref, t = torch.load(tmp_path / "forced.pt")
     assert torch.equal(got, ref) and torch.equal(t, ref) and float(ref.abs().max()) > 0
+
+
+def _ranks_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), NQ_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec = bench.collective_record()
+    codes = []
+    for expected in (world, world + 1):
+        try:
+            bench.check_ranks(expected)
+            codes.append(0)
+        except SystemExit as e:
+            codes.append(e.code)
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as fh:
+        fh.write(f"{rec['ranks_seen']} {rec['backend']} {rec['path']} {codes[0]} {codes[1]}\n")
+    dist.destroy_process_group()
+
+
+def test_rank_count_is_reported_and_a_mismatch_aborts(tmp_path):
+    """the bench record carries the number of ranks the collective library sees (config.collective.ranks_seen) and a job whose communicator
+    does not span --gpus ranks exits with a non-zero code instead of printing a record (here: a 2-rank gloo group checked against 2 and against 3)."""
+    import bench
+    assert bench.collective_record()["ranks_seen"] == 1 and bench.collective_record()["backend"] == "none"
+    bench.check_ranks(1)
+    with pytest.raises(SystemExit) as e:
+        bench.check_ranks(2)
+    assert e.value.code == 3
+    world = 2
+    mp.spawn(_ranks_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        seen, backend, path, ok, bad = open(tmp_path / f"r{r}.txt").read().split()
+        assert (int(seen), backend, path, int(ok), int(bad)) == (2, "gloo", "torch", 0, 3)

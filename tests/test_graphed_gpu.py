@@ -101,3 +101,55 @@ def test_qhnet_prepared_forward_is_free_of_host_synchronisation():
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_split_k_scratch_survives_capture_growth_and_replay():
+    """ADVICE r4 (gemm.hip split-K scratch): a HIP graph captures the raw pointer of the library-owned split-K buffer of its stream.  A later EAGER product on
+    the same stream that needs a larger buffer must not free it: the old buffer is retired, the graph still replays into live memory and reproduces its result
+    bit for bit; inside a capture nothing is allocated."""
+    import ctypes as C
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256, 128, 4096                 # 2 output tiles, contraction 4096: split into 8 ranges (csrc/gemm.hip splitk_count)
+    A, W = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+    Cg, Ce = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    M2 = 2048                                # larger product for the growth: 16 tiles x 8 ranges of slabs
+    A2, C2 = torch.randn(M2, K, generator=g).to(dev), torch.empty(M2, N, device=dev)
+
+    def state(stream):
+        p, f, c, r = C.c_uint64(0), C.c_uint64(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(lib.nq_gemm_splitk_state(stream, C.byref(p), C.byref(f), C.byref(c), C.byref(r)))
+        return p.value, f.value, c.value, r.value
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        st = _lib.stream_ptr()
+        _lib.check(lib.nq_linear_forward(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(Ce), None, M, N, K, st))     # eager: allocates the stream's buffer
+        side.synchronize()
+        p0, f0, c0, r0 = state(st)
+        assert p0 != 0 and f0 >= 8 * M * N and c0 == 0 and r0 == 0
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            st_cap = _lib.stream_ptr()
+            assert st_cap == st
+            _lib.check(lib.nq_linear_forward(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(Cg), None, M, N, K, st_cap))
+        p1, f1, c1, r1 = state(st)
+        assert (p1, f1) == (p0, f0) and c1 == 1, "the capture must reuse the existing buffer and mark it"
+        graph.replay(); side.synchronize()
+        assert torch.equal(Cg, Ce)
+        _lib.check(lib.nq_linear_forward(_lib.ptr(A2), _lib.ptr(W), None, _lib.ptr(C2), None, M2, N, K, st))    # eager, needs 8x the slabs: growth
+        side.synchronize()
+        p2, f2, c2, r2 = state(st)
+        assert p2 != p0 and f2 >= 8 * M2 * N and r2 == 1 and c2 == 0, "the captured buffer is retired, not freed"
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(8)]   # would land in the freed block if it had been freed
+        Cg.zero_()
+        graph.replay(); side.synchronize()
+        assert torch.equal(Cg, Ce), "replay after the growth must still reproduce the captured product"
+        ref = (A2.double() @ W.double().T).float()
+        assert float((C2 - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+        del junk, graph
+    lib.nq_gemm_splitk_release()
+    assert state(st)[0] == 0

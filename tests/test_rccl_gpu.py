@@ -53,7 +53,7 @@ for ov in (True, False):
     step.overlap = ov
     losses = [float(step(b)) for _ in range(3)]
     torch.cuda.synchronize()
-    out["overlap" if ov else "plain"] = dict(losses=losses, used_overlap=step._ov is not None, grad=step.grad.cpu().tolist()[:64],
+    out["overlap" if ov else "plain"] = dict(losses=losses, used_overlap=step._ov is not None, grad=step.grad.cpu().tolist()[:64], exposed_ms=step.allreduce_exposed_ms(),
                                              flat_sum=float(step._eng.flat().double().sum()), grad_norm=float(step.grad.double().norm()))
 # autograd-driven models: bucketed all-reduce from post-accumulate hooks on a side stream
 from nabladft_amd.trainer import FlatParameters, OverlappedAllReduce
@@ -77,8 +77,10 @@ if mode == "native":
         t.mul_(2.0)                                   # consumer kernel on s
     s.synchronize()
     out["native_direct"] = dict(min=float(t.min()), max=float(t.max()), world=comm.world)
+    out["comm_count"] = comm.ranks_seen()
     lib = _lib.load()
     out["available"] = int(lib.nq_rccl_available())
+out["ranks_seen"] = nqdist.ranks_seen()
 if mode != "single":
     nqdist.barrier(device=0)
     nqdist.drop_native_comm()
@@ -116,8 +118,12 @@ def test_one_rank_rccl_step_equals_the_step_without_a_group(mode, single):
     assert got["overlap"]["used_overlap"] and not got["plain"]["used_overlap"]   # the per-layer overlapped all-reduce path really ran under the forced group
     assert not single["overlap"]["used_overlap"]
     assert got["hooks"]["on"] and got["hooks"]["buckets"] >= 3 and got["hooks"]["grad"] == single["hooks"]["grad"]
+    assert got["ranks_seen"] == 1 and single["ranks_seen"] == 1
+    for key in ("overlap", "plain"):                      # the exposed all-reduce time is measured on the step's stream whenever a group is active
+        assert got[key]["exposed_ms"] is not None and 0.0 <= got[key]["exposed_ms"] < 50.0, (mode, key, got[key]["exposed_ms"])
+        assert single[key]["exposed_ms"] is None
     if mode == "native":
-        assert got["available"] == 1
+        assert got["available"] == 1 and got["comm_count"] == 1     # ncclCommCount through the C ABI (nq_rccl_comm_count)
         assert got["native_direct"] == {"min": 3.0, "max": 3.0, "world": 1}
 
 
@@ -127,11 +133,13 @@ def test_bench_one_rank_through_the_nccl_branch():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                NQ_DIST_FORCE="1")
     env.pop("NQ_DIST_BACKEND", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--sustain", "0"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     last = r.stdout.strip().splitlines()[-1]
     assert len(last) < 4096
     rec = json.loads(last)
-    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["collective"].startswith("rccl via torch.distributed")
+    col = rec["config"]["collective"]
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and col["name"].startswith("rccl via torch.distributed")
+    assert col["backend"] == "rccl" and col["ranks_seen"] == 1 and col["path"] == "torch" and col["allreduce_exposed_ms"] is not None
     assert rec["roofline"]["frac"] > 0
