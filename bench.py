@@ -216,12 +216,13 @@ def _roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
     if dom == "gwr_mol":
         # rbf_proj gradient, molecule per workgroup (csrc/molpair.hip): reads the 20 node rows of the layer once (12 primal / tangent + 8 adjoint: 20 N F floats)
         # and the per-pair records (64-float matrix-core A operand + 8-float geometry record per pair and 32-channel slice)
-        nbytes = 20.0 * n_atoms * F * 4 + (E / 2.0) * (64 + 8) * 4 * (F // 32)
+        nbytes = 20.0 * n_atoms * F * 4                                   # the contract figure: node rows only
+        design_bytes = nbytes + (E / 2.0) * (64 + 8) * 4 * (F // 32)      # + the kernel's own per-pair record streams
         ach = nbytes / (avg_ms * 1e-3) / 1e9
         traffic, tsrc = pmc_traffic_bytes("k_gwr_mol", batch)
         return {"kernel": "k_gwr_mol (+ k_gwr_mol_reduce)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": tsrc, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-                "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": nbytes, "design_bytes_per_launch": design_bytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
                 "matrix_core_flops_per_launch": 2.0 * 32 * 32 * 2 * 3 * (E / 2.0) * (F // 32),
                 "note": "compute-bound on the SIMD shared by VALU and the f32 matrix-core path (profiles/r05_mfma_valu_overlap_lab.txt: the two do not overlap): "
                         "per pair and 32-channel slice ~52 VALU instructions + 3 v_mfma_f32_32x32x2_f32"}
