@@ -127,9 +127,10 @@ def test_escn_yaml_configuration_on_10_to_90_atoms():
     torch.manual_seed(5)
     net = eSCN(**FULL).to(dev)
     # eSCN's force head sums a nearly constant scalar field times the unit vectors of 128 sphere points (escn.py:437-457): with random initial weights the sum
-    # cancels to ~1e-3 of its terms, so forces amplify last-bit differences: two pure-f32 summation orders of the SAME engine differ by 4.3e-5 of max|F| on this
-    # mix, whole batch vs single molecules across the two engines by 4.0e-5 (profiles/r03_final2_mixed_sizes_report.txt).  Fixed bound: 1e-4 (E: 2e-5 holds).
-    whole, sizes = _check(net, dev, default_tol=1e-4, default_grad_tol=1e-4)
+    # cancels to ~1e-3 of its terms.  Rounds 3-4 carried that reduction in f32 and needed a bound of 1e-4 (measured 4.0e-5 whole batch vs single molecules);
+    # since round 5 the one reduction runs with float64 accumulation (nabladft_amd/escn.py: _SphereSumFn): measured 1.6e-5 (profiles/r05_mixed_sizes_report.txt),
+    # held to the same 2e-5 as the other models.
+    whole, sizes = _check(net, dev, default_tol=2e-5, default_grad_tol=1e-4)
     G = net.build_graph(whole)
     deg = torch.maximum(torch.bincount(G.dst.cpu(), minlength=sum(sizes)), torch.bincount(G.src.cpu(), minlength=sum(sizes)))
     assert int(deg.max()) >= FULL["max_neighbors"]                     # the cap of 40 binds on the 90-atom molecule ...
