@@ -135,6 +135,17 @@ def _run(a):
             out["roofline"] = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                                "avg_launch_ms": v[0] / max(v[1], 1), "launches_per_step": int(v[1] // a.steps),
                                "note": "largest dense launcher class of the step by device time; exact-f32 MFMA peak (these launches are below the split engine's 192-tile threshold)"}
+    # SURVEY 8(d) "QHNet / PhiSNet work unit" as a contract figure: per molecule and module the node irreps (25 components x F floats per atom) are read and written
+    # once and the pair features (per ordered pair, same width) read and written once; the two output matrices are written once; a training step = forward +
+    # backward = 3 forward-equivalents (the backward streams every tensor once more as adjoint and once as saved input)
+    width = sum(2 * l + 1 for l in range(HP["order"] + 1)) * HP["num_features"] * 4.0
+    n_at, n_orb = float(out["atoms"]), float(out["orbitals"])
+    fwd_bytes = HP["num_modules"] * (2.0 * n_at * width + 2.0 * P * width) + 2.0 * n_orb * n_orb * 4.0 / max(a.molecules, 1)
+    step_bytes = 3.0 * fwd_bytes
+    ach_gbs = step_bytes / (ms * 1e-3) / 1e9
+    out["roofline_hbm_contract"] = {"bound": "hbm", "achieved": ach_gbs, "peak": 8000.0, "unit": "GB/s", "frac": ach_gbs / 8000.0,
+                                    "contract_bytes_per_step": step_bytes,
+                                    "formula": "3 x [modules x (2 N w + 2 P w) + 2 Norb^2 4 / molecules], w = 25 F 4 bytes (order 4), N atoms, P ordered pairs of the step"}
     if getattr(a, "forces", False):
         m.predict_energy = m.calculate_forces = True
         m.create_graph = False
