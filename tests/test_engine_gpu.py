@@ -757,3 +757,56 @@ def test_bench_sized_batch_linearity_and_determinism():
         assert d <= max(5e-5, 2.0 * r) and d_engine <= max(5e-5, 2.0 * r), (k, d, d_engine, r)
     net = torch.zeros(B, 3, device=dev).index_add_(0, full.batch, f)
     assert float(net.abs().max()) < 5e-4 * float(f.abs().max())
+
+
+@pytest.mark.parametrize("F,NR,sizes", [(64, 20, [1, 2, 57, 9, 30, 44]), (128, 100, [57, 3, 1, 25, 40, 12, 56]), (256, 50, [5, 31, 2, 57])])
+def test_per_molecule_weight_gradient_equals_the_pair_row_path(F, NR, sizes, monkeypatch):
+    """csrc/molpair.hip against the pair-row path it replaces, same step, same inputs: molecules of 1 and 2 atoms (no pair / one pair: empty wavefront
+    segments), the largest molecule the LDS takes (57 atoms), 2 / 4 / 8 channel slices, 8 / 38 / 88 window starts.  Every gradient must agree to f32
+    rounding (the two paths sum the same terms in different orders), energies and forces bit for bit (they do not depend on the path); one more atom
+    (58) must fall back to the pair rows silently."""
+    import nabladft_amd as nq
+    dev = _dev()
+    cfg = R.PaiNNConfig(hidden_channels=F, num_layers=2, num_rbf=NR)
+    params = R.make_params(cfg, seed=F + NR)
+    model = _model(cfg, params, dev)
+    rng = np.random.Generator(np.random.PCG64(F))
+
+    def batch_of(sz):
+        pos = np.concatenate([rng.uniform(0, (n ** (1 / 3)) * 1.7 + 1.0, size=(n, 3)) for n in sz]).astype(np.float32)
+        bt = np.concatenate([np.full(n, i) for i, n in enumerate(sz)]).astype(np.int64)
+        z = rng.choice([1, 6, 7, 8], size=len(pos)).astype(np.int64)
+        return nq.Batch(torch.tensor(pos), torch.tensor(z), torch.tensor(bt), torch.tensor(rng.normal(size=len(sz)).astype(np.float32)),
+                        torch.tensor(rng.normal(0, 0.05, size=pos.shape).astype(np.float32))).to(dev)
+
+    b = batch_of(sizes)
+    step = nq.FusedTrainStep(model, max_grad_norm=0.0)
+    out = {}
+    for path in ("pair_rows", "per_molecule"):
+        if path == "per_molecule":
+            monkeypatch.setenv("NQ_MOLGW", "1"); monkeypatch.delenv("NQ_NO_MOLGW", raising=False)
+        else:
+            monkeypatch.setenv("NQ_NO_MOLGW", "1"); monkeypatch.delenv("NQ_MOLGW", raising=False)
+        loss = float(step(b, update=False))
+        out[path] = (loss, step.energy.clone(), step.forces.clone(), step.grad.clone())
+    assert out["pair_rows"][0] == out["per_molecule"][0]
+    assert torch.equal(out["pair_rows"][1], out["per_molecule"][1]) and torch.equal(out["pair_rows"][2], out["per_molecule"][2])
+    ga, gb = out["pair_rows"][3], out["per_molecule"][3]
+    worst = 0.0
+    for (k, _), (o, n, s) in zip(model.named_parameters(), model._param_slices):
+        a_, b_ = ga[o:o + n].double(), gb[o:o + n].double()
+        e = float((a_ - b_).abs().max() / a_.abs().max().clamp_min(1e-30))
+        worst = max(worst, e)
+        if "rbf_proj" not in k:
+            assert torch.equal(ga[o:o + n], gb[o:o + n]), k          # only the rbf_proj gradient is computed differently
+        assert e < 5e-6, (k, e)
+    # deterministic: the per-molecule path twice
+    loss2 = float(step(b, update=False))
+    assert loss2 == out["per_molecule"][0] and torch.equal(step.grad, gb)
+    # 58 atoms: does not fit the LDS of one workgroup -> the pair-row path, same result as forcing it
+    b58 = batch_of([58, 4])
+    step(b58, update=False); g_auto = step.grad.clone()
+    monkeypatch.setenv("NQ_NO_MOLGW", "1"); monkeypatch.delenv("NQ_MOLGW", raising=False)
+    step(b58, update=False)
+    assert torch.equal(g_auto, step.grad)
+    print(f"molgw vs pair rows F={F} R={NR}: worst relative gradient difference {worst:.2e}")
