@@ -1146,10 +1146,17 @@ int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out
 #ifndef NQ_CH_DUAL
 #define NQ_CH_DUAL 0
 #endif
-static int fused_ch(int kind, int F) {
+#ifndef NQ_SMALL_SLICE_ATOMS
+#define NQ_SMALL_SLICE_ATOMS 3072   // below this many atoms per launch a row is split into two channel slices (two wavefronts per atom)
+#endif
+static int fused_ch(int kind, int F, int N) {
   const int forced = kind == 0 ? NQ_CH_FWD : (kind == 1 ? NQ_CH_TAN : (kind == 2 ? NQ_CH_FORCE : NQ_CH_DUAL));
   const int full = F / 64;                       // one slice: the whole row in one wavefront
   if (forced > 0 && forced <= full && full % forced == 0) return forced;
+  // Small batches (the reference's 32 conformers = 1.3 k atoms): fewer rows than wavefront slots, so a launch is one row walk per wavefront at single-wave issue
+  // rates; two half-width wavefronts per atom halve the per-edge VALU chain and the WrT fill of each workgroup.  At throughput sizes the slices only add
+  // per-edge scalar work (profiles/r01_fused_tuning.txt section 3).
+  if (N < NQ_SMALL_SLICE_ATOMS && full >= 2) return full / 2;
   return full;
 }
 static int fused_grid(int N, int F, int ch, int* threads, size_t* lds, int R, int max_threads = FUSED_THREADS) {
@@ -1190,7 +1197,7 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
   NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
-  const int ch = fused_ch(tangent ? 1 : 0, q.F);
+  const int ch = fused_ch(tangent ? 1 : 0, q.F, q.g.N);
   const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(tangent ? 1 : 0, ch));
   if (tangent) FUSED_DISPATCH(k_msgf_fwd, true, q);
   else FUSED_DISPATCH(k_msgf_fwd, false, q);
@@ -1203,7 +1210,7 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   if (q.g.N <= 0) return NQ_OK;
   int threads; size_t lds;
   const int kind = dual ? (pair_rows ? 3 : 4) : 2;
-  const int ch = fused_ch(dual ? 3 : 2, q.F);
+  const int ch = fused_ch(dual ? 3 : 2, q.F, q.g.N);
   const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(kind, ch));
   if (dual && !pair_rows) FUSED_DISPATCH(k_msgf_rev_nopair, true, q);
   else if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
