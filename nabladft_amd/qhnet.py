@@ -741,8 +741,12 @@ class QHNet(nn.Module):
         self._features(g)
         z = data.z.squeeze().long()
         node_attr = self.node_embedding(z)
-        data.node_attr, data.edge_index, data.edge_attr, data.edge_sh = node_attr, g.conv.edge_index, g.edge_attr, g.edge_sh
-        data.full_edge_index, data.full_edge_attr, data.full_edge_sh = g.full.edge_index, g.full_edge_attr, g.full_edge_sh
+        # The reference leaves these on the batch (qhnet.py:189-208) and its layers read them back; here the layers read `g`, and the copies left on the batch
+        # are DETACHED: a tracked tensor parked on `data` keeps the previous step's autograd graph -- and with it the AccumulateGrad nodes of the embedding and
+        # of the radial exponent, which belong to the stream that first created them -- alive into the next step.  Captured into a HIP graph, that step then
+        # makes the legacy default stream wait on the capture stream and hipStreamEndCapture crashes (rounds 3-5: scripts/debug_qhnet_capture.py).
+        data.node_attr, data.edge_index, data.edge_attr, data.edge_sh = node_attr.detach(), g.conv.edge_index, g.edge_attr.detach(), g.edge_sh
+        data.full_edge_index, data.full_edge_attr, data.full_edge_sh = g.full.edge_index, g.full_edge_attr.detach(), g.full_edge_sh
         x = node_attr.view(-1, 1, self.hs)
         fii = fij = None
         for layer_idx, layer in enumerate(self.e3_gnn_layer):

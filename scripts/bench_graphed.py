@@ -81,11 +81,6 @@ def run(which, molecules=None, steps=20, warmup=3, device=None):
     torch.cuda.synchronize()                           # belong to the default stream) would be touched from the capture stream and break the capture
     eager_ms = 1e3 * (time.perf_counter() - t0) / steps
     print(f"# {which}: eager {eager_ms:.3f} ms/step at {molecules} conformers", file=sys.stderr, flush=True)
-    if which == "qhnet":
-        # capturing QHNet's backward crashes hipStreamEndCapture of this ROCm build (scripts/debug_qhnet_capture.py; its forward captures): eager only
-        return {"model": which, "molecules_per_step": molecules, "eager_ms_per_step": eager_ms, "graph_replay_ms_per_step": None,
-                "eager_conformer_steps_per_s": molecules / eager_ms * 1e3, "graph_replay_conformer_steps_per_s": None,
-                "what": "one prepared batch stepped repeatedly, launches issued from Python autograd (the backward cannot be captured on this ROCm build)"}
     g = GraphedStep(step, warmup=2)
     for _ in range(2):
         g()

@@ -21,6 +21,15 @@ with torch.no_grad():
     target = net(b, packed=True).clone()
 
 
+if what.startswith("only:"):      # backward pruned to the parameters whose name contains the substring: bisects the autograd graph by depth
+    keep = what[5:]
+    n_on = 0
+    for name, p in net.named_parameters():
+        p.requires_grad_(keep in name)
+        n_on += int(keep in name)
+    print("parameters that require grad:", n_on, flush=True)
+
+
 def fn():
     if what == "fwd_blocks":
         with torch.no_grad():
@@ -48,6 +57,12 @@ def fn():
         for p in net.parameters():
             p.grad = None
         out = loss_fn(net(b, packed=True), target)
+        out.backward()
+        return out.detach()
+    if what.startswith("only:"):
+        for p in net.parameters():
+            p.grad = None
+        out = net(b, packed=True).sum()
         out.backward()
         return out.detach()
     raise SystemExit("unknown variant")

@@ -1,8 +1,8 @@
 """trainer.GraphedStep on the autograd-driven models at the reference's batch sizes: with ``data.prepared = net.prepare(data)`` the forward issues no
 host synchronisation, so the whole training step can be captured into a HIP graph; replays must give what the eager steps give (same start, same batch).
-QHNet: the forward captures and replays (tested here); capturing its BACKWARD makes hipStreamEndCapture of this ROCm build crash the process
-(scripts/debug_qhnet_capture.py bisects it: every forward variant is fine, every variant with a backward dies inside the runtime), so its training step is
-not captured -- measured eager on a prepared batch instead (scripts/bench_graphed.py would need the fix upstream)."""
+QHNet (round 5): its step captures like the others since the tensors its forward leaves on the batch are detached -- a tracked ``data.node_attr`` kept the
+previous step's AccumulateGrad nodes (default stream) alive, the captured backward then pulled the legacy stream into the capture and hipStreamEndCapture
+crashed (scripts/debug_qhnet_capture.py: ``only:node_embedding`` was the one pruned backward that died)."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ def _reset(flat, opt, snap):
                     v.zero_()
 
 
-@pytest.mark.parametrize("which", ["gemnet", "escn", "equiformer"])
+@pytest.mark.parametrize("which", ["qhnet", "gemnet", "escn", "equiformer"])
 def test_graph_replay_equals_eager_steps(which):
     import bench_graphed as BG
     from nabladft_amd.trainer import GraphedStep
