@@ -15,9 +15,10 @@
 //     five conflict-free ds_read_b128; one v_permlane32_swap + add per filter part leaves gphi (both directions summed) in lanes 0-31 and gpsi in
 //     lanes 32-63 -- the B operand [K = {phi, psi}][N = 32 channels] of v_mfma_f32_32x32x2_f32.  Its A operand [M = 32 rows][K] is the pair's window
 //     record shifted to the wavefront's rows: lane (j, half) loads rho / drho tap j - (k0 - wlo) (zero outside the 13 taps) with ONE coalesced
-//     128-byte load, requested two pairs ahead.  Row 31 carries the bias multiplier (beta, beta'), so the bias gradient rides in the same product.
+//     256-byte load (k_pair_arec prepares it once per step), requested four pairs ahead.  Row 31 carries the bias multiplier (beta, beta'), so the bias gradient rides in the same product.
 //     The rank-2 update acc[j][c] += rho_j gphi[c] + drho_j gpsi[c] is then one matrix-core instruction per filter part (exact f32, fixed order);
-//   * geometry / tangent scalars of a pair come the same way (one 8-lane load, v_readlane when consumed): no scalar-memory latency in the loop
+//   * geometry / tangent scalars of a pair come as vector loads too (32 records per coalesced chunk load into a 1-kB LDS ring private to the wavefront,
+//     broadcast ds_read_b128 + v_readfirstlane when consumed): no scalar-memory latency in the loop
 //     (the first version of this kernel read the 32-dword record with s_load per pair and ran at HBM latency: 3.7 ms per launch);
 //   * the pair lists per (molecule, wavefront) are built once per step (the windows depend on the geometry only), sorted by window start, slot-ascending,
 //     so the summation order is fixed: results are bitwise reproducible;
@@ -28,13 +29,7 @@
 #include <type_traits>
 
 #ifndef GM_THREADS
-#define GM_THREADS 1024   // 16 wavefronts = 4 per SIMD: with 12 (3 per SIMD) the VALU issued one instruction per ~4.5 cycles and nothing overlapped the matrix core
-#endif
-#ifndef GM_SKEW
-#define GM_SKEW 3          // after each barrier the wavefronts sharing a SIMD (w, w+4, w+8, w+12) start their pair loops GM_SKEW x 64 cycles apart (s_sleep)
-#endif
-#ifndef GM_ARING
-#define GM_ARING 8         // A operands in flight per wavefront (one VGPR each); even, divides 32
+#define GM_THREADS 1024   // 16 wavefronts = 4 per SIMD (8 / 12 / 16 measured within 3 %: profiles/r05_gwr_mol_wave_count_variants.txt); the staging below deals its blocks to 15 of them
 #endif
 #define GM_NW (GM_THREADS / 64)     // wavefronts per workgroup = owners of window-start ranges
 #define GM_ROWS 32                  // rows of the matrix-core tile: 31 window rows + the bias row
@@ -48,6 +43,7 @@
 #endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+static_assert(GM_THREADS == 1024 || GM_ABLATE != 0, "the staging of k_gwr_mol assigns LDS blocks to wavefronts 0-14 of 16 (other counts: timing builds only)");
 
 // ---- once per step: owners of the window starts and the per-(molecule, wavefront) pair lists -----------------------------------
 __global__ __launch_bounds__(256) void k_pair_hist(const float* __restrict__ RW, const int* __restrict__ dst, const int* __restrict__ col, int E,
@@ -256,7 +252,7 @@ __global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const floa
     // Every per-pair record is a sequential stream per wavefront, streamed once per launch, i.e. every access misses to HBM (measured: an empty pair
     // loop with a 4-deep register ring took 400 ns per pair = latency / depth).  So: the geometry records of 32 pairs at a time travel through a 1-kB
     // LDS ring private to the wavefront (one coalesced 16-byte load per lane, requested one chunk = 32 pairs ahead; consumed as two broadcast
-    // ds_read_b128: no scalar-memory waits mixed into lgkmcnt), the A operands through a register ring GM_ARING pairs deep.
+    // ds_read_b128: no scalar-memory waits mixed into lgkmcnt), the A operands through a register ring four pairs deep (R0-R3 below).
     const int pb = __builtin_amdgcn_readfirstlane(q.g.lowptr[a0]);
     const int* sp = q.sched_ptr + (long)m * (GM_NW + 1) + wave;
     const int p0 = pb + __builtin_amdgcn_readfirstlane(sp[0]), p1 = pb + ((GM_ABLATE & 15) == 1 ? __builtin_amdgcn_readfirstlane(sp[0]) : __builtin_amdgcn_readfirstlane(sp[1]));
@@ -274,20 +270,6 @@ __global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const floa
       auto geo_read = [&](Geo& o, int i) __attribute__((always_inline)) {       // record i of the wavefront's ring
         o.g0 = *reinterpret_cast<const f4*>(gring + (i & 31) * 8);
         o.g1 = *reinterpret_cast<const f4*>(gring + (i & 31) * 8 + 4);
-      };
-      auto lds_loads = [&](Ops& o, const Geo& ge) __attribute__((always_inline)) {
-        const unsigned nk = __float_as_uint(ge.g1[3]);
-        const unsigned no = (nk >> 13) * (GM_ATOM_FLOATS * 4), ko = (nk & 0x1fff) * (GM_ATOM_FLOATS * 4);
-        // operands: primal / tangent rows of the lane's SOURCE atom (n for lanes 0-31, k for 32-63), adjoint rows of its TARGET atom (k / n)
-        const unsigned x = (no ^ ko) & hmask;
-        const char* ps = reinterpret_cast<const char*>(rows) + ((no ^ x) + lbase);
-        const char* pt = reinterpret_cast<const char*>(rows) + ((ko ^ x) + lbase);
-        if (GM_ABLATE & 32) { const float z = __uint_as_float((no ^ x) + lbase) ; o.P0 = o.P1 = o.P2 = f4{z, z, 1.f, 2.f}; o.A = o.T = f4{1.f, z, __uint_as_float((ko ^ x) + lbase), 3.f}; return; }
-        o.P0 = *reinterpret_cast<const f4*>(ps);                          // xa xb xc txa
-        o.P1 = *reinterpret_cast<const f4*>(ps + GM_CH * 16);             // txb txc v0 v1
-        o.P2 = *reinterpret_cast<const f4*>(ps + 2 * GM_CH * 16);         // v2 tv0 tv1 tv2
-        o.A = *reinterpret_cast<const f4*>(pt + 3 * GM_CH * 16);          // A0 A1 A2 gma
-        o.T = *reinterpret_cast<const f4*>(pt + 4 * GM_CH * 16);          // T0 T1 T2 gtma
       };
       // One pair.  Roles rotate statically over 12 steps per trip (A ring of 4, three scalar geometry sets, two LDS operand sets: no register copies):
       //   consumes  the A register `ra` (refilled 4 pairs ahead), the geometry scalars `gc` and the operand set `cur` (requested one step ago);

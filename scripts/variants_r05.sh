@@ -25,6 +25,6 @@ else
   mkdir -p gpurun_out
   for lib in nabladft_amd/libnablaq.so nabladft_amd/_variants/libnablaq_*.so; do
     echo "== $lib"
-    NABLAQ_LIB=$PWD/$lib timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k:round(v,3) for k,v in d['kernel_ms_per_step'].items() if k.startswith('msgf') or k.startswith('gwr')}, round(d['ms_per_step'],3))"
+    NABLAQ_LIB=$PWD/$lib timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k:round(v,3) for k,v in d['kernel_ms_per_step'].items() if any(k.startswith(p) for p in '${VAR_KEYS:-msgf,gwr}'.split(','))}, round(d['ms_per_step'],3))"
   done
 fi
