@@ -4,7 +4,8 @@ all-reduce of the flat gradient -> clip + AdamW kernel.  Semantically this is on
 ``PaiNNLightning.training_step`` + Lightning's backward / clip (config/painn-oc.yaml:18-19) /
 ``torch.optim.AdamW.step`` (config/model/painn-oc.yaml:23-27)."""
 import ctypes as C
-
+import os
+import weakref
 from types import SimpleNamespace
 
 import torch
@@ -230,16 +231,24 @@ class _FlatParameter(torch.nn.Parameter):
     def __new__(cls, data, grad_buffer):
         obj = super().__new__(cls, data, requires_grad=True)
         obj._grad_buffer = grad_buffer
+        obj._owner = None                                   # weakref to the FlatParameters that built it
         return obj
 
     @property
     def grad(self):
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None and owner._detached:
+            owner.gather()                                  # first reader after a backward pass (clipping, the optimiser, an all-reduce): see FlatParameters
         return self._grad_buffer
 
     @grad.setter
     def grad(self, value):
         if value is None:
-            self._grad_buffer.zero_()
+            owner = self._owner() if self._owner is not None else None
+            if owner is not None:
+                owner.zero_grad()                           # also hands the per-parameter gradients back to autograd (FlatParameters.zero_grad)
+            else:
+                self._grad_buffer.zero_()
         elif value is not self._grad_buffer:
             self._grad_buffer.copy_(value)
 
@@ -248,10 +257,20 @@ class FlatParameters:
     """All trainable parameters of a module as views of ONE flat buffer, their gradients as views of one flat gradient buffer.  A model with
     thousands of small tensors (PhiSNet: 2.4 k) otherwise spends tens of milliseconds per step in per-tensor optimiser bookkeeping; with the
     flat pair, zero_grad is one memset, clipping one norm, and any torch optimiser (or ``nq_adamw_step``) runs on a single tensor.  The module's
-    parameter objects, names and state_dict are unchanged (``p.data`` / ``p.grad`` are re-pointed)."""
+    parameter objects, names and state_dict are unchanged (``p.data`` / ``p.grad`` are re-pointed).
 
-    def __init__(self, params):
+    Gradients (``gather=True``, the default): with ``p.grad`` pointing at its slice, autograd ADDS every parameter's gradient into the slice -- one
+    elementwise launch per tensor and step (QHNet 162, GemNet-OC 319, eSCN 339, EquiformerV2 530, PhiSNet 2.4 k: round 5 found them as the largest
+    ATen share of the profiles).  So ``zero_grad()`` zeroes the buffer AND sets ``p.grad = None``: autograd then takes ownership of the first gradient
+    tensor of each parameter without any kernel, and the first reader of the flat gradient afterwards (``flat.flat.grad``: clipping, the optimiser,
+    an all-reduce) -- normally an engine callback at the end of the backward pass, queued by one of four sentinel parameters -- copies all of them into
+    their slices with multi-tensor copies and points ``p.grad`` back at the slices (``gather()``).  A second backward without
+    ``zero_grad()`` in between (gradient accumulation) finds the views in place and adds into them as before."""
+
+    def __init__(self, params, gather: bool = True):
         self.params = [p for p in params if p.requires_grad]
+        self._gather_mode = bool(gather) and os.environ.get("NQ_FLAT_GATHER", "1") != "0"   # NQ_FLAT_GATHER=0: the in-place views of rounds 2-4 (A/B runs)
+        self._detached = False                              # True between zero_grad() and the gather: p.grad is None or autograd's own tensor
         # every tensor of 16 or more elements starts on a 16-byte boundary of the flat buffer: the tile engines of the dense products read their operands
         # with 16-byte loads and send a weight that starts off such a boundary to the generic kernels (measured on QHNet, whose 50-element radial
         # parameters shifted the [8320 x 128] weight generators behind them: 62-82 instead of 130-180 TFLOP/s).  The padding floats stay zero (zero
@@ -265,14 +284,38 @@ class FlatParameters:
         n = o
         dev = self.params[0].device
         self.flat = _FlatParameter(torch.zeros(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32))
+        self.flat._owner = weakref.ref(self)
         self.offset = {}
+        self._views = []                                                # the gradient slices, in self.params order
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 k = p.numel()
                 self.flat.data[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.flat.data[o:o + k].view(p.shape)
-                p.grad = self.flat.grad[o:o + k].view(p.shape)          # autograd accumulates into the view in place
+                p.grad = self.flat.grad[o:o + k].view(p.shape)          # until the first zero_grad(): autograd accumulates into the view in place
+                self._views.append(p.grad)
                 self.offset[id(p)] = o
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        # A handful of sentinel parameters queue the gather as an engine callback at the end of the backward pass they take part in, so that the module's
+        # ``p.grad`` are slices again as soon as ``backward()`` returns (hooks on ALL parameters were measured: 2.4 k Python hook calls per pass cost PhiSNet
+        # 8 ms per step).  If no sentinel receives a gradient the gather still happens at the first read of ``flat.grad``.
+        self._queued = False
+        self._handles = []
+        if self._gather_mode:
+            ref = weakref.ref(self)
+
+            def sentinel(_p, ref=ref):
+                me = ref()
+                if me is not None and me._detached and not me._queued:
+                    me._queued = True
+                    torch.autograd.Variable._execution_engine.queue_callback(me._gather_callback)
+            n = len(self.params)
+            for i in sorted({0, n // 3, (2 * n) // 3, n - 1}):
+                self._handles.append(self.params[i].register_post_accumulate_grad_hook(sentinel))
+
+    def _gather_callback(self):
+        self._queued = False
+        self.gather()
 
     def attach(self, model):
         """Optional: modules that keep MANY small parameter tensors side by side (``so3.SelfMixing``: one [F] vector per Clebsch-Gordan path)
@@ -297,11 +340,38 @@ class FlatParameters:
         return o0, o - o0
 
     def zero_grad(self):
-        self.flat.grad.zero_()
+        self.flat._grad_buffer.zero_()
+        if self._gather_mode:
+            for p in self.params:
+                p.grad = None                               # autograd steals the first gradient of the step instead of adding it into the slice
+            self._detached, self._queued = True, False
+
+    def gather(self, params=None):
+        """Copies the gradients autograd holds for ``params`` (default: all) into their slices of the flat gradient and points ``p.grad`` back at the
+        slices; parameters without a gradient keep their zeroed slice.  Idempotent; runs by itself when ``flat.flat.grad`` is read.  Call it by hand
+        only for part of the parameters DURING the backward pass (OverlappedAllReduce, per bucket, then reading the raw buffer)."""
+        if not self._detached:
+            return
+        pairs = zip(self.params, self._views) if params is None else ((p, self._views[self._index[id(p)]]) for p in params)
+        src, dst = [], []
+        for p, view in pairs:
+            g = p.grad
+            if g is view:
+                continue
+            if g is not None:
+                src.append(g)
+                dst.append(view)
+            p.grad = view
+        if src:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
+        if params is None:
+            self._detached = False
 
     def validate(self):
         """Raises if a parameter's ``.grad`` / ``.data`` no longer aliases the flat buffers (e.g. after ``module.zero_grad(set_to_none=True)`` on
         the MODULE, ``p.grad = None`` by hand, or ``module.to(...)``): from then on the optimiser would silently see stale gradients."""
+        self.gather()                                       # between zero_grad() and the end of the backward pass the gradients are autograd's
         g0, d0 = self.flat.grad.data_ptr(), self.flat.data.data_ptr()
         for p in self.params:
             o = self.offset[id(p)] * 4
@@ -332,6 +402,7 @@ class OverlappedAllReduce:
         self.on = nqdist.active(group)                      # world > 1, or a forced 1-rank group (NQ_DIST_FORCE=1: the single-GPU RCCL test)
         self.buckets = []                                   # [lo, hi, n_params]: ranges of the FLAT buffer (alignment padding included)
         self._bucket_of = {}
+        self._params_of = []                                # per bucket: its parameters
         # FlatParameters pads tensors of >= 16 elements to 16-byte boundaries: a bucket's range comes from the real offsets, never from a running
         # sum of numel().  A bucket = a run of consecutive parameters; it starts where the previous one ended (so the padding in front of its first
         # parameter travels with it) and the last bucket ends at the end of the buffer.
@@ -342,11 +413,16 @@ class OverlappedAllReduce:
             end = flat.offset[id(p)] + p.numel()
             count += 1
             self._bucket_of[id(p)] = len(self.buckets)
+            if len(self._params_of) == len(self.buckets):
+                self._params_of.append([])
+            self._params_of[-1].append(p)
             if (end - lo) * 4 >= bucket_bytes and i + 1 < len(flat.params):
                 self.buckets.append([lo, end, count])
                 lo, count = end, 0
         if count or not self.buckets:
             self.buckets.append([lo, total, count])
+        while len(self._params_of) < len(self.buckets):
+            self._params_of.append([])
         self.check_tiling()
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
@@ -380,7 +456,8 @@ class OverlappedAllReduce:
             return
         self._launched[b] = True
         lo, hi, _ = self.buckets[b]
-        view = self.flat.flat.grad[lo:hi]
+        self.flat.gather(self._params_of[b])                # the bucket's gradients into their slices (FlatParameters hands them to autograd between zero_grad and here)
+        view = self.flat.flat._grad_buffer[lo:hi]           # the raw buffer: reading ``.grad`` would gather every parameter, also those still to come
         if self._cuda:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())       # the accumulations into this slice are on the stream autograd runs this node on
