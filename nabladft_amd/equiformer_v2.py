@@ -307,7 +307,7 @@ class SO3_LinearV2(nn.Module):
         """x [N, (lmax+1)^2 * in] -> [N, (lmax+1)^2 * out]."""
         N = x.shape[0]
         ncomp = (self.lmax + 1) ** 2
-        y = _SphLinearFn.apply(x.view(N, ncomp, self.in_features), self.bias, *[self.weight[l] for l in range(self.lmax + 1)])
+        y = _SphLinearFn.apply(x.view(N, ncomp, self.in_features), self.bias, self.weight)     # stacked [lmax + 1, out, in]: its gradient comes back as one tensor
         return y.view(N, ncomp * self.out_features)
 
 

@@ -177,39 +177,58 @@ def _segment_add_list(base, rows, pidx, order, F):
 
 
 class _SphLinearFn(torch.autograd.Function):
-    """All per-order Linear layers of a SphericalLinear on the packed tensor: one launch forward, one for the input gradient."""
+    """All per-order Linear layers of a SphericalLinear on the packed tensor: one launch forward, one for the input gradient.  ``weights`` is either one
+    [Fout, Fin] matrix per order, or ONE stacked tensor [order + 1, Fout, Fin] (e3nn-style ``o3.Linear`` / ``SO3_LinearV2`` parameters): the stacked form
+    gets its gradient back as one tensor -- with per-order views autograd re-assembles it from order + 1 zero-filled full-size pieces."""
 
     @staticmethod
     def forward(ctx, x, bias, *weights):
         lib = _lib.load()
         x2 = x.to(torch.float32).contiguous()
         rows, ncomp, Fin = x2.shape
-        order = len(weights) - 1
-        ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+        stacked = len(weights) == 1 and weights[0].dim() == 3
+        if stacked:
+            Wst = weights[0].detach().to(torch.float32).contiguous()
+            ws = list(Wst.unbind(0))                        # contiguous slices of one buffer
+        else:
+            ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+        order = len(ws) - 1
         Fout = ws[0].shape[0]
         y = torch.empty(rows, ncomp, Fout, device=x.device, dtype=torch.float32)
         wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
         b = bias.detach().to(torch.float32).contiguous() if bias is not None else None
         _lib.check(lib.nq_sph_linear_forward(_lib.ptr(x2), wp, _lib.ptr(b), _lib.ptr(y), rows, order, Fin, Fout, _lib.stream_ptr()))
-        ctx.save_for_backward(x2, *ws)
-        ctx.has_bias = bias is not None
+        if stacked:
+            ctx.save_for_backward(x2, Wst)
+        else:
+            ctx.save_for_backward(x2, *ws)
+        ctx.has_bias, ctx.stacked = bias is not None, stacked
         return y
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         x2, *ws = ctx.saved_tensors
+        if ctx.stacked:
+            Wst = ws[0]
+            ws = list(Wst.unbind(0))
         rows, ncomp, Fin = x2.shape
         order, Fout = len(ws) - 1, ws[0].shape[0]
         g = g.to(torch.float32).contiguous()
         wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
         gx = torch.empty_like(x2)
         _lib.check(lib.nq_sph_linear_input_grad(_lib.ptr(g), wp, _lib.ptr(gx), rows, order, Fin, Fout, _lib.stream_ptr()))
-        gws = [torch.empty_like(w) for w in ws]
+        if ctx.stacked:
+            gst = torch.empty_like(Wst)
+            gws = list(gst.unbind(0))
+        else:
+            gws = [torch.empty_like(w) for w in ws]
         gwp = (C.c_void_p * len(gws))(*[w.data_ptr() for w in gws])
         gb = torch.empty(Fout, device=g.device, dtype=torch.float32) if ctx.has_bias else None
         scr = torch.empty(int(lib.nq_sph_weight_grad_scratch_floats(rows, order, Fin, Fout)) + 64, device=g.device, dtype=torch.float32)
         _lib.check(lib.nq_sph_linear_weight_grad(_lib.ptr(g), _lib.ptr(x2), gwp, _lib.ptr(gb), rows, order, Fin, Fout, _lib.ptr(scr), _lib.stream_ptr()))
+        if ctx.stacked:
+            return gx, gb, gst
         return (gx, gb, *gws)
 
 

@@ -401,6 +401,25 @@ class _ToDenseFn(torch.autograd.Function):
         return asm.from_dense(plan, g), None, None
 
 
+class _ScaledTransposeFn(torch.autograd.Function):
+    """e3nn's flat ``o3.Linear`` weight [(lmax + 1) * c_in * c_out] -> the engine's stacked [lmax + 1, c_out, c_in] * scale: ONE elementwise launch each way
+    (written as ``(w.view(..).transpose(1, 2) * scale).contiguous()`` + per-order views it was 2 launches forward and order + 3 backward, per layer)."""
+
+    @staticmethod
+    def forward(ctx, weight, n, c_in, c_out, scale):
+        W = torch.empty(n, c_out, c_in, device=weight.device, dtype=torch.float32)
+        torch.mul(weight.detach().view(n, c_in, c_out).transpose(1, 2), scale, out=W)
+        ctx.meta = (n, c_in, c_out, scale)
+        return W
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c_in, c_out, scale = ctx.meta
+        gw = torch.empty(n * c_in * c_out, device=g.device, dtype=torch.float32)
+        torch.mul(g.transpose(1, 2), scale, out=gw.view(n, c_in, c_out))
+        return gw, None, None, None, None
+
+
 # ---- e3nn-shaped parameter containers ------------------------------------------------------------------------------------------------------------
 class _TensorProductShell(nn.Module):
     """Holds what an e3nn.o3.TensorProduct contributes to a state_dict: ``weight`` (a parameter when internal, else an empty buffer) and the
@@ -442,8 +461,8 @@ class O3Linear(nn.Module):
         self.has_bias = biases
 
     def forward(self, x):
-        W = (self.weight.view(self.lmax + 1, self.c_in, self.c_out).transpose(1, 2) * (1.0 / math.sqrt(self.c_in))).contiguous()
-        return _SphLinearFn.apply(x, self.bias if self.has_bias else None, *W.unbind(0))
+        W = _ScaledTransposeFn.apply(self.weight, self.lmax + 1, self.c_in, self.c_out, 1.0 / math.sqrt(self.c_in))
+        return _SphLinearFn.apply(x, self.bias if self.has_bias else None, W)
 
 
 class _FCLayer(nn.Module):
@@ -462,13 +481,19 @@ class FullyConnectedNet(nn.Module):
         self.layer0, self.layer1 = _FCLayer(hs[0], hs[1]), _FCLayer(hs[1], hs[2])
         self.kind = {"silu": 0, "ssp": 1}[act]
         self.cst = normalize2mom_constant(act)
+        self._cs, self._cs_key = None, None
 
     def forward(self, x, col_scale=None):
         h = _MatmulFn.apply(x, self.layer0.weight * (1.0 / math.sqrt(self.hs[0])))
         h = _ActFn.apply(h, self.kind, self.cst)
-        W1 = self.layer1.weight * (1.0 / math.sqrt(self.hs[1]))
+        c1 = 1.0 / math.sqrt(self.hs[1])
         if col_scale is not None:
-            W1 = W1 * col_scale
+            key = (col_scale.data_ptr(), col_scale._version, str(col_scale.device))
+            if self._cs_key != key:                         # the path constants are a buffer of the caller: their product with 1 / sqrt(h1) is taken once
+                self._cs, self._cs_key = (col_scale.detach() * c1), key
+            W1 = self.layer1.weight * self._cs
+        else:
+            W1 = self.layer1.weight * c1
         return _MatmulFn.apply(h, W1)
 
 
