@@ -74,3 +74,21 @@ def test_stale_pmc_file_is_refused(tmp_path, monkeypatch):
     (prof / "r09_pmc_traffic.json").write_text(json.dumps({"batch": 2048, "kernels": {"k_msgf_rev<true, 2>": {"fetch_kb_per_launch": 1000.0, "write_kb_per_launch": 500.0}}}))
     val, why = bench.pmc_traffic_bytes("k_msgf_rev<true", 2048)
     assert val == 1024.0 * 2500.0 and "r09_pmc_traffic.json" in why
+
+
+def test_compact_record_carries_the_round_5_fields():
+    """the rocprofv3 launch average next to the HIP-event figure, the sustained leg, config 2 as written as ONE number marked unpinned,
+    and the collective object with the rank count RCCL itself reports."""
+    import bench
+    full = _full_record()
+    full["roofline"].update({"rocprof_avg_launch_us": 1206.9, "rocprof_source": "profiles/r05_rocprofv3_kernel_stats_painn_b2048.csv"})
+    full["sustained"] = {"value": 39000.0, "unit": "conformer-steps/s", "steps": 160, "seconds": 8.4, "what": "n" * 400}
+    full["sibling_config"] = {"workload": "BASELINE.json configs[1] as written: config/painn.yaml -> schnetpack PaiNN" + "v" * 300, "value": 39031.9, "ms_per_step": 52.47,
+                              "parity": "unpinned (third-party arithmetic restated)", "kernel_ms_per_step": {f"k{i}": float(i) for i in range(300)}}
+    full["config"]["collective"] = {"backend": "nccl", "ranks_seen": 8, "path": "native", "name": "rccl", "allreduce_exposed_ms": 0.41}
+    rec = json.loads(json.dumps(bench.compact_record(full, "gpurun_out/bench_full.json")))
+    assert rec["roofline"]["rocprof_avg_launch_us"] == 1206.9 and rec["roofline"]["rocprof_source"].startswith("profiles/r05_")
+    assert rec["sustained"] == {"value": 39000.0, "unit": "conformer-steps/s", "steps": 160, "seconds": 8.4}
+    assert set(rec["sibling_config"]) == {"workload", "value", "ms_per_step", "parity"} and rec["sibling_config"]["parity"] == "unpinned"
+    assert rec["config"]["collective"]["ranks_seen"] == 8 and rec["config"]["collective"]["allreduce_exposed_ms"] == 0.41
+    assert len(json.dumps(rec)) < bench.COMPACT_LIMIT
