@@ -229,8 +229,13 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The current HIP stream of the current device as a C pointer.  Asked once per launch by every wrapper: the raw-handle query of torch (what its own
+    compiled-kernel launchers use) instead of building a ``torch.cuda.Stream`` object each time."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(raw(torch.cuda.current_device()))
 
 
 def profile_enable(on: bool):
