@@ -1147,7 +1147,7 @@ int nq_transpose(hipStream_t st, const float* in, int rows, int cols, float* out
 #define NQ_CH_DUAL 0
 #endif
 #ifndef NQ_SMALL_SLICE_ATOMS
-#define NQ_SMALL_SLICE_ATOMS 3072   // below this many atoms per launch a row is split into two channel slices (two wavefronts per atom)
+#define NQ_SMALL_SLICE_ATOMS 2048   // below this many atoms per launch a row is split into two channel slices (two wavefronts per atom); measured at 32 / 64 / 96 / 128 / 192 conformers: profiles/r05_slice_threshold_32_to_192.txt
 #endif
 static int fused_ch(int kind, int F, int N) {
   const int forced = kind == 0 ? NQ_CH_FWD : (kind == 1 ? NQ_CH_TAN : (kind == 2 ? NQ_CH_FORCE : NQ_CH_DUAL));
