@@ -1,4 +1,6 @@
-"""Which part of the QHNet step cannot be captured into a HIP graph?  Runs one variant per process (a failed capture may take the process down)."""
+"""Which part of the QHNet step cannot be captured into a HIP graph?  Runs one variant per process (a failed capture may take the process down).
+Round 5 found the cause with the ``only:<substring>`` variants (tracked tensors parked on the batch kept default-stream AccumulateGrad nodes alive: qhnet.py forward)
+and every variant captures since; kept as the regression probe (profiles/r05_qhnet_capture_bisect_and_fix.txt)."""
 import faulthandler
 import os
 import sys
