@@ -39,7 +39,7 @@ extern "C" {
 #define NQ_ERR_WORKSPACE 4
 #define NQ_ERR_NO_EDGES 5
 
-#define NQ_ABI_VERSION 15
+#define NQ_ABI_VERSION 16
 
 /* Model hyper-parameters = constructor arguments of nablaDFT.painn_pyg.PaiNN (painn.py:28-45). */
 typedef struct nq_painn_cfg {
@@ -136,6 +136,9 @@ int nq_geb_cat_backward(const float* grad_cat, const float* v1, int64_t N, int32
 int nq_geb_gate(const float* o2, const float* v2, int64_t N, int32_t o, float* xout, float* vout, void* stream);
 int nq_geb_gate_backward(const float* o2, const float* v2, const float* grad_xout, const float* grad_vout, int64_t N, int32_t o, float* grad_o2,
                          float* grad_v2, void* stream);
+/* Largest molecule (atoms) whose rbf_proj gradient runs on the per-molecule LDS kernel (csrc/molpair.hip): its 20 rows of a 32-channel slice must fit one
+ * workgroup's LDS.  Larger molecules of a batch take the pair-row kernels, the rest of the batch is not affected (painn.py:475-509 semantics either way). */
+int32_t nq_painn_molecule_lds_atoms(void);
 /* Test/inspection hook: offset (in floats) and element count of a named workspace buffer, e.g.
  * ("x_msg", 2, tangent=0).  Returns NQ_ERR_ARG for unknown names. */
 int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B, const char* name, int32_t layer, int32_t tangent,

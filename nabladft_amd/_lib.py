@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NABLAQ_LIB") or os.path.join(_HERE, "libnablaq.so")   # NABLAQ_LIB: development builds (scripts/ablate.sh)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 NQ_OK, NQ_ERR_HIP, NQ_ERR_ARG, NQ_ERR_MOL_TOO_LARGE, NQ_ERR_WORKSPACE, NQ_ERR_NO_EDGES = range(6)
 
@@ -50,6 +50,7 @@ _P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 # name -> (restype, argtypes); every symbol include/nablaq.h declares
 SYMBOLS = {
     "nq_abi_version": (C.c_int, []),
+    "nq_painn_molecule_lds_atoms": (C.c_int32, []),
     "nq_last_error": (C.c_char_p, []),
     "nq_graph_count": (C.c_int, [_P, _P, _I32, _I32, _I32, _D, _I32, _P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
     "nq_graph_fill": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _D, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -15,6 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnablaq.so")
 SOURCES = ["graph.hip", "gemm.hip", "gemm_bf16.hip", "edge.hip", "molpair.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "qhnet.hip", "gemnet_graph.hip", "gemnet.hip", "escn.hip", "equiformer.hip", "geobasis.hip", "rccl.hip", "engine.hip"]
+# molpair.hip: the SLP vectoriser packs neighbouring scalar f32 operations into v_pk_* beside the matrix instructions, which costs more than it saves there
+# (MI355X_MICROARCH.md, "packed f32 VALU beside MFMAs"; measured 6.51 -> 6.18 ms per step, profiles/r06_gwr_mol_variants.txt)
+EXTRA = {"molpair.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 
@@ -34,7 +37,7 @@ def build(force=False, verbose=True):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

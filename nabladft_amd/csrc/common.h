@@ -34,6 +34,11 @@ int nq_fail(int code, const char* fmt, ...);
   } while (0)
 
 #define NQ_MAX_LAYERS 64
+// The opt-in to more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) is a property of (device, kernel): a process that drives several
+// GPUs has to set it on each of them.  nq_dyn_lds keeps the largest size granted per (device, kernel) under a mutex and calls hipFuncSetAttribute only when a
+// launch asks for more (engine.hip); no process-global "already set" flags in the launchers.
+int nq_dyn_lds(const void* kernel, size_t bytes);
+#define NQ_DYN_LDS(kernel, bytes) NQ_TRY(nq_dyn_lds((const void*)(kernel), (bytes)))
 static inline int nq_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-kernel timing (HIP events on the launch stream; used by bench.py for the roofline) ----
@@ -143,6 +148,7 @@ struct MsgRevArgs {
   float* GPHI; float* GPSI;                                                  // dual out: [E][3F] each
   float4* GEDGE;                                                             // force mode: [nwaves][E] {gd, grx, gry, grz} (+=)
   float* GBR;                                                                // dual out: [N][3F] per-atom sums of gphi (bias gradient partials)
+  int row_filter, mol_cap;                                                   // 0: every row; 1: only rows of molecules of <= mol_cap atoms; 2: only rows of larger molecules
 };
 
 struct UpdArgs {
@@ -205,22 +211,29 @@ void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, cons
 int nq_rbf_window(hipStream_t, const float4* geom, int E, const FilterArgs& fa, float* RW);
 int nq_transpose(hipStream_t, const float* in, int rows, int cols, float* out);
 size_t nq_k0_sort_scratch_ints(int E, int R);
-int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch, const int* row_of = nullptr, const int* col = nullptr);
+// mol_ptr / atom_mol / cap / count_out (optional, with row_of / col): only the lower slots of molecules of MORE than cap atoms; their number goes to *count_out
+int nq_k0_sort(hipStream_t, const float* RW, int E, int R, int* order, int* scratch, const int* row_of = nullptr, const int* col = nullptr,
+               const int* mol_ptr = nullptr, const int* atom_mol = nullptr, int cap = 0, int* count_out = nullptr);
 size_t nq_gwr_scratch_floats(int E, int F, int R, int parts = 3);
+// count_dev (optional): device int holding the number of valid entries of order[] (<= E)
 int nq_gwr_sorted(hipStream_t, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
-                  float* scratch, int parts = 3);
+                  float* scratch, int parts = 3, const int* count_dev = nullptr);
 int nq_msgf_fwd(hipStream_t, const MsgArgs&, const FilterArgs&, bool tangent);
-int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual, bool pair_rows = true);   // pair_rows = false: the dual flavour neither writes gphi / gpsi nor GBR (molpair.hip computes the rbf_proj gradient)
+int nq_msgf_rev(hipStream_t, const MsgRevArgs&, const FilterArgs&, bool dual, bool pair_rows = true);   // pair_rows = false: the dual flavour neither writes gphi / gpsi nor GBR (molpair.hip computes the rbf_proj gradient); MsgRevArgs::row_filter selects the rows
 // rbf_proj gradient with the molecule's node rows staged in LDS (molpair.hip): no gphi / gpsi arrays
+int nq_molgw_max_atoms(void);                      // largest molecule whose 20 rows of a 32-channel slice fit the LDS (64)
+bool nq_molgw_config_ok(int F, int R);             // channel count / window count supported
 bool nq_molgw_supported(int F, int R, int max_mol_atoms);
 size_t nq_molgw_sched_ints(int E, int B);
-size_t nq_molgw_rec_floats(int E);
+size_t nq_molgw_sched_slots(int E, int B);
+size_t nq_molgw_rec_floats(int E, int B);
 size_t nq_molgw_part_floats(int F, int B);
-int nq_molgw_schedule(hipStream_t, const NqGraphView&, const int* dst, const float* RW, int R, int* sched_ints, float* recs);
-int nq_molgw_geometry(hipStream_t, const NqGraphView&, const float* TD, const float* TR, const int* sched_ints, float* recs);
+// cap: molecules of more atoms are left out of the schedule (their pairs go through the pair-row kernels)
+int nq_molgw_schedule(hipStream_t, const NqGraphView&, const int* dst, const float* RW, int R, int cap, int* sched_ints, float* recs);
+int nq_molgw_geometry(hipStream_t, const NqGraphView&, const float* RW, const float* TD, const float* TR, const int* sched_ints, float* recs);
 int nq_gwr_mol(hipStream_t, const NqGraphView&, int F, int R, int max_mol_atoms, const float* XH, const float* V, const float* TXH, const float* TV,
                const float* GX, const float* GV, const float* GTX, const float* GTV, const int* sched_ints, const float* recs, float* part, float* gWr,
-               float* gbr);
+               float* gbr, bool accumulate = false);
 int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);
 int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* pos_dot, float* TD, float* TR);
 int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);

@@ -599,6 +599,11 @@ template <bool DUAL, int CH, bool GW>
 __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterArgs& fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   FUSED_ROWS(DUAL ? 3 : 2) {
+    if (DUAL && q.row_filter) {   // mixed batches: the pair-row flavour takes the rows of the molecules that do not fit the LDS of k_gwr_mol, the other flavour the rest
+      const int mm = __builtin_amdgcn_readfirstlane(q.g.atom_mol[n]);
+      const bool big = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[mm + 1]) - __builtin_amdgcn_readfirstlane(q.g.mol_ptr[mm]) > q.mol_cap;
+      if (big != (q.row_filter == 2)) continue;
+    }
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     const int nlow = (DUAL && GW) ? __builtin_amdgcn_readfirstlane(q.g.lowptr[n + 1]) - __builtin_amdgcn_readfirstlane(q.g.lowptr[n]) : 0;
     const long o3 = (long)n * F3 + fb;
@@ -819,17 +824,19 @@ __global__ __launch_bounds__(fused_threads(4, CH)) void k_msgf_rev_nopair(MsgRev
 #define SORT_CHUNK 256
 // pass A: per 256-edge chunk, histogram over k0 and the stable local rank of every edge inside its bin
 // row_of / col (optional): only LOWER slots (col[e] < row_of[e]) take part -- the PaiNN dual sweep stores one gphi / gpsi row per pair
-__device__ __forceinline__ int k0_key(const float* __restrict__ RW, int e, int E, const int* __restrict__ row_of, const int* __restrict__ col) {
+struct K0Filter { const int* row_of; const int* col; const int* mol_ptr; const int* atom_mol; int cap; };   // cap > 0: only molecules of more than cap atoms
+__device__ __forceinline__ int k0_key(const float* __restrict__ RW, int e, int E, const K0Filter& f) {
   if (e >= E) return -1;
-  if (row_of && col[e] >= row_of[e]) return -1;
+  if (f.row_of && f.col[e] >= f.row_of[e]) return -1;
+  if (f.cap > 0) { const int m = f.atom_mol[f.row_of[e]]; if (f.mol_ptr[m + 1] - f.mol_ptr[m] <= f.cap) return -1; }
   return __float_as_int(RW[(long)e * RW_STRIDE + 13]);
 }
 __global__ __launch_bounds__(SORT_CHUNK) void k_k0_hist(const float* __restrict__ RW, int E, int nbins, int* __restrict__ chunk_hist,
-                                                        int* __restrict__ local_rank, const int* __restrict__ row_of, const int* __restrict__ col) {
+                                                        int* __restrict__ local_rank, K0Filter flt) {
   __shared__ int keys[SORT_CHUNK];
   __shared__ int hist[256];
   const int e = blockIdx.x * SORT_CHUNK + threadIdx.x;
-  const int key = k0_key(RW, e, E, row_of, col);
+  const int key = k0_key(RW, e, E, flt);
   keys[threadIdx.x] = key;
   if (threadIdx.x < nbins) hist[threadIdx.x] = 0;
   __syncthreads();
@@ -867,15 +874,16 @@ __global__ __launch_bounds__(256) void k_k0_scan(int* __restrict__ hist, int nch
 // pass C: order[bin_base + offset_in_bin(chunk) + local_rank] = edge slot
 __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restrict__ RW, int E, int nbins, const int* __restrict__ hist,
                                                            const int* __restrict__ bin_total, const int* __restrict__ local_rank,
-                                                           int* __restrict__ order, const int* __restrict__ row_of, const int* __restrict__ col) {
+                                                           int* __restrict__ order, K0Filter flt, int* __restrict__ count_out) {
   __shared__ int base[256];
   if (threadIdx.x == 0) {
     int run = 0;
     for (int i = 0; i < nbins; ++i) { base[i] = run; run += bin_total[i]; }
+    if (count_out && blockIdx.x == 0) *count_out = run;
   }
   __syncthreads();
   const int e = blockIdx.x * SORT_CHUNK + threadIdx.x;
-  const int key = k0_key(RW, e, E, row_of, col);
+  const int key = k0_key(RW, e, E, flt);
   if (key < 0) return;
   order[base[key] + hist[(long)key * gridDim.x + blockIdx.x] + local_rank[e]] = e;
 }
@@ -895,12 +903,16 @@ __global__ __launch_bounds__(SORT_CHUNK) void k_k0_scatter(const float* __restri
 #endif
 template <int CH>
 __global__ __launch_bounds__(GWR_WAVES * 64) void k_gwr_sorted(const float* __restrict__ GPHI, const float* __restrict__ GPSI, const float* __restrict__ RW,
-                                                               const int* __restrict__ order, int E, int F, int F3, int R, int chunk_len,
-                                                               float* __restrict__ part, int* __restrict__ chunk_range) {
+                                                               const int* __restrict__ order, int E_, int F, int F3, int R, int chunk_len,
+                                                               float* __restrict__ part, int* __restrict__ chunk_range, const int* __restrict__ count_dev) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * GWR_WAVES + wave;
+  const int E = count_dev ? min(E_, __builtin_amdgcn_readfirstlane(*count_dev)) : E_;   // mixed batches: only the pairs of the large molecules are listed
   const int r0 = chunk * chunk_len, r1 = min(E, r0 + chunk_len);
-  if (r0 >= E) return;   // wave-uniform
+  if (r0 >= E) {   // wave-uniform; an empty chunk covers no row (k_gwr_reduce bisects on non-decreasing ranges)
+    if (count_dev && lane == 0 && blockIdx.y == 0 && r0 < E_) { chunk_range[2 * chunk] = 0x7fffffff; chunk_range[2 * chunk + 1] = 0x7fffffff; }
+    return;
+  }
   const int col = blockIdx.y * F + lane * CH;   // F3 = row length of GPHI/GPSI (3F for the PaiNN filter, F for SchNet's first filter layer)
   typedef VOps<CH> VO;
   typedef typename VO::V V;
@@ -1173,14 +1185,10 @@ static int fused_grid(int N, int F, int ch, int* threads, size_t* lds, int R, in
   return groups * nslices;
 }
 
-// the >64 KB dynamic-LDS opt-in is sticky per kernel: set it when the requested size grows, not on every launch
+// the >64 KB dynamic-LDS opt-in is sticky per (device, kernel): nq_dyn_lds sets it when the requested size grows, not on every launch
 #define FUSED_LAUNCH(KERN, FLAG, CHV, Q)                                                                          \
   do {                                                                                                            \
-    static size_t lds_set__ = 0;                                                                                  \
-    if (lds > lds_set__) {                                                                                        \
-      NQ_HIP(hipFuncSetAttribute((const void*)KERN<FLAG, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      lds_set__ = lds;                                                                                            \
-    }                                                                                                             \
+    NQ_DYN_LDS((KERN<FLAG, CHV>), lds);                                                                           \
     hipLaunchKernelGGL((KERN<FLAG, CHV>), dim3(grid), dim3(threads), lds, st, Q, fa, fa.RW);                      \
   } while (0)
 #define FUSED_DISPATCH(KERN, FLAG, Q)                                   \
@@ -1228,16 +1236,18 @@ static int gwr_chunks(int E) {   // ~4096 wavefronts (16 per CU) over 3 column s
 }
 size_t nq_k0_sort_scratch_ints(int E, int R) { return (size_t)nq_cdiv(E, SORT_CHUNK) * gwr_nbins(R) + (size_t)E + 256; }
 // order[] <- CSR slots sorted (stably) by window start k0 (all E slots, or the E/2 lower slots when row_of / col are given); scratch: nq_k0_sort_scratch_ints() ints
-int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* scratch, const int* row_of, const int* col) {
+int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* scratch, const int* row_of, const int* col, const int* mol_ptr,
+               const int* atom_mol, int cap, int* count_out) {
   NQ_PROF(st, "k0_sort");
+  K0Filter flt{row_of, col, mol_ptr, atom_mol, (row_of && mol_ptr && atom_mol) ? cap : 0};
   const int nbins = gwr_nbins(R), nchunks = nq_cdiv(E, SORT_CHUNK);
   if (nbins > 256) return nq_fail(NQ_ERR_ARG, "k0 sort supports at most 256 bins (num_rbf <= 268)");
   int* chunk_hist = scratch; int* local_rank = scratch + (size_t)nchunks * nbins; int* bin_total = local_rank + E;
-  hipLaunchKernelGGL(k_k0_hist, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank, row_of, col);
+  hipLaunchKernelGGL(k_k0_hist, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, local_rank, flt);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_k0_scan, dim3(nq_cdiv(nbins, 4)), dim3(256), 0, st, chunk_hist, nchunks, nbins, bin_total);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, bin_total, local_rank, order, row_of, col);
+  hipLaunchKernelGGL(k_k0_scatter, dim3(nchunks), dim3(SORT_CHUNK), 0, st, RW, E, nbins, chunk_hist, bin_total, local_rank, order, flt, count_out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -1245,7 +1255,7 @@ int nq_k0_sort(hipStream_t st, const float* RW, int E, int R, int* order, int* s
 size_t nq_gwr_scratch_floats(int E, int F, int R, int parts) { const size_t nc = gwr_chunks(E); return nc * R * parts * F + 2 * nc + 16; }
 
 int nq_gwr_sorted(hipStream_t st, const float* GPHI, const float* GPSI, const float* RW, const int* order, int E, int F, int R, float* gWr,
-                  float* scratch, int parts) {
+                  float* scratch, int parts, const int* count_dev) {
   NQ_PROF(st, "gwr_sorted");
   const int nchunks = gwr_chunks(E), chunk_len = nq_cdiv(E, nchunks);
   float* part = scratch;
@@ -1253,9 +1263,9 @@ int nq_gwr_sorted(hipStream_t st, const float* GPHI, const float* GPSI, const fl
   int* chunk_range = reinterpret_cast<int*>(scratch + (size_t)nchunks * R * F3);
   dim3 grid(nq_cdiv(nchunks, GWR_WAVES), parts);
   switch (F / 64) {
-    case 1: hipLaunchKernelGGL((k_gwr_sorted<1>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
-    case 2: hipLaunchKernelGGL((k_gwr_sorted<2>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
-    case 4: hipLaunchKernelGGL((k_gwr_sorted<4>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range); break;
+    case 1: hipLaunchKernelGGL((k_gwr_sorted<1>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range, count_dev); break;
+    case 2: hipLaunchKernelGGL((k_gwr_sorted<2>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range, count_dev); break;
+    case 4: hipLaunchKernelGGL((k_gwr_sorted<4>), grid, dim3(GWR_WAVES * 64), 0, st, GPHI, GPSI, RW, order, E, F, F3, R, chunk_len, part, chunk_range, count_dev); break;
     default: return nq_fail(NQ_ERR_ARG, "gwr_sorted needs hidden_channels in {64,128,256}");
   }
   NQ_LAUNCH_CHECK();

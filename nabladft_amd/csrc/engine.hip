@@ -20,6 +20,24 @@ int nq_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- dynamic-LDS opt-in, per (device, kernel) ---------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <utility>
+static std::mutex g_lds_mu;
+static std::map<std::pair<int, const void*>, size_t> g_lds_granted;
+int nq_dyn_lds(const void* kernel, size_t bytes) {
+  int dev = 0;
+  NQ_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_lds_mu);
+  size_t& have = g_lds_granted[std::make_pair(dev, kernel)];
+  if (bytes > have) {
+    NQ_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
+  return NQ_OK;
+}
+
 // ---- profiler ---------------------------------------------------------------------------------------
 #include <map>
 #include <mutex>
@@ -128,9 +146,9 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   W->GEDGE = take((F / 64) * E * 4);
   W->GZO = take(2 * N * H); W->TMPW = take(N * H);
   W->GRHO = take(c->rbf_type ? 2 * E * R : 0); W->BCON = take(c->rbf_type ? E * R : 0);   // learnable bases: adjoints of rho / drho, per-edge contributions
-  W->ROWCTR = take(4 * L * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]
+  W->ROWCTR = take(5 * L * NQ_ROWCTR_INTS);   // int32 row counters of the fused message launches: [kind][layer][NQ_ROWCTR_INTS]; kind 4 = the second dual-reverse launch of a mixed batch
   W->SCHED = take(W->fused ? nq_molgw_sched_ints((int)E, (int)B) : 0);      // int32: per-molecule pair lists of the molecule-per-workgroup rbf_proj gradient (molpair.hip)
-  W->GWREC = take(W->fused ? nq_molgw_rec_floats((int)E) : 0);               // its per-pair records: expanded matrix-core A operands (per step) + packed geometry (per backward sweep)
+  W->GWREC = take(W->fused ? nq_molgw_rec_floats((int)E, (int)B) : 0);               // its per-pair records: expanded matrix-core A operands (per step) + packed geometry (per backward sweep)
   W->GWPART = take(W->fused ? nq_molgw_part_floats((int)F, (int)B) : 0);   // its per-workgroup partial rows
   // scratch for split-K partials / column sums / embedding partials: max over all uses
   size_t s = 0;
@@ -148,15 +166,40 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   (void)B;
 }
 
-// rbf_proj gradient from node rows staged per molecule in LDS (molpair.hip) instead of gphi / gpsi pair rows through HBM: needs the fused filter and a
-// batch whose largest molecule fits the LDS of one workgroup (nq_graph::max_mol_atoms, 0 = unknown); NQ_NO_MOLGW=1 forces the pair-row path.
-static bool use_molgw(const nq_painn_cfg* c, const nq_graph* g, const WsLayout& W) {
+// rbf_proj gradient from node rows staged per molecule in LDS (molpair.hip) instead of gphi / gpsi pair rows through HBM: needs the fused filter.
+//   GW_PAIR_ROWS  the dual-reverse kernel writes gphi / gpsi per pair, k_gwr_sorted reads them back (small batches; NQ_NO_MOLGW=1 forces it)
+//   GW_MOLECULE   every molecule fits the LDS of one workgroup (nq_graph::max_mol_atoms <= cap): k_gwr_mol, nothing stored per pair
+//   GW_MIXED      some molecules are larger than cap: THEIR rows go through the pair-row kernels, every other molecule stays on k_gwr_mol
+// The decision is taken ONCE per step, by the forward call (which builds the schedule), and remembered per workspace: the backward call reads it back instead
+// of re-evaluating the environment (a changed NQ_MOLGW between the two calls would consume a schedule that was never built).
+enum { GW_PAIR_ROWS = 0, GW_MOLECULE = 1, GW_MIXED = 2 };
+struct GwMode { int mode; int cap; };
+static int molgw_cap() {
+  const char* c = getenv("NQ_MOLGW_CAP");   // tests: a small cap sends ordinary molecules down the mixed path
+  const int hw = nq_molgw_max_atoms();
+  if (c && atoi(c) > 0 && atoi(c) < hw) return atoi(c);
+  return hw;
+}
+static GwMode decide_molgw(const nq_painn_cfg* c, const nq_graph* g, const WsLayout& W) {
+  GwMode r{GW_PAIR_ROWS, molgw_cap()};
   const char* off = getenv("NQ_NO_MOLGW");
-  if (!W.fused || (off && off[0] == '1') || !nq_molgw_supported(c->hidden_channels, c->num_rbf, g->max_mol_atoms)) return false;
+  if (!W.fused || (off && off[0] == '1') || !nq_molgw_config_ok(c->hidden_channels, c->num_rbf) || g->max_mol_atoms <= 0) return r;
   // small batches (the reference's 32 conformers): the schedule kernels and the two launches per layer are pure latency there (measured 3.99 vs 3.72 ms per
   // step at 32 conformers), the pair rows are a few MB; NQ_MOLGW=1 forces the per-molecule path at any size (tests)
   const char* on = getenv("NQ_MOLGW");
-  return (on && on[0] == '1') || g->N >= 4096;
+  if (!((on && on[0] == '1') || g->N >= 4096)) return r;
+  r.mode = g->max_mol_atoms <= r.cap ? GW_MOLECULE : GW_MIXED;
+  return r;
+}
+static std::mutex g_gw_mu;
+static std::map<const void*, GwMode> g_gw_modes;   // by workspace: written by the forward call, read by the backward call of the same step
+static void remember_molgw(const void* ws, GwMode m) { std::lock_guard<std::mutex> lock(g_gw_mu); g_gw_modes[ws] = m; }
+static bool recall_molgw(const void* ws, GwMode* m) {
+  std::lock_guard<std::mutex> lock(g_gw_mu);
+  auto it = g_gw_modes.find(ws);
+  if (it == g_gw_modes.end()) return false;
+  *m = it->second;
+  return true;
 }
 
 static NqGraphView view_of(const nq_graph* g) {
@@ -186,6 +229,7 @@ static int check_common(const nq_painn_cfg* cfg, const nq_graph* g, const void* 
 extern "C" {
 
 int nq_abi_version(void) { return NQ_ABI_VERSION; }
+int32_t nq_painn_molecule_lds_atoms(void) { return nq_molgw_max_atoms(); }
 
 void nq_profile_enable(int32_t on) { nq_profile_on = on; }
 // Synchronises the device, folds all recorded event pairs into per-name totals and clears them.
@@ -294,11 +338,11 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
   }
   else if (!strcmp(name, "pair_sched")) {                                     // int32 payload: {slot, off << 26 | n << 13 | k} per pair (molpair.hip)
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched' exists only with the fused filter");
-    base = W.SCHED; rows = e; w = 1; dual = false;
+    base = W.SCHED; rows = 2 * nq_molgw_sched_slots((int)e, B); w = 1; dual = false;
   }
-  else if (!strcmp(name, "pair_sched_meta")) {                                // int32: sched_ptr [B][13], hist [128], wlo [13]
+  else if (!strcmp(name, "pair_sched_meta")) {                                // int32: seg [B][NW] {first batch, pairs}, sched_ptr [B][NW + 1], hist [128], wlo [NW + 1], 16 spare
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched_meta' exists only with the fused filter");
-    base = W.SCHED + ((e + 1) & ~(size_t)1); rows = nq_molgw_sched_ints((int)e, B) - ((e + 1) & ~(size_t)1); w = 1; dual = false;
+    base = W.SCHED + 2 * nq_molgw_sched_slots((int)e, B); rows = nq_molgw_sched_ints((int)e, B) - 2 * nq_molgw_sched_slots((int)e, B); w = 1; dual = false;
   }
   else if (!strcmp(name, "rw")) {
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'rw' exists only with the fused filter");
@@ -339,12 +383,18 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_HIP(hipMemsetAsync(ws + W.X[0] + NF, 0, NF * sizeof(float), st));
   NQ_HIP(hipMemsetAsync(ws + W.V[0], 0, 6 * NF * sizeof(float), st));
   float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
+  const GwMode gw = decide_molgw(cfg, graph, W);   // GW_PAIR_ROWS without the fused filter
+  remember_molgw(workspace, gw);
   if (W.fused) {
     FilterArgs fa0;
     nq_make_filter_args(&fa0, nullptr, nullptr, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
     NQ_TRY(nq_rbf_window(st, g.geom, E, fa0, ws + W.RW));
-    if (use_molgw(cfg, graph, W)) NQ_TRY(nq_molgw_schedule(st, g, graph->dst, ws + W.RW, R, reinterpret_cast<int*>(ws + W.SCHED), ws + W.GWREC));
-    else NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col));   // lower slots only
+    int* const sched = reinterpret_cast<int*>(ws + W.SCHED);
+    if (gw.mode != GW_PAIR_ROWS) NQ_TRY(nq_molgw_schedule(st, g, graph->dst, ws + W.RW, R, gw.cap, sched, ws + W.GWREC));
+    if (gw.mode == GW_PAIR_ROWS) NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col));   // lower slots only
+    else if (gw.mode == GW_MIXED)   // lower slots of the molecules above the cap only; their number stays on the device (last spare int of the schedule block)
+      NQ_TRY(nq_k0_sort(st, ws + W.RW, E, R, reinterpret_cast<int*>(ws + W.ORDER), reinterpret_cast<int*>(ws + W.scratch), graph->dst, g.col, g.mol_ptr, g.atom_mol,
+                        gw.cap, sched + nq_molgw_sched_ints(E, g.B) - 1));
   } else {
     NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho, cfg->rbf_type, params + P.basis));
   }
@@ -497,7 +547,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   const int N = g.N, E = g.E, F = cfg->hidden_channels, R = cfg->num_rbf, H = F / 2, L = cfg->num_layers, T = cfg->num_elements;
   const size_t NF = (size_t)N * F;
   int* const rowctr0 = reinterpret_cast<int*>(ws + W.ROWCTR);
-  NQ_HIP(hipMemsetAsync(rowctr0 + (size_t)2 * L * NQ_ROWCTR_INTS, 0, (size_t)2 * L * NQ_ROWCTR_INTS * sizeof(int), st));
+  NQ_HIP(hipMemsetAsync(rowctr0 + (size_t)2 * L * NQ_ROWCTR_INTS, 0, (size_t)3 * L * NQ_ROWCTR_INTS * sizeof(int), st));
   // claimed rows pay off once every wavefront gets at least a row or two (measured: 10.7 k atoms 12.16 vs 12.57 ms per step); with fewer rows than
   // wavefronts the claim atomics are a visible part of each kernel (1.3 k atoms: dual sweep 57 -> 112 us), so small batches keep the static striding
   auto row_ctr = [&](int kind, int l) { return N >= 4096 ? rowctr0 + ((size_t)kind * L + l) * NQ_ROWCTR_INTS : (int*)nullptr; };
@@ -566,8 +616,11 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   if (seeded) NQ_HIP(hipMemsetAsync(ws + W.gte, 0, (size_t)N * sizeof(float), st));   // no Edot term
   r.ge = ws + W.ge; r.gte = ws + W.gte; r.GZO = ws + W.GZO; r.GTZO = ws + W.GZO + NH; r.TMPW = ws + W.TMPW;
   NQ_TRY(nq_readout_rev(st, r, true));
+  GwMode gw;
+  if (!recall_molgw(workspace, &gw)) return nq_fail(NQ_ERR_ARG, "nq_painn_backward: no forward call has prepared this workspace");
   SideStream ss;
-  side_stream_init(ss, st, N);
+  if (gw.mode != GW_MIXED) side_stream_init(ss, st, N);   // mixed batches: the pair-row contraction of the large molecules and the per-molecule kernel add into one
+                                                           // gradient and share the scratch with the split-K products -- everything stays on the main stream (a rare path)
   hipStream_t sd = ss.fork();          // sd == st when the side stream is off
   NQ_TRY(nq_colsum(sd, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(sd, ws + W.ge, N, 1, 1, gp + P.o2, scr));
@@ -580,8 +633,11 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (seed_vec) NQ_HIP(hipMemcpyAsync(gv_cur, seed_vec, 3 * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
-  const bool molgw = use_molgw(cfg, graph, W);
-  if (molgw) NQ_TRY(nq_molgw_geometry(st, g, ws + W.TD, ws + W.TR, reinterpret_cast<const int*>(ws + W.SCHED), ws + W.GWREC));
+  const bool molgw = gw.mode != GW_PAIR_ROWS, mixed = gw.mode == GW_MIXED;
+  const int* const sched = reinterpret_cast<const int*>(ws + W.SCHED);
+  const int* const n_big_pairs = sched + nq_molgw_sched_ints(E, g.B) - 1;
+  if (molgw) NQ_TRY(nq_molgw_geometry(st, g, ws + W.RW, ws + W.TD, ws + W.TR, sched, ws + W.GWREC));
+  if (mixed) NQ_HIP(hipMemsetAsync(ws + W.GBR, 0, 3 * NF * sizeof(float), st));   // only the rows of the large molecules are written below; the column sum runs over all atoms
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     UpdRevArgs u{};
@@ -619,12 +675,20 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
       fa.row_ctr = row_ctr(3, l);
+      m.mol_cap = gw.cap;
+      m.row_filter = mixed ? 1 : 0;
       NQ_TRY(nq_msgf_rev(st, m, fa, true, !molgw));
+      if (mixed) {   // the molecules that do not fit the LDS of k_gwr_mol: pair rows, k0-sorted contraction and per-atom bias sums as in rounds 1-4, for THEIR rows only
+        m.row_filter = 2;
+        fa.row_ctr = row_ctr(4, l);
+        NQ_TRY(nq_msgf_rev(st, m, fa, true, true));
+        NQ_TRY(nq_gwr_sorted(st, gphi, gpsi, ws + W.RW, reinterpret_cast<const int*>(ws + W.ORDER), E / 2, F, R, gp + mp.Wr, scr, 3, n_big_pairs));
+        NQ_TRY(nq_colsum(st, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
+      }
       // rbf_proj weight and bias gradient from the same node rows, staged per molecule in LDS (main stream: it reads the adjoints this layer's input-gradient
-      // products overwrite next; the fork below orders the side stream and the layer event behind it)
+      // products overwrite next; the fork below orders the side stream and the layer event behind it); mixed: added to what the pair-row kernels left
       if (molgw)
-        NQ_TRY(nq_gwr_mol(st, g, F, R, graph->max_mol_atoms, m.XH, m.V, m.TXH, m.TV, m.GX, m.GV, m.GTX, m.GTV, reinterpret_cast<const int*>(ws + W.SCHED),
-                          ws + W.GWREC, ws + W.GWPART, gp + mp.Wr, gp + mp.br));
+        NQ_TRY(nq_gwr_mol(st, g, F, R, gw.cap, m.XH, m.V, m.TXH, m.TV, m.GX, m.GV, m.GTX, m.GTV, sched, ws + W.GWREC, ws + W.GWPART, gp + mp.Wr, gp + mp.br, mixed));
     } else {
       NQ_TRY(nq_msg_rev(st, m, true));
     }

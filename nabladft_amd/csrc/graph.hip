@@ -227,7 +227,7 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
     return nq_fail(NQ_ERR_MOL_TOO_LARGE, "molecule with %d atoms exceeds NQ_MAX_MOL_ATOMS=%d", max_mol_atoms, NQ_MAX_MOL_ATOMS);
   if (N <= 0 || B <= 0) return nq_fail(NQ_ERR_ARG, "empty batch (N=%d, B=%d)", N, B);
   size_t lds = graph_lds_bytes(max_mol_atoms);
-  { static size_t set__ = 0; if (lds > set__) { NQ_HIP(hipFuncSetAttribute((const void*)k_graph_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set__ = lds; } }
+  NQ_DYN_LDS(k_graph_count, lds);
   hipLaunchKernelGGL(k_graph_count, dim3(B), dim3(GRAPH_THREADS), lds, st, pos, mol_ptr, cutoff2, K, deg, lowdeg);
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, st, deg, lowdeg, N, row_ptr, lowptr);
@@ -240,7 +240,7 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
 int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st) {
   NQ_PROF(st, "graph_fill");
   size_t lds = graph_lds_bytes(max_mol_atoms);
-  { static size_t set__ = 0; if (lds > set__) { NQ_HIP(hipFuncSetAttribute((const void*)k_graph_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set__ = lds; } }
+  NQ_DYN_LDS(k_graph_fill, lds);
   hipLaunchKernelGGL(k_graph_fill, dim3(B), dim3(GRAPH_THREADS), lds, st, args);
   NQ_LAUNCH_CHECK();
   return NQ_OK;

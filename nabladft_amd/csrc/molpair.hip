@@ -1,4 +1,5 @@
-// rbf_proj weight / bias gradient of the PaiNN dual-reverse sweep, molecule per workgroup (round 5).
+// rbf_proj weight / bias gradient of the PaiNN dual-reverse sweep, molecule per workgroup (round 5; round 6: bf16-split matrix core, 8-pair batches,
+// next molecule prefetched through registers).
 // Reference semantics: painn.py:475-509 (rbfh = rbf_proj(edge_rbf); x = xh[j] * rbfh) differentiated twice -- the adjoints of
 // phi = rbf_proj(rho(d)) and of its tangent psi * t_d, contracted with the 13-tap Gaussian window:
 //     gWr[c][k0_p + t] += gphi_p[c] rho_t(d_p) + gpsi_p[c] drho_t(d_p),   p = undirected pair, both directions summed.
@@ -7,21 +8,26 @@
 //     direction s -> t:  gm_b = A_t.v_s + T_t.tv_s, gtm_b = T_t.v_s, gm_c = A_t.r + T_t.tr, gtm_c = T_t.r,
 //                        gphi = (gma_t xa_s + gtma_t txa_s,  gm_b xb_s + gtm_b txb_s,  gm_c xc_s + gtm_c txc_s),  gpsi = t_d (gtma_t xa_s, gtm_b xb_s, gtm_c xc_s)
 // (A, gma, T, gtma: adjoint rows of the target; x, tx, v, tv: primal / tangent rows of the source).  So here a workgroup stages the 20 rows
-// of ONE molecule for a 32-channel slice in LDS with coalesced loads (2.5 kB per atom) and every pair is recomputed where it is consumed:
+// of ONE molecule for a 32-channel slice in LDS with coalesced loads (2.5 kB per atom, <= 64 atoms) and every pair is recomputed where it is consumed:
 //   * wavefront w keeps GM_WMAX + 12 accumulator rows (window starts [wlo[w], wlo[w] + GM_WMAX), placed on the w-th quantile range of the batch's k0
 //     histogram) for the WHOLE launch as the C/D registers of the matrix core -- no atomics, no LDS accumulator, no sliding; neighbouring windows
 //     overlap, and every molecule's k0-sorted pair list is cut into GM_NW equal segments that respect them: all wavefronts reach the barrier together;
-//   * one wavefront iteration = one pair: lanes 0-31 the direction n -> k, lanes 32-63 the direction k -> n, one channel per lane; the 20 operands are
-//     five conflict-free ds_read_b128; one v_permlane32_swap + add per filter part leaves gphi (both directions summed) in lanes 0-31 and gpsi in
-//     lanes 32-63 -- the B operand [K = {phi, psi}][N = 32 channels] of v_mfma_f32_32x32x2_f32.  Its A operand [M = 32 rows][K] is the pair's window
-//     record shifted to the wavefront's rows: lane (j, half) loads rho / drho tap j - (k0 - wlo) (zero outside the 13 taps) with ONE coalesced
-//     256-byte load (k_pair_arec prepares it once per step), requested four pairs ahead.  Row 31 carries the bias multiplier (beta, beta'), so the bias gradient rides in the same product.
-//     The rank-2 update acc[j][c] += rho_j gphi[c] + drho_j gpsi[c] is then one matrix-core instruction per filter part (exact f32, fixed order);
-//   * geometry / tangent scalars of a pair come as vector loads too (32 records per coalesced chunk load into a 1-kB LDS ring private to the wavefront,
-//     broadcast ds_read_b128 + v_readfirstlane when consumed): no scalar-memory latency in the loop
-//     (the first version of this kernel read the 32-dword record with s_load per pair and ran at HBM latency: 3.7 ms per launch);
+//   * one pair step: lanes 0-31 the direction n -> k, lanes 32-63 the direction k -> n, one channel per lane; the 20 operands are five conflict-free
+//     ds_read_b128; one v_permlane32_swap + add per filter part leaves gphi (both directions summed) in lanes 0-31 and gpsi in lanes 32-63;
+//   * ROUND 6: the rank-2 update acc[j][c] += rho_j gphi[c] + drho_j gpsi[c] of EIGHT pairs is one K = 16 contraction of v_mfma_f32_32x32x16_bf16
+//     (k = 0..7: gphi of the pairs, lanes 0-31; k = 8..15: gpsi, lanes 32-63 -- exactly what the swap leaves).  Both operands are split into two bf16
+//     pieces (x = hi + lo, round-to-nearest twice; the window records once per step by k_pair_arec, gphi / gpsi in the loop: 3 VALU instructions per
+//     value) and the product is hi hi' + hi lo' + lo hi' accumulated in f32: 9 matrix instructions of 32 cycles per 8 pairs instead of 24 of 64 cycles
+//     (round 5: v_mfma_f32_32x32x2_f32 per pair, 192 of ~400 issue cycles per pair and slice; the f32 matrix path has no rate advantage over the VALU).
+//     Error per product <= 3 x 2^-18 (dropped lo lo', two residuals), measured against float64 in tests/test_engine_gpu.py next to the exact-f32 pair rows;
+//   * per-pair scalars (geometry, tangents, atom indices) arrive as ONE coalesced dword load per batch (lane 8 i + f = field f of pair i) and are
+//     broadcast with v_readlane (static lane index): no LDS ring, no scalar-memory latency; the A operands as two 16-byte loads per lane and batch;
+//     both requested two batches ahead (three static register sets);
+//   * the rows of the NEXT molecule of the workgroup are requested into registers before the pair loop (GM_PF of the five row blocks) and written to LDS
+//     behind the barrier that ends the loop: the staging latency (round 5: ~25 % of the kernel, one workgroup per CU because of the LDS footprint) hides
+//     behind the pair arithmetic;
 //   * the pair lists per (molecule, wavefront) are built once per step (the windows depend on the geometry only), sorted by window start, slot-ascending,
-//     so the summation order is fixed: results are bitwise reproducible;
+//     padded to whole batches, so the summation order is fixed: results are bitwise reproducible;
 //   * per-workgroup partial rows (one flush per launch) are summed in workgroup order by k_gwr_mol_reduce.
 // HBM traffic per launch: 20 rows x N x F x 4 B read once (0.88 GB at 2048 conformers) instead of 2.5 GB written + 2.5 GB read.
 #include "common.h"
@@ -29,21 +35,53 @@
 #include <type_traits>
 
 #ifndef GM_THREADS
-#define GM_THREADS 1024   // 16 wavefronts = 4 per SIMD (8 / 12 / 16 measured within 3 %: profiles/r05_gwr_mol_wave_count_variants.txt); the staging below deals its blocks to 15 of them
+#define GM_THREADS 512    // 8 wavefronts = 2 per SIMD.  12 (the kernel fits 168 registers) measured 5.28 vs 5.13 ms per step: more segments per molecule = more
+                          // padding and a longer wait at the per-molecule barrier, and the VALU is no longer the bound (profiles/r06_gwr_mol_variants.txt)
 #endif
+#define GM_STAGE_THREADS 512   // threads that stage rows: (atom, channel quad) = 64 x 8
 #define GM_NW (GM_THREADS / 64)     // wavefronts per workgroup = owners of window-start ranges
 #define GM_ROWS 32                  // rows of the matrix-core tile: 31 window rows + the bias row
 #define GM_WMAX (GM_ROWS - 1 - (FWIN - 1))   // window starts per wavefront at most (19): row off + 12 <= 30
 #define GM_CH 32                    // channels per slice
+#define GM_BATCH 8                  // pairs per matrix-core contraction (K = 16 = 8 x {gphi, gpsi})
 #define GM_ATOM_FLOATS (20 * GM_CH) // LDS floats per atom: 5 blocks [32 channels][4 rows]
+#define GM_ATOM_BYTES (GM_ATOM_FLOATS * 4)
+#define GM_RING_BYTES 512           // per wavefront: the scalar records of two batches (2 x 8 pairs x 8 dwords), read back as broadcast ds_read_b128
+#define GM_MAX_ATOMS ((160 * 1024 - GM_NW * GM_RING_BYTES) / GM_ATOM_BYTES)   // 62 with 8 wavefronts: the rows + the rings fill the 160 KB of LDS
 #define GM_PART_FLOATS (GM_ROWS * 3 * GM_CH)   // per (workgroup, wavefront): [row][part][channel]
 #define GM_MAX_BINS 128
+#define GM_PA_DWORDS (2 * 64 * 4)   // A operands of one batch: [piece hi / lo][lane][8 bf16]
+#define GM_PG_DWORDS 64             // scalars of one batch: [pair][8 fields]
+#ifndef GM_STAGE_EARLY
+#define GM_STAGE_EARLY 1
+#endif
 #ifndef GM_ABLATE
-#define GM_ABLATE 0   // development only (scripts/variants_r05.sh; results are wrong, timing only): 1 no pair loop, 2 no staging, 3 no matrix-core updates, 4 no record loads, 5 no reduce kernel; bit flags from 16: 16 no permlane swaps, 32 no LDS operand loads, 64 no per-pair arithmetic, 128 no barriers
+#define GM_ABLATE 0   // development only (results are wrong, timing only): 1 no pair steps, 2 no matrix-core updates, 4 no per-pair arithmetic, 8 no operand loads, 16 no permlane swaps, 32 no geometry broadcasts, 64 no bf16 split, 128 no barriers, 256 no per-step liveness branch
 #endif
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-static_assert(GM_THREADS == 1024 || GM_ABLATE != 0, "the staging of k_gwr_mol assigns LDS blocks to wavefronts 0-14 of 16 (other counts: timing builds only)");
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gm_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gm_bf2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+static_assert(GM_THREADS >= GM_STAGE_THREADS && GM_THREADS % 64 == 0, "the staging of k_gwr_mol deals (atom, channel quad) tasks to the first 512 threads");
+static_assert(GM_MAX_ATOMS * 8 <= GM_STAGE_THREADS, "one staging task per (atom, channel quad)");
+
+__device__ __forceinline__ unsigned gm_pack(float a, float b) {   // two f32 -> packed bf16 (round to nearest even): v_cvt_pk_bf16_f32
+  gm_bf2 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+// (x0, x1) -> hi = bf16(x), lo = bf16(x - hi) (the subtraction is exact), both packed
+__device__ __forceinline__ void gm_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  if (GM_ABLATE & 64) { hi = __float_as_uint(x0); lo = __float_as_uint(x1); return; }
+  hi = gm_pack(x0, x1);
+  lo = gm_pack(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+// first batch of molecule m's padded pair list: sum_w ceil(len_w / 8) <= pairs / 8 + GM_NW, so floor(lowptr / 8) + (GM_NW) m never overlaps the next molecule
+__host__ __device__ __forceinline__ int gm_mol_batch0(int lowptr_a0, int m) { return (lowptr_a0 >> 3) + GM_NW * m; }
+static inline size_t gm_max_batches(int E, int B) { return (size_t)(E / 2) / GM_BATCH + (size_t)GM_NW * B + GM_NW; }
 
 // ---- once per step: owners of the window starts and the per-(molecule, wavefront) pair lists -----------------------------------
 __global__ __launch_bounds__(256) void k_pair_hist(const float* __restrict__ RW, const int* __restrict__ dst, const int* __restrict__ col, int E,
@@ -94,12 +132,14 @@ __global__ void k_pair_windows(const int* __restrict__ hist, int nbins, int* __r
 
 // One wavefront per molecule: the molecule's pairs sorted (stably, by slot) by window start k0, then cut into GM_NW consecutive segments of (nearly) equal
 // length -- segment w goes to wavefront w and must fit its rows: it takes every pair with k0 < wlo[w+1] (the next window cannot hold them) and otherwise
-// fills up to ceil(pairs / GM_NW) with pairs of k0 < wlo[w] + GM_WMAX.  sched_ptr[m][w] = first entry of segment w relative to pb = lowptr[a0].
-// sched[pb + i] = {slot of the lower edge (row n, source k < n), row offset (k0 - wlo[w]) << 26 | (n - a0) << 13 | (k - a0)}.
+// fills up to ceil(pairs / GM_NW) with pairs of k0 < wlo[w] + GM_WMAX.  sched_ptr[m][w] = first pair of segment w in the molecule's sorted list (cut points).
+// Every segment starts on a batch boundary of the padded list: seg[m][w] = {first batch, pairs}; slot 8 batch + i holds
+// {CSR slot of the lower edge (row n, source k < n) or -1 (padding), row offset (k0 - wlo[w]) << 26 | (n - a0) << 13 | (k - a0)}.
 // Ranks come from ballots over the distinct keys of a 64-slot chunk (no atomics): the order is a function of the geometry only.
+// A molecule of more than cap atoms gets empty segments (its pairs go through the pair-row kernels, engine.hip).
 template <bool FILL>
 __device__ __forceinline__ void pair_sched_pass(const NqGraphView& g, const int* __restrict__ dst, const float* __restrict__ RW, const int* __restrict__ wlo,
-                                                const int* cut, int a0, int s0, int s1, int pb, int lane, int* cnt, int2* __restrict__ sched) {
+                                                const int* cut, const int* bst, int b0, int a0, int s0, int s1, int lane, int* cnt, int2* __restrict__ sched) {
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int c0 = s0; c0 < s1; c0 += 64) {
     const int s = c0 + lane;
@@ -118,7 +158,7 @@ __device__ __forceinline__ void pair_sched_pass(const NqGraphView& g, const int*
         int w = 0;
 #pragma unroll
         for (int v = 1; v < GM_NW; ++v) w += pos >= cut[v];
-        sched[pb + pos] = make_int2(s, ((kk - wlo[w]) << 26) | ((n - a0) << 13) | (k - a0));
+        sched[(long)GM_BATCH * (b0 + bst[w]) + (pos - cut[w])] = make_int2(s, ((kk - wlo[w]) << 26) | ((n - a0) << 13) | (k - a0));
       }
       __builtin_amdgcn_wave_barrier();
       if (lane == lead) cnt[kk] += __popcll(mask);
@@ -127,61 +167,101 @@ __device__ __forceinline__ void pair_sched_pass(const NqGraphView& g, const int*
     }
   }
 }
-__global__ __launch_bounds__(64) void k_pair_sched(NqGraphView g, const int* __restrict__ dst, const float* __restrict__ RW, const int* __restrict__ wlo,
-                                                    int2* __restrict__ sched, int* __restrict__ sched_ptr) {
+__global__ __launch_bounds__(64) void k_pair_sched(NqGraphView g, const int* __restrict__ dst, const float* __restrict__ RW, const int* __restrict__ wlo, int cap,
+                                                    int2* __restrict__ sched, int* __restrict__ sched_ptr, int2* __restrict__ seg) {
   __shared__ int cnt[GM_MAX_BINS + 1];
   __shared__ int cut[GM_NW + 1];
+  __shared__ int bst[GM_NW + 1];
   const int m = blockIdx.x, lane = threadIdx.x;
   const int a0 = g.mol_ptr[m], a1 = g.mol_ptr[m + 1];
-  const int s0 = g.row_ptr[a0], s1 = g.row_ptr[a1], pb = g.lowptr[a0];
+  const int s0 = g.row_ptr[a0], s1 = g.row_ptr[a1], b0 = gm_mol_batch0(g.lowptr[a0], m);
+  if (a1 - a0 > cap) {   // too large for the LDS of k_gwr_mol: nothing scheduled
+    if (lane <= GM_NW) sched_ptr[(long)m * (GM_NW + 1) + lane] = 0;
+    if (lane < GM_NW) seg[(long)m * GM_NW + lane] = make_int2(b0, 0);
+    return;
+  }
   cnt[lane] = 0; cnt[lane + 64] = 0;
   __syncthreads();
-  pair_sched_pass<false>(g, dst, RW, wlo, cut, a0, s0, s1, pb, lane, cnt, sched);
+  pair_sched_pass<false>(g, dst, RW, wlo, cut, bst, b0, a0, s0, s1, lane, cnt, sched);
   __syncthreads();
   if (lane == 0) {
     int run = 0;   // exclusive scan over the window starts (<= 128 values): cnt[b] = pairs with k0 < b
     for (int b = 0; b < GM_MAX_BINS; ++b) { const int v = cnt[b]; cnt[b] = run; run += v; }
     cnt[GM_MAX_BINS] = run;
     const int np = run, target = (np + GM_NW - 1) / GM_NW;
-    int cur = 0;
+    int cur = 0, nb = 0;
     for (int w = 0; w < GM_NW; ++w) {
-      cut[w] = cur;
+      cut[w] = cur; bst[w] = nb;
       const int forced_end = w == GM_NW - 1 ? np : cnt[min(GM_MAX_BINS, wlo[w + 1])];
       const int optional_end = min(cur + target, cnt[min(GM_MAX_BINS, wlo[w] + GM_WMAX)]);
-      cur = max(cur, max(forced_end, optional_end));
+      const int end = max(cur, max(forced_end, optional_end));
+      nb += (end - cur + GM_BATCH - 1) / GM_BATCH;
+      cur = end;
     }
-    cut[GM_NW] = np;
+    cut[GM_NW] = np; bst[GM_NW] = nb;
   }
   __syncthreads();
   if (lane <= GM_NW) sched_ptr[(long)m * (GM_NW + 1) + lane] = cut[lane];
-  pair_sched_pass<true>(g, dst, RW, wlo, cut, a0, s0, s1, pb, lane, cnt, sched);
+  if (lane < GM_NW) {
+    const int len = cut[lane + 1] - cut[lane];
+    seg[(long)m * GM_NW + lane] = make_int2(b0 + bst[lane], len);
+    for (int i = len; i < (bst[lane + 1] - bst[lane]) * GM_BATCH; ++i) sched[(long)GM_BATCH * (b0 + bst[lane]) + i] = make_int2(-1, 0);   // padding of the last batch
+  }
+  pair_sched_pass<true>(g, dst, RW, wlo, cut, bst, b0, a0, s0, s1, lane, cnt, sched);
 }
 
-// Expanded A operands, once per step (the window records depend on the geometry only): PA[pair][lane] = the value lane (row j = lane & 31, K index = lane >> 5)
-// feeds to the matrix core for this pair: rho (K = 0) / drho (K = 1) tap j - off of the window record, 0 outside the 13 taps, and in row 31 the bias
-// multiplier / its derivative.  One coalesced 256-byte load per pair in the gradient kernel instead of ~25 instructions of unpacking per pair, slice and layer.
-__global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sched, const float* __restrict__ RW, int npairs, float* __restrict__ PA) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int pr = (int)(idx >> 6), lane = (int)(idx & 63);
-  if (pr >= npairs) return;
-  const int2 en = sched[pr];
-  const int off = (int)((unsigned)en.y >> 26), j = lane & 31, half = lane >> 5;
-  const int t = j - off;
-  const bool valid = ((unsigned)t < (unsigned)FWIN) | (j == 31);
-  const int tap = j == 31 ? 14 : min(max(t, 0), FWIN - 1);
-  const float v = RW[(long)en.x * RW_STRIDE + half * 16 + tap];
-  PA[idx] = valid ? v : 0.f;
+// Expanded A operands.  PA[batch][piece][lane] = 8 bf16: what lane (row j = lane & 31, K half = lane >> 5) feeds to v_mfma_f32_32x32x16_bf16 for the 8 pairs of
+// the batch: rho (lanes 0-31) / t_d drho (lanes 32-63) tap j - off of each pair's window record, 0 outside the 13 taps and for padding, and in row 31 the bias
+// multiplier / t_d times its derivative; piece 0 = bf16(x), piece 1 = bf16(x - piece 0).  The rho half depends on the geometry only: written once per step
+// (TD == nullptr); the drho half carries the pair's tangent t_d (the factor of gpsi, folded in here so that the pair loop spends no instruction on it) and is
+// written once per backward sweep (TD set).
+__global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sched, const int2* __restrict__ seg, const float* __restrict__ RW,
+                                                    const float* __restrict__ TD, int nseg, u4* __restrict__ PA) {
+  // one wavefront per (molecule, wavefront-of-k_gwr_mol) segment, looping over its batches
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (sg >= nseg) return;
+  const int2 se = seg[sg];
+  const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, j = lane & 31, half = lane >> 5;
+  if ((half == 1) != (TD != nullptr)) return;
+  for (int b = 0; b < nb; ++b) {
+    const long batch = se.x + b;
+    float v[GM_BATCH];
+#pragma unroll
+    for (int i = 0; i < GM_BATCH; ++i) {
+      const int2 en = sched[batch * GM_BATCH + i];
+      const int off = (int)((unsigned)en.y >> 26);
+      const int t = j - off;
+      const bool valid = en.x >= 0 && (((unsigned)t < (unsigned)FWIN) | (j == 31));
+      const int tap = j == 31 ? 14 : min(max(t, 0), FWIN - 1);
+      v[i] = valid ? RW[(long)max(en.x, 0) * RW_STRIDE + half * 16 + tap] * (TD ? TD[max(en.x, 0)] : 1.0f) : 0.f;
+    }
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gm_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+    PA[(batch * 2 + 0) * 64 + lane] = u4{hi[0], hi[1], hi[2], hi[3]};
+    PA[(batch * 2 + 1) * 64 + lane] = u4{lo[0], lo[1], lo[2], lo[3]};
+  }
 }
-// Packed geometry records, once per backward sweep (the tangents t_d, t_r follow the force seeds): PG[pair] = {gx, gy, gz, t_d, t_r0, t_r1, t_r2, n << 13 | k}
-// in schedule order, so the gradient kernel reads ONE sequential scalar stream per wavefront.
-__global__ __launch_bounds__(256) void k_pair_grec(const int2* __restrict__ sched, const float4* __restrict__ geom, const float* __restrict__ TD,
-                                                    const float* __restrict__ TR, int npairs, float4* __restrict__ PG) {
-  const int pr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pr >= npairs) return;
-  const int2 en = sched[pr];
-  const float4 gm = geom[en.x];
-  PG[2 * (long)pr] = make_float4(gm.x, gm.y, gm.z, TD[en.x]);
-  PG[2 * (long)pr + 1] = make_float4(TR[3 * (long)en.x], TR[3 * (long)en.x + 1], TR[3 * (long)en.x + 2], __int_as_float(en.y & 0x3ffffff));
+// Packed scalars, once per backward sweep (the tangent t_r follows the force seeds): PG[batch][8 i + f] = field f of pair i:
+// {gx, gy, gz, 0, t_r0, t_r1, t_r2, n << 16 | k}; padding pairs: zeros (atom 0 with itself; their A operands are zero).
+__global__ __launch_bounds__(256) void k_pair_grec(const int2* __restrict__ sched, const int2* __restrict__ seg, const float4* __restrict__ geom,
+                                                    const float* __restrict__ TR, int nseg, float* __restrict__ PG) {
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (sg >= nseg) return;
+  const int2 se = seg[sg];
+  const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, i = lane >> 3, f = lane & 7;
+  for (int b = 0; b < nb; ++b) {
+    const long batch = se.x + b;
+    const int2 en = sched[batch * GM_BATCH + i];
+    float v = 0.f;
+    if (en.x >= 0) {
+      if (f < 3) v = reinterpret_cast<const float*>(geom)[4 * (long)en.x + f];
+      else if (f == 3) v = 0.f;
+      else if (f < 7) v = TR[3 * (long)en.x + (f - 4)];
+      else v = __int_as_float((((en.y >> 13) & 0x1fff) << 16) | (en.y & 0x1fff));
+    }
+    PG[batch * GM_PG_DWORDS + lane] = v;
+  }
 }
 
 // ---- the gradient kernel ----------------------------------------------------------------------------------------------------------
@@ -189,22 +269,25 @@ struct GwrMolArgs {
   NqGraphView g; int F; int nslices; int groups; int max_atoms;
   const float* XH; const float* V; const float* TXH; const float* TV;      // primal / tangent rows of the layer input side  [N][3F]
   const float* GX; const float* GV; const float* GTX; const float* GTV;    // adjoints of x_msg / vec_msg and of their tangents  [N][F], [N][3F]
-  const int* sched_ptr;
+  const int2* seg;                                                          // [B][GM_NW] {first batch, pairs}
   float* part;                                                              // [groups][nslices][GM_NW][GM_PART_FLOATS]
 };
 
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-// x and y hold one value per direction (lanes 0-31: n -> k, lanes 32-63: k -> n).  Returns the direction sum of x in lanes 0-31 and of y in lanes 32-63:
-// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second.
+// x and y hold one value per direction (lanes 0-31: n -> k, lanes 32-63: k -> n).  v_permlane32_swap exchanges the upper half of its first operand with the
+// lower half of its second: afterwards r[0] = {x(n->k), y(n->k)}, r[1] = {x(k->n), y(k->n)}.  SUM: both directions added (lanes 0-31: x, lanes 32-63: y);
+// DIFF: (k -> n) - (n -> k) -- the part that carries the pair's unit vector, whose sign flips with the direction, so the loop spends no multiply on the sign.
+template <bool DIFF>
 __device__ __forceinline__ float gm_pair_sum(float x, float y) {
-  if (GM_ABLATE & 16) return x + y;
+  if (GM_ABLATE & 16) return DIFF ? y - x : x + y;
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  return DIFF ? __uint_as_float(r[1]) - __uint_as_float(r[0]) : __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const float* __restrict__ PA, const float* __restrict__ PG) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];   // [atom][5 blocks][32 channels][4]
+struct GmOps { f4 P0, P1, P2, A, T; };
+struct GmRec { u4 hi, lo; };   // the two A pieces of this lane for one batch
+
+__global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const u4* __restrict__ PA, const unsigned* __restrict__ PG) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // [atom][5 blocks][32 channels][4], then one 512-byte scalar ring per wavefront
   const int F = q.F, F3 = 3 * q.F;
   // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8).  The nslices workgroups of one molecule group read the same per-pair records at about the
   // same time: they are placed on ONE XCD (one HBM fetch, the others hit that XCD's L2) when the grid allows it.
@@ -216,152 +299,204 @@ __global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const floa
   f16v acc0, acc1, acc2;                         // matrix-core accumulators of the three filter parts: [32 rows][32 channels] each
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0.f;
-  const float sgn = half ? 1.0f : -1.0f;         // unit vector of the lane's direction: n -> k is -geom, k -> n is +geom (same for its tangent)
   const unsigned hmask = half ? 0xffffffffu : 0u;
   const unsigned lbase = (unsigned)(c * 16);     // byte offset of the lane's channel inside a [32 channels][4] block
-  float* const gring = rows + (size_t)q.max_atoms * GM_ATOM_FLOATS + wave * 256;   // this wavefront's 32 geometry records (1 kB)
+  char* const ring = reinterpret_cast<char*>(rows) + (size_t)q.max_atoms * GM_ATOM_BYTES + wave * GM_RING_BYTES;   // [2 batches][8 pairs][8 dwords]
 
-  for (int m = group; m < q.g.B; m += q.groups) {
-    const int a0 = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[m]), na = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[m + 1]) - a0;
-    if (!(GM_ABLATE & 128)) __syncthreads();                             // every wavefront is done with the previous molecule's rows
-    // ---- stage the 20 rows of the molecule: LDS block b (four rows, transposed to [channel][4 rows]) is filled by the wavefronts b, b + 5, b + 10;
-    //      task = (atom, channel quad): four 16-byte loads (128 contiguous bytes per row and eight lanes), four ds_write_b128 ----
-    if ((GM_ABLATE & 15) != 2 && wave < 15) {
-      const int blk = wave % 5, sub = wave / 5;
-      const float* s0; const float* s1; const float* s2; const float* s3;
-      int st3 = F3;   // row stride of the fourth source (F for the scalar adjoints GX / GTX)
-      switch (blk) {
-        case 0: s0 = q.XH; s1 = q.XH + F; s2 = q.XH + 2 * F; s3 = q.TXH; break;
-        case 1: s0 = q.TXH + F; s1 = q.TXH + 2 * F; s2 = q.V; s3 = q.V + F; break;
-        case 2: s0 = q.V + 2 * F; s1 = q.TV; s2 = q.TV + F; s3 = q.TV + 2 * F; break;
-        case 3: s0 = q.GV; s1 = q.GV + F; s2 = q.GV + 2 * F; s3 = q.GX; st3 = F; break;
-        default: s0 = q.GTV; s1 = q.GTV + F; s2 = q.GTV + 2 * F; s3 = q.GTX; st3 = F; break;
-      }
-      for (int id = sub * 64 + lane; id < na * 8; id += 192) {
-        const int at = id >> 3, qd = id & 7;
-        const long n = a0 + at, o = n * F3 + cb + 4 * qd;
-        const f4 r0 = *reinterpret_cast<const f4*>(s0 + o), r1 = *reinterpret_cast<const f4*>(s1 + o), r2 = *reinterpret_cast<const f4*>(s2 + o);
-        const f4 r3 = *reinterpret_cast<const f4*>(s3 + n * st3 + cb + 4 * qd);
-        float* d = rows + at * GM_ATOM_FLOATS + blk * (GM_CH * 4) + (4 * qd) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f4*>(d + i * 4) = f4{r0[i], r1[i], r2[i], r3[i]};
-      }
+  // ---- staging: thread t < 512 owns (atom t >> 3, channel quad t & 7) of every row block: four 16-byte loads (128 contiguous bytes per row and eight lanes),
+  //      transposed to [channel][4 rows] by four ds_write_b128 ----
+  const int st_at = threadIdx.x >> 3, st_qd = threadIdx.x & 7;
+  const bool stager = threadIdx.x < GM_STAGE_THREADS;   // wave-uniform
+  auto blk_load = [&](int blk, int a0, int na, f4 (&r)[4]) __attribute__((always_inline)) {
+    const float* s0; const float* s1; const float* s2; const float* s3;
+    int st3 = F3;   // row stride of the fourth source (F for the scalar adjoints GX / GTX)
+    switch (blk) {
+      case 0: s0 = q.XH; s1 = q.XH + F; s2 = q.XH + 2 * F; s3 = q.TXH; break;
+      case 1: s0 = q.TXH + F; s1 = q.TXH + 2 * F; s2 = q.V; s3 = q.V + F; break;
+      case 2: s0 = q.V + 2 * F; s1 = q.TV; s2 = q.TV + F; s3 = q.TV + 2 * F; break;
+      case 3: s0 = q.GV; s1 = q.GV + F; s2 = q.GV + 2 * F; s3 = q.GX; st3 = F; break;
+      default: s0 = q.GTV; s1 = q.GTV + F; s2 = q.GTV + 2 * F; s3 = q.GTX; st3 = F; break;
     }
-    if (!(GM_ABLATE & 128)) __syncthreads();
-    // ---- this wavefront's pairs of the molecule: a contiguous run [p0, p1) of the schedule ----
-    // Every per-pair record is a sequential stream per wavefront, streamed once per launch, i.e. every access misses to HBM (measured: an empty pair
-    // loop with a 4-deep register ring took 400 ns per pair = latency / depth).  So: the geometry records of 32 pairs at a time travel through a 1-kB
-    // LDS ring private to the wavefront (one coalesced 16-byte load per lane, requested one chunk = 32 pairs ahead; consumed as two broadcast
-    // ds_read_b128: no scalar-memory waits mixed into lgkmcnt), the A operands through a register ring four pairs deep (R0-R3 below).
-    const int pb = __builtin_amdgcn_readfirstlane(q.g.lowptr[a0]);
-    const int* sp = q.sched_ptr + (long)m * (GM_NW + 1) + wave;
-    const int p0 = pb + __builtin_amdgcn_readfirstlane(sp[0]), p1 = pb + ((GM_ABLATE & 15) == 1 ? __builtin_amdgcn_readfirstlane(sp[0]) : __builtin_amdgcn_readfirstlane(sp[1]));
-    if (p0 < p1) {
-      struct Ops { f4 P0, P1, P2, A, T; };
-      struct Geo { f4 g0, g1; };   // {gx, gy, gz, t_d}, {t_r0, t_r1, t_r2, n << 13 | k}: the same value in every lane (broadcast LDS reads)
-      const int last = p1 - 1;
-      const f4* PG4 = reinterpret_cast<const f4*>(PG);
-      auto a_load = [&](int pr) __attribute__((always_inline)) -> float {
-        return (GM_ABLATE & 15) == 4 ? 1.f : PA[(long)min(pr, last) * 64 + lane];   // past the end the last pair is re-fetched: no branches in the pipeline
-      };
-      auto chunk_load = [&](int c0) __attribute__((always_inline)) -> f4 {   // lane L: float4 number L of the 32 records starting at pair c0
-        return PG4[min(2 * (long)c0 + lane, 2 * (long)last + 1)];
-      };
-      auto geo_read = [&](Geo& o, int i) __attribute__((always_inline)) {       // record i of the wavefront's ring
-        o.g0 = *reinterpret_cast<const f4*>(gring + (i & 31) * 8);
-        o.g1 = *reinterpret_cast<const f4*>(gring + (i & 31) * 8 + 4);
-      };
-      // One pair.  Roles rotate statically over 12 steps per trip (A ring of 4, three scalar geometry sets, two LDS operand sets: no register copies):
-      //   consumes  the A register `ra` (refilled 4 pairs ahead), the geometry scalars `gc` and the operand set `cur` (requested one step ago);
-      //   requests  the operands of pair i + 1 into `nxt` (atom indices from `gn`) and the geometry record of pair i + 2 (broadcast LDS reads -> v_readfirstlane
-      //             at the END of the step, when the data has arrived, into `gl`).
-      struct GeoS { float gx, gy, gz, td, t0, t1, t2; unsigned nk; };
-      auto to_scalar = [&](GeoS& o, const Geo& v) __attribute__((always_inline)) {
-        o.gx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g0[0]))); o.gy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g0[1])));
-        o.gz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g0[2]))); o.td = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g0[3])));
-        o.t0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g1[0]))); o.t1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g1[1])));
-        o.t2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.g1[2]))); o.nk = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(v.g1[3]));
-      };
-      auto ops_load = [&](Ops& o, unsigned nk) __attribute__((always_inline)) {
-        const unsigned no = (nk >> 13) * (GM_ATOM_FLOATS * 4), ko = (nk & 0x1fff) * (GM_ATOM_FLOATS * 4);
-        // operands: primal / tangent rows of the lane's SOURCE atom (n for lanes 0-31, k for 32-63), adjoint rows of its TARGET atom (k / n)
-        const unsigned x = (no ^ ko) & hmask;
-        const char* ps = reinterpret_cast<const char*>(rows) + ((no ^ x) + lbase);
-        const char* pt = reinterpret_cast<const char*>(rows) + ((ko ^ x) + lbase);
-        if (GM_ABLATE & 32) { const float z = __uint_as_float((no ^ x) + lbase) ; o.P0 = o.P1 = o.P2 = f4{z, z, 1.f, 2.f}; o.A = o.T = f4{1.f, z, __uint_as_float((ko ^ x) + lbase), 3.f}; return; }
-        o.P0 = *reinterpret_cast<const f4*>(ps);                          // xa xb xc txa
-        o.P1 = *reinterpret_cast<const f4*>(ps + GM_CH * 16);             // txb txc v0 v1
-        o.P2 = *reinterpret_cast<const f4*>(ps + 2 * GM_CH * 16);         // v2 tv0 tv1 tv2
-        o.A = *reinterpret_cast<const f4*>(pt + 3 * GM_CH * 16);          // A0 A1 A2 gma
-        o.T = *reinterpret_cast<const f4*>(pt + 4 * GM_CH * 16);          // T0 T1 T2 gtma
-      };
-      auto step = [&](float& ra, const GeoS& gc, const GeoS& gn, GeoS& gl, const Ops& cur, Ops& nxt, int pr, int i, bool live) __attribute__((always_inline)) {
-        const float a = live ? ra : 0.f;
-        ops_load(nxt, gn.nk);
-        Geo gv;
-        geo_read(gv, i + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        const float gx = gc.gx, gy = gc.gy, gz = gc.gz, td = gc.td, t0 = gc.t0, t1 = gc.t1, t2 = gc.t2;
-        const f4 P0 = cur.P0, P1 = cur.P1, P2 = cur.P2, A = cur.A, T = cur.T;
-        const float xa = P0[0], xb = P0[1], xc = P0[2], txa = P0[3], txb = P1[0], txc = P1[1], v0 = P1[2], v1 = P1[3], v2 = P2[0], tv0 = P2[1],
-                    tv1 = P2[2], tv2 = P2[3];
-        float ga, gb, gcc, ha, hb, hc;
-        if (GM_ABLATE & 64) { ga = xa + gx; gb = xb + txa; gcc = xc + A[0]; ha = txb + T[0]; hb = v2 + gy + td + t0; hc = tv2 + v1 + t1 + t2 + gz + sgn; }
-        else {
+    const long n = a0 + min(st_at, na - 1), o = n * F3 + cb + 4 * st_qd;   // threads past the last atom re-read it (no branch around loads that stay in flight)
+    r[0] = *reinterpret_cast<const f4*>(s0 + o); r[1] = *reinterpret_cast<const f4*>(s1 + o); r[2] = *reinterpret_cast<const f4*>(s2 + o);
+    r[3] = *reinterpret_cast<const f4*>(s3 + n * st3 + cb + 4 * st_qd);
+  };
+  auto blk_store = [&](int blk, int na, const f4 (&r)[4]) __attribute__((always_inline)) {
+    if (st_at < na) {
+      float* d = rows + st_at * GM_ATOM_FLOATS + blk * (GM_CH * 4) + (4 * st_qd) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f4*>(d + i * 4) = f4{r[0][i], r[1][i], r[2][i], r[3][i]};
+    }
+  };
+  auto ops_load = [&](GmOps& o, unsigned nk) __attribute__((always_inline)) {
+    const unsigned no = (nk >> 16) * GM_ATOM_BYTES, ko = (nk & 0xffffu) * GM_ATOM_BYTES;
+    // operands: primal / tangent rows of the lane's SOURCE atom (n for lanes 0-31, k for 32-63), adjoint rows of its TARGET atom (k / n)
+    const unsigned x = (no ^ ko) & hmask;
+    const char* ps = reinterpret_cast<const char*>(rows) + ((no ^ x) + lbase);
+    const char* pt = reinterpret_cast<const char*>(rows) + ((ko ^ x) + lbase);
+    if (GM_ABLATE & 8) { const float z = __uint_as_float((no ^ x) + lbase); o.P0 = o.P1 = o.P2 = f4{z, z, 1.f, 2.f}; o.A = o.T = f4{1.f, z, __uint_as_float((ko ^ x) + lbase), 3.f}; return; }
+    o.P0 = *reinterpret_cast<const f4*>(ps);                          // xa xb xc txa
+    o.P1 = *reinterpret_cast<const f4*>(ps + GM_CH * 16);             // txb txc v0 v1
+    o.P2 = *reinterpret_cast<const f4*>(ps + 2 * GM_CH * 16);         // v2 tv0 tv1 tv2
+    o.A = *reinterpret_cast<const f4*>(pt + 3 * GM_CH * 16);          // A0 A1 A2 gma
+    o.T = *reinterpret_cast<const f4*>(pt + 4 * GM_CH * 16);          // T0 T1 T2 gtma
+  };
+  auto rec_load = [&](GmRec& r, long batch) __attribute__((always_inline)) {
+    r.hi = PA[(batch * 2 + 0) * 64 + lane];
+    r.lo = PA[(batch * 2 + 1) * 64 + lane];
+  };
+  auto geo_load = [&](long batch) __attribute__((always_inline)) -> unsigned { return PG[batch * GM_PG_DWORDS + lane]; };
+  // scalar records of a batch: one dword per lane into the wavefront's ring (slot = parity of the batch inside its segment), read back as broadcast
+  // ds_read_b128 -- every lane gets the pair's scalars as VECTOR operands: no v_readlane / v_readfirstlane per scalar (round 5 and the first round-6 build spent
+  // 8 VALU instructions per pair on them), only the atom indices of the NEXT pair go through one v_readfirstlane for the address arithmetic
+  auto ring_put = [&](int slot, unsigned g) __attribute__((always_inline)) { *reinterpret_cast<unsigned*>(ring + slot * 256 + lane * 4) = g; };
+  auto ring_lo = [&](int slot, int i) __attribute__((always_inline)) -> f4 { return *reinterpret_cast<const f4*>(ring + slot * 256 + i * 32); };        // gx gy gz .
+  auto ring_hi = [&](int slot, int i) __attribute__((always_inline)) -> f4 { return *reinterpret_cast<const f4*>(ring + slot * 256 + i * 32 + 16); };   // t0 t1 t2 n<<16|k
+  // B operands of the matrix core: [part][pair / 2] packed bf16 pieces.  They persist across batches: a segment's last batch stops after its last live pair
+  // and leaves the previous batch's (finite) values in the remaining slots -- the A operands of padding slots are zero.
+  unsigned bh[3][4], bl[3][4];
+#pragma unroll
+  for (int p_ = 0; p_ < 3; ++p_)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bh[p_][j] = bl[p_][j] = 0u;
+  // One batch = 8 pair steps + 9 matrix-core instructions.  `L0` holds the operands of pair 0 and `gc` its {t0, t1, t2, .} on entry (requested by the previous
+  // batch / the prologue); step i requests the operands of pair i + 1 (the first pair of the next batch, ring slot `slot ^ 1`, in step 7) and consumes its own.
+  // Steps go in twos (one packed bf16 pair per part): a two-step group whose first pair is padding ends the batch (wave-uniform branch, once per group);
+  // an odd number of live pairs computes one padding step on atom 0's rows.
+  auto batch = [&](const GmRec& rc, int slot, int live, bool more, GmOps& L0, GmOps& L1, f4& gc) __attribute__((always_inline)) {
+    auto step = [&](int i, GmOps& cur, GmOps& nxt, float& ba, float& bb, float& bc) __attribute__((always_inline)) {
+      const f4 gn = ring_hi(i < GM_BATCH - 1 ? slot : slot ^ 1, (i + 1) & 7);
+      const f4 g0 = ring_lo(slot, i);
+      unsigned nkn = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(gn[3]));
+      if (i == GM_BATCH - 1 && !more) nkn = 0;   // past the segment: atom 0 with itself (rows that exist)
+      ops_load(nxt, nkn);
+      const float gx = g0[0], gy = g0[1], gz = g0[2], t0 = gc[0], t1 = gc[1], t2 = gc[2];
+      const f4 P0 = cur.P0, P1 = cur.P1, P2 = cur.P2, A = cur.A, T = cur.T;
+      const float xa = P0[0], xb = P0[1], xc = P0[2], txa = P0[3], txb = P1[0], txc = P1[1], v0 = P1[2], v1 = P1[3], v2 = P2[0], tv0 = P2[1],
+                  tv1 = P2[2], tv2 = P2[3];
+      float ga, gb, gcc, ha, hb, hc;
+      if (GM_ABLATE & 4) { ga = xa + gx; gb = xb + txa; gcc = xc + A[0]; ha = txb + T[0]; hb = v2 + gy + t0; hc = tv2 + v1 + t1 + t2 + gz + txc + v0 + tv0 + tv1; }
+      else {
+        // the unit vector of the lane's direction is -geom (n -> k) / +geom (k -> n): gmc, gtmc are computed with +geom here and the sign is applied by
+        // the DIFF form of the direction sum below; the factor t_d of gpsi sits in the drho half of the A operands (k_pair_arec)
         const float gmb = A[0] * v0 + A[1] * v1 + A[2] * v2 + (T[0] * tv0 + T[1] * tv1 + T[2] * tv2);
         const float gtmb = T[0] * v0 + T[1] * v1 + T[2] * v2;
-        const float gmc = sgn * ((A[0] * gx + A[1] * gy + A[2] * gz) + (T[0] * t0 + T[1] * t1 + T[2] * t2));
-        const float gtmc = sgn * (T[0] * gx + T[1] * gy + T[2] * gz);
+        const float gmc = (A[0] * gx + A[1] * gy + A[2] * gz) + (T[0] * t0 + T[1] * t1 + T[2] * t2);
+        const float gtmc = T[0] * gx + T[1] * gy + T[2] * gz;
         const float gma = A[3], gtma = T[3];
         ga = gma * xa + gtma * txa; gb = gmb * xb + gtmb * txb; gcc = gmc * xc + gtmc * txc;
-        ha = gtma * xa * td; hb = gtmb * xb * td; hc = gtmc * xc * td;
-        }
-        // both directions summed: lanes 0-31 <- gphi(n->k) + gphi(k->n), lanes 32-63 <- gpsi(n->k) + gpsi(k->n)
-        const float ba = gm_pair_sum(ga, ha), bb = gm_pair_sum(gb, hb), bc = gm_pair_sum(gcc, hc);
-        if ((GM_ABLATE & 15) == 3) { acc0[0] += a * ba; acc1[0] += a * bb; acc2[0] += a * bc; }
-        else if (live) {   // wave-uniform: the padding steps of the last trip of a segment skip the matrix core (they were 13 % of its instructions)
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ba, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc, acc2, 0, 0, 0);
-        }
-        ra = a_load(pr + 4);
-        to_scalar(gl, gv);
-        // Without a side-effecting instruction between the prefetches and the end of the loop body, instcombine rewrites "phi of loads" into "load of a phi of
-        // addresses", i.e. it sinks every prefetch to the top of the iteration that consumes it (first build: one exposed global latency per pair)
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      float R0 = a_load(p0), R1 = a_load(p0 + 1), R2 = a_load(p0 + 2), R3 = a_load(p0 + 3);
-      f4 gq = chunk_load(p0);
-      // chunks of 24 pairs (two trips of 12 steps) out of the 32 records the ring holds: the look-ahead of two records never leaves the ring
-      for (int c0 = p0; c0 < p1; c0 += 24) {
-        *reinterpret_cast<f4*>(gring + lane * 4) = gq;   // records of pairs [c0, c0 + 32): ordered behind this wavefront's reads of the previous chunk
-        gq = chunk_load(c0 + 24);
-        __builtin_amdgcn_sched_barrier(0);
-        const int cn = min(24, p1 - c0);
-        GeoS G0, G1, G2;
-        Ops L0, L1;
-        { Geo v0, v1; geo_read(v0, 0); geo_read(v1, 1); to_scalar(G0, v0); to_scalar(G1, v1); }
-        ops_load(L0, G0.nk);
-#pragma nounroll
-        for (int i = 0; i < cn; i += 12) {
-          const int pr = c0 + i;
-          step(R0, G0, G1, G2, L0, L1, pr, i, true);
-          step(R1, G1, G2, G0, L1, L0, pr + 1, i + 1, i + 1 < cn);
-          step(R2, G2, G0, G1, L0, L1, pr + 2, i + 2, i + 2 < cn);
-          step(R3, G0, G1, G2, L1, L0, pr + 3, i + 3, i + 3 < cn);
-          if (i + 4 >= cn) break;
-          step(R0, G1, G2, G0, L0, L1, pr + 4, i + 4, true);
-          step(R1, G2, G0, G1, L1, L0, pr + 5, i + 5, i + 5 < cn);
-          step(R2, G0, G1, G2, L0, L1, pr + 6, i + 6, i + 6 < cn);
-          step(R3, G1, G2, G0, L1, L0, pr + 7, i + 7, i + 7 < cn);
-          if (i + 8 >= cn) break;
-          step(R0, G2, G0, G1, L0, L1, pr + 8, i + 8, true);
-          step(R1, G0, G1, G2, L1, L0, pr + 9, i + 9, i + 9 < cn);
-          step(R2, G1, G2, G0, L0, L1, pr + 10, i + 10, i + 10 < cn);
-          step(R3, G2, G0, G1, L1, L0, pr + 11, i + 11, i + 11 < cn);
-        }
+        ha = gtma * xa; hb = gtmb * xb; hc = gtmc * xc;
+      }
+      // both directions combined: lanes 0-31 <- gphi(n->k) + gphi(k->n), lanes 32-63 <- gpsi(n->k) + gpsi(k->n) (part c: difference, see gm_pair_sum)
+      ba = gm_pair_sum<false>(ga, ha); bb = gm_pair_sum<false>(gb, hb); bc = gm_pair_sum<true>(gcc, hc);
+      gc = gn;
+    };
+    if (!(GM_ABLATE & 1)) {
+#pragma unroll
+      for (int j = 0; j < GM_BATCH / 2; ++j) {
+        if (!(GM_ABLATE & 256) && 2 * j >= live) break;   // wave-uniform; only in a segment's last batch (an even number of steps has run: L0 / L1 keep their roles)
+        float a0_, b0_, c0_, a1_, b1_, c1_;
+        step(2 * j, L0, L1, a0_, b0_, c0_);
+        step(2 * j + 1, L1, L0, a1_, b1_, c1_);
+        gm_split2(a0_, a1_, bh[0][j], bl[0][j]);
+        gm_split2(b0_, b1_, bh[1][j], bl[1][j]);
+        gm_split2(c0_, c1_, bh[2][j], bl[2][j]);
       }
     }
+    if (!(GM_ABLATE & 2)) {
+      const gm_bf8 ah = __builtin_bit_cast(gm_bf8, rc.hi), al = __builtin_bit_cast(gm_bf8, rc.lo);
+      const gm_bf8 h0 = __builtin_bit_cast(gm_bf8, (u4{bh[0][0], bh[0][1], bh[0][2], bh[0][3]})), l0 = __builtin_bit_cast(gm_bf8, (u4{bl[0][0], bl[0][1], bl[0][2], bl[0][3]}));
+      const gm_bf8 h1 = __builtin_bit_cast(gm_bf8, (u4{bh[1][0], bh[1][1], bh[1][2], bh[1][3]})), l1 = __builtin_bit_cast(gm_bf8, (u4{bl[1][0], bl[1][1], bl[1][2], bl[1][3]}));
+      const gm_bf8 h2 = __builtin_bit_cast(gm_bf8, (u4{bh[2][0], bh[2][1], bh[2][2], bh[2][3]})), l2 = __builtin_bit_cast(gm_bf8, (u4{bl[2][0], bl[2][1], bl[2][2], bl[2][3]}));
+      // small terms first; the three parts interleave so that no instruction waits for the accumulator of the one before it
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, h2, acc2, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, l2, acc2, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, h2, acc2, 0, 0, 0);
+    } else { acc0[0] += __uint_as_float(bh[0][0] ^ bl[1][1] ^ bh[2][2] ^ bl[0][3] ^ bh[1][0] ^ bl[2][1] ^ bh[0][1] ^ bl[0][0] ^ bh[1][2] ^ bl[1][3] ^ bh[2][0] ^ bl[2][3] ^ rc.hi[0] ^ rc.lo[1]); }
+  };
+
+  // ---- molecules of this workgroup: m, m + groups, ... (molecules larger than the LDS are skipped: their pairs are not in the schedule) ----
+  auto next_mol = [&](int m) __attribute__((always_inline)) -> int {
+    for (m += q.groups; m < q.g.B; m += q.groups)
+      if (q.g.mol_ptr[m + 1] - q.g.mol_ptr[m] <= q.max_atoms) return m;
+    return q.g.B;
+  };
+  int m = next_mol(group - q.groups);
+  if (m < q.g.B && stager) {
+    const int a0 = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[m]), na = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[m + 1]) - a0;
+#pragma unroll
+    for (int blk = 0; blk < 5; ++blk) { f4 r[4]; blk_load(blk, a0, na, r); blk_store(blk, na, r); }
+  }
+  // per segment: A operands of batch j in RX (even j) / RY (odd j), scalar records of batch j in ring slot j & 1; requested one batch ahead
+  // (scalars: two), the first ones before the barrier that ends the previous molecule
+  GmRec RX, RY;
+  unsigned gq0 = 0, gq1 = 0;
+  int2 sg = make_int2(0, 0);
+  if (m < q.g.B) {
+    sg = q.seg[(long)m * GM_NW + wave];
+    sg.x = __builtin_amdgcn_readfirstlane(sg.x); sg.y = __builtin_amdgcn_readfirstlane(sg.y);
+    rec_load(RX, sg.x); gq0 = geo_load(sg.x); gq1 = geo_load(sg.x + 1);
+  }
+  while (m < q.g.B) {
+    const int mn = next_mol(m);
+    int a0n = 0, nan = 1;
+    int2 sgn_ = make_int2(0, 0);
+    if (mn < q.g.B) {
+      a0n = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[mn]); nan = __builtin_amdgcn_readfirstlane(q.g.mol_ptr[mn + 1]) - a0n;
+      sgn_ = q.seg[(long)mn * GM_NW + wave];
+      sgn_.x = __builtin_amdgcn_readfirstlane(sgn_.x); sgn_.y = __builtin_amdgcn_readfirstlane(sgn_.y);
+    }
+    if (!(GM_ABLATE & 128)) __syncthreads();                           // the rows of molecule m are in LDS
+    // ---- this wavefront's pairs of the molecule: batches [b0, b0 + nb) of the padded schedule ----
+    const int nb = (sg.y + GM_BATCH - 1) / GM_BATCH;
+    if (nb > 0) {
+      const long b0 = sg.x, last = b0 + nb - 1;
+      GmOps L0, L1;
+      ring_put(0, gq0);
+      f4 gc = ring_hi(0, 0);
+      ops_load(L0, (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(gc[3])));
+      int left = sg.y;
+#pragma nounroll
+      for (long b = b0; b <= last; b += 2) {
+        ring_put(1, gq1);                    // scalars of batch b + 1 (requested two batches ago)
+        rec_load(RY, min(b + 1, last));
+        gq0 = geo_load(min(b + 2, last));
+        __builtin_amdgcn_sched_barrier(0);   // keeps the prefetch above the pair steps (instcombine otherwise sinks a load through its loop-carried phi)
+        batch(RX, 0, min(left, GM_BATCH), b < last, L0, L1, gc);
+        if (b + 1 > last) break;
+        ring_put(0, gq0);
+        rec_load(RX, min(b + 2, last));
+        gq1 = geo_load(min(b + 3, last));
+        __builtin_amdgcn_sched_barrier(0);
+        batch(RY, 1, min(left - GM_BATCH, GM_BATCH), b + 1 < last, L0, L1, gc);
+        left -= 2 * GM_BATCH;
+      }
+    }
+    // GM_STAGE_EARLY: the rows of the next molecule are requested into registers BEFORE the barrier that ends this molecule (the pair loop's registers are
+    // free again) and written to LDS behind it, so that their latency overlaps the wait for the slowest wavefront; otherwise they are requested behind the barrier.
+    // (Requesting them before / during the pair loop was measured and lost: the in-order load counter holds the younger record loads behind 100 kB of rows.)
+    f4 stg[5][4];
+    if (GM_STAGE_EARLY && mn < q.g.B && stager) {
+#pragma unroll
+      for (int blk = 0; blk < 5; ++blk) blk_load(blk, a0n, nan, stg[blk]);
+    }
+    // the first batches of the next molecule's segment: they arrive while the rows are being written
+    if (mn < q.g.B) { rec_load(RX, sgn_.x); gq0 = geo_load(sgn_.x); gq1 = geo_load(sgn_.x + 1); }
+    if (!(GM_ABLATE & 128)) __syncthreads();                           // every wavefront is done with the rows of molecule m
+    if (mn < q.g.B && stager) {
+#pragma unroll
+      for (int blk = 0; blk < 5; ++blk) {
+        if (!GM_STAGE_EARLY) blk_load(blk, a0n, nan, stg[blk]);
+        blk_store(blk, nan, stg[blk]);
+      }
+    }
+    m = mn; sg = sgn_;
   }
   // ---- one flush per launch.  C/D layout of the 32x32 tile: lane -> column (channel) lane & 31, register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
   float* out = q.part + ((long)(group * q.nslices + slice) * GM_NW + wave) * GM_PART_FLOATS;
@@ -375,8 +510,9 @@ __global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const floa
 }
 
 // gWr[col][k] = sum over wavefronts whose rows cover k, over the workgroups in order; gbr[col] = sum of the bias rows.  Fixed order: reproducible.
+// ACC: add to what is there (the pair-row kernels ran first for the molecules that do not fit the LDS).
 __global__ void k_gwr_mol_reduce(const float* __restrict__ part, const int* __restrict__ wlo, int groups, int nslices, int R, int F,
-                                 float* __restrict__ gWr, float* __restrict__ gbr) {
+                                 float* __restrict__ gWr, float* __restrict__ gbr, int acc) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int F3 = 3 * F;
   if (idx >= (R + 1) * F3) return;
@@ -393,15 +529,17 @@ __global__ void k_gwr_mol_reduce(const float* __restrict__ part, const int* __re
 #pragma unroll 8
     for (int g = 0; g < groups; ++g) s += part[((long)(g * nslices + slice) * GM_NW + w) * GM_PART_FLOATS + o];   // unrolled: eight loads in flight, same order
   }
-  if (k < R) gWr[(long)col * R + k] = s;
-  else gbr[col] = s;
+  if (k < R) gWr[(long)col * R + k] = acc ? gWr[(long)col * R + k] + s : s;
+  else gbr[col] = acc ? gbr[col] + s : s;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
+int nq_molgw_max_atoms(void) { return GM_MAX_ATOMS; }
+bool nq_molgw_config_ok(int F, int R) {
+  return F % GM_CH == 0 && R >= FWIN && R - FWIN + 1 <= GM_NW * GM_WMAX && R - FWIN + 1 <= GM_MAX_BINS;
+}
 bool nq_molgw_supported(int F, int R, int max_mol_atoms) {
-  if (F % GM_CH != 0 || R < FWIN || R - FWIN + 1 > GM_NW * GM_WMAX || R - FWIN + 1 > GM_MAX_BINS) return false;
-  if (max_mol_atoms <= 0 || max_mol_atoms >= 8192) return false;
-  return (size_t)max_mol_atoms * GM_ATOM_FLOATS * sizeof(float) + GM_NW * 1024 <= 160 * 1024;
+  return nq_molgw_config_ok(F, R) && max_mol_atoms > 0 && max_mol_atoms <= GM_MAX_ATOMS;
 }
 static int molgw_groups(int B, int nslices) {
   int groups = 256 / nslices;            // one workgroup per CU
@@ -409,22 +547,27 @@ static int molgw_groups(int B, int nslices) {
   if (groups > B) groups = B;
   return groups;
 }
-size_t nq_molgw_sched_ints(int E, int B) { return (size_t)E + (size_t)B * (GM_NW + 1) + GM_MAX_BINS + GM_NW + 1 + 16; }   // sched (int2 per pair) + sched_ptr + hist + wlo
-size_t nq_molgw_rec_floats(int E) { return (size_t)(E / 2) * 64 + (size_t)(E / 2) * 8 + 16; }   // PA: 64 floats per pair (once per step), PG: 8 floats per pair (once per backward sweep)
+// int32 workspace: sched (int2 per padded pair slot) + seg (int2 per molecule and wavefront) + sched_ptr + hist + wlo
+size_t nq_molgw_sched_ints(int E, int B) {
+  return 2 * GM_BATCH * gm_max_batches(E, B) + 2 * (size_t)B * GM_NW + (size_t)B * (GM_NW + 1) + GM_MAX_BINS + GM_NW + 1 + 16;
+}
+size_t nq_molgw_sched_slots(int E, int B) { return GM_BATCH * gm_max_batches(E, B); }
+size_t nq_molgw_rec_floats(int E, int B) { return gm_max_batches(E, B) * (GM_PA_DWORDS + GM_PG_DWORDS) + 16; }   // PA once per step, PG once per backward sweep
 size_t nq_molgw_part_floats(int F, int B) { const int ns = F / GM_CH; return (size_t)molgw_groups(B, ns) * ns * GM_NW * GM_PART_FLOATS; }
 
-struct MolGwBufs { int2* sched; int* sched_ptr; int* hist; int* wlo; };
+struct MolGwBufs { int2* sched; int2* seg; int* sched_ptr; int* hist; int* wlo; };
 static MolGwBufs molgw_bufs(int* base, int E, int B) {
   MolGwBufs b;
-  b.sched = reinterpret_cast<int2*>(base);                       // E / 2 pairs, 8 bytes each
-  b.sched_ptr = base + (((size_t)E + 1) & ~(size_t)1);
+  b.sched = reinterpret_cast<int2*>(base);
+  b.seg = b.sched + GM_BATCH * gm_max_batches(E, B);
+  b.sched_ptr = reinterpret_cast<int*>(b.seg + (size_t)B * GM_NW);
   b.hist = b.sched_ptr + (size_t)B * (GM_NW + 1);
   b.wlo = b.hist + GM_MAX_BINS;
   return b;
 }
 
 // once per step, after the window records: histogram of the window starts over the pairs -> row windows of the wavefronts -> per-molecule pair lists -> expanded A operands
-int nq_molgw_schedule(hipStream_t st, const NqGraphView& g, const int* dst, const float* RW, int R, int* sched_ints, float* recs) {
+int nq_molgw_schedule(hipStream_t st, const NqGraphView& g, const int* dst, const float* RW, int R, int cap, int* sched_ints, float* recs) {
   NQ_PROF(st, "pair_schedule");
   const MolGwBufs b = molgw_bufs(sched_ints, g.E, g.B);
   NQ_HIP(hipMemsetAsync(b.hist, 0, GM_MAX_BINS * sizeof(int), st));
@@ -434,43 +577,43 @@ int nq_molgw_schedule(hipStream_t st, const NqGraphView& g, const int* dst, cons
   NQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_pair_windows, dim3(1), dim3(64), 0, st, b.hist, R - FWIN + 1, b.wlo);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_pair_sched, dim3(g.B), dim3(64), 0, st, g, dst, RW, b.wlo, b.sched, b.sched_ptr);
+  hipLaunchKernelGGL(k_pair_sched, dim3(g.B), dim3(64), 0, st, g, dst, RW, b.wlo, cap < GM_MAX_ATOMS ? cap : GM_MAX_ATOMS, b.sched, b.sched_ptr, b.seg);
   NQ_LAUNCH_CHECK();
-  const int npairs = g.E / 2;
-  hipLaunchKernelGGL(k_pair_arec, dim3(nq_cdiv((long)npairs * 64, 256)), dim3(256), 0, st, b.sched, RW, npairs, recs);
+  const int nseg = g.B * GM_NW;
+  hipLaunchKernelGGL(k_pair_arec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, RW, (const float*)nullptr, nseg, reinterpret_cast<u4*>(recs));   // rho half
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 // once per backward sweep, after nq_geom_tan: geometry + tangent + atom indices of every pair in schedule order
-int nq_molgw_geometry(hipStream_t st, const NqGraphView& g, const float* TD, const float* TR, const int* sched_ints, float* recs) {
+int nq_molgw_geometry(hipStream_t st, const NqGraphView& g, const float* RW, const float* TD, const float* TR, const int* sched_ints, float* recs) {
   NQ_PROF(st, "pair_geometry");
   const MolGwBufs b = molgw_bufs(const_cast<int*>(sched_ints), g.E, g.B);
-  const int npairs = g.E / 2;
-  float* PG = recs + (size_t)npairs * 64;
-  hipLaunchKernelGGL(k_pair_grec, dim3(nq_cdiv(npairs, 256)), dim3(256), 0, st, b.sched, g.geom, TD, TR, npairs, reinterpret_cast<float4*>(PG));
+  float* PG = recs + gm_max_batches(g.E, g.B) * GM_PA_DWORDS;
+  const int nseg = g.B * GM_NW;
+  hipLaunchKernelGGL(k_pair_grec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, g.geom, TR, nseg, PG);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_pair_arec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, RW, TD, nseg, reinterpret_cast<u4*>(recs));   // t_d drho half
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
 int nq_gwr_mol(hipStream_t st, const NqGraphView& g, int F, int R, int max_mol_atoms, const float* XH, const float* V, const float* TXH, const float* TV,
                const float* GX, const float* GV, const float* GTX, const float* GTV, const int* sched_ints, const float* recs, float* part, float* gWr,
-               float* gbr) {
+               float* gbr, bool accumulate) {
   NQ_PROF(st, "gwr_mol");
   const MolGwBufs b = molgw_bufs(const_cast<int*>(sched_ints), g.E, g.B);
   GwrMolArgs q;
-  q.g = g; q.F = F; q.nslices = F / GM_CH; q.groups = molgw_groups(g.B, q.nslices); q.max_atoms = max_mol_atoms;
+  q.g = g; q.F = F; q.nslices = F / GM_CH; q.groups = molgw_groups(g.B, q.nslices);
+  q.max_atoms = max_mol_atoms < GM_MAX_ATOMS ? max_mol_atoms : GM_MAX_ATOMS;   // molecules above it are not in the schedule (pair-row kernels)
   q.XH = XH; q.V = V; q.TXH = TXH; q.TV = TV; q.GX = GX; q.GV = GV; q.GTX = GTX; q.GTV = GTV;
-  q.sched_ptr = b.sched_ptr; q.part = part;
-  const float* PA = recs; const float* PG = recs + (size_t)(g.E / 2) * 64;
-  const size_t lds = (size_t)max_mol_atoms * GM_ATOM_FLOATS * sizeof(float) + GM_NW * 1024;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    NQ_HIP(hipFuncSetAttribute((const void*)k_gwr_mol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
+  q.seg = b.seg; q.part = part;
+  const u4* PA = reinterpret_cast<const u4*>(recs);
+  const unsigned* PG = reinterpret_cast<const unsigned*>(recs + gm_max_batches(g.E, g.B) * GM_PA_DWORDS);
+  const size_t lds = (size_t)q.max_atoms * GM_ATOM_BYTES + GM_NW * GM_RING_BYTES;
+  NQ_DYN_LDS(k_gwr_mol, lds);
   hipLaunchKernelGGL(k_gwr_mol, dim3(q.groups * q.nslices), dim3(GM_THREADS), lds, st, q, PA, PG);
   NQ_LAUNCH_CHECK();
-  if ((GM_ABLATE & 15) != 5) hipLaunchKernelGGL(k_gwr_mol_reduce, dim3(nq_cdiv((long)(R + 1) * 3 * F, 256)), dim3(256), 0, st, part, b.wlo, q.groups, q.nslices, R, F, gWr, gbr);
+  hipLaunchKernelGGL(k_gwr_mol_reduce, dim3(nq_cdiv((long)(R + 1) * 3 * F, 256)), dim3(256), 0, st, part, b.wlo, q.groups, q.nslices, R, F, gWr, gbr, accumulate ? 1 : 0);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

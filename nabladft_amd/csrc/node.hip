@@ -412,7 +412,7 @@ int nq_embed_grad(hipStream_t st, const int* z, const float* GX, int N, int F, i
   const int chunk = emb_chunk(N), chunks = nq_cdiv(N, chunk);
   const size_t lds = (size_t)T * F * sizeof(float);
   if (lds > 160 * 1024) return nq_fail(NQ_ERR_ARG, "embed_grad: num_elements*F too large for LDS (%zu B)", lds);
-  { static size_t set__ = 0; if (lds > set__) { NQ_HIP(hipFuncSetAttribute((const void*)k_embed_grad_partial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set__ = lds; } }
+  NQ_DYN_LDS(k_embed_grad_partial, lds);
   hipLaunchKernelGGL(k_embed_grad_partial, dim3(chunks), dim3(F), lds, st, z, GX, N, F, T, chunk, scratch);
   NQ_LAUNCH_CHECK();
   return nq_reduce_partials(st, scratch, chunks, (long)T * F, (long)T * F, out);

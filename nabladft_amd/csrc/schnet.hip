@@ -379,11 +379,7 @@ static int sn_f1_grid(int E, size_t lds) {
 }
 #define SN_F1_LAUNCH(KERN, ...)                                                                                     \
   do {                                                                                                             \
-    static size_t lds_set__ = 0;                                                                                   \
-    if (lds > lds_set__) {                                                                                         \
-      NQ_HIP(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-      lds_set__ = lds;                                                                                             \
-    }                                                                                                              \
+    NQ_DYN_LDS(KERN, lds);                                                                                         \
     hipLaunchKernelGGL(KERN, dim3(grid), dim3(SN_F1_THREADS), lds, st, __VA_ARGS__);                                         \
   } while (0)
 

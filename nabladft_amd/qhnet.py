@@ -488,8 +488,12 @@ class FullyConnectedNet(nn.Module):
         h = _ActFn.apply(h, self.kind, self.cst)
         c1 = 1.0 / math.sqrt(self.hs[1])
         if col_scale is not None:
+            # the path constants are a buffer of the caller: their product with 1 / sqrt(h1) is taken once.  The cached tensor must be an ordinary one: a product
+            # taken under torch.inference_mode() (Lightning's sanity validation runs first) is an inference tensor that a later TRAINING forward cannot save
+            # for backward, so the cache is rebuilt when it is one and grad mode is on
             key = (col_scale.data_ptr(), col_scale._version, str(col_scale.device))
-            if self._cs_key != key:                         # the path constants are a buffer of the caller: their product with 1 / sqrt(h1) is taken once
+            stale = self._cs is not None and self._cs.is_inference() and not torch.is_inference_mode_enabled()
+            if self._cs_key != key or stale:
                 self._cs, self._cs_key = (col_scale.detach() * c1), key
             W1 = self.layer1.weight * self._cs
         else:

@@ -353,18 +353,25 @@ class FlatParameters:
         if not self._detached:
             return
         pairs = zip(self.params, self._views) if params is None else ((p, self._views[self._index[id(p)]]) for p in params)
-        src, dst = [], []
+        src, dst, odd = [], [], []
         for p, view in pairs:
             g = p.grad
             if g is view:
                 continue
             if g is not None:
-                src.append(g)
-                dst.append(view)
+                # the multi-tensor copy takes dense fp32 tensors of the slice's device; anything else autograd may hand over (a sparse gradient of
+                # nn.Embedding(sparse=True), another dtype under autocast) is added into the zeroed slice the way rounds 2-4 accumulated in place
+                if g.layout is torch.strided and g.dtype is view.dtype and g.device == view.device:
+                    src.append(g)
+                    dst.append(view)
+                else:
+                    odd.append((view, g))
             p.grad = view
-        if src:
-            with torch.no_grad():
+        with torch.no_grad():
+            if src:
                 torch._foreach_copy_(dst, src)
+            for view, g in odd:
+                view.add_((g.to_dense() if g.layout is not torch.strided else g).to(device=view.device, dtype=view.dtype))
         if params is None:
             self._detached = False
 

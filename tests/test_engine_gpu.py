@@ -299,7 +299,7 @@ def _trace_report(name, model, sw, s2c, tag, lines):
             worst = max(worst, e)
             lines.append(f"{name} {tag} {key:14s} rel_err {e:.3e}")
     elif os.environ.get("NQ_NO_MOLGW") != "1" and tag == "fwd":
-        _check_pair_schedule(model)
+        _check_pair_schedule(model, int(os.environ.get("NQ_MOLGW_CAP", "0")) or None)
     elif os.environ.get("NQ_NO_MOLGW") == "1":
         # k0-sorted order of the LOWER CSR slots (col < dst: one gphi / gpsi row per pair): every lower slot once, keys non-decreasing, stable
         nl = model._last_nl
@@ -335,55 +335,96 @@ def _trace_report(name, model, sw, s2c, tag, lines):
     return worst
 
 
-def _check_pair_schedule(model):
-    """Pair lists of the molecule-per-workgroup rbf_proj gradient (csrc/molpair.hip): every lower CSR slot (col < dst) exactly once, inside its molecule's
-    segment; entries sorted by window start k0, slot-ascending among equal k0; the wavefront segments tile the molecule's list, every pair sits inside
-    the accumulator rows of its wavefront (0 <= k0 - wlo[w] < 19 = the stored row offset) and no segment is longer than ceil(pairs / wavefronts) unless the next
-    wavefront's rows cannot hold the surplus; the local atom indices are the slot's (dst, col) relative to the molecule's first atom."""
+def _lds_cap():
+    """nq_painn_molecule_lds_atoms(): the largest molecule the per-molecule rbf_proj gradient kernel stages in LDS."""
+    from nabladft_amd import _lib
+    return int(_lib.load().nq_painn_molecule_lds_atoms())
+
+
+def _check_pair_schedule(model, cap=None):
+    """Pair lists of the molecule-per-workgroup rbf_proj gradient (csrc/molpair.hip): every lower CSR slot (col < dst) of a molecule of <= cap atoms exactly
+    once, inside its molecule's batches; entries sorted by window start k0, slot-ascending among equal k0; the wavefront segments tile the molecule's list,
+    every segment starts on a batch boundary (8 pair slots) of the padded list and its last batch is padded with -1; every pair sits inside the accumulator
+    rows of its wavefront (0 <= k0 - wlo[w] < 19 = the stored row offset) and no segment is longer than ceil(pairs / wavefronts) unless the next wavefront's
+    rows cannot hold the surplus; the local atom indices are the slot's (dst, col) relative to the molecule's first atom.  Larger molecules: empty segments."""
+    cap = _lds_cap() if cap is None else cap
     nl = model._last_nl
     col, dst = nl.t["col"].cpu().long(), nl.t["dst"].cpu().long()
     lowptr, mol_ptr = nl.t["lowptr"].cpu().long(), nl.t["mol_ptr"].cpu().long()
+    WMAX, BATCH = 19, 8
+    sched = model.workspace_view("pair_sched").cpu().view(torch.int32).view(-1, 2).long()
+    meta = model.workspace_view("pair_sched_meta").cpu().view(torch.int32).long()
+    NW = (meta.numel() - 145 - nl.B) // (3 * nl.B + 1)     # wavefronts per workgroup of k_gwr_mol (csrc/molpair.hip: GM_NW)
+    assert NW in (8, 12)
+    assert sched.shape[0] == BATCH * ((nl.E // 2) // BATCH + NW * nl.B + NW)
+    assert meta.numel() == 2 * nl.B * NW + nl.B * (NW + 1) + 128 + NW + 1 + 16
+    seg = meta[:2 * nl.B * NW].view(nl.B, NW, 2)
+    sp = meta[2 * nl.B * NW:][:nl.B * (NW + 1)].view(nl.B, NW + 1)
+    rest = meta[2 * nl.B * NW + nl.B * (NW + 1):]
+    hist, wlo = rest[:128], rest[128:][:NW + 1]
+    k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
     lower = torch.nonzero(col < dst).view(-1)
     assert lower.numel() * 2 == nl.E
-    sched = model.workspace_view("pair_sched").cpu().view(torch.int32)[:nl.E].view(-1, 2).long()
-    meta = model.workspace_view("pair_sched_meta").cpu().view(torch.int32).long()
-    NW, WMAX = (meta.numel() - 144) // (nl.B + 1) - 1, 19   # wavefronts per workgroup of k_gwr_mol (meta = sched_ptr [B][NW+1], hist [128], wlo [NW+1], 16 spare)
-    assert NW in (8, 12, 16)
-    sp = meta[:nl.B * (NW + 1)].view(nl.B, NW + 1)
-    hist, wlo = meta[nl.B * (NW + 1):][:128], meta[nl.B * (NW + 1) + 128:][:NW + 1]
-    k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
     assert torch.equal(torch.bincount(k0s[lower], minlength=128)[:128], hist)
     assert bool((wlo[1:NW] >= wlo[:NW - 1]).all()) and bool((wlo[1:NW] <= wlo[:NW - 1] + WMAX).all())
     assert int(wlo[0]) <= int(k0s[lower].min()) and int(wlo[NW - 1]) + WMAX > int(k0s[lower].max())
-    slot, word = sched[:, 0], sched[:, 1] & 0xFFFFFFFF
-    assert torch.equal(torch.sort(slot).values, lower)
-    off, nloc, kloc = word >> 26, (word >> 13) & 0x1FFF, word & 0x1FFF
+    seen = []
     for m in range(nl.B):
-        pb, pe = int(lowptr[mol_ptr[m]]), int(lowptr[mol_ptr[m + 1]])
+        a0, a1 = int(mol_ptr[m]), int(mol_ptr[m + 1])
+        pb, pe = int(lowptr[a0]), int(lowptr[a1])
+        b0 = (pb >> 3) + NW * m
+        if a1 - a0 > cap:
+            assert bool((seg[m, :, 1] == 0).all()) and bool((sp[m] == 0).all())
+            continue
         assert int(sp[m, 0]) == 0 and int(sp[m, NW]) == pe - pb and bool((sp[m, 1:] >= sp[m, :-1]).all())
-        sl, k = slot[pb:pe], k0s[slot[pb:pe]]
-        assert bool((dst[sl] >= mol_ptr[m]).all()) and bool((dst[sl] < mol_ptr[m + 1]).all())
-        assert bool((k[1:] >= k[:-1]).all()) and bool((sl[1:][k[1:] == k[:-1]] > sl[:-1][k[1:] == k[:-1]]).all())
-        assert torch.equal(nloc[pb:pe], dst[sl] - mol_ptr[m]) and torch.equal(kloc[pb:pe], col[sl] - mol_ptr[m])
         target = -(-(pe - pb) // NW)
+        nb_run, sl_all, word_all = 0, [], []
         for w in range(NW):
-            seg = slice(pb + int(sp[m, w]), pb + int(sp[m, w + 1]))
-            assert torch.equal(off[seg], k0s[slot[seg]] - wlo[w]) and bool((off[seg] >= 0).all()) and bool((off[seg] < WMAX).all())
-            n_seg = int(sp[m, w + 1] - sp[m, w])
-            if n_seg > target and w < NW - 1:   # surplus only when forced: those pairs lie below the next wavefront's first row
-                assert bool((k0s[slot[seg]][target:] < wlo[w + 1]).all())
+            fb, ln = int(seg[m, w, 0]), int(seg[m, w, 1])
+            assert fb == b0 + nb_run and ln == int(sp[m, w + 1] - sp[m, w])
+            nb = -(-ln // BATCH)
+            ent = sched[BATCH * fb:BATCH * (fb + nb)]
+            assert bool((ent[ln:, 0] == -1).all()), "the last batch of a segment is padded with -1"
+            slot, word = ent[:ln, 0], ent[:ln, 1] & 0xFFFFFFFF
+            off = word >> 26
+            assert torch.equal(off, k0s[slot] - wlo[w]) and bool((off >= 0).all()) and bool((off < WMAX).all())
+            if ln > target and w < NW - 1:   # surplus only when forced: those pairs lie below the next wavefront's first row
+                assert bool((k0s[slot][target:] < wlo[w + 1]).all())
+            sl_all.append(slot); word_all.append(word)
+            nb_run += nb
+        if m + 1 < nl.B:
+            assert b0 + nb_run <= (int(lowptr[mol_ptr[m + 1]]) >> 3) + NW * (m + 1), "a molecule's batches must end before the next molecule's first batch"
+        sl, word = torch.cat(sl_all), torch.cat(word_all)
+        k = k0s[sl]
+        assert bool((dst[sl] >= a0).all()) and bool((dst[sl] < a1).all())
+        assert bool((k[1:] >= k[:-1]).all()) and bool((sl[1:][k[1:] == k[:-1]] > sl[:-1][k[1:] == k[:-1]]).all())
+        assert torch.equal((word >> 13) & 0x1FFF, dst[sl] - a0) and torch.equal(word & 0x1FFF, col[sl] - a0)
+        seen.append(sl)
+    seen = torch.sort(torch.cat(seen)).values if seen else torch.zeros(0, dtype=torch.long)
+    natoms = (mol_ptr[1:] - mol_ptr[:-1])
+    small_atom = (natoms <= cap)[nl.t["atom_mol"].cpu().long()]
+    assert torch.equal(seen, lower[small_atom[dst[lower]]])
 
 
-@pytest.mark.parametrize("fused", ["fused", "fused_pair_rows", "materialised"])
+@pytest.mark.parametrize("fused", ["fused", "fused_mixed", "fused_pair_rows", "materialised"])
 @pytest.mark.parametrize("name", ["painn_small_ragged.npz", "painn_full_real4.npz", "painn_small_expenv.npz"])
 def test_engine_matches_reference_golden(name, fused, monkeypatch):
     """fused: radial filter evaluated inside the message kernels (WrT in LDS, 13-Gaussian window), rbf_proj gradient from node rows staged per molecule in
-    LDS (csrc/molpair.hip); fused_pair_rows: the same with the gphi / gpsi pair rows through HBM (path of molecules that do not fit the LDS);
-    materialised: fallback path (phi/psi through the GEMM) used when WrT does not fit the LDS."""
+    LDS (csrc/molpair.hip); fused_mixed: the same batch with the LDS limit lowered to the batch's median molecule size, so that about half of the molecules take
+    the per-molecule kernel and the others the pair rows INSIDE one step (the dispatch of molecules above the LDS limit); fused_pair_rows: gphi / gpsi pair rows
+    through HBM for every molecule; materialised: fallback path (phi/psi through the GEMM) used when WrT does not fit the LDS."""
     if fused == "materialised":
         monkeypatch.setenv("NQ_NO_FUSED_FILTER", "1")
     else:
         monkeypatch.delenv("NQ_NO_FUSED_FILTER", raising=False)
+    monkeypatch.delenv("NQ_MOLGW_CAP", raising=False)
+    if fused == "fused_mixed":
+        fx0 = load_case(name)[0]
+        counts = np.bincount(fx0["batch"])
+        cap = int(np.sort(counts)[(len(counts) - 1) // 2])
+        if cap >= counts.max():
+            pytest.skip("all molecules of this fixture have one size")
+        monkeypatch.setenv("NQ_MOLGW_CAP", str(cap))
     if fused == "fused_pair_rows":
         monkeypatch.setenv("NQ_NO_MOLGW", "1")
         monkeypatch.delenv("NQ_MOLGW", raising=False)
@@ -684,11 +725,65 @@ def test_every_row_is_processed_at_any_grid_size(n_conf):
         assert rel_err(p.grad.cpu().numpy(), g_ref[k].numpy()) < 5e-5, k
 
 
+def test_one_large_molecule_in_a_300_conformer_batch_takes_the_pair_rows_alone(monkeypatch):
+    """one molecule above the LDS limit of k_gwr_mol (62 atoms) used to send the WHOLE step back to the pair-row path.  300 conformers
+    (> 4096 atoms: the default per-molecule path) with ONE 70-atom molecule in the middle: against the CPU oracle, against the pair rows forced for every
+    molecule, and the schedule shows the 299 others on the per-molecule kernel (non-empty segments) and the large one with none."""
+    import nabladft_amd as nq
+    dev = torch.device("cuda:0")
+    monkeypatch.delenv("NQ_MOLGW", raising=False); monkeypatch.delenv("NQ_NO_MOLGW", raising=False); monkeypatch.delenv("NQ_MOLGW_CAP", raising=False)
+    cfg = R.PaiNNConfig(num_layers=2)
+    params = R.make_params(cfg, seed=8)
+    m = _model(cfg, params, dev)
+    pos, z, batch, y, ft = R.gen_conformers(77, 300, size=(8, 30))
+    rng = np.random.Generator(np.random.PCG64(70))
+    big = 150
+    keep_lo, keep_hi = batch < big, batch >= big
+    pos_b = torch.tensor(rng.uniform(0, 8.0, size=(70, 3)).astype(np.float32))
+    z_b = torch.tensor(rng.choice([1, 6, 7, 8], size=70).astype(np.int64))
+    pos = torch.cat([pos[keep_lo], pos_b, pos[keep_hi]]); z = torch.cat([z[keep_lo], z_b, z[keep_hi]])
+    batch = torch.cat([batch[keep_lo], torch.full((70,), big), batch[keep_hi] + 1])
+    ft = torch.cat([ft[keep_lo], torch.tensor(rng.normal(0, 0.05, size=(70, 3)).astype(np.float32)), ft[keep_hi]])
+    y = torch.cat([y[:big], torch.tensor([0.3]), y[big:]])
+    assert int(batch.max()) == 300 and pos.shape[0] > 4096
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        e, f = m(nq.Batch(pos, z, batch).to(dev))
+        loss = (e - y.to(dev)).abs().mean() + (f - ft.to(dev)).pow(2).sum(-1).sqrt().mean()
+        loss.backward()
+        return e.detach(), f.detach(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}
+    names = _kernel_names_of(lambda: run())
+    assert {"gwr_mol", "gwr_sorted", "msgf_rev_dual", "msgf_rev_dual_ng"} <= names, names
+    e, f, loss, g = run()
+    _check_pair_schedule(m)
+    meta = m.workspace_view("pair_sched_meta").cpu().view(torch.int32).long()
+    NW = (meta.numel() - 145 - 301) // (3 * 301 + 1)
+    seg = meta[:2 * 301 * NW].view(301, NW, 2)
+    npairs = seg[:, :, 1].sum(1)
+    assert int(npairs[big]) == 0 and int((npairs > 0).sum()) == 300
+    e_ref, f_ref, loss_ref, g_ref = R.train_step(params, cfg, pos, z, batch, y, ft)
+    assert rel_err(e.cpu().numpy(), e_ref.numpy()) < 1e-5 and rel_err(f.cpu().numpy(), f_ref.numpy()) < 1e-5
+    assert abs(loss - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    for k in g:
+        assert rel_err(g[k].cpu().numpy(), g_ref[k].numpy()) < 5e-5, k
+    monkeypatch.setenv("NQ_NO_MOLGW", "1")
+    e2, f2, loss2, g2 = run()
+    assert torch.equal(e, e2) and torch.equal(f, f2) and loss == loss2
+    for k in g:
+        d = float((g[k].double() - g2[k].double()).abs().max() / g2[k].double().abs().max().clamp_min(1e-30))
+        assert d < 5e-6, (k, d)
+        if "rbf_proj" not in k:
+            assert torch.equal(g[k], g2[k]), k
+
+
 def test_bench_sized_batch_linearity_and_determinism():
     """At the bench.py workload size (2048 conformers, ~86 k atoms, 1.6 M edges, full config) the oracle is out of reach; size-independent
     properties instead: (1) the parameter gradient of a LINEAR functional of energies and forces over the whole batch equals the sum of the
-    gradients of eight 256-conformer chunks (molecules do not couple) -- this runs the tangent / dual sweeps and the pair-row weight-gradient
-    path at full size; (2) two runs are bitwise identical; (3) net force per molecule vanishes.
+    gradients of eight 256-conformer chunks (molecules do not couple) -- this runs the tangent / dual sweeps, the full-width message rows and the
+    per-molecule rbf_proj gradient (k_gwr_mol, the default from 4096 atoms per step) at full size; (2) two runs are bitwise identical; (3) net force
+    per molecule vanishes.
     Yardstick for (1): on the exact-f32 engine a row's result does not depend on the batch, so chunks and full batch differ only by the partition of the
     weight-gradient sums: 5e-5 of the tensor's largest entry (measured 2e-6).  With the split-bf16 engine the chunk products partly run on the other
     engine, i.e. intermediate rows differ in the last f32 bit -- and this random-weight model turns last-bit differences of the intermediates into up to
@@ -759,12 +854,32 @@ def test_bench_sized_batch_linearity_and_determinism():
     assert float(net.abs().max()) < 5e-4 * float(f.abs().max())
 
 
-@pytest.mark.parametrize("F,NR,sizes", [(64, 20, [1, 2, 57, 9, 30, 44]), (128, 100, [57, 3, 1, 25, 40, 12, 56]), (256, 50, [5, 31, 2, 57])])
+def _kernel_names_of(fn):
+    """Names of the engine launches recorded by the C-ABI profiler (nq_profile_enable / nq_profile_read) while fn() runs."""
+    import ctypes as C
+    from nabladft_amd import _lib
+    lib = _lib.load()
+    cap = 256
+    names = C.create_string_buffer(cap * 64)
+    ms = (C.c_double * cap)()
+    cnt = (C.c_int64 * cap)()
+    lib.nq_profile_read(names, 64, ms, cnt, cap)            # drop what earlier tests left behind
+    lib.nq_profile_enable(1)
+    try:
+        fn()
+        n = lib.nq_profile_read(names, 64, ms, cnt, cap)
+    finally:
+        lib.nq_profile_enable(0)
+    return {names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode() for i in range(min(n, cap)) if cnt[i] > 0}
+
+
+@pytest.mark.parametrize("F,NR,sizes", [(64, 20, [1, 2, -1, 9, 30, 44]), (128, 100, [-1, 3, 1, 25, 40, 12, 57]), (256, 50, [5, 31, 2, -2])])   # -1: the LDS limit, -2: one below
 def test_per_molecule_weight_gradient_equals_the_pair_row_path(F, NR, sizes, monkeypatch):
     """csrc/molpair.hip against the pair-row path it replaces, same step, same inputs: molecules of 1 and 2 atoms (no pair / one pair: empty wavefront
-    segments), the largest molecule the LDS takes (57 atoms), 2 / 4 / 8 channel slices, 8 / 38 / 88 window starts.  Every gradient must agree to f32
-    rounding (the two paths sum the same terms in different orders), energies and forces bit for bit (they do not depend on the path); one more atom
-    (58) must fall back to the pair rows silently."""
+    segments, batches of padding only), the largest molecule the LDS takes (nq_painn_molecule_lds_atoms(): 62), 2 / 4 / 8 channel slices, 8 / 38 / 88 window starts.  Every gradient
+    must agree to the accuracy of the split-bf16 contraction (hi hi' + hi lo' + lo hi', <= 3 x 2^-18 per product; the pair-row path is exact f32), energies and
+    forces bit for bit (they do not depend on the path); a molecule one atom above the limit goes through the pair-row kernels while the REST of its batch stays on the
+    per-molecule kernel (schedule checked, both kernel families seen by the profiler), same result as forcing the pair rows for everything."""
     import nabladft_amd as nq
     dev = _dev()
     cfg = R.PaiNNConfig(hidden_channels=F, num_layers=2, num_rbf=NR)
@@ -779,6 +894,8 @@ def test_per_molecule_weight_gradient_equals_the_pair_row_path(F, NR, sizes, mon
         return nq.Batch(torch.tensor(pos), torch.tensor(z), torch.tensor(bt), torch.tensor(rng.normal(size=len(sz)).astype(np.float32)),
                         torch.tensor(rng.normal(0, 0.05, size=pos.shape).astype(np.float32))).to(dev)
 
+    cap = _lds_cap()
+    sizes = [cap + 1 + n if n < 0 else n for n in sizes]
     b = batch_of(sizes)
     step = nq.FusedTrainStep(model, max_grad_norm=0.0)
     out = {}
@@ -803,10 +920,22 @@ def test_per_molecule_weight_gradient_equals_the_pair_row_path(F, NR, sizes, mon
     # deterministic: the per-molecule path twice
     loss2 = float(step(b, update=False))
     assert loss2 == out["per_molecule"][0] and torch.equal(step.grad, gb)
-    # 58 atoms: does not fit the LDS of one workgroup -> the pair-row path, same result as forcing it
-    b58 = batch_of([58, 4])
-    step(b58, update=False); g_auto = step.grad.clone()
+    # one atom more: does not fit the LDS of one workgroup -> THAT molecule takes the pair rows, the others stay on the per-molecule kernel
+    b65 = batch_of([cap + 1, 4, 30, 41])
+    monkeypatch.setenv("NQ_MOLGW", "1"); monkeypatch.delenv("NQ_NO_MOLGW", raising=False)
+    names = _kernel_names_of(lambda: step(b65, update=False))
+    g_auto, e_auto, f_auto = step.grad.clone(), step.energy.clone(), step.forces.clone()
+    assert {"gwr_mol", "gwr_sorted", "msgf_rev_dual", "msgf_rev_dual_ng"} <= names, names
+    _check_pair_schedule(model)                              # the large molecule: empty segments; the three others: scheduled
+    step(b65, update=False)
+    assert torch.equal(g_auto, step.grad)                    # deterministic
     monkeypatch.setenv("NQ_NO_MOLGW", "1"); monkeypatch.delenv("NQ_MOLGW", raising=False)
-    step(b58, update=False)
-    assert torch.equal(g_auto, step.grad)
+    names = _kernel_names_of(lambda: step(b65, update=False))
+    assert "gwr_mol" not in names and "gwr_sorted" in names, names
+    assert torch.equal(e_auto, step.energy) and torch.equal(f_auto, step.forces)
+    for (k, _), (o, n, s_) in zip(model.named_parameters(), model._param_slices):
+        a_, b_ = step.grad[o:o + n].double(), g_auto[o:o + n].double()
+        e = float((a_ - b_).abs().max() / a_.abs().max().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 5e-6, (k, e)
     print(f"molgw vs pair rows F={F} R={NR}: worst relative gradient difference {worst:.2e}")

@@ -122,3 +122,46 @@ def test_gradients_are_slices_again_when_backward_returns_and_the_lazy_fallback(
     o = flat.offset[id(ps[4])]
     assert torch.equal(flat.flat.grad[o:o + 8], torch.full((8,), 2.0)) and not flat._detached
     assert ps[0].grad is not None and float(flat.flat.grad.abs().sum()) == 16.0
+
+
+def test_sparse_gradients_are_added_into_their_slices():
+    """the multi-tensor copy only takes dense fp32 gradients; a sparse one (nn.Embedding(sparse=True)) goes through the
+    add-into-the-zeroed-slice fallback and equals what per-tensor autograd holds."""
+    torch.manual_seed(5)
+    emb = torch.nn.Embedding(10, 6, sparse=True)
+    lin = torch.nn.Linear(6, 3)
+    idx = torch.tensor([1, 4, 4, 7])
+    ref_e, ref_l = copy.deepcopy(emb), copy.deepcopy(lin)
+    ref_l(ref_e(idx)).sum().backward()
+    flat = FlatParameters(list(emb.parameters()) + list(lin.parameters()))
+    flat.zero_grad()
+    lin(emb(idx)).sum().backward()
+    o = flat.offset[id(emb.weight)]
+    assert torch.equal(flat.flat.grad[o:o + 60].view(10, 6), ref_e.weight.grad.to_dense())
+    o = flat.offset[id(lin.weight)]
+    assert torch.equal(flat.flat.grad[o:o + 18].view(3, 6), ref_l.weight.grad)
+    assert emb.weight.grad.layout is torch.strided and emb.weight.grad.data_ptr() == flat.flat.grad[flat.offset[id(emb.weight)]:].data_ptr()
+    flat.validate()
+
+
+def test_overlapped_all_reduce_with_gradient_accumulation_world_1():
+    """OverlappedAllReduce reads the RAW buffer per bucket after gathering that bucket: two backward passes without zero_grad() in between must leave the
+    sum of both gradients (the second pass accumulates into the slices in place)."""
+    from nabladft_amd.trainer import OverlappedAllReduce
+    torch.manual_seed(6)
+    net = _Net()
+    xs = [torch.randn(4, 50), torch.randn(4, 50)]
+    want = _reference_grads(net, xs)
+    flat = FlatParameters(net.parameters())
+    ar = OverlappedAllReduce(flat, bucket_bytes=1024)
+    ar.check_tiling()
+    flat.zero_grad()
+    net(xs[0]).backward()
+    ar.finish()
+    net(xs[1]).backward()
+    g = ar.finish()
+    got = _flat_grads(net, flat)
+    assert g.data_ptr() == flat.flat._grad_buffer.data_ptr() and not flat._detached
+    for k in want:
+        if want[k] is not None:
+            assert torch.allclose(got[k], want[k], rtol=0, atol=1e-6), k

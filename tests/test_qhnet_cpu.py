@@ -210,3 +210,33 @@ def test_e3nn_restatement_cg_matches_the_reference_table_of_phisnet():
         assert err < 1e-12, (key, err)
         checked += 1
     assert checked == 22
+
+
+def test_fully_connected_net_scale_cache_survives_an_inference_mode_forward(monkeypatch):
+    """the cached product of the caller's path constants with 1 / sqrt(h1) must not stay an inference tensor -- Lightning's sanity validation
+    runs the first forward under torch.inference_mode(), the first TRAINING forward then has to save that factor for backward.  The dense products are replaced
+    by torch here (no GPU): the cache logic is host code."""
+    import torch
+    from nabladft_amd import qhnet as Q
+
+    class _Mat:
+        apply = staticmethod(lambda x, w: x @ w)
+
+    class _Act:
+        apply = staticmethod(lambda h, kind, cst: torch.nn.functional.silu(h) * cst)
+    monkeypatch.setattr(Q, "_MatmulFn", _Mat)
+    monkeypatch.setattr(Q, "_ActFn", _Act)
+    torch.manual_seed(0)
+    net = Q.FullyConnectedNet([8, 16, 12], "silu")
+    scale = torch.rand(12) + 0.5
+    x = torch.randn(5, 8)
+    with torch.inference_mode():
+        y0 = net(x, scale).clone()
+    assert net._cs.is_inference()
+    y1 = net(x, scale)                                  # training forward: rebuilt as an ordinary tensor
+    assert not net._cs.is_inference()
+    y1.sum().backward()
+    assert net.layer1.weight.grad is not None and torch.allclose(y0, y1.detach())
+    keep = net._cs
+    net(x, scale).sum().backward()                      # and it IS cached from then on
+    assert net._cs is keep
