@@ -238,6 +238,10 @@ int nq_msg_rev(hipStream_t, const MsgRevArgs&, bool dual);
 int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* pos_dot, float* TD, float* TR);
 int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);
 
+// the whole update block of one layer and sweep as one kernel (updfuse.hip; hidden_channels = 128): weight fragments once per forward call, then one launch
+size_t nq_updfuse_frag_floats(int F);
+int nq_updfuse_presplit(hipStream_t, const float* U, const float* V1, const float* V2, int F, float* frag);
+int nq_upd_fused(hipStream_t, const UpdArgs&, const float* frag, const float* c1, const float* c2, float* ZQ, float* Q, float* TZQ, float* TQ, bool tan);
 int nq_upd_a(hipStream_t, const UpdArgs&, bool tan);
 int nq_upd_b(hipStream_t, const UpdArgs&, bool tan);
 int nq_silu_tan(hipStream_t, const float* Z, const float* TZ, float* TH, long count);

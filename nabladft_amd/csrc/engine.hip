@@ -103,6 +103,7 @@ static int make_param_layout(const nq_painn_cfg* c, ParamLayout* P) {
 struct WsLayer {
   size_t Z1, Hh, XH, PHI, PSI, XM, VM, UU, S, CAT, ZQ, Q, Y;  // float offsets; dual buffers hold [2][rows][w]
   size_t WRT;                                                  // [R][3F] transposed rbf_proj.weight
+  size_t UFRAG;                                                // bf16 fragments of the update block's weights (updfuse.hip), rebuilt by every forward call
 };
 struct WsLayout {
   size_t X[65], V[65];
@@ -132,6 +133,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     y.PHI = take(EP * 3 * F); y.PSI = take(EP * 3 * F); y.WRT = take(R * 3 * F);
     y.XM = take(2 * N * F); y.VM = take(2 * N * 3 * F); y.UU = take(2 * N * 6 * F);
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
+    y.UFRAG = take(nq_updfuse_frag_floats((int)F));
   }
   W->RHO2 = take(2 * EP * R);   // full rho / drho rows only for the materialised-filter path (B operand of the gWr contraction)
   W->ORDER = take(W->fused ? E : 0);   // int32: CSR slots sorted by window start k0
@@ -200,6 +202,12 @@ static bool recall_molgw(const void* ws, GwMode* m) {
   if (it == g_gw_modes.end()) return false;
   *m = it->second;
   return true;
+}
+
+// update block of a layer as one kernel per sweep (updfuse.hip): hidden_channels = 128; NQ_NO_FUSED_UPDATE=1 keeps the five launches of rounds 1-5 (A/B runs, tests)
+static bool use_fused_update(const nq_painn_cfg* c) {
+  const char* off = getenv("NQ_NO_FUSED_UPDATE");
+  return nq_updfuse_frag_floats(c->hidden_channels) > 0 && !(off && off[0] == '1');
 }
 
 static NqGraphView view_of(const nq_graph* g) {
@@ -399,6 +407,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     NQ_TRY(nq_rbf(st, g.geom, E, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, rbf_offsets, rho, drho, cfg->rbf_type, params + P.basis));
   }
 
+  const bool fused_upd = use_fused_update(cfg);
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F, "W1"));
@@ -417,10 +426,15 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
       NQ_TRY(nq_gemm_nt(st, drho, params + mp.Wr, ws + y.PSI, nullptr, nullptr, E, 3 * F, R, R, R, 3 * F, "Wr"));
       NQ_TRY(nq_msg_fwd(st, m, false));
     }
-    NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.X1 = ws + W.X[l + 1]; u.V1 = ws + W.V[l + 1];
+    if (fused_upd) {
+      NQ_TRY(nq_updfuse_presplit(st, params + up.U, params + up.V1, params + up.V2, F, ws + y.UFRAG));
+      NQ_TRY(nq_upd_fused(st, u, ws + y.UFRAG, params + up.c1, params + up.c2, ws + y.ZQ, ws + y.Q, nullptr, nullptr, false));
+      continue;
+    }
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM, params + up.U, ws + y.UU, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     NQ_TRY(nq_upd_a(st, u, false));
     NQ_TRY(nq_gemm_nt(st, ws + y.CAT, params + up.V1, ws + y.ZQ, params + up.c1, ws + y.Q, N, F, 2 * F, 2 * F, 2 * F, F, "V1"));
     NQ_TRY(nq_gemm_nt(st, ws + y.Q, params + up.V2, ws + y.Y, params + up.c2, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
@@ -590,13 +604,19 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     } else {
       NQ_TRY(nq_msg_fwd(st, m, true));
     }
-    NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
     UpdArgs u{};
     u.N = N; u.F = F; u.XM = ws + y.XM; u.VM = ws + y.VM; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.TXM = ws + y.XM + NF; u.TVM = ws + y.VM + 3 * NF; u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF;
     u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF; u.TX1 = ws + W.X[l + 1] + NF; u.TV1 = ws + W.V[l + 1] + 3 * NF;
-    NQ_TRY(nq_upd_a(st, u, true));
     float* TZQ = ws + y.ZQ + NF; float* TQ = ws + y.Q + NF;
+    // Tangent flavour of the fused update block: built, parity-tested (tests/test_engine_gpu.py), NOT the default -- it re-reads the primal intermediates in the
+    // accumulator layout (4-byte loads) and measured 3.58 ms per step against 3.0 ms for the five launches below (profiles/r06_fused_update_ab.txt); NQ_FUSED_UPDATE_TAN=1 selects it.
+    if (use_fused_update(cfg) && getenv("NQ_FUSED_UPDATE_TAN") && getenv("NQ_FUSED_UPDATE_TAN")[0] == '1') {   // the fragments are the forward call's (same weights: one step)
+      NQ_TRY(nq_upd_fused(st, u, ws + y.UFRAG, nullptr, nullptr, ws + y.ZQ, ws + y.Q, TZQ, TQ, true));
+      continue;
+    }
+    NQ_TRY(nq_gemm_nt(st, ws + y.VM + 3 * NF, params + up.U, ws + y.UU + 6 * NF, nullptr, nullptr, 3 * N, 2 * F, F, F, F, 2 * F, "U"));
+    NQ_TRY(nq_upd_a(st, u, true));
     NQ_TRY(nq_gemm_nt_dsilu(st, ws + y.CAT + 2 * NF, params + up.V1, TZQ, TQ, ws + y.ZQ, N, F, 2 * F, "V1"));
     NQ_TRY(nq_gemm_nt(st, TQ, params + up.V2, ws + y.Y + 3 * NF, nullptr, nullptr, N, 3 * F, F, F, F, 3 * F, "V2"));
     NQ_TRY(nq_upd_b(st, u, true));

@@ -10,6 +10,7 @@
 #         prof:<name>:<command...>         rocprofv3 --kernel-trace --stats of a command -> <name>_kernel_stats.csv
 #         pmc:<B>:<command...>             FETCH_SIZE / WRITE_SIZE passes (separate runs) -> pmc_traffic_<B>.json
 #         sq:<B>:<kernel filter>           three SQ counter passes (wave cycles / waits, instruction counts, LDS + matrix-core busy) of bench.py at batch B -> pmc_sq_<filter>.txt
+#         sweep[:<models>]                 scripts/batch_sweep.py (throughput vs conformers per step of QHNet / GemNet-OC / eSCN / EquiformerV2) -> batch_sweep.json
 #         sh:<command...>                  anything else
 OUT=gpurun_out/$1; shift; mkdir -p $OUT; export TMPDIR=/tmp
 for step in "$@"; do
@@ -51,6 +52,7 @@ PY
         { sqrun sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES
           sqrun sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
           sqrun sq3 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM; } 2>&1 | tee $OUT/pmc_sq_${FILT//,/_}.txt ;;
+    sweep) timeout -k 5 2400 python scripts/batch_sweep.py --out $OUT/batch_sweep.json ${arg:+--models $arg} 2>&1 | tail -30 | tee $OUT/batch_sweep.log ;;
     sh) bash -c "$arg" 2>&1 | tail -40 | tee -a $OUT/sh.log ;;
     *) echo "unknown step $kind" ;;
   esac

@@ -5,7 +5,7 @@ set -e; set +e
 cd "$(dirname "$0")/.."
 D=nabladft_amd/_variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on ${VAR_BASE_FLAGS:-}"
-OBJS="graph gemm gemm_bf16 edge molpair node schnet hblock so3 qhnet gemnet_graph gemnet escn equiformer geobasis rccl engine"
+OBJS="graph gemm gemm_bf16 edge molpair updfuse node schnet hblock so3 qhnet gemnet_graph gemnet escn equiformer geobasis rccl engine"
 if [ "$1" = build ]; then
   mkdir -p $D; rm -f $D/*.so $D/*.o
   F=$2; shift 2

@@ -480,6 +480,46 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
         f.write(f"worst grad vs golden: {worst}\n")
 
 
+@pytest.mark.parametrize("mode", ["unfused", "fused_forward", "fused_forward_and_tangent"])
+def test_update_block_flavours_agree_with_the_reference(mode, monkeypatch):
+    """csrc/updfuse.hip: the update block of a layer as ONE kernel per sweep (hidden_channels = 128) against the five launches it replaces and against the
+    reference golden vectors of the full configuration: energies, forces, loss and every parameter gradient within the bounds of
+    test_engine_matches_reference_golden, for the default (fused forward sweep), the opt-in fused tangent sweep and the unfused path; the fused
+    kernels are seen by the profiler when and only when they are selected."""
+    import nabladft_amd as nq
+    from nabladft_amd import L2Loss
+    monkeypatch.delenv("NQ_NO_FUSED_UPDATE", raising=False); monkeypatch.delenv("NQ_FUSED_UPDATE_TAN", raising=False)
+    if mode == "unfused":
+        monkeypatch.setenv("NQ_NO_FUSED_UPDATE", "1")
+    if mode == "fused_forward_and_tangent":
+        monkeypatch.setenv("NQ_FUSED_UPDATE_TAN", "1")
+    dev = _dev()
+    fx, cfg, params = load_case("painn_full_real4.npz")
+    assert cfg.hidden_channels == 128
+    model = _model(cfg, params, dev)
+    batch = _batch(fx, dev)
+    model.train()
+    out = {}
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        energy, forces = model(batch)
+        loss = torch.nn.L1Loss()(energy, batch.y) + L2Loss()(forces, batch.forces)
+        loss.backward()
+        out["e"], out["f"], out["loss"] = energy.detach(), forces.detach(), float(loss.detach())
+    names = _kernel_names_of(run)
+    assert ("upd_fused" in names) == (mode != "unfused") and ("upd_fused_tan" in names) == (mode == "fused_forward_and_tangent"), names
+    assert ("upd_a" in names) == (mode != "fused_forward_and_tangent"), names       # the tangent sweep of the default still runs the five launches
+    assert_close(f"update block {mode} E", out["e"].cpu().numpy(), fx["energy"], 1e-5)
+    assert_close(f"update block {mode} F", out["f"].cpu().numpy(), fx["forces"], 1e-5)
+    assert abs(out["loss"] - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    check_grads(fx, {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}, 5e-5, f"update block {mode}")
+    e1, f1 = out["e"].clone(), out["f"].clone()
+    run()
+    assert torch.equal(e1, out["e"]) and torch.equal(f1, out["f"])                  # deterministic
+
+
 def test_fused_step_matches_golden_and_is_deterministic():
     """C-ABI-only path (HIP loss kernel, no autograd): same gradients, bitwise reproducible."""
     import nabladft_amd as nq
