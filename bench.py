@@ -509,7 +509,7 @@ def compact_record(full, full_path=None):
     if cb is not None:
         rec["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "host_cpus", "kind", "sample"))
         if cb.get("all_cores"):
-            rec["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+            rec["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores")) if cb["all_cores"].get("value") is not None else "--full only"
     if full.get("mae_vs_cpu_reference") is not None:
         mv = full["mae_vs_cpu_reference"]
         rec["mae_vs_cpu_reference"] = {k: (_num(v) if not isinstance(v, (str, dict)) else v) for k, v in mv.items() if k != "small_batch"}
@@ -658,7 +658,7 @@ def _lib_cap():
     return _lib.load().nq_painn_molecule_lds_atoms()
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=25.0, all_cores=False):
     """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
     timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
     from oracle import painn_ref as Rf
@@ -695,7 +695,10 @@ def cpu_baseline(seconds_budget=25.0):
                      f"median of {max(len(times), 1)} steps, torch {torch.__version__} CPU fp32 incl. gradient clipping + AdamW (the same work as the GPU step)"}
     # second timing line on every host core (north_star: "the GPU box's host cores"); torch-CPU on graphs of this size usually runs SLOWER there than on 16 threads
     ncpu = os.cpu_count() or 1
-    if ncpu > cores:
+    if ncpu > cores and not all_cores:
+        out["all_cores"] = {"value": None, "cores": ncpu, "sample": "measured by --full only: one step on every core takes minutes (0.121 conformer-steps/s on 256 threads, "
+                                                                    "profiles/r06_bench_default_full_record.json) -- torch-CPU collapses under oversubscription on graphs of this size"}
+    if ncpu > cores and all_cores:
         torch.set_num_threads(ncpu)
         t0 = time.perf_counter()
         cpu_step()
@@ -877,7 +880,7 @@ def main():
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline() if args.model == "painn-oc" else cpu_baseline_spk(args.model)
+        cpu, parity = cpu_baseline(all_cores=args.full) if args.model == "painn-oc" else cpu_baseline_spk(args.model)
 
     host_feed = None
     if rank == 0 and world == 1 and not args.no_roofline and args.full:

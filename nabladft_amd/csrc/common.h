@@ -196,6 +196,10 @@ int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, con
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
 int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,
                const char* tag = nullptr, float* bias_out = nullptr, long bias_rows = 0);
+// several weight-gradient products (+ bias gradients) in one launch and one reduction of the partial tiles; NQ_ERR_ARG = not eligible, nothing launched
+struct NqTnSpec { const float* G; const float* X; float* out; long rows; int Mo, No, ldg, ldx; float* bias_out; long bias_rows; };
+size_t nq_gemm_tn_group_scratch_floats(const NqTnSpec* sp, int n);
+int nq_gemm_tn_group(hipStream_t, const NqTnSpec* sp, int n, float* scratch);
 size_t nq_colsum_scratch_floats(long rows, int cols);
 int nq_colsum(hipStream_t, const float* A, long rows, int cols, int lda, float* out, float* scratch);
 int nq_reduce_partials(hipStream_t, const float* part, int nsplit, long stride, long count, float* out);
@@ -242,6 +246,7 @@ int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves
 size_t nq_updfuse_frag_floats(int F);
 int nq_updfuse_presplit(hipStream_t, const float* U, const float* V1, const float* V2, int F, float* frag);
 int nq_upd_fused(hipStream_t, const UpdArgs&, const float* frag, const float* c1, const float* c2, float* ZQ, float* Q, float* TZQ, float* TQ, bool tan);
+int nq_updrev_fused(hipStream_t, const UpdRevArgs&, const float* frag, const float* ZQ);   // force-adjoint sweep: rev1, three input-gradient products, rev2 in one kernel
 int nq_upd_a(hipStream_t, const UpdArgs&, bool tan);
 int nq_upd_b(hipStream_t, const UpdArgs&, bool tan);
 int nq_silu_tan(hipStream_t, const float* Z, const float* TZ, float* TH, long count);

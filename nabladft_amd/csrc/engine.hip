@@ -120,6 +120,7 @@ static bool use_fused_filter(const nq_painn_cfg* c) {
   return c->rbf_type == 0 && nq_filter_fits_lds(c->hidden_channels, c->num_rbf) && !(off && off[0] == '1');   // the window needs compact Gaussians
 }
 
+static void tn_group_shapes(NqTnSpec (&sp)[5], long N, int F);
 static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, WsLayout* W) {
   const size_t F = c->hidden_channels, R = c->num_rbf, H = F / 2, L = c->num_layers, T = c->num_elements;
   W->fused = use_fused_filter(c);
@@ -159,6 +160,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
   mx(W->fused ? nq_gwr_scratch_floats((int)E, (int)F, (int)R) : nq_gemm_tn_scratch_floats(2 * E, 3 * F, R));
   if (W->fused) mx(nq_k0_sort_scratch_ints((int)E, (int)R));
   mx(nq_gemm_tn_scratch_floats(2 * N, F, F)); mx(nq_gemm_tn_scratch_floats(2 * N, H, F));
+  { NqTnSpec sp[5]; tn_group_shapes(sp, (long)N, (int)F); mx(nq_gemm_tn_group_scratch_floats(sp, 5)); }
   mx(nq_colsum_scratch_floats(N > E ? N : E, 3 * F));
   if (c->rbf_type) { mx(nq_colsum_scratch_floats(E, R)); mx(nq_colsum_scratch_floats(E * R, 1)); }
   mx(nq_embed_grad_scratch_floats((int)N, (int)F, (int)T));
@@ -208,6 +210,23 @@ static bool recall_molgw(const void* ws, GwMode* m) {
 static bool use_fused_update(const nq_painn_cfg* c) {
   const char* off = getenv("NQ_NO_FUSED_UPDATE");
   return nq_updfuse_frag_floats(c->hidden_channels) > 0 && !(off && off[0] == '1');
+}
+
+// The five weight-gradient products of one layer's dual-reverse sweep as ONE grouped launch (gemm.hip: nq_gemm_tn_group): built, parity-tested,
+// NOT the default.  Measured (profiles/r06_tn_group_ab.txt): 2048 conformers 49.56-49.85 ms per step grouped vs 49.29-49.40 one launch each; 32 conformers 4.19 vs
+// 3.73 ms -- the separate launches run on the side stream UNDER the layer's critical path, the grouped launch can only start when the layer's last adjoint exists, and
+// at the large size the 4.5x smaller partial-tile traffic does not pay for the longer serial row streams per workgroup.  NQ_TN_GROUP=1 selects it.
+static bool use_tn_group() {
+  const char* on = getenv("NQ_TN_GROUP");
+  return on && on[0] == '1';
+}
+static void tn_group_shapes(NqTnSpec (&sp)[5], long N, int F) {   // rows / output shapes only (workspace sizing); the engine fills in the pointers
+  const int F2 = 2 * F, F3 = 3 * F;
+  sp[0] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F3, F, F3, F, reinterpret_cast<float*>(1), N};    // V2: gy^T q  (+ c2)
+  sp[1] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F, F2, F, F2, reinterpret_cast<float*>(1), N};    // V1: gq^T cat (+ c1)
+  sp[2] = NqTnSpec{nullptr, nullptr, nullptr, 6 * N, F2, F, F2, F, nullptr, 0};                        // U:  gu^T vec_msg
+  sp[3] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F3, F, F3, F, reinterpret_cast<float*>(1), N};    // W2: gxh^T h (+ b2)
+  sp[4] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F, F, F, F, reinterpret_cast<float*>(1), N};      // W1: gh^T x (+ b1)
 }
 
 static NqGraphView view_of(const nq_graph* g) {
@@ -461,12 +480,18 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
+    // Force-adjoint flavour of the fused update block: built, parity-tested, NOT the default -- 3.47 ms per step against 3.34 ms for the five launches below
+    // (five dependent products with ten barriers and 400 four-byte loads per lane at eight wavefronts per CU: profiles/r06_fused_update_ab.txt); NQ_FUSED_UPDATE_REV=1 selects it.
+    if (fused_upd && getenv("NQ_FUSED_UPDATE_REV") && getenv("NQ_FUSED_UPDATE_REV")[0] == '1') {
+      NQ_TRY(nq_updrev_fused(st, u, ws + y.UFRAG, ws + y.ZQ));   // no weight gradients in this sweep: gy, gq, gcat, gu never leave the chip
+    } else {
     NQ_TRY(nq_upd_rev(st, u, 1, false));
     // G_Q = (G_Y V2) * silu'(Z_Q): the activation's adjoint in the epilogue of the input-gradient product (no separate k_silu_rev pass)
     NQ_TRY(nq_gemm_nn_epi(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2"));
     NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
+    }
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
@@ -654,6 +679,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   }
   float* gphi = ws + W.GPHI2; float* gpsi = gphi + (size_t)E * 3 * F;
   const bool molgw = gw.mode != GW_PAIR_ROWS, mixed = gw.mode == GW_MIXED;
+  const bool tn_group = use_tn_group();
   const int* const sched = reinterpret_cast<const int*>(ws + W.SCHED);
   const int* const n_big_pairs = sched + nq_molgw_sched_ints(E, g.B) - 1;
   if (molgw) NQ_TRY(nq_molgw_geometry(st, g, ws + W.RW, ws + W.TD, ws + W.TR, sched, ws + W.GWREC));
@@ -668,21 +694,27 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
     ss.before_main_writes(SB_GY);
     NQ_TRY(nq_upd_rev(st, u, 1, true));
+    if (!tn_group) {
     sd = ss.fork();
     NQ_TRY(nq_gemm_tn(sd, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
     ss.read_by_side(SB_GY);
+    }
     ss.before_main_writes(SB_GQ);
     NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2"));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
+    if (!tn_group) {
     sd = ss.fork();
     NQ_TRY(nq_gemm_tn(sd, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
     ss.read_by_side(SB_GQ);
+    }
     NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
     ss.before_main_writes(SB_GU);
     NQ_TRY(nq_upd_rev(st, u, 2, true));
+    if (!tn_group) {
     sd = ss.fork();
     NQ_TRY(nq_gemm_tn(sd, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
     ss.read_by_side(SB_GU);
+    }
     NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
@@ -719,14 +751,34 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
       NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));
     if (!molgw) NQ_TRY(nq_colsum(sd, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
-    NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
-    ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); ss.read_by_side(SB_GXH);
+    if (!tn_group) NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
+    ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); if (!tn_group) ss.read_by_side(SB_GXH);
     ss.before_main_writes(SB_GH);
     NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
     sd = ss.fork();
-    NQ_TRY(nq_gemm_tn(sd, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
-    ss.read_by_side(SB_GH);
+    if (!tn_group) {
+      NQ_TRY(nq_gemm_tn(sd, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
+      ss.read_by_side(SB_GH);
+    } else {
+      // all five weight-gradient products of the layer (and their bias gradients) in one launch: gy, gq, gu, gxh, gh are final and stay untouched until the
+      // next layer's kernels overwrite them (each of those waits for this launch through its before_main_writes)
+      NqTnSpec sp[5];
+      tn_group_shapes(sp, N, F);
+      sp[0].G = ws + W.GY; sp[0].X = ws + y.Q; sp[0].out = gp + up.V2; sp[0].bias_out = gp + up.c2;
+      sp[1].G = ws + W.GQ; sp[1].X = ws + y.CAT; sp[1].out = gp + up.V1; sp[1].bias_out = gp + up.c1;
+      sp[2].G = ws + W.GU; sp[2].X = ws + y.VM; sp[2].out = gp + up.U;
+      sp[3].G = ws + W.GXH; sp[3].X = ws + y.Hh; sp[3].out = gp + mp.W2; sp[3].bias_out = gp + mp.b2;
+      sp[4].G = ws + W.GH; sp[4].X = ws + W.X[l]; sp[4].out = gp + mp.W1; sp[4].bias_out = gp + mp.b1;
+      if (nq_gemm_tn_group(sd, sp, 5, scr) != NQ_OK) {   // not eligible for the split engine (exact-f32 engine selected, unaligned operands): one launch each
+        NQ_TRY(nq_gemm_tn(sd, sp[0].G, sp[0].X, sp[0].out, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", sp[0].bias_out, N));
+        NQ_TRY(nq_gemm_tn(sd, sp[1].G, sp[1].X, sp[1].out, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", sp[1].bias_out, N));
+        NQ_TRY(nq_gemm_tn(sd, sp[2].G, sp[2].X, sp[2].out, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
+        NQ_TRY(nq_gemm_tn(sd, sp[3].G, sp[3].X, sp[3].out, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", sp[3].bias_out, N));
+        NQ_TRY(nq_gemm_tn(sd, sp[4].G, sp[4].X, sp[4].out, 2L * N, F, F, F, F, scr, "W1", sp[4].bias_out, N));
+      }
+      ss.read_by_side(SB_GY); ss.read_by_side(SB_GQ); ss.read_by_side(SB_GU); ss.read_by_side(SB_GXH); ss.read_by_side(SB_GH);
+    }
     NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
     // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final once the weight-gradient stream gets here: the caller's
     // collective stream may start reducing it

@@ -813,6 +813,93 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   return NQ_OK;
 }
 
+// ---- several weight-gradient products in one launch (k_gemm3_tn_group, gemm_split.h) + one reduction of all their partial tiles ----------------
+#define RG_MAX (2 * GEMM_GROUP_MAX)
+struct ReduceGroupArgs { const float* part[RG_MAX]; float* out[RG_MAX]; int nsplit[RG_MAX]; int count[RG_MAX]; int first[RG_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void k_reduce_partials_group(ReduceGroupArgs q) {
+  const int b = (int)blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < RG_MAX; ++i) g += (i < q.n && b >= q.first[i]) ? 1 : 0;
+  // static member indices only (see k_gemm3_tn_group)
+  const float* part = nullptr; float* out = nullptr; int nsplit = 0, count = 0, first = 0;
+#pragma unroll
+  for (int i = 0; i < RG_MAX; ++i)
+    if (g == i) { part = q.part[i]; out = q.out[i]; nsplit = q.nsplit[i]; count = q.count[i]; first = q.first[i]; }
+  const long i = (long)(b - first) * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nsplit; k += 4) {   // same combination order as k_reduce_partials
+    s0 += part[(long)k * count + i]; s1 += part[(long)(k + 1) * count + i];
+    s2 += part[(long)(k + 2) * count + i]; s3 += part[(long)(k + 3) * count + i];
+  }
+  for (; k < nsplit; ++k) s0 += part[(long)k * count + i];
+  out[i] = (s0 + s1) + (s2 + s3);
+}
+
+static const int TN_GROUP_SLOTS = 512;   // 2 workgroups per CU (the bias-gradient flavour of the split engine)
+struct TnGroupPlan { int ns[GEMM_GROUP_MAX], kper[GEMM_GROUP_MAX], nse[GEMM_GROUP_MAX]; size_t off[GEMM_GROUP_MAX], boff[GEMM_GROUP_MAX], total; };
+static void tn_group_plan(const NqTnSpec* sp, int n, TnGroupPlan* P) {
+  double wsum = 0.0;
+  long tiles[GEMM_GROUP_MAX];
+  for (int g = 0; g < n; ++g) { tiles[g] = (long)nq_cdiv(sp[g].Mo, 128) * nq_cdiv(sp[g].No, 128); wsum += (double)sp[g].rows * tiles[g]; }
+  size_t o = 0;
+  for (int g = 0; g < n; ++g) {
+    long s = (long)(TN_GROUP_SLOTS * ((double)sp[g].rows * tiles[g] / (wsum > 0 ? wsum : 1.0)) / tiles[g]);   // slots in proportion to rows x tiles, floor: never more than the slots
+    const long by_rows = (sp[g].rows + 127) / 128;
+    if (s > by_rows) s = by_rows;
+    if (s < 1) s = 1;
+    int kper = (int)((sp[g].rows + s - 1) / s);
+    kper = (kper + 31) / 32 * 32;
+    P->ns[g] = (int)s; P->kper[g] = kper; P->nse[g] = nq_cdiv(sp[g].rows, kper);
+    P->off[g] = o; o += (size_t)s * sp[g].Mo * sp[g].No;
+    P->boff[g] = o; o += sp[g].bias_out ? (size_t)s * sp[g].Mo : 0;
+    o = (o + 3) & ~(size_t)3;
+  }
+  P->total = o;
+}
+size_t nq_gemm_tn_group_scratch_floats(const NqTnSpec* sp, int n) {
+  if (n < 1 || n > GEMM_GROUP_MAX) return 0;
+  TnGroupPlan P;
+  tn_group_plan(sp, n, &P);
+  return P.total;
+}
+// All products through the split engine in one launch + one reduction; returns NQ_ERR_ARG (nothing launched) when a product is not eligible
+// (the caller then issues them one by one with nq_gemm_tn).
+int nq_gemm_tn_group(hipStream_t st, const NqTnSpec* sp, int n, float* scratch) {
+  if (n < 1 || n > GEMM_GROUP_MAX || gemm3_disabled()) return nq_fail(NQ_ERR_ARG, "gemm_tn_group: not eligible");
+  TnGroupPlan P;
+  tn_group_plan(sp, n, &P);
+  GemmGroupArgs q{};
+  ReduceGroupArgs r{};
+  int wg = 0, rb = 0, nr = 0;
+  double flops = 0.0;
+  for (int g = 0; g < GEMM_GROUP_MAX; ++g) {
+    q.first[g] = wg;
+    if (g >= n) continue;
+    const NqTnSpec& x = sp[g];
+    if (x.rows <= 0 || x.rows > 2000000000L) return nq_fail(NQ_ERR_ARG, "gemm_tn_group: bad row count");
+    float* bpart = x.bias_out ? scratch + P.boff[g] : nullptr;
+    q.a[g] = GemmArgs{x.G, x.X, scratch + P.off[g], nullptr, nullptr, x.Mo, x.No, (int)x.rows, x.ldg, x.ldx, x.No, P.kper[g], (long)x.Mo * x.No, bpart, (int)x.bias_rows};
+    if (!gemm3_ok<false, false>(q.a[g], P.kper[g], P.nse[g])) return nq_fail(NQ_ERR_ARG, "gemm_tn_group: product %d is not eligible for the split engine", g);
+    wg += nq_cdiv(x.Mo, 128) * nq_cdiv(x.No, 128) * P.nse[g];
+    flops += 2.0 * x.rows * x.Mo * x.No;
+    r.part[nr] = scratch + P.off[g]; r.out[nr] = x.out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo * x.No; r.first[nr] = rb; rb += nq_cdiv((long)x.Mo * x.No, 256); ++nr;
+    if (x.bias_out) { r.part[nr] = bpart; r.out[nr] = x.bias_out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo; r.first[nr] = rb; rb += nq_cdiv(x.Mo, 256); ++nr; }
+  }
+  q.first[GEMM_GROUP_MAX] = wg; q.n = n;
+  for (int i = nr; i <= RG_MAX; ++i) r.first[i] = rb;
+  r.n = nr;
+  NQ_PROF(st, "gemm_tn_group");
+  NQ_PROF_FLOPS(flops);
+  hipLaunchKernelGGL(k_gemm3_tn_group<0>, dim3(wg), dim3(256), 0, st, q);
+  NQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_partials_group, dim3(rb), dim3(256), 0, st, r);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
 // rows per workgroup: 2048 for large inputs, shorter chunks (more workgroups, shorter serial loops) for small ones; multiple of 16
 static int cs_rows_for(long rows) { long c = (rows + 127) / 128; c = (c + 15) / 16 * 16; return (int)(c < 64 ? 64 : (c > CS_ROWS ? CS_ROWS : c)); }
 // (the chunk count is not monotonic in `rows` below 128 chunks: callers size one scratch for several row counts, so never report fewer than 128)

@@ -113,9 +113,10 @@ struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-ti
 // ABL (lab only): 1 = no split arithmetic (the three planes get the truncated value), 2 = no global loads inside the loop, 4 = no ds_reads inside the loop
 // KTAIL: the contraction length need not be a multiple of 16 (K-contiguous operands only; costs 18 VALU instructions per step).
 // WBIAS (weight-gradient launches): also produce the bias gradient (GemmArgs::bpart).
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false>
-__global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
-  if (BATCH) gemm_apply_batch(p);
+// bid / nb: this workgroup's index and the number of workgroups that share the product (blockIdx.x / gridDim.x for a plain launch; a grouped launch deals
+// ranges of its grid to several products: k_gemm3_tn_group below)
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0>
+__device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, const int nb) {
   constexpr int BM = 128, BN = 128, BK = 16, NWN = 2, TM = 2, TN = 2;
   using SA = SplitStage<A_KC>;
   using SB = SplitStage<B_KC>;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   const int per_split = ntn * ntm;
   const int nsplit = EPI == EPI_PARTIAL ? (p.K + p.k_per_split - 1) / p.k_per_split : 1;
   const int ntiles = per_split * nsplit;
-  if ((int)blockIdx.x >= ntiles) return;
+  if (bid >= ntiles) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int wrow0 = wm * (TM * 32), wcol0 = wn * (TN * 32);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   };
   auto advance = [&](const SpStep& s) {
     if (s.k0 + BK < s.kend) { SpStep n = s; n.k0 += BK; return n; }
-    return first_step(s.tile >= ntiles ? s.tile : s.tile + (int)gridDim.x);
+    return first_step(s.tile >= ntiles ? s.tile : s.tile + nb);
   };
   __amdgpu_buffer_rsrc_t da, db;
   auto descriptors = [&](const SpStep& s) {   // of the step's tile; zero range past the end
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   // bias gradient of the weight-gradient contraction (EPI_PARTIAL, A = gy [rows][M]): column sums of A over the rows < brows, taken from the f32
   // registers on their way into LDS (a thread holds 8 of the step's 16 rows of ONE column); the two half-steps' sums meet in LDS at the end of the
   // tile, fixed order.  bnext: a tile's first step is staged while the previous tile is still being finished.
-  constexpr bool bias_on = BIAS;
+  const bool bias_on = BIAS && p.bpart != nullptr;   // (a grouped launch mixes products with and without a bias gradient)
   float bsum = 0.f, bnext = 0.f;
   float* lds_b = reinterpret_cast<float*>(lds + 2 * BUF);   // [2][128], only there for EPI_PARTIAL
   auto colsum = [&](const float (&v)[SA::NREG], const SpStep& s) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
     return o;
   };
 
-  SpStep cur = first_step(blockIdx.x), n1 = advance(cur), n2 = advance(n1);
+  SpStep cur = first_step(bid), n1 = advance(cur), n2 = advance(n1);
   float ra[2][SA::NREG], rb[2][SB::NREG];
   descriptors(cur);
   SA::fetch(ra[0], da, voff_a, p.lda, 0);
@@ -288,4 +289,28 @@ __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
       __syncthreads();
     }
   } while (cur.tile < ntiles);
+}
+
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false>
+__global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
+  if (BATCH) gemm_apply_batch(p);
+  gemm3_body<A_KC, B_KC, EPI, WPE, KTAIL, WBIAS, TERMS, ABL>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several weight-gradient contractions (EPI_PARTIAL: both operands row-major over the contracted rows) in ONE launch: workgroups [first[g], first[g + 1])
+// belong to product g.  The five products of a PaiNN layer's reverse sweep share the chip's 512 workgroup slots in proportion to their rows x tiles:
+// each workgroup streams ~10x more rows than when every product splits itself over all slots, and the per-split partial tiles (which a second kernel
+// has to read back) shrink by the same factor.
+#define GEMM_GROUP_MAX 5
+struct GemmGroupArgs { GemmArgs a[GEMM_GROUP_MAX]; int first[GEMM_GROUP_MAX + 1]; int n; };
+template <int UNUSED = 0>   // (a template only so that every translation unit that includes this header may hold its own copy)
+__global__ __launch_bounds__(256, 2) void k_gemm3_tn_group(GemmGroupArgs q) {
+  const int b = (int)blockIdx.x;
+  // (static member indices only: a dynamically indexed argument block would live in scratch memory)
+  const int g = b >= q.first[4] ? 4 : b >= q.first[3] ? 3 : b >= q.first[2] ? 2 : b >= q.first[1] ? 1 : 0;
+  if (g == 0) gemm3_body<false, false, EPI_PARTIAL, 2, false, true>(q.a[0], b - q.first[0], q.first[1] - q.first[0]);
+  else if (g == 1) gemm3_body<false, false, EPI_PARTIAL, 2, false, true>(q.a[1], b - q.first[1], q.first[2] - q.first[1]);
+  else if (g == 2) gemm3_body<false, false, EPI_PARTIAL, 2, false, true>(q.a[2], b - q.first[2], q.first[3] - q.first[2]);
+  else if (g == 3) gemm3_body<false, false, EPI_PARTIAL, 2, false, true>(q.a[3], b - q.first[3], q.first[4] - q.first[3]);
+  else gemm3_body<false, false, EPI_PARTIAL, 2, false, true>(q.a[4], b - q.first[4], q.first[5] - q.first[4]);
 }

@@ -31,10 +31,11 @@
 #endif
 typedef unsigned int uf_u4 __attribute__((ext_vector_type(4)));
 
-size_t nq_updfuse_frag_floats(int F) { return F == UF_F ? (size_t)(2 * F * F + F * 2 * F + 3 * F * F) * 6 / 4 : 0; }   // three pieces of two bytes per weight
+size_t nq_updfuse_frag_floats(int F) { return F == UF_F ? 2 * (size_t)(2 * F * F + F * 2 * F + 3 * F * F) * 6 / 4 : 0; }   // three pieces of two bytes per weight, two fragment orders (A W^T of the forward / tangent sweeps, G W of the reverse sweep)
 
 // W [OUT][IN] (the product is A W^T) -> fragments [k16 step][column block of 32][piece][lane]: lane (n, kh) holds W[32 cb + n][16 ks + 8 kh + 0..7] as bf16
-struct UfSplitArgs { const float* W[3]; int OUT[3]; int IN[3]; uf_u4* out[3]; };
+// mc = 1: the reverse products G W (W [K][N] row-major): the same fragments with the roles of the two indices exchanged -- lane (n, kh) holds W[16 ks + 8 kh + 0..7][32 cb + n]
+struct UfSplitArgs { const float* W[3]; int OUT[3]; int IN[3]; uf_u4* out[3]; int mc; };
 __global__ __launch_bounds__(256) void k_uf_presplit(UfSplitArgs a) {
   int idx = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
@@ -42,8 +43,15 @@ __global__ __launch_bounds__(256) void k_uf_presplit(UfSplitArgs a) {
     const int OUT = a.OUT[mtx], IN = a.IN[mtx], ncb = OUT / 32, total = (IN / 16) * ncb * 64;
     if (idx < total) {
       const int lane = idx & 63, cb = (idx >> 6) % ncb, ks = (idx >> 6) / ncb;
-      const float* src = a.W[mtx] + (long)(cb * 32 + (lane & 31)) * IN + ks * 16 + (lane >> 5) * 8;
-      const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+      float4 x, y;
+      if (a.mc) {
+        const float* src = a.W[mtx] + (long)(ks * 16 + (lane >> 5) * 8) * OUT + cb * 32 + (lane & 31);
+        x = make_float4(src[0], src[OUT], src[2 * (long)OUT], src[3 * (long)OUT]);
+        y = make_float4(src[4 * (long)OUT], src[5 * (long)OUT], src[6 * (long)OUT], src[7 * (long)OUT]);
+      } else {
+        const float* src = a.W[mtx] + (long)(cb * 32 + (lane & 31)) * IN + ks * 16 + (lane >> 5) * 8;
+        x = *reinterpret_cast<const float4*>(src); y = *reinterpret_cast<const float4*>(src + 4);
+      }
       unsigned h[4], m[4], l[4];
       sp_split2(x.x, x.y, h[0], m[0], l[0]); sp_split2(x.z, x.w, h[1], m[1], l[1]);
       sp_split2(y.x, y.y, h[2], m[2], l[2]); sp_split2(y.z, y.w, h[3], m[3], l[3]);
@@ -361,15 +369,26 @@ __global__ __launch_bounds__(UF_NT, 2) void k_upd_fused(UpdFuseArgs q) {
   }
 }
 
+static size_t uf_set_u4(int F) { return (size_t)(2 * F * F + 2 * F * F + 3 * F * F) / 8 * 3; }   // uint4 fragments of one order
 int nq_updfuse_presplit(hipStream_t st, const float* U, const float* V1, const float* V2, int F, float* frag) {
   NQ_PROF(st, "upd_presplit");
   if (F != UF_F) return nq_fail(NQ_ERR_ARG, "fused update block: hidden_channels must be 128");
-  UfSplitArgs a;
   uf_u4* base = reinterpret_cast<uf_u4*>(frag);
+  const int total = (2 * F * F + 2 * F * F + 3 * F * F) / 8;   // one thread per fragment lane (8 weights)
+  UfSplitArgs a;
+  // forward order (A W^T, W [OUT][IN]): U [2F][F], V1 [F][2F], V2 [3F][F]
+  a.mc = 0;
   a.W[0] = U; a.OUT[0] = 2 * F; a.IN[0] = F; a.out[0] = base;
   a.W[1] = V1; a.OUT[1] = F; a.IN[1] = 2 * F; a.out[1] = base + (size_t)2 * F * F / 8 * 3;
   a.W[2] = V2; a.OUT[2] = 3 * F; a.IN[2] = F; a.out[2] = a.out[1] + (size_t)2 * F * F / 8 * 3;
-  const int total = (2 * F * F + 2 * F * F + 3 * F * F) / 8;   // one thread per fragment lane (8 weights)
+  hipLaunchKernelGGL(k_uf_presplit, dim3(nq_cdiv(total, 256)), dim3(256), 0, st, a);
+  NQ_LAUNCH_CHECK();
+  // reverse order (G W, W [K][N] row-major; "OUT" = N columns, "IN" = K): V2 [3F][F], V1 [F][2F], U [2F][F]
+  uf_u4* rbase = base + uf_set_u4(F);
+  a.mc = 1;
+  a.W[0] = V2; a.OUT[0] = F; a.IN[0] = 3 * F; a.out[0] = rbase;
+  a.W[1] = V1; a.OUT[1] = 2 * F; a.IN[1] = F; a.out[1] = rbase + (size_t)3 * F * F / 8 * 3;
+  a.W[2] = U; a.OUT[2] = F; a.IN[2] = 2 * F; a.out[2] = a.out[1] + (size_t)2 * F * F / 8 * 3;
   hipLaunchKernelGGL(k_uf_presplit, dim3(nq_cdiv(total, 256)), dim3(256), 0, st, a);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
@@ -396,6 +415,183 @@ int nq_upd_fused(hipStream_t st, const UpdArgs& u, const float* frag, const floa
     NQ_DYN_LDS(k_upd_fused<false>, UF_LDS);
     hipLaunchKernelGGL(k_upd_fused<false>, dim3(grid), dim3(UF_NT), UF_LDS, st, q);
   }
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
+// ---- force-adjoint sweep of the update block (painn.py:535-548 reversed; node.hip k_upd_rev1 / k_upd_rev2 and the three input-gradient products) ---------
+//   gy = (gx, gx s, <gvec, vec1>);  gq = (gy V2) silu'(zq);  gcat = gq V1;  gx <- gx + gcat[:F];  gn = gcat[F:] / n;
+//   gu[c] = (gvec[c] yc + gx yb vec2[c],  gn vec2[c] + gx yb vec1[c]);  gvec[c] <- gvec[c] + gu[c] U
+// The force sweep computes no weight gradients, so NONE of gy, gq, gcat, gu has another consumer: they live in registers / LDS only.  HBM traffic per layer:
+// 15 N F floats read (gx, gvec, s, u, yb, yc, n, zq) + 4 written, against 37 + 16 for the two elementwise kernels and three products of rounds 1-5.
+struct UpdRevFuseArgs {
+  int N;
+  float* GX; float* GV;                                          // adjoints of x_upd / vec_upd in, of x_msg / vec_msg out (in place)  [N][F], [N][3][F]
+  const float* S; const float* UU; const float* Y; const float* CAT; const float* ZQ;
+  const uf_u4* V2n; const uf_u4* V1n; const uf_u4* Un;           // weight fragments, reverse order
+};
+
+__global__ __launch_bounds__(UF_NT, 2) void k_updrev_fused(UpdRevFuseArgs q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int F = UF_F, F2 = 2 * UF_F, F3 = 3 * UF_F;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), lr = lane & 31, lk = lane >> 5;
+  const int a0 = blockIdx.x * UF_R, nrows = min(UF_R, q.N - a0);
+  const int f = 32 * w + lr;
+  auto atom_of = [&](int r) __attribute__((always_inline)) -> long { return a0 + min((r & 3) + 8 * (r >> 2) + 4 * lk, nrows - 1); };
+  (void)t;
+  // ---- gy -> LDS (K = 3F: parts a, b, c at k = f, F + f, 2F + f) ----
+  float zq[16];
+  {
+    float gx[16], sv[16], gyc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long atom = atom_of(r);
+      gx[r] = q.GX[atom * F + f]; sv[r] = q.S[atom * F + f];
+      const float* gv = q.GV + atom * F3 + f;
+      const float* up = q.UU + atom * 3 * F2 + f;
+      gyc[r] = gv[0] * up[0] + gv[F] * up[F2] + gv[F2] * up[2 * F2];
+      zq[r] = q.ZQ[atom * F + f];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      uf_put2(lds, UF_PB32, f, row, row + 1, gx[r], gx[r + 1]);
+      uf_put2(lds, UF_PB32, F + f, row, row + 1, gx[r] * sv[r], gx[r + 1] * sv[r + 1]);
+      uf_put2(lds, UF_PB32, F2 + f, row, row + 1, gyc[r], gyc[r + 1]);
+    }
+  }
+  // ---- product A: gq = (gy V2) silu'(zq), K = 3F ----
+  const uf_u4* wpa = q.V2n + (long)w * 3 * 64 + lane;   // ((ks * 4 + w) * 3 + piece) * 64 + lane
+  sp_bf8 fbr[4][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fbr[d][p] = uf_wfrag(wpa + ((d * 4) * 3 + p) * 64);
+  __syncthreads();
+  f32x16 aq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aq[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 24; ++ks) {
+    if (ks + 3 < 24) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fbr[(ks + 3) & 3][p] = uf_wfrag(wpa + (((ks + 3) * 4) * 3 + p) * 64);
+    }
+    sp_bf8 fa[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fa[p] = uf_frag(lds, (ks * 3 + p) * UF_PB32 + lr * 32 + lk * 16);
+    UF_TERMS(aq, fa, fbr[ks & 3])
+  }
+  // first fragments of product B (columns f and F + f of gcat)
+  const uf_u4* wpb = q.V1n + (long)w * 3 * 64 + lane;   // ((ks * 8 + 4 h + w) * 3 + piece) * 64 + lane
+  sp_bf8 fbb[2][2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fbb[0][h][p] = uf_wfrag(wpb + ((4 * h) * 3 + p) * 64);
+  __syncthreads();                   // every wavefront is done with the gy operand
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    uf_put2(lds, UF_PB32, f, row, row + 1, aq[r] * nq_dsilu_fast(zq[r]), aq[r + 1] * nq_dsilu_fast(zq[r + 1]));
+  }
+  __syncthreads();
+  // ---- product B: gcat = gq V1, K = F ----
+  f32x16 ac[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ac[h][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < 8) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fbb[cur ^ 1][h][p] = uf_wfrag(wpb + (((ks + 1) * 8 + 4 * h) * 3 + p) * 64);
+    }
+    sp_bf8 fa[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fa[p] = uf_frag(lds, (ks * 3 + p) * UF_PB32 + lr * 32 + lk * 16);
+    UF_TERMS(ac[0], fa, fbb[cur][0])
+    UF_TERMS(ac[1], fa, fbb[cur][1])
+  }
+  // ---- gx out; gs = gx yb, gn = gcat_n / n ----
+  float gs[16], gnn[16], yc[16];
+  {
+    float gx[16], yb[16], nn[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long atom = atom_of(r);
+      gx[r] = q.GX[atom * F + f]; yb[r] = q.Y[atom * F3 + F + f]; yc[r] = q.Y[atom * F3 + F2 + f]; nn[r] = q.CAT[atom * F2 + F + f];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gs[r] = gx[r] * yb[r];
+      gnn[r] = ac[1][r] / nn[r];
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < nrows) q.GX[(long)(a0 + row) * F + f] = gx[r] + ac[0][r];
+    }
+  }
+  // ---- per component: gu[c] -> LDS (K = 2F), gvec[c] += gu[c] U ----
+  const uf_u4* wpc = q.Un + (long)w * 3 * 64 + lane;    // ((ks * 4 + w) * 3 + piece) * 64 + lane
+#pragma nounroll   // (unrolled, the compiler requests the three components' vec1 / vec2 rows at once and spills)
+  for (int c = 0; c < 3; ++c) {
+    float gvc[16];
+    {
+      float va[16], vb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long atom = atom_of(r);
+        va[r] = q.UU[atom * 3 * F2 + c * F2 + f]; vb[r] = q.UU[atom * 3 * F2 + c * F2 + F + f]; gvc[r] = q.GV[atom * F3 + c * F + f];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fbr[d][p] = uf_wfrag(wpc + ((d * 4) * 3 + p) * 64);
+      __syncthreads();               // the previous operand (gq / gu of the component before) has been consumed
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        uf_put2(lds, UF_PB32, f, row, row + 1, gvc[r] * yc[r] + gs[r] * vb[r], gvc[r + 1] * yc[r + 1] + gs[r + 1] * vb[r + 1]);
+        uf_put2(lds, UF_PB32, F + f, row, row + 1, gnn[r] * vb[r] + gs[r] * va[r], gnn[r + 1] * vb[r + 1] + gs[r + 1] * va[r + 1]);
+      }
+    }
+    __syncthreads();
+    f32x16 av;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) av[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 3 < 16) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fbr[(ks + 3) & 3][p] = uf_wfrag(wpc + (((ks + 3) * 4) * 3 + p) * 64);
+      }
+      sp_bf8 fa[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[p] = uf_frag(lds, (ks * 3 + p) * UF_PB32 + lr * 32 + lk * 16);
+      UF_TERMS(av, fa, fbr[ks & 3])
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < nrows) q.GV[(long)(a0 + row) * F3 + c * F + f] = gvc[r] + av[r];
+    }
+  }
+}
+
+// force-adjoint sweep of the update block of one layer: u.GX / u.GV updated in place; frag = the layer's fragment block (nq_updfuse_presplit)
+int nq_updrev_fused(hipStream_t st, const UpdRevArgs& u, const float* frag, const float* ZQ) {
+  NQ_PROF(st, "updrev_fused");
+  if (u.F != UF_F) return nq_fail(NQ_ERR_ARG, "fused update block: hidden_channels must be 128");
+  const int F = u.F;
+  UpdRevFuseArgs q{};
+  q.N = u.N; q.GX = u.GX; q.GV = u.GV; q.S = u.S; q.UU = u.U; q.Y = u.Y; q.CAT = u.CAT; q.ZQ = ZQ;
+  const uf_u4* rbase = reinterpret_cast<const uf_u4*>(frag) + uf_set_u4(F);
+  q.V2n = rbase; q.V1n = rbase + (size_t)3 * F * F / 8 * 3; q.Un = q.V1n + (size_t)2 * F * F / 8 * 3;
+  NQ_DYN_LDS(k_updrev_fused, UF_LDS);
+  hipLaunchKernelGGL(k_updrev_fused, dim3(nq_cdiv(u.N, UF_R)), dim3(UF_NT), UF_LDS, st, q);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

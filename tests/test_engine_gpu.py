@@ -480,15 +480,17 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
         f.write(f"worst grad vs golden: {worst}\n")
 
 
-@pytest.mark.parametrize("mode", ["unfused", "fused_forward", "fused_forward_and_tangent"])
+@pytest.mark.parametrize("mode", ["unfused", "fused_forward", "fused_forward_and_tangent", "fused_forward_and_force_adjoint"])
 def test_update_block_flavours_agree_with_the_reference(mode, monkeypatch):
     """csrc/updfuse.hip: the update block of a layer as ONE kernel per sweep (hidden_channels = 128) against the five launches it replaces and against the
     reference golden vectors of the full configuration: energies, forces, loss and every parameter gradient within the bounds of
-    test_engine_matches_reference_golden, for the default (fused forward sweep), the opt-in fused tangent sweep and the unfused path; the fused
+    test_engine_matches_reference_golden, for the default (fused forward sweep), the opt-in fused tangent and force-adjoint sweeps and the unfused path; the fused
     kernels are seen by the profiler when and only when they are selected."""
     import nabladft_amd as nq
     from nabladft_amd import L2Loss
-    monkeypatch.delenv("NQ_NO_FUSED_UPDATE", raising=False); monkeypatch.delenv("NQ_FUSED_UPDATE_TAN", raising=False)
+    monkeypatch.delenv("NQ_NO_FUSED_UPDATE", raising=False); monkeypatch.delenv("NQ_FUSED_UPDATE_TAN", raising=False); monkeypatch.delenv("NQ_FUSED_UPDATE_REV", raising=False)
+    if mode == "fused_forward_and_force_adjoint":
+        monkeypatch.setenv("NQ_FUSED_UPDATE_REV", "1")
     if mode == "unfused":
         monkeypatch.setenv("NQ_NO_FUSED_UPDATE", "1")
     if mode == "fused_forward_and_tangent":
@@ -511,6 +513,7 @@ def test_update_block_flavours_agree_with_the_reference(mode, monkeypatch):
     names = _kernel_names_of(run)
     assert ("upd_fused" in names) == (mode != "unfused") and ("upd_fused_tan" in names) == (mode == "fused_forward_and_tangent"), names
     assert ("upd_a" in names) == (mode != "fused_forward_and_tangent"), names       # the tangent sweep of the default still runs the five launches
+    assert ("updrev_fused" in names) == (mode == "fused_forward_and_force_adjoint"), names
     assert_close(f"update block {mode} E", out["e"].cpu().numpy(), fx["energy"], 1e-5)
     assert_close(f"update block {mode} F", out["f"].cpu().numpy(), fx["forces"], 1e-5)
     assert abs(out["loss"] - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
