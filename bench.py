@@ -218,17 +218,17 @@ def _roofline_record(dom, avg_ms, launches, n_atoms, E, batch):
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms, "launches_per_step": launches}
     if dom == "gwr_mol":
         # rbf_proj gradient, molecule per workgroup (csrc/molpair.hip): reads the 20 node rows of the layer once (12 primal / tangent + 8 adjoint: 20 N F floats)
-        # and the per-pair records (64-float matrix-core A operand + 8-float geometry record per pair and 32-channel slice)
+        # and the per-pair records (two bf16 pieces of the matrix-core A operand = 256 B + 32 B of scalars per pair and 32-channel slice; L2 serves three of the four slices)
         nbytes = 20.0 * n_atoms * F * 4                                   # the contract figure: node rows only
-        design_bytes = nbytes + (E / 2.0) * (64 + 8) * 4 * (F // 32)      # + the kernel's own per-pair record streams
+        design_bytes = nbytes + (E / 2.0) * (256 + 32) * (F // 32)        # + the kernel's own per-pair record streams (before the L2 reuse across slices)
         ach = nbytes / (avg_ms * 1e-3) / 1e9
         traffic, tsrc = pmc_traffic_bytes("k_gwr_mol", batch)
         return {"kernel": "k_gwr_mol (+ k_gwr_mol_reduce)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": tsrc, "traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                 "algorithmic_bytes_per_launch": nbytes, "design_bytes_per_launch": design_bytes, "avg_launch_ms": avg_ms, "launches_per_step": launches,
-                "matrix_core_flops_per_launch": 2.0 * 32 * 32 * 2 * 3 * (E / 2.0) * (F // 32),
-                "note": "compute-bound on the SIMD shared by VALU and the f32 matrix-core path (profiles/r05_mfma_valu_overlap_lab.txt: the two do not overlap): "
-                        "per pair and 32-channel slice ~52 VALU instructions + 3 v_mfma_f32_32x32x2_f32"}
+                "matrix_core_flops_per_launch": 2.0 * 32 * 32 * 16 * 9 * (E / 2.0 / 8.0) * (F // 32),
+                "note": "bound by VALU issue and per-molecule latency (2 barriers + one exposed 100-kB row load per molecule), not by bytes: per pair and 32-channel slice "
+                        "~53 VALU instructions + 9/8 v_mfma_f32_32x32x16_bf16 (bf16 hi/lo split, 8 pairs per contraction: round 6; profiles/r06_gwr_mol_variants.txt)"}
     if dom == "gwr_sorted":
         flops = 2.0 * 26 * E * 3 * F          # 26 FMAs per (edge, column)
         ach = flops / (avg_ms * 1e-3) / 1e12

@@ -255,6 +255,18 @@ int nq_qh_invariants_backward(const float* x, const float* grad_s0, int64_t N, i
  * w1, w2 (nullable second factor, multiplied in-kernel): [R][nq_qh_tp_num_paths(path_set)][C] in e3nn instruction order.  y_rows [R][25][C].
  * Backward: grad_y rows are read at idx_gy[r] (NULL = r); per-row operand adjoints grad_x1_rows [R][ncomp1][C], grad_x2_rows [R][25][C]
  * (uuu only) are summed over each atom's rows by nq_qh_pair_reduce; grad_w1 / grad_w2 like w1 / w2. */
+/* 'uuu' forward with the two weight factors generated inside the kernel (csrc/qhgen.hip; layers.py:476-481: weight = fc_node_pair(edge_attr) * fc(s0)):
+ *   w1[r] = h1[r] W1 (* col_scale), w2[r] = h2[r] W2^T + bias2, h1 / h2 [R][K] the hidden activations of the two generators (K = 32 / 64 / 128).
+ * nq_qh_gen_presplit turns a generator's last weight matrix (layout 0: [K][65 C] as x @ W; 1: [65 C][K] as nn.Linear) into nq_qh_gen_fragment_floats(C, K)
+ * floats of bf16 matrix-instruction fragments, once per optimiser step.  The weight factors never exist in HBM; nq_qh_tp_backward_gen is the reverse sweep with the same
+ * in-kernel generation (it returns the adjoints of both factors, [R][65][C] each: the operands of the generators' own weight gradients). */
+size_t nq_qh_gen_fragment_floats(int32_t C, int32_t K);
+int nq_qh_gen_presplit(const float* W, const float* col_scale, int32_t K, int32_t C, int32_t layout, float* fragments, void* stream);
+int nq_qh_tp_forward_gen(const float* x, const int32_t* idx1, const int32_t* idx2, const float* h1, const float* h2, const float* frag1, const float* frag2,
+                         const float* bias2, int64_t R, int32_t C, int32_t K, float* y_rows, void* stream);
+int nq_qh_tp_backward_gen(const float* x, const int32_t* idx1, const int32_t* idx2, const float* h1, const float* h2, const float* frag1, const float* frag2,
+                          const float* bias2, const float* grad_y, int64_t R, int32_t C, int32_t K, float* grad_x1_rows, float* grad_x2_rows, float* grad_w1,
+                          float* grad_w2, void* stream);
 int nq_qh_tp_num_paths(int32_t path_set);
 void nq_qh_set_tp_variant(int32_t variant);   /* tuning hook (process-global): 0 per-path weight loads, 1 / 2 chunked prefetch with / without scheduling barriers */
 int nq_qh_tp_forward(const float* x, int32_t ncomp1, const int32_t* idx1, const float* sh, const int32_t* idx2, const float* w1, const float* w2, int64_t R,

@@ -83,6 +83,10 @@ SYMBOLS = {
     "nq_qh_invariants_forward": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _I32, _P, _P]),
     "nq_qh_invariants_backward": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P]),
     "nq_qh_tp_num_paths": (C.c_int, [_I32]),
+    "nq_qh_gen_fragment_floats": (C.c_size_t, [_I32, _I32]),
+    "nq_qh_gen_presplit": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
+    "nq_qh_tp_forward_gen": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "nq_qh_tp_backward_gen": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "nq_qh_set_tp_variant": (None, [_I32]),
     "nq_qh_tp_forward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "nq_qh_tp_backward": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnablaq.so")
-SOURCES = ["graph.hip", "gemm.hip", "gemm_bf16.hip", "edge.hip", "molpair.hip", "updfuse.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "qhnet.hip", "gemnet_graph.hip", "gemnet.hip", "escn.hip", "equiformer.hip", "geobasis.hip", "rccl.hip", "engine.hip"]
+SOURCES = ["graph.hip", "gemm.hip", "gemm_bf16.hip", "edge.hip", "molpair.hip", "updfuse.hip", "node.hip", "schnet.hip", "hblock.hip", "so3.hip", "qhnet.hip", "qhgen.hip", "gemnet_graph.hip", "gemnet.hip", "escn.hip", "equiformer.hip", "geobasis.hip", "rccl.hip", "engine.hip"]
 # molpair.hip: the SLP vectoriser packs neighbouring scalar f32 operations into v_pk_* beside the matrix instructions, which costs more than it saves there
 # (MI355X_MICROARCH.md, "packed f32 VALU beside MFMAs"; measured 6.51 -> 6.18 ms per step, profiles/r06_gwr_mol_variants.txt)
 EXTRA = {"molpair.hip": ["-fno-slp-vectorize"]}

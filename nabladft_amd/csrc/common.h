@@ -243,6 +243,7 @@ int nq_geom_tan(hipStream_t, const NqGraphView&, const int* dst, const float* po
 int nq_geom_rev(hipStream_t, const NqGraphView&, const float4* GEDGE, int nwaves, float* forces);
 
 // the whole update block of one layer and sweep as one kernel (updfuse.hip; hidden_channels = 128): weight fragments once per forward call, then one launch
+bool nq_gemm_exact_f32_requested();   // the exact-f32 engine was asked for (NQ_GEMM_F32=1 / nq_set_gemm_variant(32)): kernels that only exist on the bf16 matrix pipe step aside
 size_t nq_updfuse_frag_floats(int F);
 int nq_updfuse_presplit(hipStream_t, const float* U, const float* V1, const float* V2, int F, float* frag);
 int nq_upd_fused(hipStream_t, const UpdArgs&, const float* frag, const float* c1, const float* c2, float* ZQ, float* Q, float* TZQ, float* TQ, bool tan);

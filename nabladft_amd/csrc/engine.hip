@@ -209,7 +209,8 @@ static bool recall_molgw(const void* ws, GwMode* m) {
 // update block of a layer as one kernel per sweep (updfuse.hip): hidden_channels = 128; NQ_NO_FUSED_UPDATE=1 keeps the five launches of rounds 1-5 (A/B runs, tests)
 static bool use_fused_update(const nq_painn_cfg* c) {
   const char* off = getenv("NQ_NO_FUSED_UPDATE");
-  return nq_updfuse_frag_floats(c->hidden_channels) > 0 && !(off && off[0] == '1');
+  // (the fused kernel's products exist on the split-bf16 matrix pipe only: a run that asks for the exact-f32 engine gets the five launches)
+  return nq_updfuse_frag_floats(c->hidden_channels) > 0 && !(off && off[0] == '1') && !nq_gemm_exact_f32_requested();
 }
 
 // The five weight-gradient products of one layer's dual-reverse sweep as ONE grouped launch (gemm.hip: nq_gemm_tn_group): built, parity-tested,

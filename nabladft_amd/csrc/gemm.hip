@@ -409,6 +409,7 @@ static bool gemm3_disabled() {
   static const int env = [] { const char* e = getenv("NQ_GEMM_F32"); return (e && e[0] && e[0] != '0') ? 1 : 0; }();
   return env || (g_gemm_variant & 32);
 }
+bool nq_gemm_exact_f32_requested() { return gemm3_disabled(); }   // NQ_GEMM_F32=1 / nq_set_gemm_variant(32): every product on the exact-f32 instruction
 template <bool A_KC, bool B_KC>
 static bool gemm3_ok(const GemmArgs& p, long kspan, int splits) {
   if (gemm3_disabled() || !gemm2_ok<A_KC, B_KC>(p, kspan)) return false;

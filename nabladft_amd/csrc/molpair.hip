@@ -23,9 +23,8 @@
 //   * per-pair scalars (geometry, tangents, atom indices) arrive as ONE coalesced dword load per batch (lane 8 i + f = field f of pair i) and are
 //     broadcast with v_readlane (static lane index): no LDS ring, no scalar-memory latency; the A operands as two 16-byte loads per lane and batch;
 //     both requested two batches ahead (three static register sets);
-//   * the rows of the NEXT molecule of the workgroup are requested into registers before the pair loop (GM_PF of the five row blocks) and written to LDS
-//     behind the barrier that ends the loop: the staging latency (round 5: ~25 % of the kernel, one workgroup per CU because of the LDS footprint) hides
-//     behind the pair arithmetic;
+//   * the rows of the NEXT molecule of the workgroup are requested into registers right after a wavefront's last pair (the pair loop's registers are free
+//     again) and written to LDS behind the barrier that ends the molecule: their latency overlaps the wait for the slowest wavefront;
 //   * the pair lists per (molecule, wavefront) are built once per step (the windows depend on the geometry only), sorted by window start, slot-ascending,
 //     padded to whole batches, so the summation order is fixed: results are bitwise reproducible;
 //   * per-workgroup partial rows (one flush per launch) are summed in workgroup order by k_gwr_mol_reduce.
@@ -217,13 +216,13 @@ __global__ __launch_bounds__(64) void k_pair_sched(NqGraphView g, const int* __r
 // written once per backward sweep (TD set).
 __global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sched, const int2* __restrict__ seg, const float* __restrict__ RW,
                                                     const float* __restrict__ TD, int nseg, u4* __restrict__ PA) {
-  // one wavefront per (molecule, wavefront-of-k_gwr_mol) segment, looping over its batches
-  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // four wavefronts per (molecule, wavefront-of-k_gwr_mol) segment, each taking every fourth batch (a segment has ~7: the loop is a chain of dependent gathers)
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), sg = wid >> 2, lane = threadIdx.x & 63;
   if (sg >= nseg) return;
   const int2 se = seg[sg];
   const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, j = lane & 31, half = lane >> 5;
   if ((half == 1) != (TD != nullptr)) return;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = wid & 3; b < nb; b += 4) {
     const long batch = se.x + b;
     float v[GM_BATCH];
 #pragma unroll
@@ -246,11 +245,11 @@ __global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sche
 // {gx, gy, gz, 0, t_r0, t_r1, t_r2, n << 16 | k}; padding pairs: zeros (atom 0 with itself; their A operands are zero).
 __global__ __launch_bounds__(256) void k_pair_grec(const int2* __restrict__ sched, const int2* __restrict__ seg, const float4* __restrict__ geom,
                                                     const float* __restrict__ TR, int nseg, float* __restrict__ PG) {
-  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), sg = wid >> 2, lane = threadIdx.x & 63;
   if (sg >= nseg) return;
   const int2 se = seg[sg];
   const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, i = lane >> 3, f = lane & 7;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = wid & 3; b < nb; b += 4) {
     const long batch = se.x + b;
     const int2 en = sched[batch * GM_BATCH + i];
     float v = 0.f;
@@ -580,7 +579,7 @@ int nq_molgw_schedule(hipStream_t st, const NqGraphView& g, const int* dst, cons
   hipLaunchKernelGGL(k_pair_sched, dim3(g.B), dim3(64), 0, st, g, dst, RW, b.wlo, cap < GM_MAX_ATOMS ? cap : GM_MAX_ATOMS, b.sched, b.sched_ptr, b.seg);
   NQ_LAUNCH_CHECK();
   const int nseg = g.B * GM_NW;
-  hipLaunchKernelGGL(k_pair_arec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, RW, (const float*)nullptr, nseg, reinterpret_cast<u4*>(recs));   // rho half
+  hipLaunchKernelGGL(k_pair_arec, dim3(nseg), dim3(256), 0, st, b.sched, b.seg, RW, (const float*)nullptr, nseg, reinterpret_cast<u4*>(recs));   // rho half
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -590,9 +589,9 @@ int nq_molgw_geometry(hipStream_t st, const NqGraphView& g, const float* RW, con
   const MolGwBufs b = molgw_bufs(const_cast<int*>(sched_ints), g.E, g.B);
   float* PG = recs + gm_max_batches(g.E, g.B) * GM_PA_DWORDS;
   const int nseg = g.B * GM_NW;
-  hipLaunchKernelGGL(k_pair_grec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, g.geom, TR, nseg, PG);
+  hipLaunchKernelGGL(k_pair_grec, dim3(nseg), dim3(256), 0, st, b.sched, b.seg, g.geom, TR, nseg, PG);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_pair_arec, dim3(nq_cdiv(nseg, 4)), dim3(256), 0, st, b.sched, b.seg, RW, TD, nseg, reinterpret_cast<u4*>(recs));   // t_d drho half
+  hipLaunchKernelGGL(k_pair_arec, dim3(nseg), dim3(256), 0, st, b.sched, b.seg, RW, TD, nseg, reinterpret_cast<u4*>(recs));   // t_d drho half
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

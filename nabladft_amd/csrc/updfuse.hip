@@ -35,16 +35,17 @@ size_t nq_updfuse_frag_floats(int F) { return F == UF_F ? 2 * (size_t)(2 * F * F
 
 // W [OUT][IN] (the product is A W^T) -> fragments [k16 step][column block of 32][piece][lane]: lane (n, kh) holds W[32 cb + n][16 ks + 8 kh + 0..7] as bf16
 // mc = 1: the reverse products G W (W [K][N] row-major): the same fragments with the roles of the two indices exchanged -- lane (n, kh) holds W[16 ks + 8 kh + 0..7][32 cb + n]
-struct UfSplitArgs { const float* W[3]; int OUT[3]; int IN[3]; uf_u4* out[3]; int mc; };
+struct UfSplitArgs { const float* W[6]; int OUT[6]; int IN[6]; uf_u4* out[6]; };   // matrices 0-2: forward order, 3-5: reverse order (mc)
 __global__ __launch_bounds__(256) void k_uf_presplit(UfSplitArgs a) {
   int idx = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
-  for (int mtx = 0; mtx < 3; ++mtx) {
+  for (int mtx = 0; mtx < 6; ++mtx) {
+    const bool mc = mtx >= 3;
     const int OUT = a.OUT[mtx], IN = a.IN[mtx], ncb = OUT / 32, total = (IN / 16) * ncb * 64;
     if (idx < total) {
       const int lane = idx & 63, cb = (idx >> 6) % ncb, ks = (idx >> 6) / ncb;
       float4 x, y;
-      if (a.mc) {
+      if (mc) {
         const float* src = a.W[mtx] + (long)(ks * 16 + (lane >> 5) * 8) * OUT + cb * 32 + (lane & 31);
         x = make_float4(src[0], src[OUT], src[2 * (long)OUT], src[3 * (long)OUT]);
         y = make_float4(src[4 * (long)OUT], src[5 * (long)OUT], src[6 * (long)OUT], src[7 * (long)OUT]);
@@ -377,19 +378,15 @@ int nq_updfuse_presplit(hipStream_t st, const float* U, const float* V1, const f
   const int total = (2 * F * F + 2 * F * F + 3 * F * F) / 8;   // one thread per fragment lane (8 weights)
   UfSplitArgs a;
   // forward order (A W^T, W [OUT][IN]): U [2F][F], V1 [F][2F], V2 [3F][F]
-  a.mc = 0;
   a.W[0] = U; a.OUT[0] = 2 * F; a.IN[0] = F; a.out[0] = base;
   a.W[1] = V1; a.OUT[1] = F; a.IN[1] = 2 * F; a.out[1] = base + (size_t)2 * F * F / 8 * 3;
   a.W[2] = V2; a.OUT[2] = 3 * F; a.IN[2] = F; a.out[2] = a.out[1] + (size_t)2 * F * F / 8 * 3;
-  hipLaunchKernelGGL(k_uf_presplit, dim3(nq_cdiv(total, 256)), dim3(256), 0, st, a);
-  NQ_LAUNCH_CHECK();
   // reverse order (G W, W [K][N] row-major; "OUT" = N columns, "IN" = K): V2 [3F][F], V1 [F][2F], U [2F][F]
   uf_u4* rbase = base + uf_set_u4(F);
-  a.mc = 1;
-  a.W[0] = V2; a.OUT[0] = F; a.IN[0] = 3 * F; a.out[0] = rbase;
-  a.W[1] = V1; a.OUT[1] = 2 * F; a.IN[1] = F; a.out[1] = rbase + (size_t)3 * F * F / 8 * 3;
-  a.W[2] = U; a.OUT[2] = F; a.IN[2] = 2 * F; a.out[2] = a.out[1] + (size_t)2 * F * F / 8 * 3;
-  hipLaunchKernelGGL(k_uf_presplit, dim3(nq_cdiv(total, 256)), dim3(256), 0, st, a);
+  a.W[3] = V2; a.OUT[3] = F; a.IN[3] = 3 * F; a.out[3] = rbase;
+  a.W[4] = V1; a.OUT[4] = 2 * F; a.IN[4] = F; a.out[4] = rbase + (size_t)3 * F * F / 8 * 3;
+  a.W[5] = U; a.OUT[5] = F; a.IN[5] = 2 * F; a.out[5] = a.out[4] + (size_t)2 * F * F / 8 * 3;
+  hipLaunchKernelGGL(k_uf_presplit, dim3(nq_cdiv(2 * total, 256)), dim3(256), 0, st, a);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -24,6 +24,7 @@ of the node features as even irreps (qhnet.py:56-58).
 import ctypes as C
 import copy
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -293,6 +294,69 @@ class _PairMixFn(torch.autograd.Function):
         return gx, gw1, gw2, None
 
 
+PAIR_GENERATOR_FUSION = os.environ.get("NQ_QH_GEN", "0") == "1"
+
+
+def set_pair_generator_fusion(on: bool):
+    """PairNetLayer: generate the per-pair path weights inside the forward tensor-product kernel (csrc/qhgen.hip) instead of materialising the two
+    [pairs, 65 * C] factors.  Default per the measurement in profiles/r06_qhnet_generator_fusion.txt."""
+    global PAIR_GENERATOR_FUSION
+    PAIR_GENERATOR_FUSION = bool(on)
+
+
+class _PairMixGenFn(torch.autograd.Function):
+    """PairNetLayer.tp_node_pair with weight = (h1 @ W1) * (h2 @ W2^T + b2) generated in the kernel (layers.py:476-481), forward and reverse: the two
+    [pairs, 65 C] factors never exist; their adjoints do (they are the operands of the generators' weight-gradient and input-gradient products)."""
+
+    @staticmethod
+    def forward(ctx, x, h1, W1, h2, W2, b2, csr):
+        lib = _lib.load()
+        x, h1, W1, h2, W2, b2 = _f32(x), _f32(h1), _f32(W1), _f32(h2), _f32(W2), _f32(b2)
+        N, _, Cc = x.shape
+        K = h1.shape[1]
+        assert h2.shape[1] == K and W1.shape == (K, W2.shape[0]) and W2.shape[1] == K
+        nfl = int(lib.nq_qh_gen_fragment_floats(Cc, K))
+        frag = torch.empty(2 * nfl, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_qh_gen_presplit(_lib.ptr(W1), None, K, Cc, 0, _lib.ptr(frag), _lib.stream_ptr()))
+        _lib.check(lib.nq_qh_gen_presplit(_lib.ptr(W2), None, K, Cc, 1, _lib.ptr(frag[nfl:]), _lib.stream_ptr()))
+        y = torch.empty(csr.R, NCOMP, Cc, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_qh_tp_forward_gen(_lib.ptr(x), _lib.ptr(csr.own), _lib.ptr(csr.col), _lib.ptr(h1), _lib.ptr(h2), _lib.ptr(frag), _lib.ptr(frag[nfl:]),
+                                            _lib.ptr(b2), csr.R, Cc, K, _lib.ptr(y), _lib.stream_ptr()))
+        ctx.save_for_backward(x, h1, W1, h2, W2, b2, frag)
+        ctx.csr = csr
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, h1, W1, h2, W2, b2, frag = ctx.saved_tensors
+        csr = ctx.csr
+        N, _, Cc = x.shape
+        R, K, ncol = csr.R, h1.shape[1], W1.shape[1]
+        nfl = frag.numel() // 2
+        g = _f32(g)
+        g1 = torch.empty(R, NCOMP, Cc, device=x.device, dtype=torch.float32)
+        g2 = torch.empty_like(g1)
+        gw1 = torch.empty(R, ncol, device=x.device, dtype=torch.float32)
+        gw2 = torch.empty_like(gw1)
+        _lib.check(lib.nq_qh_tp_backward_gen(_lib.ptr(x), _lib.ptr(csr.own), _lib.ptr(csr.col), _lib.ptr(h1), _lib.ptr(h2), _lib.ptr(frag), _lib.ptr(frag[nfl:]), _lib.ptr(b2),
+                                             _lib.ptr(g), R, Cc, K, _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(gw1), _lib.ptr(gw2), _lib.stream_ptr()))
+        gx = torch.empty_like(x)
+        _lib.check(lib.nq_qh_pair_reduce(_lib.ptr(g1), _lib.ptr(g2), None, _lib.ptr(csr.row_ptr), _lib.ptr(csr.rev), N, NCOMP * Cc, _lib.ptr(gx), _lib.stream_ptr()))
+        # the generators' own adjoints: w1 = h1 @ W1 (as _MatmulFn), w2 = h2 @ W2^T + b2 (as _LinearBiasFn)
+        gh1 = torch.empty_like(h1)
+        _lib.check(lib.nq_linear_forward(_lib.ptr(gw1), _lib.ptr(W1), None, _lib.ptr(gh1), None, R, K, ncol, _lib.stream_ptr()))
+        gW1 = torch.empty_like(W1)
+        scr = torch.empty(int(max(lib.nq_weight_grad_scratch_floats(R, K, ncol), lib.nq_weight_grad_scratch_floats(R, ncol, K))) + 64, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_linear_weight_grad(_lib.ptr(h1), _lib.ptr(gw1), _lib.ptr(gW1), R, K, ncol, _lib.ptr(scr), _lib.stream_ptr()))
+        gh2 = torch.empty_like(h2)
+        _lib.check(lib.nq_linear_input_grad(_lib.ptr(gw2), _lib.ptr(W2), _lib.ptr(gh2), R, ncol, K, 0, _lib.stream_ptr()))
+        gW2 = torch.empty_like(W2)
+        gb2 = torch.empty(ncol, device=x.device, dtype=torch.float32)
+        _lib.check(lib.nq_linear_weight_grad_bias(_lib.ptr(gw2), _lib.ptr(h2), _lib.ptr(gW2), _lib.ptr(gb2), R, ncol, K, _lib.ptr(scr), _lib.stream_ptr()))
+        return gx, gh1, gW1, gh2, gW2, gb2, None
+
+
 class _PairGatherAddFn(torch.autograd.Function):
     """out[r] = a[dst(r)] + b[src(r)] over the pair list; the reverse sums over each atom's own row / reverse slots (fixed order, no atomics)."""
 
@@ -484,6 +548,12 @@ class FullyConnectedNet(nn.Module):
         self._cs, self._cs_key = None, None
 
     def forward(self, x, col_scale=None):
+        h, W1 = self.hidden_and_weight(x, col_scale)
+        return _MatmulFn.apply(h, W1)
+
+    def hidden_and_weight(self, x, col_scale=None):
+        """(h, W1) with forward(x) = h @ W1: the hidden activations [rows, h1] and the effective last weight matrix [h1, h2] (path constants and
+        1 / sqrt(h1) folded in) -- what the generator-fused tensor product (csrc/qhgen.hip) takes instead of the materialised product."""
         h = _MatmulFn.apply(x, self.layer0.weight * (1.0 / math.sqrt(self.hs[0])))
         h = _ActFn.apply(h, self.kind, self.cst)
         c1 = 1.0 / math.sqrt(self.hs[1])
@@ -498,7 +568,7 @@ class FullyConnectedNet(nn.Module):
             W1 = self.layer1.weight * self._cs
         else:
             W1 = self.layer1.weight * c1
-        return _MatmulFn.apply(h, W1)
+        return h, W1
 
 
 def _mlp(seq: nn.Sequential, x):
@@ -616,9 +686,14 @@ class PairNetLayer(nn.Module):
         a0 = self.linear_node_pair_inner(node_attr)
         s0 = _InvFn.apply(a0, g.full, True)
         xn = self.linear_node_pair_n(self.norm_gate_pre(node_attr))
-        w1 = self.fc_node_pair(g.full_edge_attr, self._pc)
-        w2 = _mlp(self.fc, s0)
-        node_pair = _PairMixFn.apply(xn, w1, w2, g.full)
+        if PAIR_GENERATOR_FUSION and self.c % 16 == 0 and self.fc_node_pair.hs[1] == self.fc[0].out_features and self.fc[0].out_features in (32, 64, 128):
+            h1, W1 = self.fc_node_pair.hidden_and_weight(g.full_edge_attr, self._pc)
+            h2 = _LinearBiasFn.apply(s0, self.fc[0].weight, self.fc[0].bias, True)
+            node_pair = _PairMixGenFn.apply(xn, h1, W1, h2, self.fc[2].weight, self.fc[2].bias, g.full)
+        else:
+            w1 = self.fc_node_pair(g.full_edge_attr, self._pc)
+            w2 = _mlp(self.fc, s0)
+            node_pair = _PairMixFn.apply(xn, w1, w2, g.full)
         node_pair = self.linear_node_pair(self.norm_gate(node_pair))
         if self.resnet and node_pair_attr is not None:
             node_pair = node_pair + node_pair_attr

@@ -6,7 +6,7 @@
 #         bench[:<extra bench.py args>]    default driver command -> bench_default.json, full record, kernel events
 #         benchq                           bench.py --model qhnet
 #         full                             bench.py --full
-#         variants[:<bench args>]          every nabladft_amd/_variants/libnablaq_*.so next to the shipped library (scripts/variants_r05.sh build ...)
+#         variants[:<bench args>]          every nabladft_amd/_variants/libnablaq_*.so next to the shipped library (scripts/variants.sh build ...)
 #         prof:<name>:<command...>         rocprofv3 --kernel-trace --stats of a command -> <name>_kernel_stats.csv
 #         pmc:<B>:<command...>             FETCH_SIZE / WRITE_SIZE passes (separate runs) -> pmc_traffic_<B>.json
 #         sq:<B>:<kernel filter>           three SQ counter passes (wave cycles / waits, instruction counts, LDS + matrix-core busy) of bench.py at batch B -> pmc_sq_<filter>.txt
