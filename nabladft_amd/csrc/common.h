@@ -183,15 +183,17 @@ int nq_graph_count_impl(const float* pos, const int* mol_ptr, int N, int B, int 
                         int* row_ptr, int* lowptr, int* E_host, hipStream_t st);
 int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t st);
 
+// Bpre (optional): the weight pre-split into bf16 planes by nq_gemm_presplit_kn (same values as W): the split engine then loads it with 16-byte loads, no split arithmetic
 int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode,
-                   const char* tag = nullptr);
+                   const char* tag = nullptr, const void* Bpre = nullptr);
+int nq_gemm_presplit_kn(hipStream_t st, int n, const float* const* W, const int* Kc, const int* N, void* const* out);
 int nq_gemm_nt_dsilu(hipStream_t st, const float* A, const float* W, float* C, float* C2, const float* aux, int M, int N, int K, const char* tag = nullptr);
 int nq_gemm_nt_act(hipStream_t, const float* A, const float* W, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
                    const char* tag = nullptr);
 int nq_gemm_nt(hipStream_t, const float* A, const float* W, float* C, const float* bias, float* C2_silu, int M, int N, int K, int lda,
                int ldw, int ldc, const char* tag = nullptr);
 int nq_gemm_nn(hipStream_t, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc, int accumulate,
-               const char* tag = nullptr);
+               const char* tag = nullptr, const void* Bpre = nullptr);
 int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, const float* aux, float ea, int M, int N, int K);
 size_t nq_gemm_tn_scratch_floats(long rows, int Mo, int No);
 int nq_gemm_tn(hipStream_t, const float* GY, const float* X, float* out, long rows, int Mo, int No, int ldg, int ldx, float* scratch,

@@ -104,6 +104,7 @@ struct WsLayer {
   size_t Z1, Hh, XH, PHI, PSI, XM, VM, UU, S, CAT, ZQ, Q, Y;  // float offsets; dual buffers hold [2][rows][w]
   size_t WRT;                                                  // [R][3F] transposed rbf_proj.weight
   size_t UFRAG;                                                // bf16 fragments of the update block's weights (updfuse.hip), rebuilt by every forward call
+  size_t WPRE;                                                 // bf16 planes of V2, V1, U, W2, W1 for the input-gradient products (gemm_split.h PreStageB), rebuilt by every forward call
 };
 struct WsLayout {
   size_t X[65], V[65];
@@ -135,6 +136,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     y.XM = take(2 * N * F); y.VM = take(2 * N * 3 * F); y.UU = take(2 * N * 6 * F);
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
     y.UFRAG = take(nq_updfuse_frag_floats((int)F));
+    y.WPRE = take(11 * F * F * 6 / 4);
   }
   W->RHO2 = take(2 * EP * R);   // full rho / drho rows only for the materialised-filter path (B operand of the gWr contraction)
   W->ORDER = take(W->fused ? E : 0);   // int32: CSR slots sorted by window start k0
@@ -228,6 +230,24 @@ static void tn_group_shapes(NqTnSpec (&sp)[5], long N, int F) {   // rows / outp
   sp[2] = NqTnSpec{nullptr, nullptr, nullptr, 6 * N, F2, F, F2, F, nullptr, 0};                        // U:  gu^T vec_msg
   sp[3] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F3, F, F3, F, reinterpret_cast<float*>(1), N};    // W2: gxh^T h (+ b2)
   sp[4] = NqTnSpec{nullptr, nullptr, nullptr, 2 * N, F, F, F, F, reinterpret_cast<float*>(1), N};      // W1: gh^T x (+ b1)
+}
+
+// Weights pre-split into bf16 planes once per step for the input-gradient products of both reverse sweeps: they load their weight tile with
+// three 16-byte loads per thread instead of eight 4-byte loads + the split arithmetic.  Measured SLOWER at 2048 conformers (49.53 / 49.56 ms per step against
+// 48.81 / 48.95 ms, same box, profiles/r06_presplit_nn_ab.txt: the planes are 6 bytes per element against 4 and one epilogue flavour spills), so it is opt-in:
+// NQ_PRESPLIT=1, hidden_channels % 128 == 0, never under the exact-f32 engine.
+struct PrePlanes { const void* V2; const void* V1; const void* U; const void* W2; const void* W1; };
+static bool use_presplit(const nq_painn_cfg* c) {
+  const char* on = getenv("NQ_PRESPLIT");
+  return c->hidden_channels % 128 == 0 && on && on[0] == '1' && !nq_gemm_exact_f32_requested();
+}
+static PrePlanes pre_planes(const nq_painn_cfg* c, float* base) {
+  PrePlanes q{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!use_presplit(c)) return q;
+  const size_t F = c->hidden_channels, FF = F * F;
+  unsigned short* b = reinterpret_cast<unsigned short*>(base);
+  q.V2 = b; q.V1 = b + 3 * 3 * FF; q.U = b + 3 * 5 * FF; q.W2 = b + 3 * 7 * FF; q.W1 = b + 3 * 10 * FF;
+  return q;
 }
 
 static NqGraphView view_of(const nq_graph* g) {
@@ -430,6 +450,13 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   const bool fused_upd = use_fused_update(cfg);
   for (int l = 0; l < L; ++l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    if (use_presplit(cfg)) {
+      const PrePlanes pp = pre_planes(cfg, ws + y.WPRE);
+      const float* Wm[5] = {params + up.V2, params + up.V1, params + up.U, params + mp.W2, params + mp.W1};
+      const int Kc[5] = {3 * F, F, 2 * F, 3 * F, F}, Nc[5] = {F, 2 * F, F, F, F};
+      void* outp[5] = {const_cast<void*>(pp.V2), const_cast<void*>(pp.V1), const_cast<void*>(pp.U), const_cast<void*>(pp.W2), const_cast<void*>(pp.W1)};
+      NQ_TRY(nq_gemm_presplit_kn(st, 5, Wm, Kc, Nc, outp));
+    }
     NQ_TRY(nq_gemm_nt(st, ws + W.X[l], params + mp.W1, ws + y.Z1, params + mp.b1, ws + y.Hh, N, F, F, F, F, F, "W1"));
     NQ_TRY(nq_gemm_nt(st, ws + y.Hh, params + mp.W2, ws + y.XH, params + mp.b2, nullptr, N, 3 * F, F, F, F, 3 * F, "W2"));
     MsgArgs m{};
@@ -478,6 +505,7 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_HIP(hipMemsetAsync(ws + W.GEDGE, 0, (size_t)nwaves * E * 4 * sizeof(float), st));
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    const PrePlanes pp = pre_planes(cfg, ws + y.WPRE);
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
@@ -488,10 +516,10 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     } else {
     NQ_TRY(nq_upd_rev(st, u, 1, false));
     // G_Q = (G_Y V2) * silu'(Z_Q): the activation's adjoint in the epilogue of the input-gradient product (no separate k_silu_rev pass)
-    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2"));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
+    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2", pp.V2));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
     }
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
@@ -505,8 +533,8 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
       NQ_TRY(nq_msg_rev(st, m, false));
     }
     { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2"));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1, "W1"));
+    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2", pp.W2));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1, "W1", pp.W1));
   }
   NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
   return NQ_OK;
@@ -687,6 +715,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   if (mixed) NQ_HIP(hipMemsetAsync(ws + W.GBR, 0, 3 * NF * sizeof(float), st));   // only the rows of the large molecules are written below; the column sum runs over all atoms
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
+    const PrePlanes pp = pre_planes(cfg, ws + y.WPRE);
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF; u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF;
@@ -701,14 +730,14 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     ss.read_by_side(SB_GY);
     }
     ss.before_main_writes(SB_GQ);
-    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2", pp.V2));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
     if (!tn_group) {
     sd = ss.fork();
     NQ_TRY(nq_gemm_tn(sd, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
     ss.read_by_side(SB_GQ);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     ss.before_main_writes(SB_GU);
     NQ_TRY(nq_upd_rev(st, u, 2, true));
     if (!tn_group) {
@@ -716,7 +745,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     NQ_TRY(nq_gemm_tn(sd, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
     ss.read_by_side(SB_GU);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
@@ -755,7 +784,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (!tn_group) NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); if (!tn_group) ss.read_by_side(SB_GXH);
     ss.before_main_writes(SB_GH);
-    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2", pp.W2));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
     sd = ss.fork();
     if (!tn_group) {
@@ -780,7 +809,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       }
       ss.read_by_side(SB_GY); ss.read_by_side(SB_GQ); ss.read_by_side(SB_GU); ss.read_by_side(SB_GXH); ss.read_by_side(SB_GH);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1"));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1", pp.W1));
     // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final once the weight-gradient stream gets here: the caller's
     // collective stream may start reducing it
     if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], ss.on ? ss.side : st));

@@ -430,6 +430,9 @@ static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
     const dim3 gt((unsigned)(tiles < 256 * WT ? tiles : 256 * WT));
     hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WT, true>), gt, dim3(256), 0, st, p);
   } else {
+    if constexpr (A_KC && !B_KC) {   // input-gradient layout: the weight operand may come pre-split (GemmArgs::Bpre)
+      if (p.Bpre) { hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false, false, 6, 0, false, true>), grid, dim3(256), 0, st, p); return NQ_OK; }
+    }
     hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false>), grid, dim3(256), 0, st, p);
   }
   return NQ_OK;
@@ -685,15 +688,16 @@ int nq_gemm_nt_res(hipStream_t st, const float* A, const float* W, float* C, con
 
 // C[M, Kin] (+)= G[M, Nout] * W[Nout, Kin]
 int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, int ldg, int ldw, int ldc,
-               int accumulate, const char* tag) {
+               int accumulate, const char* tag, const void* Bpre) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, ldg, ldw, ldc, 0, 0, nullptr, 0};
+  if (Bpre && !(Kin & 127) && !(Nout & 15) && ldw == Kin) { p.Bpre = Bpre; p.ldbpre = Nout; p.bpre_plane_bytes = Kin * Nout * 2; }
   {
     int rc;
-    if (try_splitk<true, false>(st, p, nullptr, accumulate, rc)) { NQ_TRY(rc); NQ_LAUNCH_CHECK(); return NQ_OK; }
+    if (!p.Bpre && try_splitk<true, false>(st, p, nullptr, accumulate, rc)) { NQ_TRY(rc); NQ_LAUNCH_CHECK(); return NQ_OK; }
   }
   if (gemm3_ok<true, false>(p, Nout, 1)) {
     if (accumulate) NQ_TRY((launch_gemm3<true, false, EPI_ACC>(st, p, 1)));
@@ -722,13 +726,15 @@ int nq_gemm_nn(hipStream_t st, const float* G, const float* W, float* C, int M, 
 }
 
 // C[M, Kin] = epilogue(G[M, Nout] * W[Nout, Kin]): mode 1: eb * v * silu'(aux), mode 2: ea * aux + v   (aux [M, Kin])
-int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode, const char* tag) {
+int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode, const char* tag,
+                   const void* Bpre) {
   char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
   NQ_PROF(st, nm__);
   NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
   if (M <= 0) return NQ_OK;
   GemmArgs p{G, W, C, nullptr, nullptr, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
   p.resid = aux; p.ea = ea; p.eb = eb;
+  if (Bpre && !(Kin & 127) && !(Nout & 15)) { p.Bpre = Bpre; p.ldbpre = Nout; p.bpre_plane_bytes = Kin * Nout * 2; }
   if (gemm3_ok<true, false>(p, Nout, 1)) {
     if (mode == 1) NQ_TRY((launch_gemm3<true, false, EPI_DSILU>(st, p, 1)));
     else NQ_TRY((launch_gemm3<true, false, EPI_RES>(st, p, 1)));
@@ -811,6 +817,52 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
     hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Mo, 64)), dim3(64), 0, st, bpart, nse, (long)Mo, (long)Mo, bias_out);
     NQ_LAUNCH_CHECK();
   }
+  return NQ_OK;
+}
+
+// ---- weights pre-split for the input-gradient products (GemmArgs::Bpre) -----------------------------------------------------------------------
+// W [Kc][N] row-major (Kc = the contracted index of C = G W) -> planes [piece][N][Kc] bf16, Kc-contiguous: what PreStageB (gemm_split.h) loads
+struct PresplitArgs { const float* W[5]; int Kc[5]; int N[5]; unsigned short* out[5]; int first[6]; int n; };
+__global__ __launch_bounds__(256) void k_presplit_kn(PresplitArgs a) {
+  const int b = (int)blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < 5; ++i) g += (i < a.n && b >= a.first[i]) ? 1 : 0;
+  const float* W = nullptr; int Kc = 0, N = 0, first = 0; unsigned short* out = nullptr;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (g == i) { W = a.W[i]; Kc = a.Kc[i]; N = a.N[i]; out = a.out[i]; first = a.first[i]; }
+  const long idx = (long)(b - first) * 256 + threadIdx.x;     // (n, k octet), n fastest: coalesced reads of W rows
+  const int n = (int)(idx % N), oct = (int)(idx / N);
+  if (oct >= Kc / 8) return;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = W[(long)(oct * 8 + i) * N + n];
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sp_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  const long plane = (long)N * Kc;
+  gemm_u32x4* o = reinterpret_cast<gemm_u32x4*>(out + (long)n * Kc + oct * 8);
+  *o = gemm_u32x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<gemm_u32x4*>(out + plane + (long)n * Kc + oct * 8) = gemm_u32x4{m[0], m[1], m[2], m[3]};
+  *reinterpret_cast<gemm_u32x4*>(out + 2 * plane + (long)n * Kc + oct * 8) = gemm_u32x4{l[0], l[1], l[2], l[3]};
+}
+// up to five matrices in one launch; out[i]: 3 * Kc[i] * N[i] bf16 (16-byte aligned)
+int nq_gemm_presplit_kn(hipStream_t st, int n, const float* const* W, const int* Kc, const int* N, void* const* out) {
+  if (n < 1 || n > 5) return nq_fail(NQ_ERR_ARG, "presplit: 1-5 matrices");
+  NQ_PROF(st, "gemm_presplit");
+  PresplitArgs a{};
+  int blocks = 0;
+  for (int i = 0; i < 5; ++i) {
+    a.first[i] = blocks;
+    if (i >= n) continue;
+    if ((Kc[i] & 7) || !W[i] || !out[i]) return nq_fail(NQ_ERR_ARG, "presplit: bad matrix %d", i);
+    a.W[i] = W[i]; a.Kc[i] = Kc[i]; a.N[i] = N[i]; a.out[i] = reinterpret_cast<unsigned short*>(out[i]);
+    blocks += nq_cdiv((long)N[i] * (Kc[i] / 8), 256);
+  }
+  a.first[5] = blocks; a.n = n;
+  hipLaunchKernelGGL(k_presplit_kn, dim3(blocks), dim3(256), 0, st, a);
+  NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 

@@ -13,6 +13,7 @@
 // Inf / NaN: a non-finite operand value gives NaN (inf - inf in the split) where the f32 pipe would give inf.
 #pragma once
 #include "gemm_tile.h"
+#include <type_traits>
 
 typedef __bf16 sp_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sp_bf2 __attribute__((ext_vector_type(2)));
@@ -104,6 +105,45 @@ struct SplitStage {
 };
 
 
+// B operand from PRE-SPLIT planes (GemmArgs::Bpre: [piece][N][K] bf16, K-contiguous): same LDS image and fragments as SplitStage<true>, no arithmetic.
+// Thread t loads the 8 consecutive k's  8 (t & 1) ..  of row t >> 1 of each plane (three 16-byte loads) and writes one ds_write_b128 per plane.
+// N % 128 == 0 and K % 16 == 0 (host-checked): nothing of a valid tile is out of range; a tile past the end gets a zero-range descriptor.
+struct PreStageB {
+  static constexpr int ROWS = 128, BK = 16, NT = 256;
+  static constexpr int PITCH = 32, PLANE = ROWS * PITCH, BYTES = 3 * PLANE;
+  static constexpr int NREG = 12, NLOADS = 3;
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t descriptor(const void* planes, long ldk, long plane_bytes, int r0, int R, int kbeg, int kend) {
+    const char* base = reinterpret_cast<const char*>(planes) + ((long)r0 * ldk + kbeg) * 2;
+    const long rr = min(R - r0, ROWS), kl = kend - kbeg;
+    const long bytes = rr > 0 ? 2 * plane_bytes + ((rr - 1) * ldk + kl) * 2 : 0;
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int nrec = __builtin_amdgcn_readfirstlane((int)max(0L, min(bytes, 0xffffffffL)));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, nrec, 0x00020000);
+  }
+  static __device__ __forceinline__ int lane_offset(int ldk) { const int t = threadIdx.x; return ((t >> 1) * ldk + (t & 1) * 8) * 2; }
+  // `plane_bytes` travels in the argument that carries the leading dimension of the other stages
+  static __device__ __forceinline__ void fetch(float (&v)[NREG], __amdgpu_buffer_rsrc_t rsrc, int voff, int plane_bytes, int krel_) {
+    const int krel = __builtin_amdgcn_readfirstlane(krel_);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const gemm_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, krel * 2 + pl * plane_bytes, 0);
+      v[4 * pl] = __uint_as_float(x.x); v[4 * pl + 1] = __uint_as_float(x.y); v[4 * pl + 2] = __uint_as_float(x.z); v[4 * pl + 3] = __uint_as_float(x.w);
+    }
+  }
+  template <bool CHEAP = false, bool KTAIL = true>
+  static __device__ __forceinline__ void stash(char* __restrict__ tile, const float (&v)[NREG], int) {
+    const int t = threadIdx.x;
+    char* q = tile + (t >> 1) * PITCH + (t & 1) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<gemm_u32x4*>(q + pl * PLANE) = gemm_u32x4{__float_as_uint(v[4 * pl]), __float_as_uint(v[4 * pl + 1]), __float_as_uint(v[4 * pl + 2]), __float_as_uint(v[4 * pl + 3])};
+  }
+  static __device__ __forceinline__ sp_bf8 frag(const char* __restrict__ tile, int pl, int base, int lr, int lk) {
+    return *reinterpret_cast<const sp_bf8*>(tile + pl * PLANE + (base + lr) * PITCH + lk * 16);
+  }
+};
+
 struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-tile) step of a workgroup; tile >= ntiles: past the end (kbeg == kend == 0)
 
 // Software pipeline, prefetch distance TWO: a k16 step is 24 MFMAs = 768 cycles of the matrix pipe, less than one trip to L2 / HBM, so the loads of
@@ -115,11 +155,12 @@ struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-ti
 // WBIAS (weight-gradient launches): also produce the bias gradient (GemmArgs::bpart).
 // bid / nb: this workgroup's index and the number of workgroups that share the product (blockIdx.x / gridDim.x for a plain launch; a grouped launch deals
 // ranges of its grid to several products: k_gemm3_tn_group below)
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0>
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool B_PRE = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, const int nb) {
   constexpr int BM = 128, BN = 128, BK = 16, NWN = 2, TM = 2, TN = 2;
   using SA = SplitStage<A_KC>;
-  using SB = SplitStage<B_KC>;
+  using SB = std::conditional_t<B_PRE, PreStageB, SplitStage<B_KC>>;
+  const int ldb_ = B_PRE ? p.bpre_plane_bytes : p.ldb;   // what the stage's fetch takes as its third argument (PreStageB: the plane stride)
   constexpr int BUF = SA::BYTES + SB::BYTES;   // 24 KB: two buffers (+ the bias-gradient lines) = 49 KB, three workgroups per CU
   constexpr int NLOADS = SA::NLOADS + SB::NLOADS;   // load instructions of one step's fetch
   constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES || EPI == EPI_DSILU2;
@@ -135,7 +176,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
   const int wm = wave / NWN, wn = wave % NWN;
   const int wrow0 = wm * (TM * 32), wcol0 = wn * (TN * 32);
   const int lr = lane & 31, lk = lane >> 5;
-  const int voff_a = SA::lane_offset(p.lda), voff_b = SB::lane_offset(p.ldb);
+  const int voff_a = SA::lane_offset(p.lda), voff_b = SB::lane_offset(B_PRE ? p.ldbpre : p.ldb);
 
   auto first_step = [&](int tile) {
     SpStep s;
@@ -157,7 +198,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
   auto descriptors = [&](const SpStep& s) {   // of the step's tile; zero range past the end
     const bool v = s.tile < ntiles;
     da = SA::descriptor(p.A, p.lda, v ? s.m0 : p.M, p.M, s.kbeg, s.kend);
-    db = SB::descriptor(p.B, p.ldb, v ? s.n0 : p.N, p.N, s.kbeg, s.kend);
+    if constexpr (B_PRE) db = PreStageB::descriptor(p.Bpre, p.ldbpre, p.bpre_plane_bytes, v ? s.n0 : p.N, p.N, s.kbeg, s.kend);
+    else db = SB::descriptor(p.B, p.ldb, v ? s.n0 : p.N, p.N, s.kbeg, s.kend);
   };
 
   f32x16 acc[TM][TN];
@@ -187,10 +229,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
   float ra[2][SA::NREG], rb[2][SB::NREG];
   descriptors(cur);
   SA::fetch(ra[0], da, voff_a, p.lda, 0);
-  SB::fetch(rb[0], db, voff_b, p.ldb, 0);
+  SB::fetch(rb[0], db, voff_b, ldb_, 0);
   if (n1.k0 == n1.kbeg) descriptors(n1);
   SA::fetch(ra[1], da, voff_a, p.lda, n1.k0 - n1.kbeg);
-  SB::fetch(rb[1], db, voff_b, p.ldb, n1.k0 - n1.kbeg);
+  SB::fetch(rb[1], db, voff_b, ldb_, n1.k0 - n1.kbeg);
   SA::template stash<false, KTAIL>(lds, ra[0], cur.kend - cur.k0);
   SB::template stash<false, KTAIL>(lds + SA::BYTES, rb[0], cur.kend - cur.k0);
   if (bias_on && cur.n0 == 0) bsum = colsum(ra[0], cur);
@@ -227,7 +269,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
       descriptors(n2);   // every step (scalar work): a conditional update would be a block merge with loads pending, which costs a vmcnt(0)
       if (!(ABL & 2)) {
         SA::fetch(ra[u], da, voff_a, p.lda, n2.k0 - n2.kbeg);
-        SB::fetch(rb[u], db, voff_b, p.ldb, n2.k0 - n2.kbeg);
+        SB::fetch(rb[u], db, voff_b, ldb_, n2.k0 - n2.kbeg);
       }
       {
         sp_bf8 fa[3][TM], fb[3][TN];
@@ -291,10 +333,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
   } while (cur.tile < ntiles);
 }
 
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false>
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false, bool B_PRE = false>
 __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   if (BATCH) gemm_apply_batch(p);
-  gemm3_body<A_KC, B_KC, EPI, WPE, KTAIL, WBIAS, TERMS, ABL>(p, (int)blockIdx.x, (int)gridDim.x);
+  gemm3_body<A_KC, B_KC, EPI, WPE, KTAIL, WBIAS, TERMS, ABL, B_PRE>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Several weight-gradient contractions (EPI_PARTIAL: both operands row-major over the contracted rows) in ONE launch: workgroups [first[g], first[g + 1])

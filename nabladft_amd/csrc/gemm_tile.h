@@ -33,6 +33,9 @@ struct GemmArgs {
   // batched launches of the tile engines (round 4: the spherical linears as one plain strided product per packed component): blockIdx.y = z shifts the
   // operands, A += z * bsA, C += z * bsC, B = Bz[order of component z] (bz) or B + z * bsB; bias and bias-gradient partials belong to z = 0 only
   int nbatch, bz; long bsA, bsB, bsC;
+  // round 6: B operand already split (gemm_split.h PreStageB): three bf16 planes [piece][N][K], K-contiguous, made once per optimiser step (nq_gemm_presplit_kn):
+  // the input-gradient products then load their weight tile with three 16-byte loads per thread instead of eight 4-byte loads + the split arithmetic
+  const void* Bpre; int ldbpre; int bpre_plane_bytes;
 };
 __device__ __forceinline__ void gemm_apply_batch(GemmArgs& p) {
   const int z = blockIdx.y;

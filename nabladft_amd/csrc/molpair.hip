@@ -43,7 +43,11 @@
 #define GM_WMAX (GM_ROWS - 1 - (FWIN - 1))   // window starts per wavefront at most (19): row off + 12 <= 30
 #define GM_CH 32                    // channels per slice
 #define GM_BATCH 8                  // pairs per matrix-core contraction (K = 16 = 8 x {gphi, gpsi})
-#define GM_ATOM_FLOATS (20 * GM_CH) // LDS floats per atom: 5 blocks [32 channels][4 rows]
+#ifndef GM_ATOM_PAD
+#define GM_ATOM_PAD 4       // floats between atoms: with 2560-byte atoms the staging writes of the 8 atoms a wavefront holds fell on the same banks (16-way; SQ_LDS_BANK_CONFLICT
+                         // 2.1e7 cycles per launch, profiles/r06_pmc_sq_*.txt); 16 bytes of padding spread them (two-way left: channel quads q and q + 4)
+#endif
+#define GM_ATOM_FLOATS (20 * GM_CH + GM_ATOM_PAD) // LDS floats per atom: 5 blocks [32 channels][4 rows] + padding
 #define GM_ATOM_BYTES (GM_ATOM_FLOATS * 4)
 #define GM_RING_BYTES 512           // per wavefront: the scalar records of two batches (2 x 8 pairs x 8 dwords), read back as broadcast ds_read_b128
 #define GM_MAX_ATOMS ((160 * 1024 - GM_NW * GM_RING_BYTES) / GM_ATOM_BYTES)   // 62 with 8 wavefronts: the rows + the rings fill the 160 KB of LDS
