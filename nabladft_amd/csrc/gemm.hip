@@ -431,7 +431,7 @@ static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
     hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WT, true>), gt, dim3(256), 0, st, p);
   } else {
     if constexpr (A_KC && !B_KC) {   // input-gradient layout: the weight operand may come pre-split (GemmArgs::Bpre)
-      if (p.Bpre) { hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false, false, 6, 0, false, true>), grid, dim3(256), 0, st, p); return NQ_OK; }
+      if (p.Bpre) { hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false, false, NQ_GEMM3_TERMS, 0, false, true>), grid, dim3(256), 0, st, p); return NQ_OK; }
     }
     hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false>), grid, dim3(256), 0, st, p);
   }
@@ -453,7 +453,7 @@ static bool launch_batched(hipStream_t st, const GemmArgs& p, int splits, long k
   if (use3) {
     const long cap = 256 * 3;
     const unsigned gx = (unsigned)std::min<long>(t128, std::max<long>(1, (cap + p.nbatch - 1) / p.nbatch));
-    hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 3, false, false, 6, 0, true>), dim3(gx, p.nbatch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 3, false, false, NQ_GEMM3_TERMS, 0, true>), dim3(gx, p.nbatch), dim3(256), 0, st, p);
   } else if (gemm2_small_tiles(p.M * p.nbatch, p.N, splits)) {
     const unsigned gx = (unsigned)std::min<long>(t64, std::max<long>(1, (1024 + p.nbatch - 1) / p.nbatch));
     hipLaunchKernelGGL((k_gemm2<A_KC, B_KC, EPI, 64, 64, 32, 2, 2, 4, 0, true>), dim3(gx, p.nbatch), dim3(256), 0, st, p);

@@ -15,6 +15,9 @@
 #include "gemm_tile.h"
 #include <type_traits>
 
+#ifndef NQ_GEMM3_TERMS
+#define NQ_GEMM3_TERMS 6   // piece products kept (lab builds: 3 = the two-piece product, 9 = all)
+#endif
 typedef __bf16 sp_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sp_bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned int sp_u32x2 __attribute__((ext_vector_type(2)));
@@ -155,7 +158,7 @@ struct SpStep { int tile, split, m0, n0, kbeg, kend, k0; };   // one (tile, k-ti
 // WBIAS (weight-gradient launches): also produce the bias gradient (GemmArgs::bpart).
 // bid / nb: this workgroup's index and the number of workgroups that share the product (blockIdx.x / gridDim.x for a plain launch; a grouped launch deals
 // ranges of its grid to several products: k_gemm3_tn_group below)
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool B_PRE = false>
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = NQ_GEMM3_TERMS, int ABL = 0, bool B_PRE = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, const int nb) {
   constexpr int BM = 128, BN = 128, BK = 16, NWN = 2, TM = 2, TN = 2;
   using SA = SplitStage<A_KC>;
@@ -333,7 +336,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, const int bid, con
   } while (cur.tile < ntiles);
 }
 
-template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = 6, int ABL = 0, bool BATCH = false, bool B_PRE = false>
+template <bool A_KC, bool B_KC, int EPI, int WPE = 3, bool KTAIL = true, bool WBIAS = false, int TERMS = NQ_GEMM3_TERMS, int ABL = 0, bool BATCH = false, bool B_PRE = false>
 __global__ __launch_bounds__(256, WPE) void k_gemm3(GemmArgs p) {
   if (BATCH) gemm_apply_batch(p);
   gemm3_body<A_KC, B_KC, EPI, WPE, KTAIL, WBIAS, TERMS, ABL, B_PRE>(p, (int)blockIdx.x, (int)gridDim.x);
