@@ -658,7 +658,7 @@ def _lib_cap():
     return _lib.load().nq_painn_molecule_lds_atoms()
 
 
-def cpu_baseline(seconds_budget=25.0, all_cores=False):
+def cpu_baseline(seconds_budget=25.0, all_cores=False, gemm_variant=1):
     """The oracle (pure-torch CPU restatement of the reference path, autograd forces + double backward)
     timed on this box's host cores on a bounded sample: B=32 conformers of the same generator, full config."""
     from oracle import painn_ref as Rf
@@ -710,6 +710,7 @@ def cpu_baseline(seconds_budget=25.0, all_cores=False):
     #     counters, the per-molecule rbf_proj gradient (k_gwr_mol) and the fused update block;
     #   * the B = 32 sample of the timing above (two-slice rows, pair-row gradient: the small-batch paths), kept as a second entry.
     import nabladft_amd as nq
+    from nabladft_amd import _lib as _lib_mod
     dev = torch.device("cuda", torch.cuda.current_device())
     m = nq.PaiNN(F, L, R, CUTOFF, KNBR, {"name": "gaussian"}, {"name": "polynomial", "exponent": 5}, True, False, False, True, 100)
     m.load_state_dict(params, strict=False)
@@ -731,10 +732,19 @@ def cpu_baseline(seconds_budget=25.0, all_cores=False):
                 "max_rel_grad": float((fs.grad.cpu() - gref).abs().max() / gref.abs().max()),
                 "mean_abs_energy_ref": float(e_ref.abs().mean()), "mean_abs_forces_ref": float(f_ref.abs().mean())}
     big = Rf.gen_conformers(4321, 128)
-    parity = parity_of(big)
+    # the timed region's products are all >= 192 tiles (split-bf16 engine); at 128 conformers most are not and would fall to the exact-f32 engine:
+    # bit 6 of the variant word sends every eligible product of this sample to the engine the timed region uses
+    split = gemm_engine_name() == "split-bf16"
+    if split:
+        _lib_mod.load().nq_set_gemm_variant(gemm_variant | 64)
+    try:
+        parity = parity_of(big)
+    finally:
+        if split:
+            _lib_mod.load().nq_set_gemm_variant(gemm_variant)
     lds_cap = int(_lib_cap())
     n_max = int(torch.bincount(big[2]).max())
-    parity["accuracy_path"] = ("molgw" if n_max <= lds_cap else "molgw+pair_rows(mixed)") + "+full_rows" + ("+fused_update" if F == 128 and os.environ.get("NQ_NO_FUSED_UPDATE") != "1" else "")
+    parity["accuracy_path"] = ("molgw" if n_max <= lds_cap else "molgw+pair_rows(mixed)") + "+full_rows" + ("+fused_update" if F == 128 and os.environ.get("NQ_NO_FUSED_UPDATE") != "1" else "") + ("+split_bf16_products" if split else "+exact_f32_products")
     assert big[0].shape[0] >= 4096, "the accuracy sample must be large enough for the default large-batch paths"
     parity["small_batch"] = dict(parity_of((pos, z, batch, y, ft), ei), accuracy_path="pair_rows+two_slice_rows" + ("+fused_update" if F == 128 and os.environ.get("NQ_NO_FUSED_UPDATE") != "1" else ""))
     return out, parity
@@ -880,7 +890,7 @@ def main():
 
     cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(all_cores=args.full) if args.model == "painn-oc" else cpu_baseline_spk(args.model)
+        cpu, parity = cpu_baseline(all_cores=args.full, gemm_variant=args.gemm_variant if args.gemm_variant is not None else 1) if args.model == "painn-oc" else cpu_baseline_spk(args.model)
 
     host_feed = None
     if rank == 0 and world == 1 and not args.no_roofline and args.full:
