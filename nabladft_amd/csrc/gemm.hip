@@ -330,19 +330,42 @@ static void launch_gemm(hipStream_t st, dim3 grid, const GemmArgs& p) {
   }
 }
 
-// out[i] = sum_s part[s*stride + i]  (fixed order -> deterministic)
-__global__ void k_reduce_partials(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+// out[i] = sum_s part[s*stride + i], fixed order -> deterministic.  A thread that walks all splits of one element is a serial chain of loads (512 splits of a
+// 128 x 128 weight-gradient tile: 128 trips of ~0.3 us with 4 loads in flight, one wavefront per CU: 30 us for 33 MB), so the splits of an element are cut
+// into RP_CHUNKS contiguous ranges summed by 8 threads (each as before: 4 interleaved accumulators), combined through LDS as ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)).
+// Few splits (< RP_MIN_SPLITS): one thread per element as before.  The order depends on (nsplit) only, never on the launch geometry.
+#define RP_CHUNKS 8
+#define RP_ELEMS 32          // elements per workgroup of RP_CHUNKS * RP_ELEMS threads: a half-wavefront reads one 128-byte segment of a split
+#define RP_MIN_SPLITS 32
+__device__ __forceinline__ float reduce_range(const float* __restrict__ part, long stride, long i, int k, int kend) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nsplit; k += 4) {  // 4 independent loads in flight; the combination order is fixed
+  for (; k + 3 < kend; k += 4) {   // 4 independent loads in flight; the combination order is fixed
     s0 += part[(long)k * stride + i]; s1 += part[(long)(k + 1) * stride + i];
     s2 += part[(long)(k + 2) * stride + i]; s3 += part[(long)(k + 3) * stride + i];
   }
-  for (; k < nsplit; ++k) s0 += part[(long)k * stride + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  for (; k < kend; ++k) s0 += part[(long)k * stride + i];
+  return (s0 + s1) + (s2 + s3);
 }
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out, long block) {
+  if (nsplit < RP_MIN_SPLITS) {
+    const long i = block * (RP_CHUNKS * RP_ELEMS) + threadIdx.x;
+    if (i < count) out[i] = reduce_range(part, stride, i, 0, nsplit);
+    return;
+  }
+  __shared__ float red[RP_CHUNKS][RP_ELEMS];
+  const int e = threadIdx.x & (RP_ELEMS - 1), c = threadIdx.x / RP_ELEMS;
+  const long i = block * RP_ELEMS + e;
+  const int per = (nsplit + RP_CHUNKS - 1) / RP_CHUNKS;
+  red[c][e] = i < count ? reduce_range(part, stride, i, min(nsplit, c * per), min(nsplit, (c + 1) * per)) : 0.f;
+  __syncthreads();
+  if (c == 0 && i < count) out[i] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+}
+__global__ __launch_bounds__(RP_CHUNKS * RP_ELEMS) void k_reduce_partials(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
+  reduce_partials_body(part, nsplit, stride, count, out, (long)blockIdx.x);
+}
+static unsigned reduce_partials_blocks(int nsplit, long count) { return (unsigned)nq_cdiv(count, nsplit < RP_MIN_SPLITS ? (long)RP_CHUNKS * RP_ELEMS : (long)RP_ELEMS); }
+#define LAUNCH_REDUCE_PARTIALS(st, part, nsplit, stride, count, out) \
+  hipLaunchKernelGGL(k_reduce_partials, dim3(reduce_partials_blocks(nsplit, count)), dim3(RP_CHUNKS * RP_ELEMS), 0, st, part, nsplit, stride, count, out)
 
 // column sums of A[rows][cols] (bias gradients): 256 threads = 64 columns x 4 row lanes, one 2048-row chunk per
 // workgroup (coalesced 256-B row segments, 4 independent accumulators per thread), lanes combined through LDS;
@@ -421,7 +444,7 @@ static int launch_gemm3(hipStream_t st, const GemmArgs& p, int splits) {
   constexpr bool AUX = EPI == EPI_ACC || EPI == EPI_DSILU || EPI == EPI_RES || EPI == EPI_SILU_RES || EPI == EPI_DSILU2;
   constexpr int WPE = AUX ? 2 : 3;
   const long tiles = (long)nq_cdiv(p.M, 128) * nq_cdiv(p.N, 128) * splits;
-  const dim3 grid((unsigned)(tiles < 256 * WPE ? tiles : 256 * WPE));
+  const dim3 grid((unsigned)(tiles < 256 * WPE ? tiles : 256 * WPE));   // (measured round 6: capping the grid at 2 / 1 workgroups per CU costs +0.2 / +1.4 ms per step)
   if constexpr (EPI == EPI_PARTIAL) {   // weight gradient: no K-contiguous operand, so no k-tail code; the bias gradient is a second instantiation
     if (p.bpart) hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, 2, false, true>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, st, p);   // (one register short of 168)
     else hipLaunchKernelGGL((k_gemm3<A_KC, B_KC, EPI, WPE, false, false>), grid, dim3(256), 0, st, p);
@@ -811,10 +834,10 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   else launch_gemm<false, false, EPI_PARTIAL>(st, dim3(nq_cdiv(Mo, BM), nq_cdiv(No, BN), nse), p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cnt, 64)), dim3(64), 0, st, scratch, nse, cnt, cnt, out);
+  LAUNCH_REDUCE_PARTIALS(st, scratch, nse, cnt, cnt, out);
   NQ_LAUNCH_CHECK();
   if (bias_out) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Mo, 64)), dim3(64), 0, st, bpart, nse, (long)Mo, (long)Mo, bias_out);
+    LAUNCH_REDUCE_PARTIALS(st, bpart, nse, (long)Mo, (long)Mo, bias_out);
     NQ_LAUNCH_CHECK();
   }
   return NQ_OK;
@@ -879,16 +902,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials_group(ReduceGroupArgs q
 #pragma unroll
   for (int i = 0; i < RG_MAX; ++i)
     if (g == i) { part = q.part[i]; out = q.out[i]; nsplit = q.nsplit[i]; count = q.count[i]; first = q.first[i]; }
-  const long i = (long)(b - first) * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nsplit; k += 4) {   // same combination order as k_reduce_partials
-    s0 += part[(long)k * count + i]; s1 += part[(long)(k + 1) * count + i];
-    s2 += part[(long)(k + 2) * count + i]; s3 += part[(long)(k + 3) * count + i];
-  }
-  for (; k < nsplit; ++k) s0 += part[(long)k * count + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  reduce_partials_body(part, nsplit, (long)count, (long)count, out, (long)(b - first));   // same combination order as k_reduce_partials
 }
 
 static const int TN_GROUP_SLOTS = 512;   // 2 workgroups per CU (the bias-gradient flavour of the split engine)
@@ -938,8 +952,8 @@ int nq_gemm_tn_group(hipStream_t st, const NqTnSpec* sp, int n, float* scratch) 
     if (!gemm3_ok<false, false>(q.a[g], P.kper[g], P.nse[g])) return nq_fail(NQ_ERR_ARG, "gemm_tn_group: product %d is not eligible for the split engine", g);
     wg += nq_cdiv(x.Mo, 128) * nq_cdiv(x.No, 128) * P.nse[g];
     flops += 2.0 * x.rows * x.Mo * x.No;
-    r.part[nr] = scratch + P.off[g]; r.out[nr] = x.out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo * x.No; r.first[nr] = rb; rb += nq_cdiv((long)x.Mo * x.No, 256); ++nr;
-    if (x.bias_out) { r.part[nr] = bpart; r.out[nr] = x.bias_out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo; r.first[nr] = rb; rb += nq_cdiv(x.Mo, 256); ++nr; }
+    r.part[nr] = scratch + P.off[g]; r.out[nr] = x.out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo * x.No; r.first[nr] = rb; rb += (int)reduce_partials_blocks(P.nse[g], (long)x.Mo * x.No); ++nr;
+    if (x.bias_out) { r.part[nr] = bpart; r.out[nr] = x.bias_out; r.nsplit[nr] = P.nse[g]; r.count[nr] = x.Mo; r.first[nr] = rb; rb += (int)reduce_partials_blocks(P.nse[g], (long)x.Mo); ++nr; }
   }
   q.first[GEMM_GROUP_MAX] = wg; q.n = n;
   for (int i = nr; i <= RG_MAX; ++i) r.first[i] = rb;
@@ -967,13 +981,13 @@ int nq_colsum(hipStream_t st, const float* A, long rows, int cols, int lda, floa
   const int csr = cs_rows_for(rows), chunks = nq_cdiv(rows, csr);
   hipLaunchKernelGGL(k_colsum_partial, dim3(nq_cdiv(cols, 64), chunks), dim3(256), 0, st, A, rows, cols, lda, scratch, csr);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(cols, 256)), dim3(256), 0, st, scratch, chunks, (long)cols, (long)cols, out);
+  LAUNCH_REDUCE_PARTIALS(st, scratch, chunks, (long)cols, (long)cols, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
 int nq_reduce_partials(hipStream_t st, const float* part, int nsplit, long stride, long count, float* out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(count, 256)), dim3(256), 0, st, part, nsplit, stride, count, out);
+  LAUNCH_REDUCE_PARTIALS(st, part, nsplit, stride, count, out);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
@@ -1113,7 +1127,7 @@ int nq_sph_linear_weight_grad(const float* gy, const float* x, float* const* gW_
     if (rows == 0) NQ_HIP(hipMemsetAsync(gbias0, 0, sizeof(float) * Fout, st));
     else {   // fixed-order sum of the per-split partials written by the contraction above (no separate pass over gy)
       const int sps = sph_tn_splits(rows, ncomp);
-      hipLaunchKernelGGL(k_reduce_partials, dim3(nq_cdiv(Fout, 64)), dim3(64), 0, st, scratch + (size_t)ncomp * sps * Fout * Fin, sps, (long)Fout, (long)Fout, gbias0);
+      LAUNCH_REDUCE_PARTIALS(st, scratch + (size_t)ncomp * sps * Fout * Fin, sps, (long)Fout, (long)Fout, gbias0);
       NQ_LAUNCH_CHECK();
     }
   }

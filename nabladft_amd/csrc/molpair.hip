@@ -514,24 +514,35 @@ __global__ __launch_bounds__(GM_THREADS) void k_gwr_mol(GwrMolArgs q, const u4* 
 
 // gWr[col][k] = sum over wavefronts whose rows cover k, over the workgroups in order; gbr[col] = sum of the bias rows.  Fixed order: reproducible.
 // ACC: add to what is there (the pair-row kernels ran first for the molecules that do not fit the LDS).
-__global__ void k_gwr_mol_reduce(const float* __restrict__ part, const int* __restrict__ wlo, int groups, int nslices, int R, int F,
-                                 float* __restrict__ gWr, float* __restrict__ gbr, int acc) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// Four threads per output element, each over a quarter of the workgroups (a single thread's 128-load chain at 2.4 wavefronts per CU was latency-bound: 33 us), combined
+// through LDS as (q0 + q1) + (q2 + q3).
+#define GMR_Q 4
+__global__ __launch_bounds__(256) void k_gwr_mol_reduce(const float* __restrict__ part, const int* __restrict__ wlo, int groups, int nslices, int R, int F,
+                                                        float* __restrict__ gWr, float* __restrict__ gbr, int acc) {
+  __shared__ float red[GMR_Q][256 / GMR_Q];
+  const int e = threadIdx.x & (256 / GMR_Q - 1), qd = threadIdx.x / (256 / GMR_Q);
+  const int idx = blockIdx.x * (256 / GMR_Q) + e;
   const int F3 = 3 * F;
-  if (idx >= (R + 1) * F3) return;
-  const int k = idx / F3, col = idx % F3;
+  const bool live = idx < (R + 1) * F3;
+  const int k = live ? idx / F3 : 0, col = live ? idx % F3 : 0;
   const int p = col / F, ch = col % F, slice = ch / GM_CH, c = ch % GM_CH;
+  const int gper = (groups + GMR_Q - 1) / GMR_Q, g0 = min(groups, qd * gper), g1 = min(groups, g0 + gper);
   float s = 0.f;
-  for (int w = 0; w < GM_NW; ++w) {
-    int row = GM_ROWS - 1;             // bias row
-    if (k < R) {
-      row = k - wlo[w];
-      if (row < 0 || row >= GM_ROWS - 1) continue;
-    }
-    const int o = (row * 3 + p) * GM_CH + c;
+  if (live)
+    for (int w = 0; w < GM_NW; ++w) {
+      int row = GM_ROWS - 1;             // bias row
+      if (k < R) {
+        row = k - wlo[w];
+        if (row < 0 || row >= GM_ROWS - 1) continue;
+      }
+      const int o = (row * 3 + p) * GM_CH + c;
 #pragma unroll 8
-    for (int g = 0; g < groups; ++g) s += part[((long)(g * nslices + slice) * GM_NW + w) * GM_PART_FLOATS + o];   // unrolled: eight loads in flight, same order
-  }
+      for (int g = g0; g < g1; ++g) s += part[((long)(g * nslices + slice) * GM_NW + w) * GM_PART_FLOATS + o];   // unrolled: eight loads in flight, same order
+    }
+  red[qd][e] = s;
+  __syncthreads();
+  if (qd != 0 || !live) return;
+  s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
   if (k < R) gWr[(long)col * R + k] = acc ? gWr[(long)col * R + k] + s : s;
   else gbr[col] = acc ? gbr[col] + s : s;
 }
@@ -616,7 +627,7 @@ int nq_gwr_mol(hipStream_t st, const NqGraphView& g, int F, int R, int max_mol_a
   NQ_DYN_LDS(k_gwr_mol, lds);
   hipLaunchKernelGGL(k_gwr_mol, dim3(q.groups * q.nslices), dim3(GM_THREADS), lds, st, q, PA, PG);
   NQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gwr_mol_reduce, dim3(nq_cdiv((long)(R + 1) * 3 * F, 256)), dim3(256), 0, st, part, b.wlo, q.groups, q.nslices, R, F, gWr, gbr, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(k_gwr_mol_reduce, dim3(nq_cdiv((long)(R + 1) * 3 * F, 256 / GMR_Q)), dim3(256), 0, st, part, b.wlo, q.groups, q.nslices, R, F, gWr, gbr, accumulate ? 1 : 0);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
