@@ -280,20 +280,22 @@ __device__ __forceinline__ float bcast_lane(float v, int t) {
 
 // Per-edge window record, computed ONCE per step (the distances do not change between layers / sweeps):
 // RW[e][0..12] = rho_{k0+t}(d_e), RW[e][13] = k0 (int bits), RW[e][16..28] = d rho_{k0+t} / d d.  128 B per edge.
-__global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs fa, float* __restrict__ RW) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = (int)(idx >> 4), t = (int)(idx & 15);
-  if (e >= E) return;
-  const int R = fa.R;
-  const float ds = geom[e].w * fa.inv_cutoff;
-  const int nwin = R < FWIN ? R : FWIN;
-  int kc = (int)rintf(ds * (float)(R - 1));
-  kc = min(max(kc, 0), R - 1);
-  const int k0 = min(max(kc - FWIN / 2, 0), R - nwin);
-  float rl = 0.f, drl = 0.f, beta = 1.f, dbeta = 0.f;
-  if (fa.mode == 0) {
-    if (t < nwin) {
-      float env = 0.f, denv = 0.f;
+// One thread per edge (the envelope, its powf and the window start are per-edge work: with 16 threads per edge every wavefront repeated them for 4 edges
+// only), 13 taps in a loop, the 32-float record transposed through LDS so that the stores are whole contiguous rows.
+#define RBFW_THREADS 256
+__global__ __launch_bounds__(RBFW_THREADS) void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs fa, float* __restrict__ RW) {
+  __shared__ float tile[RBFW_THREADS][RW_STRIDE + 1];
+  const int e0 = blockIdx.x * RBFW_THREADS, e = e0 + threadIdx.x;
+  if (e < E) {
+    const int R = fa.R;
+    const float dist = geom[e].w;
+    const float ds = dist * fa.inv_cutoff;
+    const int nwin = R < FWIN ? R : FWIN;
+    int kc = (int)rintf(ds * (float)(R - 1));
+    kc = min(max(kc, 0), R - 1);
+    const int k0 = min(max(kc - FWIN / 2, 0), R - nwin);
+    float beta = 1.f, dbeta = 0.f, env = 0.f, denv = 0.f;
+    if (fa.mode == 0) {
       if (ds < 1.0f) {
         if (fa.p > 0.f) {
           const float pm1 = powf(ds, fa.p - 1.0f);
@@ -306,44 +308,73 @@ __global__ void k_rbf_window(const float4* __restrict__ geom, int E, FilterArgs 
           denv = -env * 2.0f * ds / (om * om);
         }
       }
-      const float diff = ds - fa.mu[k0 + t];
-      const float g = expf(fa.coeff * (diff * diff));
-      rl = env * g;
-      drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
+    } else {
+      // schnetpack: W_ij = fcut(d) * (filter_net(gauss(d)) + b)  ->  rho = fcut * gauss (unscaled d), bias multiplier beta = fcut
+      const float arg = dist * (3.14159265358979323846f / fa.cutoff);
+      const bool inside = dist < fa.cutoff;
+      beta = inside ? 0.5f * (cosf(arg) + 1.0f) : 0.f;
+      dbeta = inside ? -0.5f * (3.14159265358979323846f / fa.cutoff) * sinf(arg) : 0.f;
     }
-  } else {
-    // schnetpack: W_ij = fcut(d) * (filter_net(gauss(d)) + b)  ->  rho = fcut * gauss (unscaled d), bias multiplier beta = fcut
-    const float d = geom[e].w;
-    const float arg = d * (3.14159265358979323846f / fa.cutoff);
-    const bool inside = d < fa.cutoff;
-    beta = inside ? 0.5f * (cosf(arg) + 1.0f) : 0.f;
-    dbeta = inside ? -0.5f * (3.14159265358979323846f / fa.cutoff) * sinf(arg) : 0.f;
-    if (t < nwin) {
-      const float diff = d - fa.mu[k0 + t];
-      const float g = expf(fa.coeff * (diff * diff));
-      if (fa.mode == 2) {   // SchNet: the filter network sees the bare Gaussians; fcut multiplies its OUTPUT (slots 14 / 30 carry fcut, fcut')
-        rl = g;
-        drl = g * (2.0f * fa.coeff) * diff;
-      } else {
-        rl = beta * g;
-        drl = dbeta * g + beta * g * (2.0f * fa.coeff) * diff;
+    float* rw = tile[threadIdx.x];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float rl = 0.f, drl = 0.f;
+      if (t < nwin) {
+        if (fa.mode == 0) {
+          const float diff = ds - fa.mu[k0 + t];
+          const float g = expf(fa.coeff * (diff * diff));
+          rl = env * g;
+          drl = fa.inv_cutoff * g * (denv + env * (2.0f * fa.coeff) * diff);
+        } else {
+          const float diff = dist - fa.mu[k0 + t];
+          const float g = expf(fa.coeff * (diff * diff));
+          if (fa.mode == 2) {   // SchNet: the filter network sees the bare Gaussians; fcut multiplies its OUTPUT (slots 14 / 30 carry fcut, fcut')
+            rl = g;
+            drl = g * (2.0f * fa.coeff) * diff;
+          } else {
+            rl = beta * g;
+            drl = dbeta * g + beta * g * (2.0f * fa.coeff) * diff;
+          }
+        }
       }
+      rw[t] = (t == 13) ? __int_as_float(k0) : (t == 14 ? beta : rl);    // [14] = bias multiplier, [30] = its derivative
+      rw[16 + t] = (t == 14) ? dbeta : drl;
     }
   }
-  float* rw = RW + (long)e * RW_STRIDE;
-  rw[t] = (t == 13) ? __int_as_float(k0) : (t == 14 ? beta : rl);    // [14] = bias multiplier, [30] = its derivative
-  rw[16 + t] = (t == 14) ? dbeta : drl;
+  __syncthreads();
+  const long base = (long)e0 * RW_STRIDE;
+  const long lim = (long)min(RBFW_THREADS, E - e0) * RW_STRIDE;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < RBFW_THREADS * RW_STRIDE; i += RBFW_THREADS)
+    if (i < lim) RW[base + i] = tile[i / RW_STRIDE][i % RW_STRIDE];
 }
 
 // ---- row preload: lane L of the wavefront holds index / geometry (/ tangents) of the row's edge L ------------
-struct RowRegs { int kk; float gx, gy, gz, td, t0, t1, t2; };
+struct RowRegs { int kk; float gx, gy, gz, td, t0, t1, t2, pf; };
+// The window records are streamed once per launch (128 B per edge: an HBM miss for every edge's scalar loads, issued only half an edge ahead because SMEM and
+// LDS share a counter).  Lane L of the row preload therefore TOUCHES edge L's record with a vector load: the line is in L2 by the time the scalar loads of
+// edges 1.. ask for it.  row_touch_done() keeps the load alive (its value is not used) and is placed after the row's last edge, where the wait is free.
+// Measured (profiles/r06_message_kernel_prefetch_ab.txt): -0.8 ms per step over the four message kernels.  Touching the NEXT row's records one row early, touching
+// every edge's record three edges ahead, and preloading the next row's index / geometry registers were all measured slower than this (a 4-MB L2 turns over
+// within one row: a touch must be young; the row-start bubble is covered by the other wavefronts) and removed.
+#ifndef NQ_RW_TOUCH
+#define NQ_RW_TOUCH 1
+#endif
+__device__ __forceinline__ void row_touch_done(const RowRegs& r) {
+#if NQ_RW_TOUCH
+  asm volatile("" ::"v"(r.pf));
+#endif
+}
 
 template <bool NEED_T>
 __device__ __forceinline__ void load_row(RowRegs& r, const NqGraphView& g, const float* __restrict__ TD, const float* __restrict__ TR,
-                                         int sp0, int cnt, int lane) {
-  r.kk = 0; r.gx = r.gy = r.gz = 0.f; r.td = r.t0 = r.t1 = r.t2 = 0.f;
+                                         const float* __restrict__ RW, int sp0, int cnt, int lane) {
+  r.kk = 0; r.gx = r.gy = r.gz = 0.f; r.td = r.t0 = r.t1 = r.t2 = 0.f; r.pf = 0.f;
   if (lane < cnt) {
     const int sp = sp0 + lane;
+#if NQ_RW_TOUCH
+    r.pf = RW[(long)sp * RW_STRIDE + 15];
+#endif
     r.kk = g.col[sp];
     const float4 gm = g.geom[sp];
     r.gx = gm.x; r.gy = gm.y; r.gz = gm.z;
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(Msg
     for (int c0 = beg; c0 < end; c0 += 64) {
       const int cnt = min(64, end - c0);
       RowRegs row;
-      load_row<TAN>(row, q.g, q.TD, q.TR, c0, cnt, lane);
+      load_row<TAN>(row, q.g, q.TD, q.TR, RW, c0, cnt, lane);
       // Per edge: issue the NEXT edge's gathers, evaluate the filter of the current one from LDS, only then issue the next
       // window's scalar loads (SMEM and LDS share lgkmcnt: an outstanding s_load would turn every LDS wait of the filter
       // into a wait for the scalar cache), then the arithmetic.
@@ -532,6 +563,7 @@ __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(Msg
         step(opB, opA, j + 1, std::true_type());
       }
       if (cnt & 1) step(opA, opB, cnt - 1, std::false_type());
+      row_touch_done(row);
     }
     const long o = (long)n * F + fb, o3 = (long)n * F3 + fb;
     float x0[CH], w0[CH], w1[CH], w2[CH];
@@ -636,7 +668,7 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
       const int cnt = min(64, end - c0);
       const int nlo = (DUAL && GW) ? max(0, min(cnt, nlow - (c0 - beg))) : 0;   // lower edges of this chunk come first
       RowRegs row;
-      load_row<DUAL>(row, q.g, q.TD, q.TR, c0, cnt, lane);
+      load_row<DUAL>(row, q.g, q.TD, q.TR, RW, c0, cnt, lane);
       RevOps<DUAL, CH> opA, opB;   // ping-pong operands; scalar window loads are issued after the filter's LDS reads (see k_msgf_fwd)
       load_rev<DUAL, CH>(opA, q, ABL_K(0), F, F3, fb);
       WinRegs<true> win;
@@ -777,6 +809,7 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
       }
       if (j < cnt) step(opA, opB, j, std::false_type());
 #endif
+      row_touch_done(row);
       if (!DUAL && lane < cnt) {
         float4* dstp = q.GEDGE + (long)slice * q.g.E + c0 + lane;   // one accumulator plane per channel slice (summed by k_geom_rev)
         float4 acc = *dstp;
@@ -1130,7 +1163,7 @@ void nq_make_filter_args(FilterArgs* fa, const float* WRT, const float* br, cons
 int nq_rbf_window(hipStream_t st, const float4* geom, int E, const FilterArgs& fa, float* RW) {
   NQ_PROF(st, "rbf_window");
   if (E <= 0) return NQ_OK;
-  hipLaunchKernelGGL(k_rbf_window, dim3(nq_cdiv((long)E * 16, 256)), dim3(256), 0, st, geom, E, fa, RW);
+  hipLaunchKernelGGL(k_rbf_window, dim3(nq_cdiv(E, RBFW_THREADS)), dim3(RBFW_THREADS), 0, st, geom, E, fa, RW);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(1024) void k_loss(const float* __restrict__ E, cons
       gE[b] = ce * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (float)B;
     }
   }
+#pragma unroll 4   // (one workgroup: the trips are a serial chain of load latencies unless several are in flight)
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     const float dx = Fc[3 * (long)n] - Ft[3 * (long)n], dy = Fc[3 * (long)n + 1] - Ft[3 * (long)n + 1], dz = Fc[3 * (long)n + 2] - Ft[3 * (long)n + 2];
     float sc;
