@@ -696,8 +696,8 @@ def cpu_baseline(seconds_budget=25.0, all_cores=False, gemm_variant=1):
     # second timing line on every host core (north_star: "the GPU box's host cores"); torch-CPU on graphs of this size usually runs SLOWER there than on 16 threads
     ncpu = os.cpu_count() or 1
     if ncpu > cores and not all_cores:
-        out["all_cores"] = {"value": None, "cores": ncpu, "sample": "measured by --full only: one step on every core takes minutes (0.121 conformer-steps/s on 256 threads, "
-                                                                    "profiles/r06_bench_default_full_record.json) -- torch-CPU collapses under oversubscription on graphs of this size"}
+        out["all_cores"] = {"value": None, "cores": ncpu, "sample": "measured by --full only: one step on every core takes minutes (0.12-0.13 conformer-steps/s on 256 threads, "
+                                                                    "profiles/r06_bench_full.json) -- torch-CPU collapses under oversubscription on graphs of this size"}
     if ncpu > cores and all_cores:
         torch.set_num_threads(ncpu)
         t0 = time.perf_counter()
