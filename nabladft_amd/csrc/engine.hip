@@ -388,7 +388,7 @@ int nq_painn_ws_lookup(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B,
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched' exists only with the fused filter");
     base = W.SCHED; rows = 2 * nq_molgw_sched_slots((int)e, B); w = 1; dual = false;
   }
-  else if (!strcmp(name, "pair_sched_meta")) {                                // int32: seg [B][NW] {first batch, pairs}, sched_ptr [B][NW + 1], hist [128], wlo [NW + 1], 16 spare
+  else if (!strcmp(name, "pair_sched_meta")) {                                // int32: seg [B][NW] {first batch, pairs}, sched_ptr [B][NW + 1], hist [128], wlo [NW + 1], order [B], 16 spare
     if (!W.fused) return nq_fail(NQ_ERR_ARG, "buffer 'pair_sched_meta' exists only with the fused filter");
     base = W.SCHED + 2 * nq_molgw_sched_slots((int)e, B); rows = nq_molgw_sched_ints((int)e, B) - 2 * nq_molgw_sched_slots((int)e, B); w = 1; dual = false;
   }

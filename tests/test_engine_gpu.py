@@ -346,7 +346,8 @@ def _check_pair_schedule(model, cap=None):
     once, inside its molecule's batches; entries sorted by window start k0, slot-ascending among equal k0; the wavefront segments tile the molecule's list,
     every segment starts on a batch boundary (8 pair slots) of the padded list and its last batch is padded with -1; every pair sits inside the accumulator
     rows of its wavefront (0 <= k0 - wlo[w] < 19 = the stored row offset) and no segment is longer than ceil(pairs / wavefronts) unless the next wavefront's
-    rows cannot hold the surplus; the local atom indices are the slot's (dst, col) relative to the molecule's first atom.  Larger molecules: empty segments."""
+    rows cannot hold the surplus; the local atom indices are the slot's (dst, col) relative to the molecule's first atom.  Larger molecules: empty segments.
+    The list the workgroups deal molecules from is a permutation ordered by descending pair count."""
     cap = _lds_cap() if cap is None else cap
     nl = model._last_nl
     col, dst = nl.t["col"].cpu().long(), nl.t["dst"].cpu().long()
@@ -354,14 +355,21 @@ def _check_pair_schedule(model, cap=None):
     WMAX, BATCH = 19, 8
     sched = model.workspace_view("pair_sched").cpu().view(torch.int32).view(-1, 2).long()
     meta = model.workspace_view("pair_sched_meta").cpu().view(torch.int32).long()
-    NW = (meta.numel() - 145 - nl.B) // (3 * nl.B + 1)     # wavefronts per workgroup of k_gwr_mol (csrc/molpair.hip: GM_NW)
+    NW = (meta.numel() - 145 - 2 * nl.B) // (3 * nl.B + 1)     # wavefronts per workgroup of k_gwr_mol (csrc/molpair.hip: GM_NW)
     assert NW in (8, 12)
     assert sched.shape[0] == BATCH * ((nl.E // 2) // BATCH + NW * nl.B + NW)
-    assert meta.numel() == 2 * nl.B * NW + nl.B * (NW + 1) + 128 + NW + 1 + 16
+    assert meta.numel() == 2 * nl.B * NW + nl.B * (NW + 1) + 128 + NW + 1 + nl.B + 16
     seg = meta[:2 * nl.B * NW].view(nl.B, NW, 2)
     sp = meta[2 * nl.B * NW:][:nl.B * (NW + 1)].view(nl.B, NW + 1)
     rest = meta[2 * nl.B * NW + nl.B * (NW + 1):]
     hist, wlo = rest[:128], rest[128:][:NW + 1]
+    # the deal of molecules to workgroups: a permutation by descending pair count (molecules above the LDS limit count 0), ties by ascending index
+    order = rest[128 + NW + 1:][:nl.B]
+    natoms_m = mol_ptr[1:] - mol_ptr[:-1]
+    npairs = torch.where(natoms_m <= cap, lowptr[mol_ptr[1:]] - lowptr[mol_ptr[:-1]], torch.zeros_like(natoms_m))
+    assert torch.equal(torch.sort(order).values, torch.arange(nl.B))
+    key = npairs[order] * (nl.B + 1) + (nl.B - order)
+    assert bool((key[1:] < key[:-1]).all()), "molecules must be ordered by descending pair count, equal counts by ascending index"
     k0s = model.workspace_view("rw").cpu().view(-1, 32)[:, 13].contiguous().view(torch.int32).long()
     lower = torch.nonzero(col < dst).view(-1)
     assert lower.numel() * 2 == nl.E
