@@ -583,13 +583,13 @@ static std::mutex g_side_mu;
 static std::map<std::pair<int, hipStream_t>, SidePool*> g_side_pools;
 static void side_stream_init(SideStream& s, hipStream_t main, int n_atoms) {
   s.main = main;
-  // Measured: round 2 (profiles/r02_side_stream_ab.txt) found no gain at 2048 conformers (60.5 vs 60.1 ms: every kernel filled the chip) and switched it off above
-  // 16 k atoms.  Re-measured on the round-6 kernels (profiles/r06_helper_kernels_ab.txt, item 6): the message kernels leave matrix-core and bandwidth gaps (half of
-  // their wave cycles are parked) that the weight-gradient products fill -- 2048 conformers 45.45 -> 45.1-45.2 ms, 1024: 23.90 -> 23.60, 512: 13.74 -> 13.14,
-  // 256: 8.51 -> 8.23, 32: 4.71 -> 4.40 (round 2).  Default: on at every size; NQ_SIDE_STREAM=0 / 1 forces it.
-  (void)n_atoms;
+  // Measured (profiles/r02_side_stream_ab.txt): at 2048 conformers / step 60.5 ms with the side stream vs 60.1 ms without; at 32 conformers (1.3 k atoms, the step is
+  // a chain of ~330 small dependent kernels) 4.40 vs 4.71 ms, at 256 conformers 11.57 vs 11.78 ms: the weight gradients leave the critical path.  Re-measured on
+  // the round-6 kernels (profiles/r06_helper_kernels_ab.txt, item 6): now a small gain at every size (2048 conformers 45.45 -> 45.1-45.2 ms, 512: 13.74 -> 13.14),
+  // but two streams sharing the chip make every per-kernel duration (HIP events and rocprofv3 alike) depend on what ran beside it, and the record's roofline
+  // is a per-kernel figure: the default stays "on up to 16 k atoms"; NQ_SIDE_STREAM=0 / 1 forces it.
   const char* env = getenv("NQ_SIDE_STREAM");
-  const bool want = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : true;
+  const bool want = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : n_atoms <= 16384;
   if (!want) return;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return;
