@@ -149,6 +149,7 @@ struct MsgRevArgs {
   float4* GEDGE;                                                             // force mode: [nwaves][E] {gd, grx, gry, grz} (+=)
   float* GBR;                                                                // dual out: [N][3F] per-atom sums of gphi (bias gradient partials)
   int row_filter, mol_cap;                                                   // 0: every row; 1: only rows of molecules of <= mol_cap atoms; 2: only rows of larger molecules
+  int lite;                                                                  // dual: GTXH / GTV_out are not written (they are the force sweep's GXH / GV_out, read from its per-layer store)
 };
 
 struct UpdArgs {
@@ -167,6 +168,10 @@ struct UpdRevArgs {
   float* GY; float* GTY;                                                     // [N][3F] out of rev1
   const float* GCAT; const float* GTCAT;                                     // [N][2F] in to rev2
   float* GU; float* GTU;                                                     // [N][3][2F] out of rev2
+  // The tangent adjoints (GT*) of the second-order sweep obey the force-adjoint sweep's recursion with the same seeds: they ARE that sweep's adjoints.  lite = 1
+  // (dual flavours): the GT* operands are read from where the force sweep stored them and nothing is written to them.  GX_out (force sweep, rev2): where
+  // gx_upd + gcat[:F] goes (null: in place), so that the stage the second-order sweep reads stays intact.
+  int lite; float* GX_out;
 };
 
 struct ReadoutArgs {

@@ -824,12 +824,14 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
     for (int c = 0; c < CH; ++c) { g0[c] += gv0[c]; g1[c] += gv1[c]; g2[c] += gv2[c]; }
     stv<CH>(q.GV_out + o3, g0); stv<CH>(q.GV_out + o3 + F, g1); stv<CH>(q.GV_out + o3 + 2 * F, g2);
     if (DUAL) {
-      stv<CH>(q.GTXH + o3, gtxa); stv<CH>(q.GTXH + o3 + F, gtxb); stv<CH>(q.GTXH + o3 + 2 * F, gtxc);
       if (GW) { stv<CH>(q.GBR + o3, sba); stv<CH>(q.GBR + o3 + F, sbb); stv<CH>(q.GBR + o3 + 2 * F, sbc); }
-      ldv<CH>(g0, q.GTV + o3); ldv<CH>(g1, q.GTV + o3 + F); ldv<CH>(g2, q.GTV + o3 + 2 * F);
+      if (!q.lite) {   // (lite: the adjoints of t_xh / t_vec are the force sweep's gxh / gvec_out of this layer, already stored)
+        stv<CH>(q.GTXH + o3, gtxa); stv<CH>(q.GTXH + o3 + F, gtxb); stv<CH>(q.GTXH + o3 + 2 * F, gtxc);
+        ldv<CH>(g0, q.GTV + o3); ldv<CH>(g1, q.GTV + o3 + F); ldv<CH>(g2, q.GTV + o3 + 2 * F);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) { g0[c] += gtv0[c]; g1[c] += gtv1[c]; g2[c] += gtv2[c]; }
-      stv<CH>(q.GTV_out + o3, g0); stv<CH>(q.GTV_out + o3 + F, g1); stv<CH>(q.GTV_out + o3 + 2 * F, g2);
+        for (int c = 0; c < CH; ++c) { g0[c] += gtv0[c]; g1[c] += gtv1[c]; g2[c] += gtv2[c]; }
+        stv<CH>(q.GTV_out + o3, g0); stv<CH>(q.GTV_out + o3 + F, g1); stv<CH>(q.GTV_out + o3 + 2 * F, g2);
+      }
     }
   }
 }

@@ -105,6 +105,10 @@ struct WsLayer {
   size_t WRT;                                                  // [R][3F] transposed rbf_proj.weight
   size_t UFRAG;                                                // bf16 fragments of the update block's weights (updfuse.hip), rebuilt by every forward call
   size_t WPRE;                                                 // bf16 planes of V2, V1, U, W2, W1 for the input-gradient products (gemm_split.h PreStageB), rebuilt by every forward call
+  // Per-layer adjoint store (fused filter only).  The tangent adjoints of the second-order sweep ARE the adjoints of the force sweep (same recursion, same seeds),
+  // so the force sweep writes its gy, gcat, gu, gxh into the SECOND halves of these stacked [2][rows][w] buffers and keeps the four stages of gx / gvec
+  // (a: adjoint of x_upd / vec_upd, b: of x_msg / vec_msg); the second-order sweep fills the first halves and reads the second ones instead of recomputing them.
+  size_t LGY, LGCAT, LGU, LGXH, LGXA, LGXB, LGVA, LGVB;
 };
 struct WsLayout {
   size_t X[65], V[65];
@@ -137,6 +141,9 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     y.S = take(2 * N * F); y.CAT = take(2 * N * 2 * F); y.ZQ = take(2 * N * F); y.Q = take(2 * N * F); y.Y = take(2 * N * 3 * F);
     y.UFRAG = take(nq_updfuse_frag_floats((int)F));
     y.WPRE = take(11 * F * F * 6 / 4);
+    const size_t st_ = W->fused ? 1 : 0;
+    y.LGY = take(st_ * 2 * N * 3 * F); y.LGCAT = take(st_ * 2 * N * 2 * F); y.LGU = take(st_ * 2 * N * 6 * F); y.LGXH = take(st_ * 2 * N * 3 * F);
+    y.LGXA = take(st_ * N * F); y.LGXB = take(st_ * N * F); y.LGVA = take(st_ * N * 3 * F); y.LGVB = take(st_ * N * 3 * F);
   }
   W->RHO2 = take(2 * EP * R);   // full rho / drho rows only for the materialised-filter path (B operand of the gWr contraction)
   W->ORDER = take(W->fused ? E : 0);   // int32: CSR slots sorted by window start k0
@@ -179,7 +186,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
 // The decision is taken ONCE per step, by the forward call (which builds the schedule), and remembered per workspace: the backward call reads it back instead
 // of re-evaluating the environment (a changed NQ_MOLGW between the two calls would consume a schedule that was never built).
 enum { GW_PAIR_ROWS = 0, GW_MOLECULE = 1, GW_MIXED = 2 };
-struct GwMode { int mode; int cap; };
+struct GwMode { int mode; int cap; int lite; };   // lite: the force sweep of this step left its per-layer adjoints in the workspace (WsLayer::LG*)
 static int molgw_cap() {
   const char* c = getenv("NQ_MOLGW_CAP");   // tests: a small cap sends ordinary molecules down the mixed path
   const int hw = nq_molgw_max_atoms();
@@ -187,7 +194,7 @@ static int molgw_cap() {
   return hw;
 }
 static GwMode decide_molgw(const nq_painn_cfg* c, const nq_graph* g, const WsLayout& W) {
-  GwMode r{GW_PAIR_ROWS, molgw_cap()};
+  GwMode r{GW_PAIR_ROWS, molgw_cap(), 0};
   const char* off = getenv("NQ_NO_MOLGW");
   if (!W.fused || (off && off[0] == '1') || !nq_molgw_config_ok(c->hidden_channels, c->num_rbf) || g->max_mol_atoms <= 0) return r;
   // small batches (the reference's 32 conformers): the schedule kernels and the two launches per layer are pure latency there (measured 3.99 vs 3.72 ms per
@@ -431,7 +438,11 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_HIP(hipMemsetAsync(ws + W.X[0] + NF, 0, NF * sizeof(float), st));
   NQ_HIP(hipMemsetAsync(ws + W.V[0], 0, 6 * NF * sizeof(float), st));
   float* rho = ws + W.RHO2; float* drho = rho + (size_t)E * R;
-  const GwMode gw = decide_molgw(cfg, graph, W);   // GW_PAIR_ROWS without the fused filter
+  GwMode gw = decide_molgw(cfg, graph, W);   // GW_PAIR_ROWS without the fused filter
+  // the force sweep below stores its per-layer adjoints for the second-order sweep (WsLayer::LG*): fused filter, the five-launch update reverse, NQ_NO_LITE unset
+  const bool lite_store = W.fused && forces != nullptr && !(getenv("NQ_FUSED_UPDATE_REV") && getenv("NQ_FUSED_UPDATE_REV")[0] == '1') &&
+                          !(getenv("NQ_NO_LITE") && getenv("NQ_NO_LITE")[0] == '1');
+  gw.lite = lite_store ? 1 : 0;
   remember_molgw(workspace, gw);
   if (W.fused) {
     FilterArgs fa0;
@@ -498,17 +509,28 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
   NQ_TRY(nq_atom_seeds(st, nullptr, g.atom_mol, N, ws + W.ge, nullptr));
   r.ge = ws + W.ge; r.GZO = ws + W.GZO;
   NQ_TRY(nq_readout_rev(st, r, false));
-  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, N, H, F, H, F, F, 0, "O1"));
-  float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
+  // lite_store: every stage of the sweep goes to its own per-layer buffer (no in-place updates), in the layout the second-order sweep reads as its tangent adjoints
+  float* gx_cur = lite_store ? ws + W.lay[L - 1].LGXA : ws + W.GX;     // adjoint of x_upd of the layer being processed
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, gx_cur, N, H, F, H, F, F, 0, "O1"));
+  float* gv_cur = lite_store ? ws + W.lay[L - 1].LGVA : ws + W.GVa; float* gv_oth = ws + W.GVb;
   NQ_HIP(hipMemsetAsync(gv_cur, 0, 3 * NF * sizeof(float), st));
   const int nwaves = F / 64;
   NQ_HIP(hipMemsetAsync(ws + W.GEDGE, 0, (size_t)nwaves * E * 4 * sizeof(float), st));
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     const PrePlanes pp = pre_planes(cfg, ws + y.WPRE);
+    float* const GY = lite_store ? ws + y.LGY + 3 * NF : ws + W.GY;
+    float* const GCAT = lite_store ? ws + y.LGCAT + 2 * NF : ws + W.GCAT;
+    float* const GU = lite_store ? ws + y.LGU + 6 * NF : ws + W.GU;
+    float* const GXH = lite_store ? ws + y.LGXH + 3 * NF : ws + W.GXH;
+    float* const gx_msg = lite_store ? ws + y.LGXB : gx_cur;            // adjoint of x_msg: gx_upd + gcat[:F]
+    float* const gv_msg = lite_store ? ws + y.LGVB : gv_cur;            // adjoint of vec_msg: gvec_upd + gu U
+    float* const gx_next = lite_store ? (l > 0 ? ws + W.lay[l - 1].LGXA : ws + W.GX) : gx_cur;
+    float* const gv_next = lite_store ? (l > 0 ? ws + W.lay[l - 1].LGVA : ws + W.GVb) : gv_oth;
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
-    u.GX = ws + W.GX; u.GV = gv_cur; u.GY = ws + W.GY; u.GCAT = ws + W.GCAT; u.GU = ws + W.GU;
+    u.GX = gx_cur; u.GV = gv_cur; u.GY = GY; u.GCAT = GCAT; u.GU = GU;
+    u.GX_out = lite_store ? gx_msg : nullptr;
     // Force-adjoint flavour of the fused update block: built, parity-tested, NOT the default -- 3.47 ms per step against 3.34 ms for the five launches below
     // (five dependent products with ten barriers and 400 four-byte loads per lane at eight wavefronts per CU: profiles/r06_fused_update_ab.txt); NQ_FUSED_UPDATE_REV=1 selects it.
     if (fused_upd && getenv("NQ_FUSED_UPDATE_REV") && getenv("NQ_FUSED_UPDATE_REV")[0] == '1') {
@@ -516,14 +538,15 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     } else {
     NQ_TRY(nq_upd_rev(st, u, 1, false));
     // G_Q = (G_Y V2) * silu'(Z_Q): the activation's adjoint in the epilogue of the input-gradient product (no separate k_silu_rev pass)
-    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2", pp.V2));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
+    NQ_TRY(nq_gemm_nn_epi(st, GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2", pp.V2));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
+    if (lite_store) NQ_TRY(nq_gemm_nn_epi(st, GU, params + up.U, gv_msg, 3 * N, 2 * F, F, gv_cur, 1.f, 0.f, 0, "U", pp.U));   // gv_msg = gv_upd + gu U
+    else NQ_TRY(nq_gemm_nn(st, GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
     }
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
-    m.GX = ws + W.GX; m.GV = gv_cur; m.GXH = ws + W.GXH; m.GV_out = gv_oth; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
+    m.GX = gx_msg; m.GV = gv_msg; m.GXH = GXH; m.GV_out = gv_next; m.GEDGE = reinterpret_cast<float4*>(ws + W.GEDGE);
     if (W.fused) {
       FilterArgs fa;
       nq_make_filter_args(&fa, ws + y.WRT, params + mp.br, rbf_offsets, ws + W.RW, R, cfg->cutoff, cfg->envelope_exponent, cfg->rbf_coeff, cfg->filter_mode);
@@ -532,9 +555,14 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     } else {
       NQ_TRY(nq_msg_rev(st, m, false));
     }
-    { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-    NQ_TRY(nq_gemm_nn_epi(st, ws + W.GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2", pp.W2));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, N, F, F, F, F, F, 1, "W1", pp.W1));
+    NQ_TRY(nq_gemm_nn_epi(st, GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2", pp.W2));
+    if (lite_store) {
+      NQ_TRY(nq_gemm_nn_epi(st, ws + W.GH, params + mp.W1, gx_next, N, F, F, gx_msg, 1.f, 0.f, 0, "W1", pp.W1));   // gx_upd of the layer below = gx_msg + gz1 W1
+      gx_cur = gx_next; gv_cur = gv_next;
+    } else {
+      { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
+      NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, gx_cur, N, F, F, F, F, F, 1, "W1", pp.W1));
+    }
   }
   NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
   return NQ_OK;
@@ -694,6 +722,10 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   NQ_TRY(nq_readout_rev(st, r, true));
   GwMode gw;
   if (!recall_molgw(workspace, &gw)) return nq_fail(NQ_ERR_ARG, "nq_painn_backward: no forward call has prepared this workspace");
+  // lite: the tangent adjoints (every GT* operand below) are the force sweep's adjoints of this step, stored per layer by nq_painn_forward: they are read, not
+  // recomputed -- the input-gradient products of V1, U, W1 and O1 run over the primal-adjoint rows only, the elementwise and message kernels skip their GT* stores.
+  // (V2 and W2 keep their stacked form: the force sweep folds silu' into those products' epilogues, so the pre-activation adjoints gtq / gth are not in the store.)
+  const bool lite = gw.lite && !seeded && W.fused;
   SideStream ss;
   if (gw.mode != GW_MIXED) side_stream_init(ss, st, N);   // mixed batches: the pair-row contraction of the large molecules and the per-molecule kernel add into one
                                                            // gradient and share the scratch with the split-K products -- everything stays on the main stream (a rare path)
@@ -701,9 +733,9 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   NQ_TRY(nq_colsum(sd, ws + W.TMPW, N, H, H, gp + P.w2, scr));
   NQ_TRY(nq_colsum(sd, ws + W.ge, N, 1, 1, gp + P.o2, scr));
   NQ_TRY(nq_gemm_tn(sd, ws + W.GZO, ws + W.X[L], gp + P.O1, 2L * N, H, F, H, F, scr, "O1", gp + P.o1, N));
-  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, 2 * N, H, F, H, F, F, 0, "O1"));
+  NQ_TRY(nq_gemm_nn(st, ws + W.GZO, params + P.O1, ws + W.GX, lite ? N : 2 * N, H, F, H, F, F, 0, "O1"));
   float* gv_cur = ws + W.GVa; float* gv_oth = ws + W.GVb;
-  NQ_HIP(hipMemsetAsync(gv_cur, 0, 6 * NF * sizeof(float), st));
+  NQ_HIP(hipMemsetAsync(gv_cur, 0, (lite ? 3 : 6) * NF * sizeof(float), st));
   if (seeded) {   // adjoints of the final (x, vec) coming from the force head
     if (seed_x) NQ_TRY(nq_axpy(st, seed_x, ws + W.GX, (long)NF));
     if (seed_vec) NQ_HIP(hipMemcpyAsync(gv_cur, seed_vec, 3 * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -718,41 +750,47 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   for (int l = L - 1; l >= 0; --l) {
     const WsLayer& y = W.lay[l]; const MsgP& mp = P.msg[l]; const UpdP& up = P.upd[l];
     const PrePlanes pp = pre_planes(cfg, ws + y.WPRE);
+    float* const GYs = lite ? ws + y.LGY : ws + W.GY;         // stacked [2][N][3F]: the second half is the force sweep's (lite) or written below
+    float* const GCATs = lite ? ws + y.LGCAT : ws + W.GCAT;
+    float* const GUs = lite ? ws + y.LGU : ws + W.GU;
+    float* const GXHs = lite ? ws + y.LGXH : ws + W.GXH;
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF; u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF;
-    u.GX = ws + W.GX; u.GTX = ws + W.GX + NF; u.GV = gv_cur; u.GTV = gv_cur + 3 * NF;
-    u.GY = ws + W.GY; u.GTY = ws + W.GY + 3 * NF; u.GCAT = ws + W.GCAT; u.GTCAT = ws + W.GCAT + 2 * NF;
-    u.GU = ws + W.GU; u.GTU = ws + W.GU + 6 * NF;
+    u.GX = ws + W.GX; u.GTX = lite ? ws + y.LGXA : ws + W.GX + NF; u.GV = gv_cur; u.GTV = lite ? ws + y.LGVA : gv_cur + 3 * NF;
+    u.GY = GYs; u.GTY = GYs + 3 * NF; u.GCAT = GCATs; u.GTCAT = GCATs + 2 * NF;
+    u.GU = GUs; u.GTU = GUs + 6 * NF;
+    u.lite = lite ? 1 : 0;
     ss.before_main_writes(SB_GY);
     NQ_TRY(nq_upd_rev(st, u, 1, true));
     if (!tn_group) {
     sd = ss.fork();
-    NQ_TRY(nq_gemm_tn(sd, ws + W.GY, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
+    NQ_TRY(nq_gemm_tn(sd, GYs, ws + y.Q, gp + up.V2, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", gp + up.c2, N));
     ss.read_by_side(SB_GY);
     }
     ss.before_main_writes(SB_GQ);
-    NQ_TRY(nq_gemm_nn(st, ws + W.GY, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2", pp.V2));
+    NQ_TRY(nq_gemm_nn(st, GYs, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2", pp.V2));
     NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
     if (!tn_group) {
     sd = ss.fork();
     NQ_TRY(nq_gemm_tn(sd, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
     ss.read_by_side(SB_GQ);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, ws + W.GCAT, 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, GCATs, lite ? N : 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     ss.before_main_writes(SB_GU);
     NQ_TRY(nq_upd_rev(st, u, 2, true));
     if (!tn_group) {
     sd = ss.fork();
-    NQ_TRY(nq_gemm_tn(sd, ws + W.GU, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
+    NQ_TRY(nq_gemm_tn(sd, GUs, ws + y.VM, gp + up.U, 6L * N, 2 * F, F, 2 * F, F, scr, "U"));
     ss.read_by_side(SB_GU);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GU, params + up.U, gv_cur, 6 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
+    NQ_TRY(nq_gemm_nn(st, GUs, params + up.U, gv_cur, lite ? 3 * N : 6 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
     MsgRevArgs m{};
     m.g = g; m.F = F; m.V = ws + W.V[l]; m.XH = ws + y.XH; m.PHI = ws + y.PHI; m.PSI = ws + y.PSI;
     m.TV = ws + W.V[l] + 3 * NF; m.TXH = ws + y.XH + 3 * NF; m.TD = ws + W.TD; m.TR = ws + W.TR;
-    m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = ws + W.GX + NF; m.GTV = gv_cur + 3 * NF;
-    m.GXH = ws + W.GXH; m.GTXH = ws + W.GXH + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
+    m.GX = ws + W.GX; m.GV = gv_cur; m.GTX = lite ? ws + y.LGXB : ws + W.GX + NF; m.GTV = lite ? ws + y.LGVB : gv_cur + 3 * NF;
+    m.GXH = GXHs; m.GTXH = GXHs + 3 * NF; m.GV_out = gv_oth; m.GTV_out = gv_oth + 3 * NF;
+    m.lite = lite ? 1 : 0;
     m.GPHI = gphi; m.GPSI = gpsi; m.GBR = ws + W.GBR;
     ss.before_main_writes(SB_GXH); ss.before_main_writes(SB_GPHI); ss.before_main_writes(SB_GBR);
     if (W.fused) {
@@ -783,10 +821,10 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (cfg->rbf_type)   // adjoints of rho / drho (shared by all layers): [gphi; gpsi] Wr, accumulated over the layers
       NQ_TRY(nq_gemm_nn(st, gphi, params + mp.Wr, ws + W.GRHO, 2 * E, 3 * F, R, 3 * F, R, R, l == L - 1 ? 0 : 1, "Wr"));
     if (!molgw) NQ_TRY(nq_colsum(sd, ws + W.GBR, N, 3 * F, 3 * F, gp + mp.br, scr));
-    if (!tn_group) NQ_TRY(nq_gemm_tn(sd, ws + W.GXH, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
+    if (!tn_group) NQ_TRY(nq_gemm_tn(sd, GXHs, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); if (!tn_group) ss.read_by_side(SB_GXH);
     ss.before_main_writes(SB_GH);
-    NQ_TRY(nq_gemm_nn(st, ws + W.GXH, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2", pp.W2));
+    NQ_TRY(nq_gemm_nn(st, GXHs, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2", pp.W2));
     NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
     sd = ss.fork();
     if (!tn_group) {
@@ -797,10 +835,10 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       // next layer's kernels overwrite them (each of those waits for this launch through its before_main_writes)
       NqTnSpec sp[5];
       tn_group_shapes(sp, N, F);
-      sp[0].G = ws + W.GY; sp[0].X = ws + y.Q; sp[0].out = gp + up.V2; sp[0].bias_out = gp + up.c2;
+      sp[0].G = GYs; sp[0].X = ws + y.Q; sp[0].out = gp + up.V2; sp[0].bias_out = gp + up.c2;
       sp[1].G = ws + W.GQ; sp[1].X = ws + y.CAT; sp[1].out = gp + up.V1; sp[1].bias_out = gp + up.c1;
-      sp[2].G = ws + W.GU; sp[2].X = ws + y.VM; sp[2].out = gp + up.U;
-      sp[3].G = ws + W.GXH; sp[3].X = ws + y.Hh; sp[3].out = gp + mp.W2; sp[3].bias_out = gp + mp.b2;
+      sp[2].G = GUs; sp[2].X = ws + y.VM; sp[2].out = gp + up.U;
+      sp[3].G = GXHs; sp[3].X = ws + y.Hh; sp[3].out = gp + mp.W2; sp[3].bias_out = gp + mp.b2;
       sp[4].G = ws + W.GH; sp[4].X = ws + W.X[l]; sp[4].out = gp + mp.W1; sp[4].bias_out = gp + mp.b1;
       if (nq_gemm_tn_group(sd, sp, 5, scr) != NQ_OK) {   // not eligible for the split engine (exact-f32 engine selected, unaligned operands): one launch each
         NQ_TRY(nq_gemm_tn(sd, sp[0].G, sp[0].X, sp[0].out, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", sp[0].bias_out, N));
@@ -811,7 +849,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       }
       ss.read_by_side(SB_GY); ss.read_by_side(SB_GQ); ss.read_by_side(SB_GU); ss.read_by_side(SB_GXH); ss.read_by_side(SB_GH);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, 2 * N, F, F, F, F, F, 1, "W1", pp.W1));
+    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, lite ? N : 2 * N, F, F, F, F, F, 1, "W1", pp.W1));
     // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final once the weight-gradient stream gets here: the caller's
     // collective stream may start reducing it
     if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], ss.on ? ss.side : st));

@@ -123,10 +123,12 @@ __global__ void k_upd_rev1(UpdRevArgs q) {
     const V gtv0 = nq_ld<V>(gtv + f), gtv1 = nq_ld<V>(gtv + F + f), gtv2 = nq_ld<V>(gtv + 2 * F + f);
     gyb += gtx * nq_ld<V>(q.TS + nf);
     gyc += gtv0 * nq_ld<V>(tu + f) + gtv1 * nq_ld<V>(tu + 2 * F + f) + gtv2 * nq_ld<V>(tu + 4 * F + f);
-    float* gty = q.GTY + n * 3 * F;
-    nq_st<V>(gty + f, gtx);
-    nq_st<V>(gty + F + f, gtx * s);
-    nq_st<V>(gty + 2 * F + f, gtv0 * u0 + gtv1 * u1 + gtv2 * u2);
+    if (!q.lite) {
+      float* gty = q.GTY + n * 3 * F;
+      nq_st<V>(gty + f, gtx);
+      nq_st<V>(gty + F + f, gtx * s);
+      nq_st<V>(gty + 2 * F + f, gtv0 * u0 + gtv1 * u1 + gtv2 * u2);
+    }
   }
   float* gy = q.GY + n * 3 * F;
   nq_st<V>(gy + f, gx); nq_st<V>(gy + F + f, gyb); nq_st<V>(gy + 2 * F + f, gyc);
@@ -169,15 +171,17 @@ __global__ void k_upd_rev2(UpdRevArgs q) {
       const V gtvc = nq_ld<V>(gtv + c * F + f);
       g1 += gtvc * tyc + gts * tb;
       g2 += gtn_n * (tb - tn_n * b) + gts * ta;
-      float* gtu = q.GTU + n * 6 * F;
-      nq_st<V>(gtu + c * 2 * F + f, gtvc * yc + gts * b);
-      nq_st<V>(gtu + c * 2 * F + F + f, gtn_n * b + gts * a);
+      if (!q.lite) {
+        float* gtu = q.GTU + n * 6 * F;
+        nq_st<V>(gtu + c * 2 * F + f, gtvc * yc + gts * b);
+        nq_st<V>(gtu + c * 2 * F + F + f, gtn_n * b + gts * a);
+      }
     }
     nq_st<V>(gu + c * 2 * F + f, g1);
     nq_st<V>(gu + c * 2 * F + F + f, g2);
   }
-  nq_st<V>(q.GX + nf, gx + nq_ld<V>(q.GCAT + n * 2 * F + f));
-  if (DUAL) nq_st<V>(q.GTX + nf, gtx + nq_ld<V>(q.GTCAT + n * 2 * F + f));
+  nq_st<V>((q.GX_out ? q.GX_out : q.GX) + nf, gx + nq_ld<V>(q.GCAT + n * 2 * F + f));
+  if (DUAL && !q.lite) nq_st<V>(q.GTX + nf, gtx + nq_ld<V>(q.GTCAT + n * 2 * F + f));
 }
 
 // ---------------------------------------------------------------------------------------------
