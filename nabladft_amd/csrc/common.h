@@ -191,6 +191,7 @@ int nq_graph_fill_impl(GraphFillArgs args, int B, int max_mol_atoms, hipStream_t
 // Bpre (optional): the weight pre-split into bf16 planes by nq_gemm_presplit_kn (same values as W): the split engine then loads it with 16-byte loads, no split arithmetic
 int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int M, int Nout, int Kin, const float* aux, float ea, float eb, int mode,
                    const char* tag = nullptr, const void* Bpre = nullptr);
+int nq_gemm_nn_dsilu2(hipStream_t st, const float* G, const float* W, float* C, float* C2, const float* aux, int M, int Nout, int Kin, const char* tag, const void* Bpre = nullptr);
 int nq_gemm_presplit_kn(hipStream_t st, int n, const float* const* W, const int* Kc, const int* N, void* const* out);
 int nq_gemm_nt_dsilu(hipStream_t st, const float* A, const float* W, float* C, float* C2, const float* aux, int M, int N, int K, const char* tag = nullptr);
 int nq_gemm_nt_act(hipStream_t, const float* A, const float* W, float* C, float* C2, const float* resid, float ea, float eb, int M, int N, int K,
@@ -258,7 +259,7 @@ int nq_updrev_fused(hipStream_t, const UpdRevArgs&, const float* frag, const flo
 int nq_upd_a(hipStream_t, const UpdArgs&, bool tan);
 int nq_upd_b(hipStream_t, const UpdArgs&, bool tan);
 int nq_silu_tan(hipStream_t, const float* Z, const float* TZ, float* TH, long count);
-int nq_silu_rev(hipStream_t, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual);
+int nq_silu_rev(hipStream_t, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual, bool lite = false);   // lite: GT = the tangent adjoint of the layer OUTPUT, read only
 int nq_upd_rev(hipStream_t, const UpdRevArgs&, int stage, bool dual);
 int nq_embed(hipStream_t, const int* z, const float* emb, int N, int F, float* X0);
 size_t nq_embed_grad_scratch_floats(int N, int F, int T);

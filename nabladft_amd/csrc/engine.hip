@@ -109,6 +109,7 @@ struct WsLayer {
   // so the force sweep writes its gy, gcat, gu, gxh into the SECOND halves of these stacked [2][rows][w] buffers and keeps the four stages of gx / gvec
   // (a: adjoint of x_upd / vec_upd, b: of x_msg / vec_msg); the second-order sweep fills the first halves and reads the second ones instead of recomputing them.
   size_t LGY, LGCAT, LGU, LGXH, LGXA, LGXB, LGVA, LGVB;
+  size_t LGQ, LGH, LGQP, LGHP;   // stacked [2][N][F] adjoints of the two SiLU layers' pre-activations (second half: force sweep) and, [N][F], of their outputs
 };
 struct WsLayout {
   size_t X[65], V[65];
@@ -144,6 +145,7 @@ static void make_ws_layout(const nq_painn_cfg* c, size_t N, size_t E, size_t B, 
     const size_t st_ = W->fused ? 1 : 0;
     y.LGY = take(st_ * 2 * N * 3 * F); y.LGCAT = take(st_ * 2 * N * 2 * F); y.LGU = take(st_ * 2 * N * 6 * F); y.LGXH = take(st_ * 2 * N * 3 * F);
     y.LGXA = take(st_ * N * F); y.LGXB = take(st_ * N * F); y.LGVA = take(st_ * N * 3 * F); y.LGVB = take(st_ * N * 3 * F);
+    y.LGQ = take(st_ * 2 * N * F); y.LGH = take(st_ * 2 * N * F); y.LGQP = take(st_ * N * F); y.LGHP = take(st_ * N * F);
   }
   W->RHO2 = take(2 * EP * R);   // full rho / drho rows only for the materialised-filter path (B operand of the gWr contraction)
   W->ORDER = take(W->fused ? E : 0);   // int32: CSR slots sorted by window start k0
@@ -538,8 +540,10 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     } else {
     NQ_TRY(nq_upd_rev(st, u, 1, false));
     // G_Q = (G_Y V2) * silu'(Z_Q): the activation's adjoint in the epilogue of the input-gradient product (no separate k_silu_rev pass)
-    NQ_TRY(nq_gemm_nn_epi(st, GY, params + up.V2, ws + W.GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2", pp.V2));
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
+    float* const GQ = lite_store ? ws + y.LGQ + NF : ws + W.GQ;
+    if (lite_store) NQ_TRY(nq_gemm_nn_dsilu2(st, GY, params + up.V2, ws + y.LGQP, GQ, ws + y.ZQ, N, 3 * F, F, "V2", pp.V2));   // keeps G_Y V2 as well (silu'' term of the second-order sweep)
+    else NQ_TRY(nq_gemm_nn_epi(st, GY, params + up.V2, GQ, N, 3 * F, F, ws + y.ZQ, 0.f, 1.f, 1, "V2", pp.V2));
+    NQ_TRY(nq_gemm_nn(st, GQ, params + up.V1, GCAT, N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     NQ_TRY(nq_upd_rev(st, u, 2, false));
     if (lite_store) NQ_TRY(nq_gemm_nn_epi(st, GU, params + up.U, gv_msg, 3 * N, 2 * F, F, gv_cur, 1.f, 0.f, 0, "U", pp.U));   // gv_msg = gv_upd + gu U
     else NQ_TRY(nq_gemm_nn(st, GU, params + up.U, gv_cur, 3 * N, 2 * F, F, 2 * F, F, F, 1, "U", pp.U));
@@ -555,13 +559,15 @@ int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* 
     } else {
       NQ_TRY(nq_msg_rev(st, m, false));
     }
-    NQ_TRY(nq_gemm_nn_epi(st, GXH, params + mp.W2, ws + W.GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2", pp.W2));
+    float* const GH = lite_store ? ws + y.LGH + NF : ws + W.GH;
+    if (lite_store) NQ_TRY(nq_gemm_nn_dsilu2(st, GXH, params + mp.W2, ws + y.LGHP, GH, ws + y.Z1, N, 3 * F, F, "W2", pp.W2));
+    else NQ_TRY(nq_gemm_nn_epi(st, GXH, params + mp.W2, GH, N, 3 * F, F, ws + y.Z1, 0.f, 1.f, 1, "W2", pp.W2));
     if (lite_store) {
-      NQ_TRY(nq_gemm_nn_epi(st, ws + W.GH, params + mp.W1, gx_next, N, F, F, gx_msg, 1.f, 0.f, 0, "W1", pp.W1));   // gx_upd of the layer below = gx_msg + gz1 W1
+      NQ_TRY(nq_gemm_nn_epi(st, GH, params + mp.W1, gx_next, N, F, F, gx_msg, 1.f, 0.f, 0, "W1", pp.W1));   // gx_upd of the layer below = gx_msg + gz1 W1
       gx_cur = gx_next; gv_cur = gv_next;
     } else {
       { float* t = gv_cur; gv_cur = gv_oth; gv_oth = t; }
-      NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, gx_cur, N, F, F, F, F, F, 1, "W1", pp.W1));
+      NQ_TRY(nq_gemm_nn(st, GH, params + mp.W1, gx_cur, N, F, F, F, F, F, 1, "W1", pp.W1));
     }
   }
   NQ_TRY(nq_geom_rev(st, g, reinterpret_cast<const float4*>(ws + W.GEDGE), nwaves, forces));
@@ -723,8 +729,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
   GwMode gw;
   if (!recall_molgw(workspace, &gw)) return nq_fail(NQ_ERR_ARG, "nq_painn_backward: no forward call has prepared this workspace");
   // lite: the tangent adjoints (every GT* operand below) are the force sweep's adjoints of this step, stored per layer by nq_painn_forward: they are read, not
-  // recomputed -- the input-gradient products of V1, U, W1 and O1 run over the primal-adjoint rows only, the elementwise and message kernels skip their GT* stores.
-  // (V2 and W2 keep their stacked form: the force sweep folds silu' into those products' epilogues, so the pre-activation adjoints gtq / gth are not in the store.)
+  // recomputed -- every input-gradient product runs over the primal-adjoint rows only, the elementwise and message kernels skip their GT* stores.
+  // (The force sweep's V2 / W2 products keep both forms of their result: the adjoint of the SiLU layer's output, for the silu'' term here, and of its pre-activation.)
   const bool lite = gw.lite && !seeded && W.fused;
   SideStream ss;
   if (gw.mode != GW_MIXED) side_stream_init(ss, st, N);   // mixed batches: the pair-row contraction of the large molecules and the per-molecule kernel add into one
@@ -754,6 +760,8 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     float* const GCATs = lite ? ws + y.LGCAT : ws + W.GCAT;
     float* const GUs = lite ? ws + y.LGU : ws + W.GU;
     float* const GXHs = lite ? ws + y.LGXH : ws + W.GXH;
+    float* const GQs = lite ? ws + y.LGQ : ws + W.GQ;         // stacked [2][N][F] adjoints of zq (lite: second half = the force sweep's)
+    float* const GHs = lite ? ws + y.LGH : ws + W.GH;
     UpdRevArgs u{};
     u.N = N; u.F = F; u.U = ws + y.UU; u.Y = ws + y.Y; u.S = ws + y.S; u.CAT = ws + y.CAT;
     u.TU = ws + y.UU + 6 * NF; u.TY = ws + y.Y + 3 * NF; u.TS = ws + y.S + NF; u.TCAT = ws + y.CAT + 2 * NF;
@@ -769,14 +777,14 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     ss.read_by_side(SB_GY);
     }
     ss.before_main_writes(SB_GQ);
-    NQ_TRY(nq_gemm_nn(st, GYs, params + up.V2, ws + W.GQ, 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2", pp.V2));
-    NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, ws + W.GQ, ws + W.GQ + NF, (long)NF, true));
+    NQ_TRY(nq_gemm_nn(st, GYs, params + up.V2, GQs, lite ? N : 2 * N, 3 * F, F, 3 * F, F, F, 0, "V2", pp.V2));
+    NQ_TRY(nq_silu_rev(st, ws + y.ZQ, ws + y.ZQ + NF, GQs, lite ? ws + y.LGQP : GQs + NF, (long)NF, true, lite));
     if (!tn_group) {
     sd = ss.fork();
-    NQ_TRY(nq_gemm_tn(sd, ws + W.GQ, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
+    NQ_TRY(nq_gemm_tn(sd, GQs, ws + y.CAT, gp + up.V1, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", gp + up.c1, N));
     ss.read_by_side(SB_GQ);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GQ, params + up.V1, GCATs, lite ? N : 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
+    NQ_TRY(nq_gemm_nn(st, GQs, params + up.V1, GCATs, lite ? N : 2 * N, F, 2 * F, F, 2 * F, 2 * F, 0, "V1", pp.V1));
     ss.before_main_writes(SB_GU);
     NQ_TRY(nq_upd_rev(st, u, 2, true));
     if (!tn_group) {
@@ -824,11 +832,11 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
     if (!tn_group) NQ_TRY(nq_gemm_tn(sd, GXHs, ws + y.Hh, gp + mp.W2, 2L * N, 3 * F, F, 3 * F, F, scr, "W2", gp + mp.b2, N));
     ss.read_by_side(SB_GPHI); ss.read_by_side(SB_GBR); if (!tn_group) ss.read_by_side(SB_GXH);
     ss.before_main_writes(SB_GH);
-    NQ_TRY(nq_gemm_nn(st, GXHs, params + mp.W2, ws + W.GH, 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2", pp.W2));
-    NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, ws + W.GH, ws + W.GH + NF, (long)NF, true));
+    NQ_TRY(nq_gemm_nn(st, GXHs, params + mp.W2, GHs, lite ? N : 2 * N, 3 * F, F, 3 * F, F, F, 0, "W2", pp.W2));
+    NQ_TRY(nq_silu_rev(st, ws + y.Z1, ws + y.Z1 + NF, GHs, lite ? ws + y.LGHP : GHs + NF, (long)NF, true, lite));
     sd = ss.fork();
     if (!tn_group) {
-      NQ_TRY(nq_gemm_tn(sd, ws + W.GH, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
+      NQ_TRY(nq_gemm_tn(sd, GHs, ws + W.X[l], gp + mp.W1, 2L * N, F, F, F, F, scr, "W1", gp + mp.b1, N));
       ss.read_by_side(SB_GH);
     } else {
       // all five weight-gradient products of the layer (and their bias gradients) in one launch: gy, gq, gu, gxh, gh are final and stay untouched until the
@@ -836,10 +844,10 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       NqTnSpec sp[5];
       tn_group_shapes(sp, N, F);
       sp[0].G = GYs; sp[0].X = ws + y.Q; sp[0].out = gp + up.V2; sp[0].bias_out = gp + up.c2;
-      sp[1].G = ws + W.GQ; sp[1].X = ws + y.CAT; sp[1].out = gp + up.V1; sp[1].bias_out = gp + up.c1;
+      sp[1].G = GQs; sp[1].X = ws + y.CAT; sp[1].out = gp + up.V1; sp[1].bias_out = gp + up.c1;
       sp[2].G = GUs; sp[2].X = ws + y.VM; sp[2].out = gp + up.U;
       sp[3].G = GXHs; sp[3].X = ws + y.Hh; sp[3].out = gp + mp.W2; sp[3].bias_out = gp + mp.b2;
-      sp[4].G = ws + W.GH; sp[4].X = ws + W.X[l]; sp[4].out = gp + mp.W1; sp[4].bias_out = gp + mp.b1;
+      sp[4].G = GHs; sp[4].X = ws + W.X[l]; sp[4].out = gp + mp.W1; sp[4].bias_out = gp + mp.b1;
       if (nq_gemm_tn_group(sd, sp, 5, scr) != NQ_OK) {   // not eligible for the split engine (exact-f32 engine selected, unaligned operands): one launch each
         NQ_TRY(nq_gemm_tn(sd, sp[0].G, sp[0].X, sp[0].out, 2L * N, 3 * F, F, 3 * F, F, scr, "V2", sp[0].bias_out, N));
         NQ_TRY(nq_gemm_tn(sd, sp[1].G, sp[1].X, sp[1].out, 2L * N, F, 2 * F, F, 2 * F, scr, "V1", sp[1].bias_out, N));
@@ -849,7 +857,7 @@ static int painn_backward_impl(const nq_painn_cfg* cfg, const float* params, con
       }
       ss.read_by_side(SB_GY); ss.read_by_side(SB_GQ); ss.read_by_side(SB_GU); ss.read_by_side(SB_GXH); ss.read_by_side(SB_GH);
     }
-    NQ_TRY(nq_gemm_nn(st, ws + W.GH, params + mp.W1, ws + W.GX, lite ? N : 2 * N, F, F, F, F, F, 1, "W1", pp.W1));
+    NQ_TRY(nq_gemm_nn(st, GHs, params + mp.W1, ws + W.GX, lite ? N : 2 * N, F, F, F, F, F, 1, "W1", pp.W1));
     // every gradient slice of layer l (and, for l = L-1, of the read-out head) is final once the weight-gradient stream gets here: the caller's
     // collective stream may start reducing it
     if (layer_events && layer_events[L - 1 - l]) NQ_HIP(hipEventRecord((hipEvent_t)layer_events[L - 1 - l], ss.on ? ss.side : st));

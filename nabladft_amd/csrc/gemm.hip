@@ -783,6 +783,24 @@ int nq_gemm_nn_epi(hipStream_t st, const float* G, const float* W, float* C, int
   return NQ_OK;
 }
 
+// C = G W (the adjoint of a SiLU layer's OUTPUT) and C2 = C * silu'(aux) (the adjoint of its pre-activation) in one pass: the force sweep keeps both, because the
+// second-order sweep needs the first for its silu'' term and the second as an operand of the weight gradient (engine.hip: per-layer adjoint store)
+int nq_gemm_nn_dsilu2(hipStream_t st, const float* G, const float* W, float* C, float* C2, const float* aux, int M, int Nout, int Kin, const char* tag, const void* Bpre) {
+  char nm__[48]; if (nq_profile_on) snprintf(nm__, sizeof nm__, "gemm_nn:%s[n=%d,k=%d]", tag ? tag : "", Kin, Nout); else nm__[0] = 0;
+  NQ_PROF(st, nm__);
+  NQ_PROF_FLOPS(2.0 * M * Nout * Kin);
+  if (M <= 0) return NQ_OK;
+  GemmArgs p{G, W, C, nullptr, C2, M, Kin, Nout, Nout, Kin, Kin, 0, 0, nullptr, 0};
+  p.resid = aux; p.ea = 0.f; p.eb = 1.f;
+  if (Bpre && !(Kin & 127) && !(Nout & 15)) { p.Bpre = Bpre; p.ldbpre = Nout; p.bpre_plane_bytes = Kin * Nout * 2; }
+  if (gemm3_ok<true, false>(p, Nout, 1)) NQ_TRY((launch_gemm3<true, false, EPI_DSILU2>(st, p, 1)));
+  else if (gemm2_ok<true, false>(p, Nout)) launch_gemm2<true, false, EPI_DSILU2>(st, p, 1);
+  else if (gemm_is_small(M, Kin) && !(g_gemm_variant & 8)) hipLaunchKernelGGL((k_gemm_small<false, EPI_DSILU2>), dim3(nq_cdiv(M, SM), nq_cdiv(Kin, SM), 1), dim3(256), 0, st, p);
+  else launch_gemm<true, false, EPI_DSILU2, 16>(st, dim3(nq_cdiv(M, BM), nq_cdiv(Kin, BN), 1), p);
+  NQ_LAUNCH_CHECK();
+  return NQ_OK;
+}
+
 // out[Mo, No] = sum_{r<rows} GY[r, Mo] * X[r, No];  scratch must hold nq_gemm_tn_scratch_floats()
 // Split count for the weight-gradient contraction: enough workgroups to fill 256 CUs (~768) given the number
 // of 128x128 output tiles, but at least 512 rows per split so the 64-KB partial slab stays amortised.

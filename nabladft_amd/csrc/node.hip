@@ -82,7 +82,8 @@ __global__ void k_silu_tan(const float* __restrict__ Z, const float* __restrict_
 }
 
 // reverse of SiLU, in place on the adjoint(s):  G <- G dsilu(Z) (+ GT d2silu(Z) TZ) ;  GT <- GT dsilu(Z).  Four consecutive elements per thread (count % 4 == 0: N x F)
-template <bool DUAL>
+// LITE (dual): GT holds the tangent adjoint of the layer's OUTPUT (from the force sweep's store) and is only read; its pre-activation form is in the store already
+template <bool DUAL, bool LITE = false>
 __global__ void k_silu_rev(const float* __restrict__ Z, const float* __restrict__ TZ, float* __restrict__ G, float* __restrict__ GT, long count) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= count) return;
@@ -100,7 +101,7 @@ __global__ void k_silu_rev(const float* __restrict__ Z, const float* __restrict_
     g[c] = gc;
   }
   nq_st<nq_f4>(G + i, g);
-  if (DUAL) nq_st<nq_f4>(GT + i, gt);
+  if (DUAL && !LITE) nq_st<nq_f4>(GT + i, gt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -379,11 +380,12 @@ int nq_silu_tan(hipStream_t st, const float* Z, const float* TZ, float* TH, long
   NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
-int nq_silu_rev(hipStream_t st, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual) {
+int nq_silu_rev(hipStream_t st, const float* Z, const float* TZ, float* G, float* GT, long count, bool dual, bool lite) {
   NQ_PROF(st, "silu_rev");
   if (count <= 0) return NQ_OK;
   if (count & 3) return nq_fail(NQ_ERR_ARG, "silu_rev: element count %ld is not a multiple of 4", count);
-  if (dual) hipLaunchKernelGGL((k_silu_rev<true>), grid1d(count / 4, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
+  if (dual && lite) hipLaunchKernelGGL((k_silu_rev<true, true>), grid1d(count / 4, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
+  else if (dual) hipLaunchKernelGGL((k_silu_rev<true>), grid1d(count / 4, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
   else hipLaunchKernelGGL((k_silu_rev<false>), grid1d(count / 4, 256), dim3(256), 0, st, Z, TZ, G, GT, count);
   NQ_LAUNCH_CHECK();
   return NQ_OK;
