@@ -488,6 +488,39 @@ def test_engine_matches_reference_golden(name, fused, monkeypatch):
         f.write(f"worst grad vs golden: {worst}\n")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["painn_full_real4.npz", "painn_small_ragged.npz"])
+def test_second_order_sweep_with_stored_tangent_adjoints_equals_the_full_dual_sweep(name, monkeypatch):
+    """csrc/engine.hip (round 6): the tangent adjoints of the second-order sweep obey the force sweep's recursion with the same seeds, so the force sweep stores
+    its per-layer adjoints and the second-order sweep reads them (input-gradient products, SiLU reverse and the GT* stores run over / touch the primal-adjoint
+    half only).  NQ_NO_LITE=1 keeps the full stacked sweep of rounds 1-5.  Both must give the reference's gradients (golden vectors, the bounds of
+    test_engine_matches_reference_golden) and agree with each other to f32 rounding; energies and forces are bitwise equal (the force sweep computes the same
+    values, only into other buffers)."""
+    import nabladft_amd as nq
+    from nabladft_amd import L2Loss
+    dev = _dev()
+    fx, cfg, params = load_case(name)
+    res = {}
+    for mode in ("stored", "full"):
+        if mode == "full":
+            monkeypatch.setenv("NQ_NO_LITE", "1")
+        else:
+            monkeypatch.delenv("NQ_NO_LITE", raising=False)
+        model = _model(cfg, params, dev)
+        batch = _batch(fx, dev)
+        model.train()
+        energy, forces = model(batch)
+        loss = torch.nn.L1Loss()(energy, batch.y) + L2Loss()(forces, batch.forces)
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+        check_grads(fx, grads, 5e-5, f"second-order sweep ({mode} tangent adjoints)")
+        res[mode] = (energy.detach().cpu(), forces.detach().cpu(), grads)
+    assert torch.equal(res["stored"][0], res["full"][0]) and torch.equal(res["stored"][1], res["full"][1])
+    for k in res["full"][2]:
+        a, b = res["stored"][2][k], res["full"][2][k]
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(float(np.abs(b).max()), 1e-30), k
+
+
 @pytest.mark.parametrize("mode", ["unfused", "fused_forward", "fused_forward_and_tangent", "fused_forward_and_force_adjoint"])
 def test_update_block_flavours_agree_with_the_reference(mode, monkeypatch):
     """csrc/updfuse.hip: the update block of a layer as ONE kernel per sweep (hidden_channels = 128) against the five launches it replaces and against the
