@@ -627,7 +627,8 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
 #endif
 // GW (dual only): this kernel also produces the pair rows gphi / gpsi and the per-atom bias sums for the rbf_proj gradient (rounds 1-4, still the path
 // for molecules that do not fit the LDS of molpair.hip); GW = false: the gradient is recomputed from node rows by k_gwr_mol, nothing is stored per pair.
-template <bool DUAL, int CH, bool GW>
+// LITE (dual, compile time): the adjoints of t_xh / t_vec are not accumulated at all (MsgRevArgs::lite at run time only skips their stores)
+template <bool DUAL, int CH, bool GW, bool LITE = false>
 __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterArgs& fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
   FUSED_ROWS(DUAL ? 3 : 2) {
@@ -726,9 +727,9 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
             gmc += T0 * tr0 + T1 * tr1 + T2 * tr2;
             const float gtmc = T0 * r0 + T1 * r1 + T2 * r2;
             gv0[c] += T0 * tmb; gv1[c] += T1 * tmb; gv2[c] += T2 * tmb;
-            gtv0[c] += T0 * mb; gtv1[c] += T1 * mb; gtv2[c] += T2 * mb;
+            if (!LITE) { gtv0[c] += T0 * mb; gtv1[c] += T1 * mb; gtv2[c] += T2 * mb; }
             gxa[c] += gma * pa[c] + gtma * tpa; gxb[c] += gmb * pb[c] + gtmb * tpb; gxc[c] += gmc * pc[c] + gtmc * tpc;
-            gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c];
+            if (!LITE) { gtxa[c] += gtma * pa[c]; gtxb[c] += gtmb * pb[c]; gtxc[c] += gtmc * pc[c]; }
             if (GW) {
               ga[c] = gma * xa[c] + gtma * txa[c]; gb[c] = gmb * xb[c] + gtmb * txb[c]; gc[c] = gmc * xc[c] + gtmc * txc[c];
               ha[c] = gtma * xa[c] * td; hb[c] = gtmb * xb[c] * td; hc[c] = gtmc * xc[c] * td;
@@ -825,7 +826,7 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
     stv<CH>(q.GV_out + o3, g0); stv<CH>(q.GV_out + o3 + F, g1); stv<CH>(q.GV_out + o3 + 2 * F, g2);
     if (DUAL) {
       if (GW) { stv<CH>(q.GBR + o3, sba); stv<CH>(q.GBR + o3 + F, sbb); stv<CH>(q.GBR + o3 + 2 * F, sbc); }
-      if (!q.lite) {   // (lite: the adjoints of t_xh / t_vec are the force sweep's gxh / gvec_out of this layer, already stored)
+      if (!LITE && !q.lite) {   // (lite: the adjoints of t_xh / t_vec are the force sweep's gxh / gvec_out of this layer, already stored)
         stv<CH>(q.GTXH + o3, gtxa); stv<CH>(q.GTXH + o3 + F, gtxb); stv<CH>(q.GTXH + o3 + 2 * F, gtxc);
         ldv<CH>(g0, q.GTV + o3); ldv<CH>(g1, q.GTV + o3 + F); ldv<CH>(g2, q.GTV + o3 + 2 * F);
 #pragma unroll
@@ -841,9 +842,9 @@ template <bool DUAL, int CH>
 __global__ __launch_bounds__(fused_threads(DUAL ? 3 : 2, CH)) void k_msgf_rev(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
   msgf_rev_body<DUAL, CH, DUAL>(q, fa, RW);
 }
-template <bool DUAL, int CH>   // DUAL is always true here (same template shape as k_msgf_rev for the dispatch macros)
+template <bool LITE, int CH>   // always the dual flavour; LITE = the stored-tangent-adjoint form of engine.hip (the default), false = the full dual sweep
 __global__ __launch_bounds__(fused_threads(4, CH)) void k_msgf_rev_nopair(MsgRevArgs q, FilterArgs fa, const float* __restrict__ RW) {
-  msgf_rev_body<true, CH, false>(q, fa, RW);
+  msgf_rev_body<true, CH, false, LITE>(q, fa, RW);
 }
 
 // =============================================================================================
@@ -1255,7 +1256,8 @@ int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool 
   const int kind = dual ? (pair_rows ? 3 : 4) : 2;
   const int ch = fused_ch(dual ? 3 : 2, q.F, q.g.N);
   const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(kind, ch));
-  if (dual && !pair_rows) FUSED_DISPATCH(k_msgf_rev_nopair, true, q);
+  if (dual && !pair_rows && q.lite) FUSED_DISPATCH(k_msgf_rev_nopair, true, q);
+  else if (dual && !pair_rows) FUSED_DISPATCH(k_msgf_rev_nopair, false, q);
   else if (dual) FUSED_DISPATCH(k_msgf_rev, true, q);
   else FUSED_DISPATCH(k_msgf_rev, false, q);
   NQ_LAUNCH_CHECK();
