@@ -363,6 +363,12 @@ __device__ __forceinline__ void reduce_partials_body(const float* __restrict__ p
 __global__ __launch_bounds__(RP_CHUNKS * RP_ELEMS) void k_reduce_partials(const float* __restrict__ part, int nsplit, long stride, long count, float* __restrict__ out) {
   reduce_partials_body(part, nsplit, stride, count, out, (long)blockIdx.x);
 }
+// two reductions of the same split count in one launch (a weight-gradient product and its bias gradient): blocks [0, blocks_a) take the first
+__global__ __launch_bounds__(RP_CHUNKS * RP_ELEMS) void k_reduce_partials2(const float* __restrict__ part_a, long count_a, float* __restrict__ out_a, int blocks_a,
+                                                                           const float* __restrict__ part_b, long count_b, float* __restrict__ out_b, int nsplit) {
+  if ((int)blockIdx.x < blocks_a) reduce_partials_body(part_a, nsplit, count_a, count_a, out_a, (long)blockIdx.x);
+  else reduce_partials_body(part_b, nsplit, count_b, count_b, out_b, (long)blockIdx.x - blocks_a);
+}
 static unsigned reduce_partials_blocks(int nsplit, long count) { return (unsigned)nq_cdiv(count, nsplit < RP_MIN_SPLITS ? (long)RP_CHUNKS * RP_ELEMS : (long)RP_ELEMS); }
 #define LAUNCH_REDUCE_PARTIALS(st, part, nsplit, stride, count, out) \
   hipLaunchKernelGGL(k_reduce_partials, dim3(reduce_partials_blocks(nsplit, count)), dim3(RP_CHUNKS * RP_ELEMS), 0, st, part, nsplit, stride, count, out)
@@ -852,12 +858,13 @@ int nq_gemm_tn(hipStream_t st, const float* GY, const float* X, float* out, long
   else launch_gemm<false, false, EPI_PARTIAL>(st, dim3(nq_cdiv(Mo, BM), nq_cdiv(No, BN), nse), p);
   NQ_LAUNCH_CHECK();
   const long cnt = (long)Mo * No;
-  LAUNCH_REDUCE_PARTIALS(st, scratch, nse, cnt, cnt, out);
-  NQ_LAUNCH_CHECK();
-  if (bias_out) {
-    LAUNCH_REDUCE_PARTIALS(st, bpart, nse, (long)Mo, (long)Mo, bias_out);
-    NQ_LAUNCH_CHECK();
+  if (bias_out) {   // weights and bias in one launch (the reduction order of each is the one k_reduce_partials uses)
+    const unsigned ba = reduce_partials_blocks(nse, cnt), bb = reduce_partials_blocks(nse, (long)Mo);
+    hipLaunchKernelGGL(k_reduce_partials2, dim3(ba + bb), dim3(RP_CHUNKS * RP_ELEMS), 0, st, scratch, cnt, out, (int)ba, bpart, (long)Mo, bias_out, nse);
+  } else {
+    LAUNCH_REDUCE_PARTIALS(st, scratch, nse, cnt, cnt, out);
   }
+  NQ_LAUNCH_CHECK();
   return NQ_OK;
 }
 
