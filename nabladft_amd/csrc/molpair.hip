@@ -143,7 +143,6 @@ __global__ void k_pair_windows(const int* __restrict__ hist, int nbins, int* __r
 template <bool FILL>
 __device__ __forceinline__ void pair_sched_pass(const NqGraphView& g, const int* __restrict__ dst, const float* __restrict__ RW, const int* __restrict__ wlo,
                                                 const int* cut, const int* bst, int b0, int a0, int s0, int s1, int lane, int* cnt, int2* __restrict__ sched) {
-  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int c0 = s0; c0 < s1; c0 += 64) {
     const int s = c0 + lane;
     int key = -1, n = 0, k = 0;
@@ -151,23 +150,26 @@ __device__ __forceinline__ void pair_sched_pass(const NqGraphView& g, const int*
       n = dst[s]; k = g.col[s];
       if (k < n) key = min(GM_MAX_BINS - 1, __float_as_int(RW[(long)s * RW_STRIDE + 13]));
     }
-    unsigned long long todo = __ballot(key >= 0);
-    while (todo) {   // one round per distinct key of the chunk
-      const int lead = __builtin_ctzll(todo);
-      const int kk = __builtin_amdgcn_readlane(key, lead);
-      const unsigned long long mask = __ballot(key == kk);
-      if (FILL && key == kk) {
-        const int pos = cnt[kk] + __popcll(mask & lt);
-        int w = 0;
+    // rank of the lane among the chunk's lanes with the same key (lower lane index first: slot order) and whether it is the last of them: 64 lane broadcasts,
+    // no LDS and no loop over the distinct keys (that loop was a chain of ~10 dependent LDS operations per key: 0.22 ms per step at 2048 conformers)
+    int below = 0;
+    bool last = true;
 #pragma unroll
-        for (int v = 1; v < GM_NW; ++v) w += pos >= cut[v];
-        sched[(long)GM_BATCH * (b0 + bst[w]) + (pos - cut[w])] = make_int2(s, ((kk - wlo[w]) << 26) | ((n - a0) << 13) | (k - a0));
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane == lead) cnt[kk] += __popcll(mask);
-      __builtin_amdgcn_wave_barrier();
-      todo &= ~mask;
+    for (int i = 0; i < 64; ++i) {
+      const bool same = __builtin_amdgcn_readlane(key, i) == key;
+      below += (same && i < lane) ? 1 : 0;
+      last = last && !(same && i > lane);
     }
+    const int pos = key >= 0 ? cnt[key] + below : 0;
+    if (FILL && key >= 0) {
+      int w = 0;
+#pragma unroll
+      for (int v = 1; v < GM_NW; ++v) w += pos >= cut[v];
+      sched[(long)GM_BATCH * (b0 + bst[w]) + (pos - cut[w])] = make_int2(s, ((key - wlo[w]) << 26) | ((n - a0) << 13) | (k - a0));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (key >= 0 && last) cnt[key] = pos + 1;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 __global__ __launch_bounds__(64) void k_pair_sched(NqGraphView g, const int* __restrict__ dst, const float* __restrict__ RW, const int* __restrict__ wlo, int cap,
@@ -220,13 +222,14 @@ __global__ __launch_bounds__(64) void k_pair_sched(NqGraphView g, const int* __r
 // written once per backward sweep (TD set).
 __global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sched, const int2* __restrict__ seg, const float* __restrict__ RW,
                                                     const float* __restrict__ TD, int nseg, u4* __restrict__ PA) {
-  // four wavefronts per (molecule, wavefront-of-k_gwr_mol) segment, each taking every fourth batch (a segment has ~7: the loop is a chain of dependent gathers)
+  // four wavefronts per (molecule, wavefront-of-k_gwr_mol) segment; each HALF-wavefront takes every eighth batch (a segment has ~7: the loop is a chain of
+  // dependent gathers; a launch writes only one half of the 64-lane records -- rho, or t_d drho -- so 32 lanes cover a batch)
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), sg = wid >> 2, lane = threadIdx.x & 63;
   if (sg >= nseg) return;
   const int2 se = seg[sg];
-  const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, j = lane & 31, half = lane >> 5;
-  if ((half == 1) != (TD != nullptr)) return;
-  for (int b = wid & 3; b < nb; b += 4) {
+  const int nb = (se.y + GM_BATCH - 1) / GM_BATCH, j = lane & 31, sub = lane >> 5;
+  const int half = TD != nullptr ? 1 : 0, olane = half * 32 + j;
+  for (int b = (wid & 3) * 2 + sub; b < nb; b += 8) {
     const long batch = se.x + b;
     float v[GM_BATCH];
 #pragma unroll
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(256) void k_pair_arec(const int2* __restrict__ sche
     unsigned hi[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
-    PA[(batch * 2 + 0) * 64 + lane] = u4{hi[0], hi[1], hi[2], hi[3]};
-    PA[(batch * 2 + 1) * 64 + lane] = u4{lo[0], lo[1], lo[2], lo[3]};
+    PA[(batch * 2 + 0) * 64 + olane] = u4{hi[0], hi[1], hi[2], hi[3]};
+    PA[(batch * 2 + 1) * 64 + olane] = u4{lo[0], lo[1], lo[2], lo[3]};
   }
 }
 // Packed scalars, once per backward sweep (the tangent t_r follows the force seeds): PG[batch][8 i + f] = field f of pair i:
