@@ -40,3 +40,20 @@ def test_tangent_is_directional_derivative():
     edot = sw.tangent(v)
     # Edot = v . dE/dpos = -v . F
     assert abs(float(edot) + float((v * sw.ws["forces"]).sum())) < 1e-9 * max(1.0, abs(float(edot)))
+
+
+def test_tangent_adjoints_of_the_second_order_sweep_are_the_force_sweep_adjoints():
+    """The identity csrc/engine.hip relies on since round 6: in the dual reverse sweep the adjoints of the TANGENT variables obey the force
+    sweep's recursion with the same seeds (E_dot = sum of the atom energy tangents is linear in them), so they equal the force sweep's adjoints at every layer
+    boundary -- whatever direction the tangent sweep took and whatever the energy seeds are.  float64, 1e-12."""
+    cfg, P, pos, z, batch, y, ft, ei = _case(torch.float64)
+    sw = Sweeps(P, cfg, pos, z, batch, ei)
+    energy, forces = sw.energy_forces()
+    lam = {k: v.clone() for k, v in sw.ws.items() if k.startswith("g_x_in") or k.startswith("g_vec_in")}      # left by the force sweep
+    assert len(lam) == 2 * cfg.num_layers
+    _, gE, gF = loss_and_seeds(energy, forces, y, ft)
+    sw.backward(gE, gF)                                                                                         # tangent sweep along -gF, then the dual sweep
+    for k, v in lam.items():
+        gt = sw.ws["gt_" + k[2:]]
+        assert float((gt - v).abs().max()) <= 1e-12 * max(1.0, float(v.abs().max())), k
+        assert float((sw.ws[k] - v).abs().max()) > 1e-6 * float(v.abs().max()), k                               # (the primal adjoints are something else)
