@@ -493,23 +493,27 @@ __device__ __forceinline__ void filter_eval(const WinRegs<PSI>& w, const float* 
 template <bool TAN, int CH>
 struct FwdOps { float xa[CH], xb[CH], xc[CH], va[CH], vb[CH], vc[CH], txa[CH], txb[CH], txc[CH], tva[CH], tvb[CH], tvc[CH]; };
 
+// Neighbour rows through buffer descriptors (lanes.h: ldv_buf): the row byte offsets are scalars, the lane offset one constant VGPR.
+template <bool TAN>
+struct FwdSrc {
+  __amdgpu_buffer_rsrc_t xh, v, txh, tv;
+  __device__ __forceinline__ FwdSrc(const MsgArgs& q) : xh(row_rsrc(q.XH)), v(row_rsrc(q.V)), txh(row_rsrc(TAN ? q.TXH : q.XH)), tv(row_rsrc(TAN ? q.TV : q.V)) {}
+};
 template <bool TAN, int CH>
-__device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const MsgArgs& q, int k, int F, int F3, int fb) {
-  const float* xh = q.XH + (long)k * F3 + fb;
-  const float* vk = q.V + (long)k * F3 + fb;
-  ldv<CH>(o.xa, xh); ldv<CH>(o.xb, xh + F); ldv<CH>(o.xc, xh + 2 * F);
-  ldv<CH>(o.va, vk); ldv<CH>(o.vb, vk + F); ldv<CH>(o.vc, vk + 2 * F);
+__device__ __forceinline__ void load_fwd(FwdOps<TAN, CH>& o, const FwdSrc<TAN>& src, int k, int F, int F3, int fb) {
+  const int ob = fb * 4, r0 = k * F3 * 4, r1 = r0 + F * 4, r2 = r1 + F * 4;
+  ldv_buf<CH>(o.xa, src.xh, ob, r0); ldv_buf<CH>(o.xb, src.xh, ob, r1); ldv_buf<CH>(o.xc, src.xh, ob, r2);
+  ldv_buf<CH>(o.va, src.v, ob, r0); ldv_buf<CH>(o.vb, src.v, ob, r1); ldv_buf<CH>(o.vc, src.v, ob, r2);
   if (TAN) {
-    const float* txh = q.TXH + (long)k * F3 + fb;
-    const float* tvk = q.TV + (long)k * F3 + fb;
-    ldv<CH>(o.txa, txh); ldv<CH>(o.txb, txh + F); ldv<CH>(o.txc, txh + 2 * F);
-    ldv<CH>(o.tva, tvk); ldv<CH>(o.tvb, tvk + F); ldv<CH>(o.tvc, tvk + 2 * F);
+    ldv_buf<CH>(o.txa, src.txh, ob, r0); ldv_buf<CH>(o.txb, src.txh, ob, r1); ldv_buf<CH>(o.txc, src.txh, ob, r2);
+    ldv_buf<CH>(o.tva, src.tv, ob, r0); ldv_buf<CH>(o.tvb, src.tv, ob, r1); ldv_buf<CH>(o.tvc, src.tv, ob, r2);
   }
 }
 
 template <bool TAN, int CH>
 __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(MsgArgs q, FilterArgs fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
+  const FwdSrc<TAN> src(q);
   FUSED_ROWS(TAN ? 1 : 0) {
     const int beg = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n]), end = __builtin_amdgcn_readfirstlane(q.g.row_ptr[n + 1]);  // scalar
     float dx[CH], d0[CH], d1[CH], d2[CH];
@@ -524,12 +528,12 @@ __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(Msg
       // into a wait for the scalar cache), then the arithmetic.
       // Two operand sets in ping-pong (no register copies, so the wait for a gather sits at its first use one edge later).
       FwdOps<TAN, CH> opA, opB;
-      load_fwd<TAN, CH>(opA, q, bl_i(row.kk, 0), F, F3, fb);
+      load_fwd<TAN, CH>(opA, src, bl_i(row.kk, 0), F, F3, fb);
       WinRegs<TAN> win;               // ONE window register set: it is dead once the filter is evaluated
       load_win<TAN>(win, RW, c0);
       auto step = [&](FwdOps<TAN, CH>& cur, FwdOps<TAN, CH>& nxt, int j, auto prefetch) __attribute__((always_inline)) {
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded (keeps the loop one basic block)
-        if (decltype(prefetch)::value) load_fwd<TAN, CH>(nxt, q, bl_i(row.kk, jn), F, F3, fb);
+        if (decltype(prefetch)::value) load_fwd<TAN, CH>(nxt, src, bl_i(row.kk, jn), F, F3, fb);
         float pa[CH], pb[CH], pc[CH], qa[CH], qb[CH], qc[CH];
         filter_eval<TAN, CH>(win, wrt, FL, 3 * FL, lfb, bra, brb, brc, pa, pb, pc, qa, qb, qc);
         __builtin_amdgcn_sched_barrier(0);
@@ -599,15 +603,19 @@ __global__ __launch_bounds__(fused_threads(TAN ? 1 : 0, CH)) void k_msgf_fwd(Msg
 template <bool DUAL, int CH>
 struct RevOps { float A0[CH], A1[CH], A2[CH], gma[CH], T0[CH], T1[CH], T2[CH], gtma[CH]; };
 
+template <bool DUAL>
+struct RevSrc {
+  __amdgpu_buffer_rsrc_t gv, gx, gtv, gtx;
+  __device__ __forceinline__ RevSrc(const MsgRevArgs& q) : gv(row_rsrc(q.GV)), gx(row_rsrc(q.GX)), gtv(row_rsrc(DUAL ? q.GTV : q.GV)), gtx(row_rsrc(DUAL ? q.GTX : q.GX)) {}
+};
 template <bool DUAL, int CH>
-__device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& q, int k, int F, int F3, int fb) {
-  const float* A = q.GV + (long)k * F3 + fb;
-  ldv<CH>(o.A0, A); ldv<CH>(o.A1, A + F); ldv<CH>(o.A2, A + 2 * F);
-  ldv<CH>(o.gma, q.GX + (long)k * F + fb);
+__device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const RevSrc<DUAL>& src, int k, int F, int F3, int fb) {
+  const int ob = fb * 4, r0 = k * F3 * 4, r1 = r0 + F * 4, r2 = r1 + F * 4, rx = k * F * 4;   // (see load_fwd)
+  ldv_buf<CH>(o.A0, src.gv, ob, r0); ldv_buf<CH>(o.A1, src.gv, ob, r1); ldv_buf<CH>(o.A2, src.gv, ob, r2);
+  ldv_buf<CH>(o.gma, src.gx, ob, rx);
   if (DUAL) {
-    const float* T = q.GTV + (long)k * F3 + fb;
-    ldv<CH>(o.T0, T); ldv<CH>(o.T1, T + F); ldv<CH>(o.T2, T + 2 * F);
-    ldv<CH>(o.gtma, q.GTX + (long)k * F + fb);
+    ldv_buf<CH>(o.T0, src.gtv, ob, r0); ldv_buf<CH>(o.T1, src.gtv, ob, r1); ldv_buf<CH>(o.T2, src.gtv, ob, r2);
+    ldv_buf<CH>(o.gtma, src.gtx, ob, rx);
   }
 }
 
@@ -631,6 +639,7 @@ __device__ __forceinline__ void load_rev(RevOps<DUAL, CH>& o, const MsgRevArgs& 
 template <bool DUAL, int CH, bool GW, bool LITE = false>
 __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterArgs& fa, const float* __restrict__ RW) {
   FUSED_PROLOGUE
+  const RevSrc<DUAL> src(q);
   FUSED_ROWS(DUAL ? 3 : 2) {
     if (DUAL && q.row_filter) {   // mixed batches: the pair-row flavour takes the rows of the molecules that do not fit the LDS of k_gwr_mol, the other flavour the rest
       const int mm = __builtin_amdgcn_readfirstlane(q.g.atom_mol[n]);
@@ -671,7 +680,7 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
       RowRegs row;
       load_row<DUAL>(row, q.g, q.TD, q.TR, RW, c0, cnt, lane);
       RevOps<DUAL, CH> opA, opB;   // ping-pong operands; scalar window loads are issued after the filter's LDS reads (see k_msgf_fwd)
-      load_rev<DUAL, CH>(opA, q, ABL_K(0), F, F3, fb);
+      load_rev<DUAL, CH>(opA, src, ABL_K(0), F, F3, fb);
       WinRegs<true> win;
       load_win<true>(win, RW, ABL_SP(c0));
       float4 eacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -680,7 +689,7 @@ __device__ __forceinline__ void msgf_rev_body(const MsgRevArgs& q, const FilterA
         constexpr bool LOW = decltype(low_tag)::value;
         const int sp = c0 + j;
         const int jn = min(j + 1, cnt - 1);   // branch-free: past the end the last edge is re-loaded
-        load_rev<DUAL, CH>(nxt, q, ABL_K(jn), F, F3, fb);
+        load_rev<DUAL, CH>(nxt, src, ABL_K(jn), F, F3, fb);
         float kxa[CH], kxb[CH], kxc[CH], kv0[CH], kv1[CH], kv2[CH], ktxa[CH], ktxb[CH], ktxc[CH], ktv0[CH], ktv1[CH], ktv2[CH];
         if (DUAL && GW && LOW && NQ_DUAL_KX_EARLY) {
           const long k3 = (long)ABL_K(j) * F3 + fb;
@@ -1240,6 +1249,7 @@ static int fused_grid(int N, int F, int ch, int* threads, size_t* lds, int R, in
 int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tangent) {
   NQ_PROF(st, tangent ? "msgf_tan" : "msgf_fwd");
   if (q.g.N <= 0) return NQ_OK;
+  if ((size_t)q.g.N * 3 * q.F * 4 >= 0xfffff000ull) return nq_fail(NQ_ERR_ARG, "fused message kernels: a node array of %d atoms x %d channels exceeds the 4 GB a buffer descriptor's scalar offset reaches", q.g.N, 3 * q.F);
   int threads; size_t lds;
   const int ch = fused_ch(tangent ? 1 : 0, q.F, q.g.N);
   const int grid = fused_grid(q.g.N, q.F, ch, &threads, &lds, fa.R, fused_threads(tangent ? 1 : 0, ch));
@@ -1252,6 +1262,7 @@ int nq_msgf_fwd(hipStream_t st, const MsgArgs& q, const FilterArgs& fa, bool tan
 int nq_msgf_rev(hipStream_t st, const MsgRevArgs& q, const FilterArgs& fa, bool dual, bool pair_rows) {
   NQ_PROF(st, dual ? (pair_rows ? "msgf_rev_dual" : "msgf_rev_dual_ng") : "msgf_rev_force");
   if (q.g.N <= 0) return NQ_OK;
+  if ((size_t)q.g.N * 3 * q.F * 4 >= 0xfffff000ull) return nq_fail(NQ_ERR_ARG, "fused message kernels: a node array of %d atoms x %d channels exceeds the 4 GB a buffer descriptor's scalar offset reaches", q.g.N, 3 * q.F);
   int threads; size_t lds;
   const int kind = dual ? (pair_rows ? 3 : 4) : 2;
   const int ch = fused_ch(dual ? 3 : 2, q.F, q.g.N);

@@ -24,6 +24,27 @@ __device__ __forceinline__ void ldv(float (&o)[CH], const float* p) {
     for (int c = 0; c < CH; ++c) o[c] = v[c];
   }
 }
+// Gathers of neighbour rows through a buffer descriptor: address = descriptor base + lane byte offset (VGPR, constant for the kernel) + row byte offset (SGPR:
+// the neighbour index comes from a lane broadcast).  No vector address arithmetic per load (the flat form costs one v_lshl_add_u64 per load: 12 of the 138
+// VALU instructions per edge of the tangent flavour).  The scalar offset is 32-bit: an array half must stay below 4 GB (2.8 M atoms at F = 128; the launchers check).
+typedef unsigned int lanes_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lanes_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
+}
+template <int CH>
+__device__ __forceinline__ void ldv_buf(float (&o)[CH], __amdgpu_buffer_rsrc_t r, int lane_bytes, int row_bytes) {
+  if constexpr (CH == 1) o[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, row_bytes, 0));
+  else if constexpr (CH == 2) {
+    const lanes_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 0);
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y);
+  } else {
+    const lanes_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, row_bytes, 0);
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
+}
 template <int CH>
 __device__ __forceinline__ void stv(float* p, const float (&o)[CH]) {
   if constexpr (CH == 1) { *p = o[0]; }
