@@ -104,7 +104,9 @@ size_t nq_painn_num_params(const nq_painn_cfg* cfg);
 size_t nq_painn_workspace_bytes(const nq_painn_cfg* cfg, int32_t N, int32_t E, int32_t B);
 
 /* energy[B] and (if forces != NULL) forces[N][3] = -dE_tot/dpos.  Keeps every activation in `workspace`
- * for nq_painn_backward.  rbf_offsets: f32[R] = buffer radial_basis.rbf.offset. */
+ * for nq_painn_backward -- and, when forces are computed, the per-layer adjoints of that force sweep: they are the
+ * tangent adjoints of the second-order sweep, which nq_painn_backward reads instead of recomputing (same parameters
+ * required in both calls, as before).  rbf_offsets: f32[R] = buffer radial_basis.rbf.offset. */
 int nq_painn_forward(const nq_painn_cfg* cfg, const float* params, const float* rbf_offsets, const nq_graph* graph, void* workspace,
                      size_t workspace_bytes, float* energy, float* forces, void* stream);
 /* Given dL/dE[B] and dL/dF[N][3] (either may be NULL = zeros) writes dL/dparams[num_params] (overwrites).
